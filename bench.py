@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the one `metric` is quoted on): apps/local_laplacian, 8 pyramid
+levels (J=8), levels=8, alpha=1/7, beta=1, uint16 RGB planar 3840x2160 in/out, fp32 internal arithmetic.
+A "step" = one pass of the pipeline over a batch of FRAMES_PER_STEP distinct synthetic frames per GPU,
+called through the C ABI (libhlmi.so, `local_laplacian(halide_buffer_t*, ...)`), inputs and outputs
+resident in HBM (uploaded once before the timed region, like apps/local_laplacian/process.cpp:31-39 where
+the first call pays the copies and `benchmark()` times calls + device_sync).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+
+Frames are independent units: ranks shard them with no data-path collective ("scaling": "weak");
+torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the elapsed time.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, C = 3840, 2160, 3
+LEVELS, ALPHA, BETA = 8, 1.0 / 7.0, 1.0
+FRAMES_PER_STEP = 4           # distinct frames per GPU per step (4 x 99.5 MB of u16 I/O > 256 MB MALL)
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
+ALG_BYTES_PER_PX = 12         # SURVEY.md §8(d) primary figure: 6 B read + 6 B written per pixel
+
+
+def synth_frame(seed):
+    """Smooth natural-like frame + noise (data-dependent level selection is cache sensitive)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    base = (np.sin(xx / 311.0 + seed) + np.cos(yy / 173.0) + np.sin((xx + yy) / 97.0) + 3.3) / 6.6
+    img = np.stack([base * 65535.0, np.roll(base, 64, 1) * 52000.0, base[::-1] * 46000.0])
+    img += rng.normal(0.0, 900.0, img.shape).astype(np.float32)
+    return np.clip(img, 0, 65535).astype(np.uint16)
+
+
+def cpu_baseline(frame):
+    """The CPU oracle (kind "port": restated algorithm, OpenMP, untuned schedule — NOT Halide's tuned CPU
+    schedule, which cannot be built here) timed on the host cores on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib  # cpu_baseline leg only
+    cores = os.cpu_count() or 1
+    oracle_lib.local_laplacian(frame, LEVELS, ALPHA, BETA)  # warm
+    n, t0 = 0, time.perf_counter()
+    while True:
+        oracle_lib.local_laplacian(frame, LEVELS, ALPHA, BETA)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > 12.0 or n >= 12:
+            break
+    return {"value": round(n * W * H / dt / 1e6, 3), "unit": "Mpx/s", "cores": cores, "kind": "port",
+            "sample": f"{n} frames of {W}x{H} u16 RGB in {dt:.2f} s (OpenMP, all host threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import halide_amd as hl
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    hl.set_gpu_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # --- synthetic frames, resident in HBM before the timed region
+    frames = [synth_frame(1000 * rank + i) for i in range(FRAMES_PER_STEP)]
+    ins = [hl.Buffer(f) for f in frames]
+    outs = [hl.Buffer(np.zeros_like(f)) for f in frames]
+    for a, o in zip(ins, outs):  # first call uploads the input and allocates the output on the device
+        hl.local_laplacian(a, LEVELS, ALPHA, BETA, o)
+    outs[-1].device_sync()
+
+    def step():
+        for a, o in zip(ins, outs):
+            hl.local_laplacian(a, LEVELS, ALPHA, BETA, o)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # --- per-kernel durations, HIP events on the launch stream, separate untimed pass
+    hl.kernel_timing_reset()
+    hl.kernel_timing(True)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    hl.kernel_timing(False)
+    kernels = hl.kernel_timing_report()
+    hl.kernel_timing_reset()
+
+    if rank == 0:
+        px_per_step = world * FRAMES_PER_STEP * W * H
+        value = px_per_step * args.steps / elapsed / 1e6
+        frame_ms = elapsed / (args.steps * FRAMES_PER_STEP) * 1e3
+        # dominant kernel = largest share of the summed kernel time per frame
+        per_frame = {}
+        for k in kernels:
+            per_frame[k["name"]] = per_frame.get(k["name"], 0.0) + k["total_ms"] / (3 * FRAMES_PER_STEP)
+        dom = max(per_frame, key=per_frame.get)
+        dom_rec = next(k for k in kernels if k["name"] == dom)
+        # algorithmic bytes per launch of each full-resolution kernel:
+        #   ll_level0_down: read u16x3 (6 B/px) + write 9 quarter-res f32 planes (9 B/px)  = 15 B/px
+        #   ll_level0_up  : read u16x3 (6) + 2 selected quarter-res planes (2) + outG1 (1) + write u16x3 (6) = 15 B/px
+        alg_bytes = {"ll_level0_down": 15, "ll_level0_up": 15}.get(dom, ALG_BYTES_PER_PX) * W * H
+        achieved = alg_bytes / (dom_rec["avg_ms"] * 1e-3) / 1e9
+        result = {
+            "metric": "megapixels/sec local_laplacian 8-level fp32 4K",
+            "value": round(value, 2), "unit": "Mpx/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "apps/local_laplacian J=8 levels=8 alpha=1/7 beta=1, u16 RGB planar 3840x2160",
+                       "frames_per_step_per_gpu": FRAMES_PER_STEP, "frame_ms": round(frame_ms, 4),
+                       "boundary": "C ABI local_laplacian(halide_buffer_t*,int32,float,float,halide_buffer_t*)",
+                       "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel_avg_ms": round(dom_rec["avg_ms"], 5),
+                         "pipeline_alg_bytes_per_frame": ALG_BYTES_PER_PX * W * H,
+                         "pipeline_frac": round(ALG_BYTES_PER_PX * W * H / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "kernel_ms_per_frame": {k: round(v, 5) for k, v in per_frame.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(frames[0])
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

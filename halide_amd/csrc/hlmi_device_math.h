@@ -1,0 +1,109 @@
+// hlmi_device_math.h — device-side arithmetic primitives shared by the gfx950 kernels.
+//
+// These restate, for the GPU, the scalar semantics the reference's code generator gives the same
+// operators on its CPU targets (paths relative to /root/reference); the kernels must be compiled with
+// -ffp-contract=off and without fast-math so that every expression below rounds exactly once per
+// operator, IEEE binary32 (division is the correctly-rounded `/`).
+//   integer division / modulo by a positive constant round toward -inf       src/IR.h:145-166
+//   clamp(a, lo, hi) = max(min(a, hi), lo)                                    src/IROperator.h
+//   float lerp(zero, one, w) = zero*(1-w) + one*w                             src/Lerp.cpp:82-83,127-128
+//   evaluate_polynomial (even/odd Horner on x^2)                              src/IROperator.cpp:33-65
+//   exp  -> halide_exp                                                        src/IROperator.cpp:921-966
+//   log  -> halide_log + range_reduce_log                                     src/IROperator.cpp:847-919
+//   pow  -> exp(log|x|*y) + select chain                                      src/CodeGen_LLVM.cpp:3925-3941
+//   fast_exp                                                                  src/IROperator.cpp:1616-1643
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hlmi {
+namespace dev {
+
+__device__ __forceinline__ int fdiv2(int a) { return a >> 1; }           // floor(a / 2)
+__device__ __forceinline__ int fmod2(int a) { return a & 1; }            // a mod 2, always in {0,1}
+__device__ __forceinline__ int fdiv8(int a) { return a >> 3; }
+__device__ __forceinline__ int fmod8(int a) { return a & 7; }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ float clampf(float v, float lo, float hi) {
+    float m = v < hi ? v : hi;
+    return m > lo ? m : lo;
+}
+__device__ __forceinline__ float lerpf(float zero, float one, float w) { return zero * (1.0f - w) + one * w; }
+
+template<int N>
+__device__ __forceinline__ float poly(float x, const float (&c)[N]) {
+    float x2 = x * x;
+    float even = c[0], odd = c[1];
+#pragma unroll
+    for (int i = 2; i < N; i++) {
+        if ((i & 1) == 0) {
+            even = (c[i] == 0.0f) ? even * x2 : even * x2 + c[i];
+        } else {
+            odd = (c[i] == 0.0f) ? odd * x2 : odd * x2 + c[i];
+        }
+    }
+    return ((N & 1) == 0) ? even * x + odd : odd * x + even;
+}
+
+__device__ __forceinline__ float halide_exp(float x_full) {
+    const float ln2_part1 = 0.6931457519f, ln2_part2 = 1.4286067653e-6f;
+    const float one_over_ln2 = __uint_as_float(0x3fb8aa3bu);  // 1.0f / logf(2.0f)
+    const float coeff[8] = {0.00031965933071842413f, 0.00119156835564003744f, 0.00848988645943932717f,
+                            0.04160188091348320655f, 0.16667983794100929562f, 0.49999899033463041098f,
+                            1.0f, 1.0f};
+    float scaled = x_full * one_over_ln2;
+    float k_real = floorf(scaled);
+    int k = (int)k_real;
+    float x = x_full - k_real * ln2_part1;
+    x = x - k_real * ln2_part2;
+    float result = poly<8>(x, coeff);
+    int biased = k + 127;
+    result = result * __uint_as_float((uint32_t)biased << 23);
+    if (!(biased < 255)) result = __uint_as_float(0x7f800000u);
+    if (!(biased > 0)) result = 0.0f;
+    return result;
+}
+
+__device__ __forceinline__ float halide_log(float x_full) {
+    const float coeff[10] = {0.05111976432738144643f, -0.11793923497136414580f, 0.14971993724699017569f,
+                             -0.16862004708254804686f, 0.19980668101718729313f, -0.24991211576292837737f,
+                             0.33333435275479328386f, -0.50000106292873236491f, 1.0f, 0.0f};
+    bool use_nan = x_full < 0.0f, use_neg_inf = x_full == 0.0f;
+    float patched = (use_nan || use_neg_inf) ? 1.0f : x_full;
+    int32_t iv = (int32_t)__float_as_uint(patched);
+    int32_t no_exponent = iv & (int32_t)0x807fffff;
+    int32_t new_biased = 127 - (no_exponent >> 22);
+    int32_t exponent = (iv >> 23) - new_biased;
+    float reduced = __uint_as_float((uint32_t)(no_exponent | (new_biased << 23)));
+    float result = poly<10>(reduced - 1.0f, coeff);
+    result = result + (float)exponent * __uint_as_float(0x3f317218u);  // logf(2.0)
+    if (use_nan) return __uint_as_float(0x7fc00000u);
+    if (use_neg_inf) return __uint_as_float(0xff800000u);
+    return result;
+}
+
+__device__ __forceinline__ float halide_pow(float x, float y) {
+    float ax = x < 0.0f ? -x : x;
+    float e = halide_exp(halide_log(ax) * y);
+    if (x > 0.0f) return e;
+    if (y == 0.0f) return 1.0f;
+    if (x == 0.0f) return 0.0f;
+    float yi = floorf(y);
+    if (yi != y) return __uint_as_float(0x7fc00000u);
+    return ((((long long)yi) & 1) != 0) ? -e : e;
+}
+
+__device__ __forceinline__ float fast_exp(float x_full) {
+    const float ln2 = __uint_as_float(0x3f317218u);           // logf(2.0)
+    const float inv_ln2 = __uint_as_float(0x3fb8aa3bu);       // fold(1 / logf(2.0))
+    const float coeff[6] = {0.01314350012789660196f, 0.03668965196652099192f, 0.16873890085469545053f,
+                            0.49970514590562437052f, 1.0f, 1.0f};
+    float k_real = floorf(x_full * inv_ln2);
+    float x = x_full - k_real * ln2;
+    float result = poly<6>(x, coeff);
+    int biased = clampi((int)k_real + 127, 0, 255);
+    return result * __uint_as_float((uint32_t)biased << 23);
+}
+
+}  // namespace dev
+}  // namespace hlmi

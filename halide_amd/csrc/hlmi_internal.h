@@ -1,0 +1,122 @@
+// hlmi_internal.h — shared plumbing between the runtime slice and the per-pipeline host shims.
+// Nothing here is exported; the exported C ABI is declared in include/hlmi_runtime.h and
+// include/hlmi_pipelines.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "hlmi_pipelines.h"
+#include "hlmi_runtime.h"
+
+namespace hlmi {
+
+// ---------------------------------------------------------------------------------------------
+// errors: format a message, hand it to halide_error() (default handler aborts, like the reference's
+// posix_error_handler.cpp:9-21) and return the code so callers can `return report(...)`.
+int report(void *uc, int code, const char *fmt, ...) __attribute__((format(printf, 3, 4)));
+int hip_failed(void *uc, hipError_t e, const char *what);  // -> halide_error_code_gpu_device_error
+
+#define HLMI_HIP(uc, call)                                           \
+    do {                                                             \
+        hipError_t e__ = (call);                                     \
+        if (e__ != hipSuccess) return ::hlmi::hip_failed(uc, e__, #call); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// ABI helpers
+constexpr uint32_t type_abi(int code, int bits) { return (uint32_t)code | ((uint32_t)bits << 8); }
+constexpr uint32_t T_U8 = type_abi(1, 8), T_U16 = type_abi(1, 16), T_I16 = type_abi(0, 16),
+                   T_I32 = type_abi(0, 32), T_F32 = type_abi(2, 32);
+inline uint32_t buf_type_abi(const halide_buffer_t *b) {
+    uint32_t v;
+    memcpy(&v, &b->type, 4);
+    return v;
+}
+const char *type_name(uint32_t abi, char tmp[16]);
+
+struct BufArg {
+    const char *name;
+    halide_buffer_t *buf;
+    uint32_t type;  // required element type (type_abi)
+    int dims;       // required dimensionality
+    bool is_output;
+};
+
+// step 1 of the entry protocol (src/UnpackBuffers.cpp:148)
+int check_not_null(void *uc, const BufArg *args, int n);
+// step 2 (src/AddImageChecks.cpp:315-318, HalideRuntime.h:1851-1853)
+bool any_bounds_query(const BufArg *args, int n);
+// steps 3-4 (src/AddImageChecks.cpp:329-347)
+int check_type_and_dims(void *uc, const BufArg *args, int n);
+// step 5a: extents >= 0, dim[0].stride == 1 (src/Parameter.cpp:30-35), sizes < 2^31
+// (src/AddImageChecks.cpp:414-471)
+int check_shape(void *uc, const BufArg &a);
+// step 5b: [min, min+extent) of dimension d must cover [req_min, req_min+req_extent)
+// (src/AddImageChecks.cpp:436-458 -> halide_error_access_out_of_bounds)
+int check_covers(void *uc, const BufArg &a, int d, int req_min, int req_extent);
+// pinned constraint helper (halide_error_constraint_violated, src/runtime/errors.cpp:104)
+int check_equal(void *uc, const char *what, int val, const char *expect_what, int expect);
+// bounds-query answer: rewrite dim[] to a dense planar shape (stride[0]=1) — only if `buf` is itself
+// a query buffer (host==NULL && device==0), as the reference does (AddImageChecks.cpp:480-497).
+void answer_query(halide_buffer_t *buf, const int *mins, const int *extents);
+
+// ---------------------------------------------------------------------------------------------
+// device context
+struct DeviceCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+};
+// choose device (halide_set_gpu_device / HL_GPU_DEVICE / 0), hipSetDevice, choose stream.
+// Fails with -29 when no gfx950 device is usable: there is NO CPU fallback.
+int acquire_device(void *uc, DeviceCtx *ctx);
+// scratch arena owned by (device, stream); contents valid until the next call that asks for a
+// workspace on the same stream (stream order makes reuse across back-to-back calls safe).
+int get_workspace(void *uc, const DeviceCtx &ctx, size_t bytes, void **ptr);
+
+// dirty-flag protocol for pipeline arguments (src/InjectHostDevBufferCopies.cpp:197-217,285-304)
+int input_to_device(void *uc, const DeviceCtx &ctx, const BufArg &a);
+int output_on_device(void *uc, const DeviceCtx &ctx, const BufArg &a);
+void mark_output_written(halide_buffer_t *buf);  // device_dirty = 1, host_dirty = 0
+
+template<typename T>
+inline T *dev_ptr(const halide_buffer_t *b) { return reinterpret_cast<T *>((uintptr_t)b->device); }
+
+// ---------------------------------------------------------------------------------------------
+// optional per-kernel HIP-event timing (include/hlmi_runtime.h: hlmi_kernel_timing_*)
+bool timing_enabled();
+void timing_begin(const char *name, hipStream_t s);
+void timing_end(hipStream_t s);
+struct ScopedKernelTimer {
+    hipStream_t s;
+    bool on;
+    ScopedKernelTimer(const char *name, hipStream_t stream) : s(stream), on(timing_enabled()) {
+        if (on) timing_begin(name, s);
+    }
+    ~ScopedKernelTimer() {
+        if (on) timing_end(s);
+    }
+};
+// launch + error check; kernel errors surface as -23 (device_run_failed)
+int launch_failed(void *uc, const char *kernel);
+#define HLMI_LAUNCH(uc, name, stream, kernel, grid, block, shmem, ...)                      \
+    do {                                                                                    \
+        ::hlmi::ScopedKernelTimer t__(name, stream);                                        \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                \
+        if (hipGetLastError() != hipSuccess) return ::hlmi::launch_failed(uc, name);        \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// metadata helper: every pipeline defines a static halide_filter_metadata_t
+// (layout: src/runtime/HalideRuntime.h:1937-1975; contents as emitted by src/CodeGen_C.cpp:760-912)
+extern const char *const kTargetString;  // "x86-64-linux-hip-gfx950" (canonical-style target string)
+
+inline int floor_div(int a, int b) {  // b > 0 ; Halide integer division rounds toward -inf (src/IR.h:145-166)
+    int q = a / b, r = a % b;
+    return (r != 0 && r < 0) ? q - 1 : q;
+}
+
+}  // namespace hlmi

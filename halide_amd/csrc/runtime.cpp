@@ -1,0 +1,972 @@
+// runtime.cpp — the slice of the runtime that callers of the AOT entry points touch:
+// error/print/malloc hooks, the HIP device interface with the reference's dirty-flag protocol,
+// per-device streams + scratch arenas + an allocation cache, and optional per-kernel event timing.
+//
+// Reference behaviour restated here (paths relative to /root/reference):
+//   src/runtime/posix_error_handler.cpp:9-41   default error handler prints and aborts
+//   src/runtime/posix_allocator.cpp            halide_malloc alignment
+//   src/runtime/device_interface.cpp:28-727    dirty-flag state machine, validation order
+//   src/runtime/cuda.cpp:586-760               allocation cache ("reuse_device_allocations")
+//   src/runtime/gpu_device_selection.cpp:29    HL_GPU_DEVICE
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include <stdlib.h>
+
+#include "hlmi_internal.h"
+
+namespace hlmi {
+
+const char *const kTargetString = "x86-64-linux-hip-gfx950";
+
+// ------------------------------------------------------------------------------------------------
+// hooks
+static void default_error_handler(void *, const char *msg) {
+    fprintf(stderr, "Error: %s\n", msg);
+    fflush(stderr);
+    abort();
+}
+static void default_print(void *, const char *msg) { fputs(msg, stderr); }
+static void *default_malloc(void *, size_t x) {
+    void *p = nullptr;
+    // 128-byte alignment like the reference allocator / Buffer<> (HalideBuffer.h:894-951)
+    if (posix_memalign(&p, 128, (x + 127) & ~(size_t)127) != 0) return nullptr;
+    return p;
+}
+static void default_free(void *, void *p) { free(p); }
+
+static std::atomic<halide_error_handler_t> g_error_handler{default_error_handler};
+static std::atomic<halide_print_t> g_print{default_print};
+static std::atomic<halide_malloc_t> g_malloc{default_malloc};
+static std::atomic<halide_free_t> g_free{default_free};
+
+int report(void *uc, int code, const char *fmt, ...) {
+    char msg[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(msg, sizeof msg, fmt, ap);
+    va_end(ap);
+    halide_error(uc, msg);
+    return code;
+}
+
+int hip_failed(void *uc, hipError_t e, const char *what) {
+    return report(uc, halide_error_code_gpu_device_error, "HIP: %s failed: %s", what, hipGetErrorString(e));
+}
+
+int launch_failed(void *uc, const char *kernel) {
+    return report(uc, halide_error_code_device_run_failed, "HIP: launch of kernel %s failed", kernel);
+}
+
+const char *type_name(uint32_t abi, char tmp[16]) {
+    static const char *codes[] = {"int", "uint", "float", "handle", "bfloat"};
+    unsigned code = abi & 0xff, bits = (abi >> 8) & 0xff;
+    snprintf(tmp, 16, "%s%u", code < 5 ? codes[code] : "type?", bits);
+    return tmp;
+}
+
+// ------------------------------------------------------------------------------------------------
+// argument checks
+int check_not_null(void *uc, const BufArg *args, int n) {
+    for (int i = 0; i < n; i++) {
+        if (!args[i].buf) {
+            return report(uc, halide_error_code_buffer_argument_is_null, "Buffer argument %s is nullptr",
+                          args[i].name);
+        }
+    }
+    return 0;
+}
+
+bool any_bounds_query(const BufArg *args, int n) {
+    for (int i = 0; i < n; i++) {
+        if (args[i].buf->host == nullptr && args[i].buf->device == 0) return true;
+    }
+    return false;
+}
+
+int check_type_and_dims(void *uc, const BufArg *args, int n) {
+    for (int i = 0; i < n; i++) {
+        const BufArg &a = args[i];
+        uint32_t given = buf_type_abi(a.buf);
+        if (given != a.type) {
+            char t0[16], t1[16];
+            return report(uc, halide_error_code_bad_type,
+                          "%s buffer %s has type %s but type of the buffer passed in is %s",
+                          a.is_output ? "Output" : "Input", a.name, type_name(a.type, t0), type_name(given, t1));
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        const BufArg &a = args[i];
+        if (a.buf->dimensions != a.dims) {
+            return report(uc, halide_error_code_bad_dimensions,
+                          "%s buffer %s requires a buffer of exactly %d dimensions, but the buffer passed in has %d "
+                          "dimensions",
+                          a.is_output ? "Output" : "Input", a.name, a.dims, a.buf->dimensions);
+        }
+        if (a.dims > 0 && a.buf->dim == nullptr) {
+            return report(uc, halide_error_code_buffer_is_null, "%s buffer %s has a null dim pointer",
+                          a.is_output ? "Output" : "Input", a.name);
+        }
+    }
+    return 0;
+}
+
+int check_shape(void *uc, const BufArg &a) {
+    const halide_buffer_t *b = a.buf;
+    const char *io = a.is_output ? "Output" : "Input";
+    int64_t total = 1;
+    for (int d = 0; d < b->dimensions; d++) {
+        if (b->dim[d].extent < 0) {
+            return report(uc, halide_error_code_buffer_extents_negative,
+                          "The extents for buffer %s dimension %d is negative (%d)", a.name, d, b->dim[d].extent);
+        }
+    }
+    if (b->dimensions > 0 && b->dim[0].stride != 1) {
+        char what[96];
+        snprintf(what, sizeof what, "%s.stride.0", a.name);
+        return check_equal(uc, what, b->dim[0].stride, "1", 1);
+    }
+    for (int d = 0; d < b->dimensions; d++) {
+        int64_t span = (int64_t)b->dim[d].extent * (int64_t)(b->dim[d].stride < 0 ? -(int64_t)b->dim[d].stride
+                                                                                : (int64_t)b->dim[d].stride);
+        if (span > 0x7fffffffLL) {
+            return report(uc, halide_error_code_buffer_allocation_too_large,
+                          "Total allocation for buffer %s %s is %lld, which exceeds the maximum size of %lld", io,
+                          a.name, (long long)span, (long long)0x7fffffffLL);
+        }
+        total *= b->dim[d].extent;
+        if (total > 0x7fffffffLL) {
+            return report(uc, halide_error_code_buffer_extents_too_large,
+                          "Product of extents for buffer %s %s is %lld, which exceeds the maximum size of %lld", io,
+                          a.name, (long long)total, (long long)0x7fffffffLL);
+        }
+    }
+    return 0;
+}
+
+int check_covers(void *uc, const BufArg &a, int d, int req_min, int req_extent) {
+    const halide_dimension_t &dm = a.buf->dim[d];
+    int req_max = req_min + req_extent - 1, have_max = dm.min + dm.extent - 1;
+    if (req_extent > 0 && (req_min < dm.min || req_max > have_max)) {
+        return report(uc, halide_error_code_access_out_of_bounds,
+                      "%s buffer %s is accessed at %d, which is %s the %s (%d) in dimension %d",
+                      a.is_output ? "Output" : "Input", a.name, req_min < dm.min ? req_min : req_max,
+                      req_min < dm.min ? "before" : "beyond", req_min < dm.min ? "min" : "max",
+                      req_min < dm.min ? dm.min : have_max, d);
+    }
+    return 0;
+}
+
+int check_equal(void *uc, const char *what, int val, const char *expect_what, int expect) {
+    if (val != expect) {
+        return report(uc, halide_error_code_constraint_violated, "Constraint violated: %s (%d) == %s (%d)", what, val,
+                      expect_what, expect);
+    }
+    return 0;
+}
+
+void answer_query(halide_buffer_t *buf, const int *mins, const int *extents) {
+    if (!(buf->host == nullptr && buf->device == 0)) return;
+    int stride = 1;
+    for (int d = 0; d < buf->dimensions; d++) {
+        buf->dim[d].min = mins[d];
+        buf->dim[d].extent = extents[d];
+        buf->dim[d].stride = stride;
+        stride *= extents[d];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// devices, streams, workspaces, allocation cache
+static thread_local int t_gpu_device = -1;
+static thread_local hipStream_t t_stream_override = nullptr;
+
+struct Arena {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+struct DeviceState {
+    bool inited = false;
+    bool usable = false;
+    hipStream_t stream = nullptr;
+    std::map<hipStream_t, Arena> arenas;             // scratch per stream
+    std::unordered_map<uint64_t, std::pair<void *, size_t>> owned;  // device handle -> (base, bytes)
+    std::multimap<size_t, void *> cache;             // free allocations kept for reuse
+};
+
+static std::mutex g_mu;  // guards g_dev[*] bookkeeping (device_copy_mutex analogue, device_interface.cpp:28)
+static DeviceState g_dev[64];
+static std::atomic<int> g_reuse{1};
+static int g_device_count = -1;
+
+static int device_count_locked() {
+    if (g_device_count < 0) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+        (void)hipGetLastError();
+        g_device_count = n > 64 ? 64 : n;
+    }
+    return g_device_count;
+}
+
+static int pick_device() {
+    if (t_gpu_device >= 0) return t_gpu_device;
+    const char *e = getenv("HL_GPU_DEVICE");
+    if (e && *e) return atoi(e);
+    return 0;
+}
+
+int acquire_device(void *uc, DeviceCtx *ctx) {
+    int dev = pick_device();
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        int n = device_count_locked();
+        if (n <= 0) {
+            return report(uc, halide_error_code_gpu_device_error,
+                          "hlmi: no HIP device is visible; the gfx950 kernels have no CPU fallback");
+        }
+        if (dev < 0 || dev >= n) {
+            return report(uc, halide_error_code_gpu_device_error, "hlmi: GPU device %d requested, %d visible", dev, n);
+        }
+        DeviceState &st = g_dev[dev];
+        if (!st.inited) {
+            st.inited = true;
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0 &&
+                hipSetDevice(dev) == hipSuccess &&
+                hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking) == hipSuccess) {
+                st.usable = true;
+            }
+        }
+        if (!st.usable) {
+            return report(uc, halide_error_code_gpu_device_error,
+                          "hlmi: device %d is not a usable gfx950 (MI355X) device; kernels are built for gfx950 only",
+                          dev);
+        }
+        ctx->device = dev;
+        ctx->stream = t_stream_override ? t_stream_override : st.stream;
+    }
+    HLMI_HIP(uc, hipSetDevice(dev));
+    return 0;
+}
+
+int get_workspace(void *uc, const DeviceCtx &ctx, size_t bytes, void **ptr) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    Arena &a = g_dev[ctx.device].arenas[ctx.stream];
+    if (a.bytes < bytes) {
+        if (a.ptr) {
+            HLMI_HIP(uc, hipStreamSynchronize(ctx.stream));
+            HLMI_HIP(uc, hipFree(a.ptr));
+            a.ptr = nullptr;
+            a.bytes = 0;
+        }
+        size_t want = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+        HLMI_HIP(uc, hipMalloc(&a.ptr, want));
+        a.bytes = want;
+    }
+    *ptr = a.ptr;
+    return 0;
+}
+
+// ---- raw allocation with cache ---------------------------------------------------------------
+static int dev_alloc_locked(void *uc, int dev, size_t bytes, void **out) {
+    DeviceState &st = g_dev[dev];
+    auto it = st.cache.find(bytes);
+    if (it != st.cache.end()) {
+        *out = it->second;
+        st.cache.erase(it);
+        return 0;
+    }
+    hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        // drop the cache and retry once (cuda.cpp does the same on OOM)
+        for (auto &kv : st.cache) (void)hipFree(kv.second);
+        st.cache.clear();
+        e = hipMalloc(out, bytes ? bytes : 1);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return report(uc, halide_error_code_device_malloc_failed, "hlmi: hipMalloc(%zu) failed: %s", bytes,
+                      hipGetErrorString(e));
+    }
+    return 0;
+}
+
+static void dev_free_locked(int dev, void *base, size_t bytes) {
+    DeviceState &st = g_dev[dev];
+    if (g_reuse.load()) {
+        st.cache.emplace(bytes, base);
+    } else {
+        (void)hipFree(base);
+    }
+}
+
+// ---- helpers over halide_buffer_t ---------------------------------------------------------------
+static ptrdiff_t begin_offset(const halide_buffer_t *b) {
+    ptrdiff_t idx = 0;
+    for (int i = 0; i < b->dimensions; i++) {
+        if (b->dim[i].stride < 0) idx += (ptrdiff_t)b->dim[i].stride * (b->dim[i].extent - 1);
+    }
+    return idx;
+}
+static ptrdiff_t end_offset(const halide_buffer_t *b) {
+    ptrdiff_t idx = 0;
+    for (int i = 0; i < b->dimensions; i++) {
+        if (b->dim[i].stride > 0) idx += (ptrdiff_t)b->dim[i].stride * (b->dim[i].extent - 1);
+    }
+    return idx + 1;
+}
+static size_t elem_bytes(const halide_buffer_t *b) { return (b->type.bits + 7) / 8; }
+static bool is_empty(const halide_buffer_t *b) {
+    for (int i = 0; i < b->dimensions; i++) {
+        if (b->dim[i].extent <= 0) return true;
+    }
+    return false;
+}
+
+// validation order of device_interface.cpp:84-128
+static int validate(void *uc, const halide_buffer_t *buf, const char *routine) {
+    if (buf == nullptr) return report(uc, halide_error_code_buffer_is_null, "Buffer pointer passed to %s is null", routine);
+    bool has_if = buf->device_interface != nullptr, has_dev = buf->device != 0;
+    if (has_dev && !has_if) {
+        return report(uc, halide_error_code_no_device_interface, "Buffer has a non-zero device but no device interface");
+    }
+    if (has_if && !has_dev) {
+        return report(uc, halide_error_code_device_interface_no_device, "Buffer has a non-null device_interface but device is 0");
+    }
+    if ((buf->flags & halide_buffer_flag_host_dirty) && (buf->flags & halide_buffer_flag_device_dirty)) {
+        return report(uc, halide_error_code_host_and_device_dirty, "Buffer has both host and device dirty bits set");
+    }
+    return 0;
+}
+
+// strided copy between host and device images of the same buffer (same strides on both sides).
+// Contiguous runs are merged; the rest goes through hipMemcpy2DAsync row bundles.
+static int copy_strided(void *uc, const halide_buffer_t *b, bool to_device, hipStream_t stream) {
+    if (is_empty(b)) return 0;
+    const size_t es = elem_bytes(b);
+    // sort dims by |stride|
+    int order[16], nd = b->dimensions;
+    if (nd > 16) return report(uc, halide_error_code_unimplemented, "hlmi: more than 16 dimensions");
+    for (int i = 0; i < nd; i++) order[i] = i;
+    for (int i = 1; i < nd; i++) {
+        for (int j = i; j > 0 && llabs((long long)b->dim[order[j]].stride) < llabs((long long)b->dim[order[j - 1]].stride); j--) {
+            int t = order[j];
+            order[j] = order[j - 1];
+            order[j - 1] = t;
+        }
+    }
+    for (int i = 0; i < nd; i++) {
+        if (b->dim[i].stride < 0) return report(uc, halide_error_code_unimplemented, "hlmi: negative strides are not supported on the device");
+    }
+    // merge the contiguous inner run
+    size_t run = 1;  // elements
+    int k = 0;
+    while (k < nd && (size_t)b->dim[order[k]].stride == run) {
+        run *= (size_t)b->dim[order[k]].extent;
+        k++;
+    }
+    uint8_t *h0 = b->host;
+    uint8_t *d0 = reinterpret_cast<uint8_t *>((uintptr_t)b->device);
+    hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+    if (k == nd) {
+        HLMI_HIP(uc, hipMemcpyAsync(to_device ? (void *)d0 : (void *)h0, to_device ? (void *)h0 : (void *)d0, run * es, kind, stream));
+        return 0;
+    }
+    // dimension order[k] becomes the "rows" of a 2-D copy; iterate over the remaining dims
+    const int rd = order[k];
+    const size_t pitch = (size_t)b->dim[rd].stride * es, rows = (size_t)b->dim[rd].extent;
+    int idx[16] = {0};
+    for (;;) {
+        size_t off = 0;
+        for (int j = k + 1; j < nd; j++) off += (size_t)idx[j] * (size_t)b->dim[order[j]].stride * es;
+        uint8_t *h = h0 + off, *d = d0 + off;
+        HLMI_HIP(uc, hipMemcpy2DAsync(to_device ? (void *)d : (void *)h, pitch, to_device ? (void *)h : (void *)d, pitch,
+                                      run * es, rows, kind, stream));
+        int j = k + 1;
+        for (; j < nd; j++) {
+            if (++idx[j] < b->dim[order[j]].extent) break;
+            idx[j] = 0;
+        }
+        if (j >= nd) break;
+    }
+    return 0;
+}
+
+// ---- impl functions of the HIP interface -----------------------------------------------------
+static int hip_device_malloc(void *uc, halide_buffer_t *buf) {
+    if (buf->device) return 0;  // already allocated (cuda.cpp:601-606)
+    DeviceCtx ctx;
+    int r = acquire_device(uc, &ctx);
+    if (r) return r;
+    for (int i = 0; i < buf->dimensions; i++) {
+        if (buf->dim[i].stride < 0) return report(uc, halide_error_code_unimplemented, "hlmi: negative strides are not supported on the device");
+    }
+    size_t bytes = (size_t)(end_offset(buf) - begin_offset(buf)) * elem_bytes(buf);
+    if (is_empty(buf)) bytes = 0;
+    bytes = (bytes + 255) & ~(size_t)255;  // kernels may over-read whole 16-byte vectors at row ends
+    if (bytes == 0) bytes = 256;
+    void *base = nullptr;
+    std::lock_guard<std::mutex> lock(g_mu);
+    r = dev_alloc_locked(uc, ctx.device, bytes, &base);
+    if (r) return r;
+    buf->device = (uint64_t)(uintptr_t)base;
+    buf->device_interface = halide_hip_device_interface();
+    g_dev[ctx.device].owned[buf->device] = {base, bytes};
+    return 0;
+}
+
+static int find_owner_locked(uint64_t handle, int *dev_out) {
+    int n = device_count_locked();
+    for (int d = 0; d < n; d++) {
+        if (g_dev[d].owned.count(handle)) {
+            *dev_out = d;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+static int hip_device_free(void *uc, halide_buffer_t *buf) {
+    if (buf->device == 0) return 0;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        int dev;
+        if (find_owner_locked(buf->device, &dev)) {
+            auto rec = g_dev[dev].owned[buf->device];
+            g_dev[dev].owned.erase(buf->device);
+            if (!g_reuse.load()) {
+                (void)hipSetDevice(dev);
+                (void)hipDeviceSynchronize();
+            }
+            dev_free_locked(dev, rec.first, rec.second);
+        }
+        // not owned: a wrapped native pointer or a crop — nothing to free
+    }
+    buf->device = 0;
+    buf->device_interface = nullptr;
+    buf->flags &= ~(uint64_t)halide_buffer_flag_device_dirty;
+    return 0;
+}
+
+static int hip_device_sync(void *uc, halide_buffer_t *) {
+    DeviceCtx ctx;
+    int r = acquire_device(uc, &ctx);
+    if (r) return r;
+    HLMI_HIP(uc, hipStreamSynchronize(ctx.stream));
+    return 0;
+}
+
+static int hip_device_release(void *uc) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    int n = device_count_locked();
+    for (int d = 0; d < n; d++) {
+        DeviceState &st = g_dev[d];
+        if (!st.inited || !st.usable) continue;
+        (void)hipSetDevice(d);
+        (void)hipDeviceSynchronize();
+        for (auto &kv : st.cache) (void)hipFree(kv.second);
+        st.cache.clear();
+        for (auto &kv : st.arenas) {
+            if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+        }
+        st.arenas.clear();
+    }
+    (void)uc;
+    return 0;
+}
+
+static int hip_copy_to_host(void *uc, halide_buffer_t *buf) {
+    DeviceCtx ctx;
+    int r = acquire_device(uc, &ctx);
+    if (r) return r;
+    r = copy_strided(uc, buf, false, ctx.stream);
+    if (r) return r;
+    HLMI_HIP(uc, hipStreamSynchronize(ctx.stream));
+    return 0;
+}
+
+static int hip_copy_to_device(void *uc, halide_buffer_t *buf) {
+    DeviceCtx ctx;
+    int r = acquire_device(uc, &ctx);
+    if (r) return r;
+    r = copy_strided(uc, buf, true, ctx.stream);
+    if (r) return r;
+    // host memory is pageable: the runtime has staged it by the time the call returns, but keep the
+    // contract simple and identical to the reference (copy complete on return)
+    HLMI_HIP(uc, hipStreamSynchronize(ctx.stream));
+    return 0;
+}
+
+static int hip_wrap_native(void *uc, halide_buffer_t *buf, uint64_t handle) {
+    if (buf->device != 0) {
+        return report(uc, halide_error_code_device_wrap_native_failed, "hlmi: wrap_native on a buffer that already has a device allocation");
+    }
+    buf->device = handle;
+    buf->device_interface = halide_hip_device_interface();
+    return 0;
+}
+
+static int hip_detach_native(void *uc, halide_buffer_t *buf) {
+    if (buf->device == 0) return 0;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        int dev;
+        if (find_owner_locked(buf->device, &dev)) {
+            return report(uc, halide_error_code_device_detach_native_failed, "hlmi: detach_native on a buffer whose device memory is owned by the runtime");
+        }
+    }
+    buf->device = 0;
+    buf->device_interface = nullptr;
+    return 0;
+}
+
+static int hip_device_crop(void *uc, const halide_buffer_t *src, halide_buffer_t *dst) {
+    // dst already has the cropped dim[]; the device handle is the address of dst's min element
+    (void)uc;
+    ptrdiff_t off = 0;
+    for (int i = 0; i < src->dimensions; i++) off += (ptrdiff_t)(dst->dim[i].min - src->dim[i].min) * src->dim[i].stride;
+    dst->device = src->device + (uint64_t)(off * (ptrdiff_t)elem_bytes(src));
+    dst->device_interface = src->device_interface;
+    return 0;
+}
+
+static int hip_device_slice(void *uc, const halide_buffer_t *src, int slice_dim, int slice_pos, halide_buffer_t *dst) {
+    (void)uc;
+    ptrdiff_t off = (ptrdiff_t)(slice_pos - src->dim[slice_dim].min) * src->dim[slice_dim].stride;
+    dst->device = src->device + (uint64_t)(off * (ptrdiff_t)elem_bytes(src));
+    dst->device_interface = src->device_interface;
+    return 0;
+}
+
+static int hip_device_release_crop(void *uc, halide_buffer_t *buf) {
+    (void)uc;
+    buf->device = 0;
+    buf->device_interface = nullptr;
+    return 0;
+}
+
+// ---- pipeline argument protocol -------------------------------------------------------------------
+int input_to_device(void *uc, const DeviceCtx &ctx, const BufArg &a) {
+    halide_buffer_t *b = a.buf;
+    int r = validate(uc, b, a.name);
+    if (r) return r;
+    if (b->device && b->device_interface != halide_hip_device_interface()) {
+        return report(uc, halide_error_code_incompatible_device_interface,
+                      "Input buffer %s carries a device allocation of a different device interface", a.name);
+    }
+    bool fresh = false;
+    if (b->device == 0) {
+        if (b->host == nullptr) return report(uc, halide_error_code_host_is_null, "Input buffer %s host pointer is null", a.name);
+        r = hip_device_malloc(uc, b);
+        if (r) return r;
+        fresh = true;
+    }
+    if ((b->flags & halide_buffer_flag_host_dirty) || fresh) {
+        if (b->host == nullptr) return report(uc, halide_error_code_host_is_null, "Input buffer %s host pointer is null", a.name);
+        r = copy_strided(uc, b, true, ctx.stream);
+        if (r) return halide_error_code_copy_to_device_failed;
+        // pageable host memory: the async copy has consumed the host data when it returns
+        b->flags &= ~(uint64_t)halide_buffer_flag_host_dirty;
+    }
+    return 0;
+}
+
+int output_on_device(void *uc, const DeviceCtx &ctx, const BufArg &a) {
+    (void)ctx;
+    halide_buffer_t *b = a.buf;
+    int r = validate(uc, b, a.name);
+    if (r) return r;
+    if (b->device && b->device_interface != halide_hip_device_interface()) {
+        return report(uc, halide_error_code_incompatible_device_interface,
+                      "Output buffer %s carries a device allocation of a different device interface", a.name);
+    }
+    if (b->device == 0) {
+        r = hip_device_malloc(uc, b);
+        if (r) return r;
+    }
+    return 0;
+}
+
+void mark_output_written(halide_buffer_t *b) {
+    b->flags |= halide_buffer_flag_device_dirty;
+    b->flags &= ~(uint64_t)halide_buffer_flag_host_dirty;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-kernel timing
+struct TimedLaunch {
+    std::string name;
+    hipEvent_t e0, e1;
+};
+static std::atomic<int> g_timing{0};
+static std::mutex g_timing_mu;
+static std::vector<TimedLaunch> g_launches;
+static thread_local hipEvent_t t_pending_e1;
+
+bool timing_enabled() { return g_timing.load(std::memory_order_relaxed) != 0; }
+
+void timing_begin(const char *name, hipStream_t s) {
+    TimedLaunch t;
+    t.name = name;
+    if (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess) return;
+    (void)hipEventRecord(t.e0, s);
+    t_pending_e1 = t.e1;
+    std::lock_guard<std::mutex> lock(g_timing_mu);
+    g_launches.push_back(t);
+}
+
+void timing_end(hipStream_t s) {
+    if (t_pending_e1) (void)hipEventRecord(t_pending_e1, s);
+    t_pending_e1 = nullptr;
+}
+
+}  // namespace hlmi
+
+// ====================================================================================================
+// exported C ABI
+using namespace hlmi;
+
+extern "C" {
+
+void halide_error(void *uc, const char *msg) { g_error_handler.load()(uc, msg); }
+halide_error_handler_t halide_set_error_handler(halide_error_handler_t h) {
+    return g_error_handler.exchange(h ? h : default_error_handler);
+}
+void halide_print(void *uc, const char *msg) { g_print.load()(uc, msg); }
+halide_print_t halide_set_custom_print(halide_print_t p) { return g_print.exchange(p ? p : default_print); }
+void *halide_malloc(void *uc, size_t x) { return g_malloc.load()(uc, x); }
+void halide_free(void *uc, void *p) { g_free.load()(uc, p); }
+halide_malloc_t halide_set_custom_malloc(halide_malloc_t m) { return g_malloc.exchange(m ? m : default_malloc); }
+halide_free_t halide_set_custom_free(halide_free_t f) { return g_free.exchange(f ? f : default_free); }
+
+// ---- generic wrappers: validation + dispatch through buf->device_interface (device_interface.cpp) ----
+static const halide_device_interface_t *resolve(const halide_buffer_t *buf, const halide_device_interface_t *di) {
+    return di ? di : buf->device_interface;
+}
+
+int halide_device_malloc(void *uc, halide_buffer_t *buf, const halide_device_interface_t *di) {
+    int r = validate(uc, buf, "halide_device_malloc");
+    if (r) return r;
+    if (buf->device_interface && di && buf->device_interface != di) {
+        return report(uc, halide_error_code_incompatible_device_interface, "halide_device_malloc doesn't support switching interfaces");
+    }
+    di = resolve(buf, di);
+    if (!di) return report(uc, halide_error_code_no_device_interface, "halide_device_malloc: no device interface");
+    return di->device_malloc(uc, buf, di);
+}
+
+int halide_device_free(void *uc, halide_buffer_t *buf) {
+    int r = validate(uc, buf, "halide_device_free");
+    if (r) return r;
+    if (buf->device_interface) return buf->device_interface->device_free(uc, buf);
+    buf->flags &= ~(uint64_t)halide_buffer_flag_device_dirty;
+    return 0;
+}
+
+int halide_device_sync(void *uc, halide_buffer_t *buf) {
+    int r = validate(uc, buf, "halide_device_sync");
+    if (r) return r;
+    if (!buf->device_interface) return report(uc, halide_error_code_no_device_interface, "halide_device_sync: buffer has no device interface");
+    return buf->device_interface->device_sync(uc, buf);
+}
+
+int halide_device_sync_global(void *uc, const halide_device_interface_t *di) {
+    if (!di) return halide_error_code_no_device_interface;
+    return di->device_sync(uc, nullptr);
+}
+
+int halide_copy_to_host(void *uc, halide_buffer_t *buf) {
+    int r = validate(uc, buf, "halide_copy_to_host");
+    if (r) return r;
+    if (!(buf->flags & halide_buffer_flag_device_dirty)) return 0;  // nothing to do (device_interface.cpp:48-50)
+    if (!buf->device_interface) return report(uc, halide_error_code_no_device_interface, "halide_copy_to_host: device dirty but no device interface");
+    return buf->device_interface->copy_to_host(uc, buf);
+}
+
+int halide_copy_to_device(void *uc, halide_buffer_t *buf, const halide_device_interface_t *di) {
+    int r = validate(uc, buf, "halide_copy_to_device");
+    if (r) return r;
+    di = resolve(buf, di);
+    if (!di) return report(uc, halide_error_code_no_device_interface, "halide_copy_to_device: no device interface");
+    if (buf->device && buf->device_interface != di) {
+        return report(uc, halide_error_code_incompatible_device_interface, "halide_copy_to_device does not support switching interfaces");
+    }
+    return di->copy_to_device(uc, buf, di);
+}
+
+int halide_device_and_host_malloc(void *uc, halide_buffer_t *buf, const halide_device_interface_t *di) {
+    int r = validate(uc, buf, "halide_device_and_host_malloc");
+    if (r) return r;
+    di = resolve(buf, di);
+    if (!di) return report(uc, halide_error_code_no_device_interface, "halide_device_and_host_malloc: no device interface");
+    return di->device_and_host_malloc(uc, buf, di);
+}
+
+int halide_device_and_host_free(void *uc, halide_buffer_t *buf) {
+    int r = validate(uc, buf, "halide_device_and_host_free");
+    if (r) return r;
+    if (buf->device_interface) return buf->device_interface->device_and_host_free(uc, buf);
+    if (buf->host) {
+        halide_free(uc, buf->host);
+        buf->host = nullptr;
+    }
+    buf->flags &= ~(uint64_t)halide_buffer_flag_device_dirty;
+    return 0;
+}
+
+int halide_buffer_copy(void *uc, halide_buffer_t *src, const halide_device_interface_t *dst_di, halide_buffer_t *dst) {
+    const halide_device_interface_t *di = dst_di ? dst_di : src->device_interface;
+    if (!di) di = halide_hip_device_interface();
+    return di->buffer_copy(uc, src, dst_di, dst);
+}
+
+int halide_device_wrap_native(void *uc, halide_buffer_t *buf, uint64_t handle, const halide_device_interface_t *di) {
+    int r = validate(uc, buf, "halide_device_wrap_native");
+    if (r) return r;
+    if (!di) return report(uc, halide_error_code_no_device_interface, "halide_device_wrap_native: no device interface");
+    return di->wrap_native(uc, buf, handle, di);
+}
+
+int halide_device_detach_native(void *uc, halide_buffer_t *buf) {
+    int r = validate(uc, buf, "halide_device_detach_native");
+    if (r) return r;
+    if (!buf->device_interface) return 0;
+    return buf->device_interface->detach_native(uc, buf);
+}
+
+void halide_device_release(void *uc, const halide_device_interface_t *di) {
+    if (di) di->device_release(uc, di);
+}
+
+int halide_reuse_device_allocations(void *uc, int flag) {
+    g_reuse.store(flag ? 1 : 0);
+    if (!flag) return halide_hip_release_unused_device_allocations(uc);
+    return 0;
+}
+
+// ---- the interface table ---------------------------------------------------------------------------
+static int if_device_malloc(void *uc, halide_buffer_t *buf, const halide_device_interface_t *) {
+    int r = hip_device_malloc(uc, buf);
+    return r ? (r == halide_error_code_gpu_device_error ? r : halide_error_code_device_malloc_failed) : 0;
+}
+static int if_device_free(void *uc, halide_buffer_t *buf) { return hip_device_free(uc, buf); }
+static int if_device_sync(void *uc, halide_buffer_t *buf) {
+    return hip_device_sync(uc, buf) ? halide_error_code_device_sync_failed : 0;
+}
+static void if_device_release(void *uc, const halide_device_interface_t *) { (void)hip_device_release(uc); }
+static int if_copy_to_host(void *uc, halide_buffer_t *buf) {
+    // device_interface.cpp:43-80
+    if (!(buf->flags & halide_buffer_flag_device_dirty)) return 0;
+    if (buf->host == nullptr) return report(uc, halide_error_code_host_is_null, "copy_to_host: host pointer is null");
+    if (buf->device == 0) return report(uc, halide_error_code_no_device_interface, "copy_to_host: device dirty without a device allocation");
+    if (hip_copy_to_host(uc, buf)) return halide_error_code_copy_to_host_failed;
+    buf->flags &= ~(uint64_t)halide_buffer_flag_device_dirty;
+    return 0;
+}
+static int if_copy_to_device(void *uc, halide_buffer_t *buf, const halide_device_interface_t *di) {
+    // device_interface.cpp:155-205
+    if (buf->device == 0) {
+        int r = if_device_malloc(uc, buf, di);
+        if (r) return r;
+    }
+    if (buf->flags & halide_buffer_flag_host_dirty) {
+        if (buf->flags & halide_buffer_flag_device_dirty) return halide_error_code_copy_to_device_failed;
+        if (buf->host == nullptr) return report(uc, halide_error_code_host_is_null, "copy_to_device: host pointer is null");
+        if (hip_copy_to_device(uc, buf)) return halide_error_code_copy_to_device_failed;
+        buf->flags &= ~(uint64_t)halide_buffer_flag_host_dirty;
+    }
+    return 0;
+}
+static int if_device_and_host_malloc(void *uc, halide_buffer_t *buf, const halide_device_interface_t *di) {
+    // default implementation of the reference (device_interface.cpp:390-420): separate host + device allocations
+    size_t bytes = (size_t)(end_offset(buf) - begin_offset(buf)) * elem_bytes(buf);
+    buf->host = (uint8_t *)halide_malloc(uc, bytes ? bytes : 1);
+    if (!buf->host) return halide_error_code_out_of_memory;
+    int r = if_device_malloc(uc, buf, di);
+    if (r) {
+        halide_free(uc, buf->host);
+        buf->host = nullptr;
+    }
+    return r;
+}
+static int if_device_and_host_free(void *uc, halide_buffer_t *buf) {
+    int r = hip_device_free(uc, buf);
+    if (buf->host) {
+        halide_free(uc, buf->host);
+        buf->host = nullptr;
+    }
+    buf->flags &= ~(uint64_t)(halide_buffer_flag_host_dirty | halide_buffer_flag_device_dirty);
+    return r;
+}
+static int if_buffer_copy(void *uc, halide_buffer_t *src, const halide_device_interface_t *dst_di, halide_buffer_t *dst) {
+    // Supported: same-shape copies host<->device / device<->device / host<->host over the overlap of
+    // src and dst (device_buffer_utils.h semantics for the cases the drivers use).
+    if (src->dimensions != dst->dimensions || buf_type_abi(src) != buf_type_abi(dst)) {
+        return report(uc, halide_error_code_device_buffer_copy_failed, "buffer_copy: type/dimension mismatch");
+    }
+    bool from_host = !(src->device && (src->flags & halide_buffer_flag_device_dirty)) && src->host;
+    bool to_host = dst_di == nullptr;
+    if (!to_host && dst->device == 0) {
+        int r = if_device_malloc(uc, dst, dst_di);
+        if (r) return r;
+    }
+    if (!from_host && src->device == 0) return report(uc, halide_error_code_device_buffer_copy_failed, "buffer_copy: source has no data");
+    if (to_host && dst->host == nullptr) return report(uc, halide_error_code_host_is_null, "buffer_copy: destination host is null");
+    DeviceCtx ctx;
+    int r = acquire_device(uc, &ctx);
+    if (r) return r;
+    // element-run copies over the overlapping box
+    int nd = src->dimensions;
+    int lo[16], ext[16];
+    for (int i = 0; i < nd; i++) {
+        int a = src->dim[i].min > dst->dim[i].min ? src->dim[i].min : dst->dim[i].min;
+        int s1 = src->dim[i].min + src->dim[i].extent, d1 = dst->dim[i].min + dst->dim[i].extent;
+        int bmax = s1 < d1 ? s1 : d1;
+        lo[i] = a;
+        ext[i] = bmax - a;
+        if (ext[i] <= 0) return 0;
+    }
+    const size_t es = elem_bytes(src);
+    uint8_t *sbase = from_host ? src->host : (uint8_t *)(uintptr_t)src->device;
+    uint8_t *dbase = to_host ? dst->host : (uint8_t *)(uintptr_t)dst->device;
+    hipMemcpyKind kind = from_host ? (to_host ? hipMemcpyHostToHost : hipMemcpyHostToDevice)
+                                   : (to_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
+    int idx[16] = {0};
+    bool rows_contig = nd >= 1 && src->dim[0].stride == 1 && dst->dim[0].stride == 1;
+    for (;;) {
+        ptrdiff_t so = 0, doff = 0;
+        for (int i = 0; i < nd; i++) {
+            so += (ptrdiff_t)(lo[i] + idx[i] - src->dim[i].min) * src->dim[i].stride;
+            doff += (ptrdiff_t)(lo[i] + idx[i] - dst->dim[i].min) * dst->dim[i].stride;
+        }
+        size_t n = rows_contig ? (size_t)ext[0] : 1;
+        HLMI_HIP(uc, hipMemcpyAsync(dbase + doff * (ptrdiff_t)es, sbase + so * (ptrdiff_t)es, n * es, kind, ctx.stream));
+        int j = rows_contig ? 1 : 0;
+        for (; j < nd; j++) {
+            if (++idx[j] < ext[j]) break;
+            idx[j] = 0;
+        }
+        if (j >= nd) break;
+    }
+    HLMI_HIP(uc, hipStreamSynchronize(ctx.stream));
+    if (to_host) {
+        dst->flags |= halide_buffer_flag_host_dirty;
+    } else {
+        dst->flags |= halide_buffer_flag_device_dirty;
+        dst->flags &= ~(uint64_t)halide_buffer_flag_host_dirty;
+    }
+    return 0;
+}
+static int if_device_crop(void *uc, const halide_buffer_t *src, halide_buffer_t *dst) { return hip_device_crop(uc, src, dst); }
+static int if_device_slice(void *uc, const halide_buffer_t *src, int d, int pos, halide_buffer_t *dst) {
+    return hip_device_slice(uc, src, d, pos, dst);
+}
+static int if_device_release_crop(void *uc, halide_buffer_t *buf) { return hip_device_release_crop(uc, buf); }
+static int if_wrap_native(void *uc, halide_buffer_t *buf, uint64_t handle, const halide_device_interface_t *) {
+    return hip_wrap_native(uc, buf, handle);
+}
+static int if_detach_native(void *uc, halide_buffer_t *buf) { return hip_detach_native(uc, buf); }
+static int if_compute_capability(void *uc, int *major, int *minor) {
+    (void)uc;
+    *major = 9;  // gfx950
+    *minor = 5;
+    return 0;
+}
+
+static const halide_device_interface_t g_hip_interface = {
+    if_device_malloc, if_device_free, if_device_sync, if_device_release, if_copy_to_host, if_copy_to_device,
+    if_device_and_host_malloc, if_device_and_host_free, if_buffer_copy, if_device_crop, if_device_slice,
+    if_device_release_crop, if_wrap_native, if_detach_native, if_compute_capability, nullptr};
+
+const halide_device_interface_t *halide_hip_device_interface(void) { return &g_hip_interface; }
+
+int halide_hip_wrap_device_ptr(void *uc, halide_buffer_t *buf, uint64_t device_ptr) {
+    return halide_device_wrap_native(uc, buf, device_ptr, &g_hip_interface);
+}
+int halide_hip_detach_device_ptr(void *uc, halide_buffer_t *buf) {
+    if (buf->device_interface && buf->device_interface != &g_hip_interface) {
+        return report(uc, halide_error_code_incompatible_device_interface, "halide_hip_detach_device_ptr: not a HIP buffer");
+    }
+    return halide_device_detach_native(uc, buf);
+}
+uintptr_t halide_hip_get_device_ptr(void *uc, halide_buffer_t *buf) {
+    (void)uc;
+    if (buf->device == 0 || buf->device_interface != &g_hip_interface) return 0;
+    return (uintptr_t)buf->device;
+}
+int halide_hip_release_unused_device_allocations(void *uc) {
+    (void)uc;
+    std::lock_guard<std::mutex> lock(g_mu);
+    int n = device_count_locked();
+    for (int d = 0; d < n; d++) {
+        DeviceState &st = g_dev[d];
+        if (st.cache.empty()) continue;
+        (void)hipSetDevice(d);
+        (void)hipDeviceSynchronize();
+        for (auto &kv : st.cache) (void)hipFree(kv.second);
+        st.cache.clear();
+    }
+    return 0;
+}
+
+void halide_set_gpu_device(int n) { t_gpu_device = n; }
+int halide_get_gpu_device(void *) { return pick_device(); }
+void halide_hip_set_stream(void *stream) { t_stream_override = (hipStream_t)stream; }
+void *halide_hip_get_stream(void *uc) {
+    DeviceCtx ctx;
+    if (acquire_device(uc, &ctx)) return nullptr;
+    return (void *)ctx.stream;
+}
+
+void hlmi_kernel_timing_enable(int on) { g_timing.store(on ? 1 : 0); }
+void hlmi_kernel_timing_reset(void) {
+    std::lock_guard<std::mutex> lock(g_timing_mu);
+    for (auto &t : g_launches) {
+        (void)hipEventDestroy(t.e0);
+        (void)hipEventDestroy(t.e1);
+    }
+    g_launches.clear();
+}
+size_t hlmi_kernel_timing_report(char *out, size_t cap) {
+    std::lock_guard<std::mutex> lock(g_timing_mu);
+    struct Agg {
+        int calls = 0;
+        double ms = 0;
+    };
+    std::vector<std::string> order;
+    std::unordered_map<std::string, Agg> agg;
+    for (auto &t : g_launches) {
+        (void)hipEventSynchronize(t.e1);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, t.e0, t.e1) != hipSuccess) continue;
+        if (!agg.count(t.name)) order.push_back(t.name);
+        Agg &a = agg[t.name];
+        a.calls++;
+        a.ms += ms;
+    }
+    std::string s = "[";
+    for (size_t i = 0; i < order.size(); i++) {
+        const Agg &a = agg[order[i]];
+        char line[256];
+        snprintf(line, sizeof line, "%s{\"name\":\"%s\",\"calls\":%d,\"total_ms\":%.6f,\"avg_ms\":%.6f}", i ? "," : "",
+                 order[i].c_str(), a.calls, a.ms, a.ms / (a.calls ? a.calls : 1));
+        s += line;
+    }
+    s += "]";
+    if (out && cap) {
+        size_t n = s.size() < cap - 1 ? s.size() : cap - 1;
+        memcpy(out, s.data(), n);
+        out[n] = 0;
+    }
+    return s.size() + 1;
+}
+
+const char *hlmi_version(void) { return "hlmi 0.1 gfx950"; }
+
+}  // extern "C"

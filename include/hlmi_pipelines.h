@@ -1,0 +1,99 @@
+/* hlmi_pipelines.h — the AOT entry points libhlmi.so exports.
+ *
+ * Each pipeline keeps the exact C signature the reference's code generator emits for it
+ * (src/CodeGen_C.cpp:1085-1112: buffers as `struct halide_buffer_t *`, scalars by value, inputs in
+ * declaration order then outputs — src/AbstractGenerator.cpp:41-52), plus the argv-call variant
+ * (src/CodeGen_C.cpp:675-705) and the metadata getter (src/CodeGen_C.cpp:707-720), so that the
+ * object is a drop-in for `<name>.a` + `<name>.h` of the reference.  Return value: 0 or a negative
+ * halide_error_code_t; on error `halide_error()` is called first (default handler aborts).
+ *
+ * Entry protocol, identical for all pipelines (reference: src/UnpackBuffers.cpp:148,
+ * src/AddImageChecks.cpp:315-347, 414-471, 591-671, 709-713):
+ *   1. a NULL buffer argument            -> -12 (buffer_argument_is_null)
+ *   2. any buffer with host==NULL && device==0 -> BOUNDS QUERY: dim[] of every such buffer is
+ *      rewritten to the region the pipeline needs/produces, nothing is computed, return 0
+ *   3. element type mismatch             -> -3   4. wrong dimensionality -> -43
+ *   5. negative extents -> -28; dim[0].stride != 1 (or other pinned constraint) -> -8;
+ *      region required > region supplied -> -4; > 2^31-1 elements -> -6 / -5
+ *   6. host==NULL with device set but no usable device interface -> -34 / -42
+ * Device protocol (what the reference emits for a GPU target,
+ * src/InjectHostDevBufferCopies.cpp:197-217, 285-304): inputs are brought to the device with
+ * halide_copy_to_device (allocation is attached to the caller's buffer and stays there), the
+ * output gets a device allocation, kernels are ENQUEUED on the HIP stream, the output is marked
+ * device_dirty and the call returns; the caller uses halide_device_sync / halide_copy_to_host
+ * (Halide::Runtime::Buffer::device_sync()/copy_to_host()) exactly as with the reference's GPU
+ * targets.  There is no CPU fallback: without a usable gfx950 device the call fails with -29.
+ */
+#ifndef HLMI_PIPELINES_H
+#define HLMI_PIPELINES_H
+
+#include "hlmi_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HLMI_DECLARE_AUX(name)                                   \
+    int name##_argv(void **args);                                \
+    const struct halide_filter_metadata_t *name##_metadata(void);
+
+/* apps/local_laplacian/local_laplacian_generator.cpp:12-16,287 — u16 [W,H,3] planar in/out,
+ * pyramid_levels J=8 (compile-time GeneratorParam :10), `levels` K in [2,16] at run time.
+ * Drivers pass alpha/(levels-1) (apps/local_laplacian/process.cpp:31). */
+int local_laplacian(struct halide_buffer_t *input, int32_t levels, float alpha, float beta,
+                    struct halide_buffer_t *output);
+HLMI_DECLARE_AUX(local_laplacian)
+
+/* apps/bilateral_grid/bilateral_grid_generator.cpp:10-12,203 — f32 [W,H]; s_sigma=8 compile-time (:8). */
+int bilateral_grid(struct halide_buffer_t *input, float r_sigma, struct halide_buffer_t *bilateral_grid);
+HLMI_DECLARE_AUX(bilateral_grid)
+
+/* apps/blur/halide_blur_generator.cpp:31-32,117 — u16 [W+2,H+2] -> u16 [W,H]; no boundary condition. */
+int halide_blur(struct halide_buffer_t *input, struct halide_buffer_t *blur_y);
+HLMI_DECLARE_AUX(halide_blur)
+
+/* apps/nl_means/nl_means_generator.cpp:9-14,162 — f32 [W,H,3] in/out. */
+int nl_means(struct halide_buffer_t *input, int32_t patch_size, int32_t search_area, float sigma,
+             struct halide_buffer_t *non_local_means);
+HLMI_DECLARE_AUX(nl_means)
+
+/* apps/stencil_chain/stencil_chain_generator.cpp:9-10,150 — u16 [W,H], stencils=32 compile-time (:7). */
+int stencil_chain(struct halide_buffer_t *input, struct halide_buffer_t *output);
+HLMI_DECLARE_AUX(stencil_chain)
+
+/* apps/conv_layer/conv_layer_generator.cpp:9-12,207 — f32 input [CI,W+2,H+2,N], filter [CO,3,3,CI],
+ * bias [CO], relu [CO,W,H,N] (c fastest).  The reference pins N=5, CI=CO=128, W=100, H=80 (:15,35-50);
+ * this entry point accepts any N,W,H with CI, CO multiples of 32 (superset). */
+int conv_layer(struct halide_buffer_t *input, struct halide_buffer_t *filter, struct halide_buffer_t *bias,
+               struct halide_buffer_t *relu);
+HLMI_DECLARE_AUX(conv_layer)
+
+/* apps/camera_pipe/camera_pipe_generator.cpp:219-228,622 — raw u16 Bayer -> u8 [W,H,3]. */
+int camera_pipe(struct halide_buffer_t *input, struct halide_buffer_t *matrix_3200,
+                struct halide_buffer_t *matrix_7000, float color_temp, float gamma, float contrast,
+                float sharpen_strength, int32_t blackLevel, int32_t whiteLevel,
+                struct halide_buffer_t *processed);
+HLMI_DECLARE_AUX(camera_pipe)
+
+/* `<name>_auto_schedule` variants: the reference's drivers link both objects
+ * (apps/local_laplacian/process.cpp:5-7,42-49); same algorithm, so they alias the entry above. */
+int local_laplacian_auto_schedule(struct halide_buffer_t *input, int32_t levels, float alpha, float beta,
+                                  struct halide_buffer_t *output);
+int bilateral_grid_auto_schedule(struct halide_buffer_t *input, float r_sigma, struct halide_buffer_t *out);
+int halide_blur_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *blur_y);
+int nl_means_auto_schedule(struct halide_buffer_t *input, int32_t patch_size, int32_t search_area, float sigma,
+                           struct halide_buffer_t *non_local_means);
+int stencil_chain_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);
+int conv_layer_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *filter,
+                             struct halide_buffer_t *bias, struct halide_buffer_t *relu);
+int camera_pipe_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *matrix_3200,
+                              struct halide_buffer_t *matrix_7000, float color_temp, float gamma, float contrast,
+                              float sharpen_strength, int32_t blackLevel, int32_t whiteLevel,
+                              struct halide_buffer_t *processed);
+
+#undef HLMI_DECLARE_AUX
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HLMI_PIPELINES_H */

@@ -1,0 +1,98 @@
+/* hlmi_runtime.h — the slice of the runtime C API that callers of the AOT entry points use.
+ *
+ * Every symbol here keeps the NAME, argument meaning and error behaviour of the reference symbol
+ * it replaces (paths relative to /root/reference); the HIP-specific ones mirror the reference's
+ * per-API runtime header (src/runtime/HalideRuntimeCuda.h) with "hip" in place of the API name.
+ * All functions are exported from libhlmi.so with C linkage.
+ */
+#ifndef HLMI_RUNTIME_H
+#define HLMI_RUNTIME_H
+
+#include "hlmi_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error / print hooks -------------------------------------------------------------------
+ * halide_error / halide_set_error_handler: src/runtime/HalideRuntime.h:192-195;
+ * default handler prints "Error: <msg>" and abort()s (src/runtime/posix_error_handler.cpp:9-21);
+ * halide_set_error_handler returns the previous handler (posix_error_handler.cpp:40). */
+typedef void (*halide_error_handler_t)(void *user_context, const char *msg);
+void halide_error(void *user_context, const char *msg);
+halide_error_handler_t halide_set_error_handler(halide_error_handler_t handler);
+
+/* halide_print / halide_set_custom_print: src/runtime/HalideRuntime.h:178-181 */
+typedef void (*halide_print_t)(void *user_context, const char *msg);
+void halide_print(void *user_context, const char *msg);
+halide_print_t halide_set_custom_print(halide_print_t print);
+
+/* halide_malloc / halide_free (+ custom hooks): src/runtime/HalideRuntime.h:444-451;
+ * default returns memory aligned to 128 bytes (src/runtime/posix_allocator.cpp). */
+typedef void *(*halide_malloc_t)(void *user_context, size_t x);
+typedef void (*halide_free_t)(void *user_context, void *ptr);
+void *halide_malloc(void *user_context, size_t x);
+void halide_free(void *user_context, void *ptr);
+halide_malloc_t halide_set_custom_malloc(halide_malloc_t user_malloc);
+halide_free_t halide_set_custom_free(halide_free_t user_free);
+
+/* ---- device bookkeeping (dirty-flag protocol) ------------------------------------------------
+ * Declared at src/runtime/HalideRuntime.h:908-1011; semantics follow src/runtime/device_interface.cpp:141-330:
+ *   halide_copy_to_device : device_malloc if buf->device==0, then H2D iff host_dirty (clears it);
+ *   halide_copy_to_host   : D2H iff device_dirty (clears it); host must be non-null;
+ *   halide_device_sync    : wait until work queued for this buffer's device has finished;
+ *   halide_device_malloc / halide_device_free : attach / release the device allocation;
+ *   halide_device_release : free cached allocations + per-device state of an interface. */
+int halide_device_malloc(void *user_context, struct halide_buffer_t *buf,
+                         const struct halide_device_interface_t *device_interface);
+int halide_device_free(void *user_context, struct halide_buffer_t *buf);
+int halide_device_sync(void *user_context, struct halide_buffer_t *buf);
+int halide_device_sync_global(void *user_context, const struct halide_device_interface_t *device_interface);
+int halide_copy_to_host(void *user_context, struct halide_buffer_t *buf);
+int halide_copy_to_device(void *user_context, struct halide_buffer_t *buf,
+                          const struct halide_device_interface_t *device_interface);
+int halide_device_and_host_malloc(void *user_context, struct halide_buffer_t *buf,
+                                  const struct halide_device_interface_t *device_interface);
+int halide_device_and_host_free(void *user_context, struct halide_buffer_t *buf);
+int halide_buffer_copy(void *user_context, struct halide_buffer_t *src,
+                       const struct halide_device_interface_t *dst_device_interface, struct halide_buffer_t *dst);
+int halide_device_wrap_native(void *user_context, struct halide_buffer_t *buf, uint64_t handle,
+                              const struct halide_device_interface_t *device_interface);
+int halide_device_detach_native(void *user_context, struct halide_buffer_t *buf);
+void halide_device_release(void *user_context, const struct halide_device_interface_t *device_interface);
+/* src/runtime/HalideRuntime.h:2343 (bool there; int here is ABI-identical on x86-64);
+ * tools/RunGenMain.cpp:608 calls it with (nullptr, true). */
+int halide_reuse_device_allocations(void *user_context, int flag);
+
+/* ---- the HIP device interface (mirrors HalideRuntimeCuda.h:21-82) ----------------------------- */
+const struct halide_device_interface_t *halide_hip_device_interface(void);
+/* Wrap an existing device pointer (e.g. a torch tensor's data_ptr()) without taking ownership. */
+int halide_hip_wrap_device_ptr(void *user_context, struct halide_buffer_t *buf, uint64_t device_ptr);
+int halide_hip_detach_device_ptr(void *user_context, struct halide_buffer_t *buf);
+uintptr_t halide_hip_get_device_ptr(void *user_context, struct halide_buffer_t *buf);
+int halide_hip_release_unused_device_allocations(void *user_context);
+/* Device selection: src/runtime/HalideRuntime.h:1019-1026 (halide_set_gpu_device / HL_GPU_DEVICE);
+ * -1 = "use HL_GPU_DEVICE or device 0".  The setting is per calling thread, so that one host
+ * thread per GPU can drive its own device (the multi-GPU frame sharder does exactly that). */
+void halide_set_gpu_device(int n);
+int halide_get_gpu_device(void *user_context);
+/* Stream override (mirrors halide_set_cuda_get_stream, HalideRuntimeCuda.h:76-82, simplified to a
+ * per-thread value): all work of subsequent calls on this thread is enqueued on `stream`
+ * (a hipStream_t); NULL restores the library's own per-device stream. */
+void halide_hip_set_stream(void *stream);
+void *halide_hip_get_stream(void *user_context);
+
+/* ---- measurement hooks (no reference counterpart; used by bench.py) ---------------------------
+ * When enabled, every kernel launch is bracketed by hipEvents on its stream; the report is a
+ * JSON array [{"name":..,"calls":..,"total_ms":..,"avg_ms":..}] written into `out` (returns the
+ * number of bytes needed).  Off by default; never enabled inside a timed throughput region. */
+void hlmi_kernel_timing_enable(int on);
+void hlmi_kernel_timing_reset(void);
+size_t hlmi_kernel_timing_report(char *out, size_t cap);
+/* Library identification: returns e.g. "hlmi 0.1 gfx950". */
+const char *hlmi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HLMI_RUNTIME_H */

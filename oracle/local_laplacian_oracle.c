@@ -1,0 +1,219 @@
+/* local_laplacian_oracle.c — TEST INFRASTRUCTURE ONLY (see oracle_common.h).
+ *
+ * CPU restatement of apps/local_laplacian/local_laplacian_generator.cpp:18-87 ("THE ALGORITHM") with
+ * downsample :267-273 and upsample :276-282 of /root/reference.  PARITY UNPINNED for the float stages:
+ * the reference ships no golden image for this pipeline (its only test is that the driver prints
+ * "Success!", apps/local_laplacian/CMakeLists.txt:50-60) and the Halide compiler cannot be built in
+ * this environment (no LLVM), so this file *defines* the canonical evaluation order (oracle_common.h).
+ *
+ * Every Func is a total function on Z^2; only the input is edge-clamped (:28).  Level j is therefore
+ * evaluated on the region the levels above/below demand of it (bounds inference), NOT on ceil(W/2^j):
+ *   R_0 = [0, W-1];  R_{j+1} = [fdiv(minR_j - 1, 2), fdiv(maxR_j + 1, 2)]         (source of `upsample`)
+ *   G_{J-1} = R_{J-1};  G_j = R_j U [2*minG_{j+1} - 1, 2*maxG_{j+1} + 2]          (source of `downsample`)
+ */
+#include "oracle_common.h"
+
+#define LL_MAXJ 20
+
+typedef struct {
+    int x0, x1, y0, y1; /* inclusive */
+    int w, h;
+    float *p;
+} plane_t;
+
+static void plane_alloc(plane_t *pl, int x0, int x1, int y0, int y1) {
+    pl->x0 = x0, pl->x1 = x1, pl->y0 = y0, pl->y1 = y1;
+    pl->w = x1 - x0 + 1, pl->h = y1 - y0 + 1;
+    pl->p = (float *)malloc(sizeof(float) * (size_t)pl->w * (size_t)pl->h);
+}
+static inline float P(const plane_t *pl, int x, int y) {
+    /* callers only touch coordinates inside the region by construction; assert via abort in debug */
+    return pl->p[(size_t)(y - pl->y0) * (size_t)pl->w + (size_t)(x - pl->x0)];
+}
+static inline float *PP(plane_t *pl, int x, int y) {
+    return &pl->p[(size_t)(y - pl->y0) * (size_t)pl->w + (size_t)(x - pl->x0)];
+}
+
+/* downsample (:267-273): downy first, then downx; "/ 8.0f" -> "* 0.125f" (exact either way). */
+static void downsample(const plane_t *f, plane_t *out) {
+    /* downy needed on x in [2*out.x0-1, 2*out.x1+2], y in [out.y0, out.y1] */
+    plane_t dy;
+    plane_alloc(&dy, 2 * out->x0 - 1, 2 * out->x1 + 2, out->y0, out->y1);
+#pragma omp parallel for schedule(static)
+    for (int y = dy.y0; y <= dy.y1; y++) {
+        for (int x = dy.x0; x <= dy.x1; x++) {
+            float a = P(f, x, 2 * y - 1), b = P(f, x, 2 * y), c = P(f, x, 2 * y + 1), d = P(f, x, 2 * y + 2);
+            *PP(&dy, x, y) = ((a + 3.0f * (b + c)) + d) * 0.125f;
+        }
+    }
+#pragma omp parallel for schedule(static)
+    for (int y = out->y0; y <= out->y1; y++) {
+        for (int x = out->x0; x <= out->x1; x++) {
+            float a = P(&dy, 2 * x - 1, y), b = P(&dy, 2 * x, y), c = P(&dy, 2 * x + 1, y), d = P(&dy, 2 * x + 2, y);
+            *PP(out, x, y) = ((a + 3.0f * (b + c)) + d) * 0.125f;
+        }
+    }
+    free(dy.p);
+}
+
+/* upsample (:276-282) evaluated at one point */
+static inline float upx_at(const plane_t *f, int x, int y) {
+    float w = (float)(o_fmod(x, 2) * 2 + 1) * 0.25f;
+    return o_lerp(P(f, o_fdiv(x + 1, 2), y), P(f, o_fdiv(x - 1, 2), y), w);
+}
+static inline float up_at(const plane_t *f, int x, int y) {
+    float w = (float)(o_fmod(y, 2) * 2 + 1) * 0.25f;
+    return o_lerp(upx_at(f, x, o_fdiv(y + 1, 2)), upx_at(f, x, o_fdiv(y - 1, 2)), w);
+}
+
+/* remap LUT (:23-25): remap(i) = alpha * fx * exp(-fx * fx / 2.0f), fx = float(i) / 256.0f */
+static float remap_at(int i, float alpha) {
+    float fx = (float)i * (1.0f / 256.0f);
+    return (alpha * fx) * o_halide_exp(((-fx) * fx) * 0.5f);
+}
+
+/* Exported helper: the LUT itself, for unit tests of the GPU LUT kernel. n = 2*(levels-1)*256+1. */
+void oracle_ll_remap_lut(int levels, float alpha, float *lut) {
+    int half = (levels - 1) * 256;
+    for (int i = -half; i <= half; i++) lut[i + half] = remap_at(i, alpha);
+}
+
+float oracle_halide_exp(float x) { return o_halide_exp(x); }
+float oracle_halide_log(float x) { return o_halide_log(x); }
+float oracle_halide_pow(float x, float y) { return o_halide_pow(x, y); }
+float oracle_fast_exp(float x) { return o_fast_exp(x); }
+
+/* Full pipeline.  in/out: planar u16 [3][H][W] with row stride `in_sy`/`out_sy` and plane stride
+ * `in_sc`/`out_sc` (elements).  J = pyramid_levels (8 in the reference build, :10), levels = K.
+ * If dbg_level >= 0, additionally copies outGPyramid[dbg_level] restricted to R_j into dbg (row-major,
+ * width = R_j extent) — used by the tests to localise a GPU mismatch; pass -1/NULL otherwise.
+ * Returns 0, or -1 on bad arguments. */
+int oracle_local_laplacian(const uint16_t *in, int W, int H, int in_sy, int in_sc, int J, int levels, float alpha,
+                           float beta, uint16_t *out, int out_sy, int out_sc, int dbg_level, float *dbg) {
+    if (J < 1 || J > LL_MAXJ || levels < 2 || W < 1 || H < 1) return -1;
+    const int K = levels;
+    int Rx0[LL_MAXJ], Rx1[LL_MAXJ], Ry0[LL_MAXJ], Ry1[LL_MAXJ];
+    int Gx0[LL_MAXJ], Gx1[LL_MAXJ], Gy0[LL_MAXJ], Gy1[LL_MAXJ];
+    Rx0[0] = 0, Rx1[0] = W - 1, Ry0[0] = 0, Ry1[0] = H - 1;
+    for (int j = 0; j + 1 < J; j++) {
+        Rx0[j + 1] = o_fdiv(Rx0[j] - 1, 2), Rx1[j + 1] = o_fdiv(Rx1[j] + 1, 2);
+        Ry0[j + 1] = o_fdiv(Ry0[j] - 1, 2), Ry1[j + 1] = o_fdiv(Ry1[j] + 1, 2);
+    }
+    Gx0[J - 1] = Rx0[J - 1], Gx1[J - 1] = Rx1[J - 1], Gy0[J - 1] = Ry0[J - 1], Gy1[J - 1] = Ry1[J - 1];
+    for (int j = J - 2; j >= 0; j--) {
+        int a = 2 * Gx0[j + 1] - 1, b = 2 * Gx1[j + 1] + 2, c = 2 * Gy0[j + 1] - 1, d = 2 * Gy1[j + 1] + 2;
+        Gx0[j] = a < Rx0[j] ? a : Rx0[j], Gx1[j] = b > Rx1[j] ? b : Rx1[j];
+        Gy0[j] = c < Ry0[j] ? c : Ry0[j], Gy1[j] = d > Ry1[j] ? d : Ry1[j];
+    }
+
+    /* remap LUT */
+    const int half = (K - 1) * 256;
+    float *lut = (float *)malloc(sizeof(float) * (size_t)(2 * half + 1));
+    oracle_ll_remap_lut(K, alpha, lut);
+
+    /* gray on G_0 with clamped input coordinates (:28-36).  floating = u16 / 65535.0f -> * (1/65535.0f) */
+    const float r65535 = 1.0f / 65535.0f;
+    plane_t gray;
+    plane_alloc(&gray, Gx0[0], Gx1[0], Gy0[0], Gy1[0]);
+#pragma omp parallel for schedule(static)
+    for (int y = gray.y0; y <= gray.y1; y++) {
+        int yc = o_clampi(y, 0, H - 1);
+        for (int x = gray.x0; x <= gray.x1; x++) {
+            int xc = o_clampi(x, 0, W - 1);
+            size_t o = (size_t)yc * (size_t)in_sy + (size_t)xc;
+            float f0 = (float)in[o] * r65535, f1 = (float)in[o + (size_t)in_sc] * r65535,
+                  f2 = (float)in[o + 2 * (size_t)in_sc] * r65535;
+            *PP(&gray, x, y) = (0.299f * f0 + 0.587f * f1) + 0.114f * f2;
+        }
+    }
+
+    /* processed Gaussian pyramid (:38-47): g[j][k], j >= 1 materialised; g0 is pointwise */
+    plane_t(*g)[LL_MAXJ] = (plane_t(*)[LL_MAXJ])calloc((size_t)K, sizeof(plane_t[LL_MAXJ]));
+    const float Km1 = (float)(K - 1);
+    const float inv_Km1 = 1.0f / Km1; /* (1.0f / (levels - 1)) :41 */
+#define G0_AT(gr, k) \
+    ((beta * ((gr) - (float)(k) * inv_Km1) + (float)(k) * inv_Km1) + \
+     lut[o_clampi((int)(((gr) * Km1) * 256.0f), 0, half) - 256 * (k) + half])
+    for (int k = 0; k < K; k++) {
+        plane_t g0;
+        plane_alloc(&g0, Gx0[0], Gx1[0], Gy0[0], Gy1[0]);
+#pragma omp parallel for schedule(static)
+        for (int y = g0.y0; y <= g0.y1; y++) {
+            for (int x = g0.x0; x <= g0.x1; x++) {
+                float gr = P(&gray, x, y);
+                *PP(&g0, x, y) = G0_AT(gr, k);
+            }
+        }
+        const plane_t *prev = &g0;
+        for (int j = 1; j < J; j++) {
+            plane_alloc(&g[k][j], Gx0[j], Gx1[j], Gy0[j], Gy1[j]);
+            downsample(prev, &g[k][j]);
+            prev = &g[k][j];
+        }
+        free(g0.p);
+    }
+
+    /* Gaussian pyramid of the input (:57-61) */
+    plane_t inG[LL_MAXJ];
+    inG[0] = gray;
+    for (int j = 1; j < J; j++) {
+        plane_alloc(&inG[j], Gx0[j], Gx1[j], Gy0[j], Gy1[j]);
+        downsample(&inG[j - 1], &inG[j]);
+    }
+
+    /* output pyramids (:50-54, :63-79), coarse to fine, each on R_j */
+    plane_t outG[LL_MAXJ];
+    for (int j = J - 1; j >= 0; j--) {
+        plane_alloc(&outG[j], Rx0[j], Rx1[j], Ry0[j], Ry1[j]);
+#pragma omp parallel for schedule(static)
+        for (int y = Ry0[j]; y <= Ry1[j]; y++) {
+            for (int x = Rx0[j]; x <= Rx1[j]; x++) {
+                float level = P(&inG[j], x, y) * Km1;
+                int li = o_clampi((int)level, 0, K - 2);
+                float lf = level - (float)li;
+                float l0, l1;
+                if (j == 0) {
+                    float gr = P(&gray, x, y);
+                    l0 = G0_AT(gr, li);
+                    l1 = G0_AT(gr, li + 1);
+                } else {
+                    l0 = P(&g[li][j], x, y);
+                    l1 = P(&g[li + 1][j], x, y);
+                }
+                if (j < J - 1) { /* lPyramid[j] = gPyramid[j] - upsample(gPyramid[j+1]) */
+                    l0 = l0 - up_at(&g[li][j + 1], x, y);
+                    l1 = l1 - up_at(&g[li + 1][j + 1], x, y);
+                }
+                float outL = (1.0f - lf) * l0 + lf * l1;
+                *PP(&outG[j], x, y) = (j == J - 1) ? outL : up_at(&outG[j + 1], x, y) + outL;
+            }
+        }
+    }
+    if (dbg && dbg_level >= 0 && dbg_level < J) {
+        memcpy(dbg, outG[dbg_level].p, sizeof(float) * (size_t)outG[dbg_level].w * (size_t)outG[dbg_level].h);
+    }
+
+    /* colour + u16 (:82-87); `input` here is the UNclamped input, read inside the image only */
+    const float eps = 0.01f;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; y++) {
+        for (int x = 0; x < W; x++) {
+            float og = P(&outG[0], x, y) + eps, gr = P(&gray, x, y) + eps;
+            for (int c = 0; c < 3; c++) {
+                float v = ((float)in[(size_t)y * (size_t)in_sy + (size_t)x + (size_t)c * (size_t)in_sc] * og) / gr;
+                out[(size_t)y * (size_t)out_sy + (size_t)x + (size_t)c * (size_t)out_sc] =
+                    (uint16_t)o_clampf(v, 0.0f, 65535.0f);
+            }
+        }
+    }
+
+    for (int j = 0; j < J; j++) free(outG[j].p);
+    for (int j = 1; j < J; j++) free(inG[j].p);
+    for (int k = 0; k < K; k++) {
+        for (int j = 1; j < J; j++) free(g[k][j].p);
+    }
+    free(g);
+    free(gray.p);
+    free(lut);
+    return 0;
+}

@@ -1,0 +1,139 @@
+/* oracle_common.h — TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement of the arithmetic primitives every pipeline oracle uses.  Nothing under oracle/ is
+ * linked into, imported by, or executed from the product (halide_amd/, libhlmi.so); only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may call it, and only as the checker /
+ * the timed CPU baseline.
+ *
+ * All paths below are relative to /root/reference.  Build with -ffp-contract=off: the canonical
+ * evaluation order is "expression order as written in the generator, IEEE binary32, round to nearest
+ * even, no FMA contraction", with the simplifier's deterministic float rewrite
+ * x / c -> x * (1/c) (src/Simplify_Div.cpp:204) applied.
+ */
+#ifndef ORACLE_COMMON_H
+#define ORACLE_COMMON_H
+
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* Halide integer division / modulo round toward -inf for positive divisors (src/IR.h:145-166). */
+static inline int o_fdiv(int a, int b) {
+    int q = a / b, r = a % b;
+    return (r < 0) ? q - 1 : q;
+}
+static inline int o_fmod(int a, int b) {
+    int r = a % b;
+    return (r < 0) ? r + b : r;
+}
+static inline int o_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+/* clamp(a, lo, hi) = max(min(a, hi), lo)  (src/IROperator.cpp clamp) */
+static inline float o_clampf(float v, float lo, float hi) {
+    float m = v < hi ? v : hi;
+    return m > lo ? m : lo;
+}
+static inline float o_bits2f(uint32_t u) {
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline uint32_t o_f2bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+
+/* lerp(zero, one, w) for floats = zero*(1-w) + one*w  (src/Lerp.cpp:82-83,127-128) */
+static inline float o_lerp(float zero, float one, float w) { return zero * (1.0f - w) + one * w; }
+
+/* evaluate_polynomial (src/IROperator.cpp:33-65): even/odd Horner split on x^2, high order first.
+ * A zero coefficient multiplies by x2 without the add. */
+static inline float o_poly(float x, const float *c, int n) {
+    float x2 = x * x;
+    float even = c[0], odd = c[1];
+    for (int i = 2; i < n; i++) {
+        if ((i & 1) == 0) {
+            even = (c[i] == 0.0f) ? even * x2 : even * x2 + c[i];
+        } else {
+            odd = (c[i] == 0.0f) ? odd * x2 : odd * x2 + c[i];
+        }
+    }
+    return ((n & 1) == 0) ? even * x + odd : odd * x + even;
+}
+
+/* halide_exp (src/IROperator.cpp:921-966).  one_over_ln2 = 1.0f / logf(2.0f) evaluated in float when
+ * the compiler was built (:927) = 0x3fb8aa3b; ln2_part1/2 as written (:924-925). */
+static inline float o_halide_exp(float x_full) {
+    const float ln2_part1 = 0.6931457519f, ln2_part2 = 1.4286067653e-6f;
+    const float one_over_ln2 = 1.0f / 0.693147182464599609375f; /* logf(2.0f) */
+    static const float coeff[8] = {0.00031965933071842413f, 0.00119156835564003744f, 0.00848988645943932717f,
+                                   0.04160188091348320655f, 0.16667983794100929562f, 0.49999899033463041098f,
+                                   1.0f, 1.0f};
+    float scaled = x_full * one_over_ln2;
+    float k_real = floorf(scaled);
+    int k = (int)k_real;
+    float x = x_full - k_real * ln2_part1;
+    x = x - k_real * ln2_part2;
+    float result = o_poly(x, coeff, 8);
+    int biased = k + 127;
+    float two_to_the_n = o_bits2f((uint32_t)biased << 23);
+    result = result * two_to_the_n;
+    if (!(biased < 255)) result = INFINITY;
+    if (!(biased > 0)) result = 0.0f;
+    return result;
+}
+
+/* range_reduce_log + halide_log (src/IROperator.cpp:847-919) */
+static inline float o_halide_log(float x_full) {
+    static const float coeff[10] = {0.05111976432738144643f, -0.11793923497136414580f, 0.14971993724699017569f,
+                                    -0.16862004708254804686f, 0.19980668101718729313f, -0.24991211576292837737f,
+                                    0.33333435275479328386f, -0.50000106292873236491f, 1.0f, 0.0f};
+    int use_nan = x_full < 0.0f, use_neg_inf = x_full == 0.0f;
+    float patched = (use_nan || use_neg_inf) ? 1.0f : x_full;
+    int32_t iv = (int32_t)o_f2bits(patched);
+    int32_t no_exponent = iv & (int32_t)0x807fffff;
+    int32_t new_exponent = no_exponent >> 22;
+    int32_t new_biased = 127 - new_exponent;
+    int32_t old_biased = iv >> 23;
+    int32_t exponent = old_biased - new_biased;
+    float reduced = o_bits2f((uint32_t)(no_exponent | (new_biased << 23)));
+    float x1 = reduced - 1.0f;
+    float result = o_poly(x1, coeff, 10);
+    result = result + (float)exponent * 0.693147182464599609375f; /* logf(2.0) */
+    if (use_nan) return NAN;
+    if (use_neg_inf) return -INFINITY;
+    return result;
+}
+
+/* pow(x, y) for non-constant y on LLVM CPU targets (src/CodeGen_LLVM.cpp:3925-3941):
+ * exp(log(x) * y) with the select chain for x <= 0. */
+static inline float o_halide_pow(float x, float y) {
+    float e = o_halide_exp(o_halide_log(x) * y);
+    if (x > 0.0f) return e;
+    if (y == 0.0f) return 1.0f;
+    if (x == 0.0f) return 0.0f;
+    /* negative base: integer y -> sign by parity, else NaN */
+    float yi = floorf(y);
+    if (yi != y) return NAN;
+    float mag = o_halide_exp(o_halide_log(-x) * y);
+    int odd = (((int64_t)yi) & 1) != 0;
+    return odd ? -mag : mag;
+}
+
+/* fast_exp (src/IROperator.cpp:1616-1643) */
+static inline float o_fast_exp(float x_full) {
+    const float ln2 = 0.693147182464599609375f; /* logf(2.0) */
+    static const float coeff[6] = {0.01314350012789660196f, 0.03668965196652099192f, 0.16873890085469545053f,
+                                   0.49970514590562437052f, 1.0f, 1.0f};
+    float scaled = x_full * (1.0f / ln2); /* x / logf(2) -> x * fold(1/c) */
+    float k_real = floorf(scaled);
+    float x = x_full - k_real * ln2;
+    float result = o_poly(x, coeff, 6);
+    int k = (int)k_real;
+    int biased = o_clampi(k + 127, 0, 255);
+    float two_to_the_n = o_bits2f((uint32_t)biased << 23);
+    return result * two_to_the_n;
+}
+
+#endif /* ORACLE_COMMON_H */

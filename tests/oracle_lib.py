@@ -1,0 +1,74 @@
+"""ctypes bindings to the CPU oracle (oracle/lib/liboracle.so) — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the product
+(halide_amd/, libhlmi.so) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "lib", "liboracle.so")
+
+
+def build_oracle() -> None:
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+
+
+def load():
+    if not os.path.exists(ORACLE_SO):
+        build_oracle()
+    return C.CDLL(ORACLE_SO)
+
+
+_lib = load()
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+for _name in ("oracle_halide_exp", "oracle_halide_log", "oracle_fast_exp"):
+    getattr(_lib, _name).argtypes = [C.c_float]
+    getattr(_lib, _name).restype = C.c_float
+_lib.oracle_halide_pow.argtypes = [C.c_float, C.c_float]
+_lib.oracle_halide_pow.restype = C.c_float
+_lib.oracle_ll_remap_lut.argtypes = [C.c_int, C.c_float, _f32p]
+_lib.oracle_local_laplacian.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                        C.c_float, _u16p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+_lib.oracle_local_laplacian.restype = C.c_int
+
+
+def halide_exp(x: float) -> float:
+    return _lib.oracle_halide_exp(x)
+
+
+def halide_log(x: float) -> float:
+    return _lib.oracle_halide_log(x)
+
+
+def halide_pow(x: float, y: float) -> float:
+    return _lib.oracle_halide_pow(x, y)
+
+
+def fast_exp(x: float) -> float:
+    return _lib.oracle_fast_exp(x)
+
+
+def ll_remap_lut(levels: int, alpha: float) -> np.ndarray:
+    lut = np.zeros(2 * (levels - 1) * 256 + 1, np.float32)
+    _lib.oracle_ll_remap_lut(levels, alpha, lut)
+    return lut
+
+
+def local_laplacian(inp: np.ndarray, levels: int, alpha: float, beta: float, J: int = 8) -> np.ndarray:
+    """inp: u16 array of shape (3, H, W) (planar). Returns the same shape."""
+    inp = np.ascontiguousarray(inp, np.uint16)
+    c, h, w = inp.shape
+    assert c == 3
+    out = np.zeros_like(inp)
+    r = _lib.oracle_local_laplacian(inp, w, h, w, w * h, J, levels, alpha, beta, out, w, w * h, -1, None)
+    assert r == 0
+    return out
