@@ -136,7 +136,7 @@ lib.halide_hip_set_stream.argtypes = [C.c_void_p]
 lib.halide_hip_get_stream.argtypes = [C.c_void_p]
 lib.halide_hip_get_stream.restype = C.c_void_p
 lib.halide_device_release.argtypes = [C.c_void_p, C.c_void_p]
-lib.halide_reuse_device_allocations.argtypes = [C.c_void_p, C.c_int]
+lib.halide_reuse_device_allocations.argtypes = [C.c_void_p, C.c_bool]
 lib.hlmi_kernel_timing_enable.argtypes = [C.c_int]
 lib.hlmi_kernel_timing_report.argtypes = [C.c_char_p, C.c_size_t]
 lib.hlmi_kernel_timing_report.restype = C.c_size_t

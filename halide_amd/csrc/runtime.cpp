@@ -744,7 +744,7 @@ void halide_device_release(void *uc, const halide_device_interface_t *di) {
     if (di) di->device_release(uc, di);
 }
 
-int halide_reuse_device_allocations(void *uc, int flag) {
+int halide_reuse_device_allocations(void *uc, bool flag) {
     g_reuse.store(flag ? 1 : 0);
     if (!flag) return halide_hip_release_unused_device_allocations(uc);
     return 0;

@@ -1,0 +1,151 @@
+// stencil_chain.hip — gfx950 implementation of the reference's stencil_chain AOT pipeline.
+//
+// Algorithm: /root/reference/apps/stencil_chain/stencil_chain_generator.cpp:18-34 — 32 chained 5x5
+// stencils with weights (i+3)*(j+3) in wrapping uint16 arithmetic; only stage 0 is edge-clamped, so stage
+// s is needed on the output grown by 2*(32-s).  Boundary: `int stencil_chain(halide_buffer_t *input,
+// halide_buffer_t *output)` (:9-10, :150).
+//
+// Design.  mod-2^16 arithmetic is a commutative ring, so (a) the weight matrix (i+3)(j+3) factors into a
+// horizontal [1 2 3 4 5] pass followed by a vertical [1 2 3 4 5] pass with bit-identical results, and
+// (b) sums may be carried in 32-bit registers and truncated on store.  FUSE = 8 stages are computed per
+// launch inside LDS (temporal tiling, like the reference's CPU schedule fuses groups of stages per tile,
+// :115-143): a workgroup loads a (64+32)x(64+32) u16 window, ping-pongs it through 8 stages (the valid
+// box shrinks by 2 per stage) and writes the central 64x64.  Intermediates between launches live on the
+// grown domain in a scratch arena.  HBM traffic: 4 launches x (2 B read + 2 B written)/px (+halo).
+#include "hlmi_internal.h"
+
+using namespace hlmi;
+
+namespace {
+
+constexpr int STENCILS = 32;  // GeneratorParam stencils (:7)
+constexpr int FUSE = 8, TW = 64, TH = 64, RW = TW + 4 * FUSE, RH = TH + 4 * FUSE;
+constexpr int LDW = RW + 2;   // +2 u16 = one bank: rows start on different banks
+
+// src: u16 image with origin (sx0, sy0) in absolute coords and extent sw x sh; CLAMP => repeat_edge (stage 0)
+template<bool CLAMP>
+__global__ __launch_bounds__(256) void stencil_fused8(const uint16_t *__restrict__ src, long src_sy, int sx0, int sy0, int sw,
+                                                      int sh, uint16_t *__restrict__ dst, long dst_sy, int dx0, int dy0,
+                                                      int dw, int dh) {
+    __shared__ uint16_t buf[2][RH * LDW];
+    const int tid = threadIdx.x;
+    const int ox = dx0 + blockIdx.x * TW, oy = dy0 + blockIdx.y * TH;  // absolute coords of the output tile
+    const int gx = ox - 2 * FUSE, gy = oy - 2 * FUSE;                  // absolute coords of the window origin
+    for (int i = tid; i < RW * RH; i += 256) {
+        int r = i / RW, c = i - r * RW;
+        int x = gx + c - sx0, y = gy + r - sy0;
+        if (CLAMP) {
+            x = min(max(x, 0), sw - 1);
+            y = min(max(y, 0), sh - 1);
+            buf[0][r * LDW + c] = src[(long)y * src_sy + x];
+        } else {
+            // windows of edge tiles may poke outside the producer's domain; those cells only ever feed outputs
+            // outside the destination domain, which are not stored
+            bool ok = x >= 0 && x < sw && y >= 0 && y < sh;
+            buf[0][r * LDW + c] = ok ? src[(long)y * src_sy + x] : (uint16_t)0;
+        }
+    }
+    __syncthreads();
+    int cur = 0;
+#pragma unroll 1
+    for (int m = 0; m < FUSE; m++) {
+        const int lo = 2 * (m + 1);           // output box [lo, RW-1-lo] x [lo, RH-1-lo] in window coords
+        const int ow = RW - 2 * lo, oh = RH - 2 * lo;
+        const int nseg = 256 / ow;            // 2..4
+        const int seglen = (oh + nseg - 1) / nseg;
+        const uint16_t *s = buf[cur];
+        uint16_t *d = buf[cur ^ 1];
+        if (tid < ow * nseg) {
+            const int seg = tid / ow, x = lo + (tid - seg * ow);
+            const int ys = lo + seg * seglen, ye = min(ys + seglen, lo + oh);
+            unsigned h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0;
+            for (int y = ys - 2; y < ye + 2; y++) {
+                const uint16_t *p = s + y * LDW + x;
+                unsigned h = (unsigned)p[-2] + 2u * p[-1] + 3u * p[0] + 4u * p[1] + 5u * p[2];
+                h0 = h1, h1 = h2, h2 = h3, h3 = h4, h4 = h;
+                if (y >= ys + 2) d[(y - 2) * LDW + x] = (uint16_t)(h0 + 2u * h1 + 3u * h2 + 4u * h3 + 5u * h4);
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    const uint16_t *res = buf[cur];
+    for (int i = tid; i < TW * TH; i += 256) {
+        int r = i / TW, c = i - r * TW;
+        int X = ox + c - dx0, Y = oy + r - dy0;
+        if (X < dw && Y < dh) dst[(long)Y * dst_sy + X] = res[(r + 2 * FUSE) * LDW + c + 2 * FUSE];
+    }
+}
+
+const int64_t e0 = 0, ew = 1536, eh = 2560;
+const int64_t *const est[4] = {&e0, &ew, &e0, &eh};
+const halide_type_t ty_u16 = {(decltype(halide_type_t::code))1, 16, 0};
+const halide_filter_argument_t sc_args[2] = {
+    {"input", halide_argument_kind_input_buffer, 2, ty_u16, nullptr, nullptr, nullptr, nullptr, est},
+    {"output", halide_argument_kind_output_buffer, 2, ty_u16, nullptr, nullptr, nullptr, nullptr, est},
+};
+const halide_filter_metadata_t sc_md = {1, 2, sc_args, kTargetString, "stencil_chain"};
+
+}  // namespace
+
+extern "C" int stencil_chain(halide_buffer_t *input, halide_buffer_t *output) {
+    void *uc = nullptr;
+    BufArg args[2] = {{"input", input, T_U16, 2, false}, {"output", output, T_U16, 2, true}};
+    int r = check_not_null(uc, args, 2);
+    if (r) return r;
+    if ((r = check_type_and_dims(uc, args, 2))) return r;
+    if (any_bounds_query(args, 2)) {
+        // every tap of the input goes through repeat_edge (:18): any non-empty input is acceptable; propose
+        // the output's region (what tools/RunGen.h:1212-1250 then allocates)
+        int mins[2] = {output->dim[0].min, output->dim[1].min}, ext[2] = {output->dim[0].extent, output->dim[1].extent};
+        answer_query(input, mins, ext);
+        answer_query(output, mins, ext);
+        return 0;
+    }
+    if ((r = check_shape(uc, args[0])) || (r = check_shape(uc, args[1]))) return r;
+    const int W = output->dim[0].extent, H = output->dim[1].extent;
+    if (W > 0 && H > 0 && (input->dim[0].extent < 1 || input->dim[1].extent < 1)) {
+        return report(uc, halide_error_code_access_out_of_bounds, "Input buffer input is empty but is accessed (clamped) at 0");
+    }
+    DeviceCtx ctx;
+    if ((r = acquire_device(uc, &ctx))) return r;
+    if ((r = input_to_device(uc, ctx, args[0]))) return r;
+    if ((r = output_on_device(uc, ctx, args[1]))) return r;
+    if (W == 0 || H == 0) {
+        mark_output_written(output);
+        return 0;
+    }
+    constexpr int NL = STENCILS / FUSE;  // launches
+    const int ox0 = output->dim[0].min, oy0 = output->dim[1].min;
+    // domain after launch L (0-based): output grown by g_L = 2*FUSE*(NL-1-L)
+    auto grow = [&](int L) { return 2 * FUSE * (NL - 1 - L); };
+    size_t plane = (size_t)(W + 2 * grow(0)) * (H + 2 * grow(0));
+    void *ws = nullptr;
+    if ((r = get_workspace(uc, ctx, 2 * ((plane * 2 + 255) & ~(size_t)255), &ws))) return r;
+    uint16_t *tmp[2] = {(uint16_t *)ws, (uint16_t *)((char *)ws + ((plane * 2 + 255) & ~(size_t)255))};
+
+    const uint16_t *src = dev_ptr<uint16_t>(input);
+    long src_sy = input->dim[1].stride;
+    int sx0 = input->dim[0].min, sy0 = input->dim[1].min, sw = input->dim[0].extent, sh = input->dim[1].extent;
+    for (int L = 0; L < NL; L++) {
+        const int g = grow(L);
+        const int dx0 = ox0 - g, dy0 = oy0 - g, dw = W + 2 * g, dh = H + 2 * g;
+        uint16_t *dst = (L == NL - 1) ? dev_ptr<uint16_t>(output) : tmp[L & 1];
+        long dst_sy = (L == NL - 1) ? (long)output->dim[1].stride : (long)dw;
+        dim3 grid((dw + TW - 1) / TW, (dh + TH - 1) / TH);
+        if (L == 0) {
+            HLMI_LAUNCH(uc, "stencil_fused8", ctx.stream, stencil_fused8<true>, grid, dim3(256), 0, src, src_sy, sx0, sy0, sw, sh,
+                        dst, dst_sy, dx0, dy0, dw, dh);
+        } else {
+            HLMI_LAUNCH(uc, "stencil_fused8", ctx.stream, stencil_fused8<false>, grid, dim3(256), 0, src, src_sy, sx0, sy0, sw, sh,
+                        dst, dst_sy, dx0, dy0, dw, dh);
+        }
+        src = dst, src_sy = dst_sy, sx0 = dx0, sy0 = dy0, sw = dw, sh = dh;
+    }
+    mark_output_written(output);
+    return 0;
+}
+
+extern "C" int stencil_chain_argv(void **a) { return stencil_chain((halide_buffer_t *)a[0], (halide_buffer_t *)a[1]); }
+extern "C" const halide_filter_metadata_t *stencil_chain_metadata(void) { return &sc_md; }
+extern "C" int stencil_chain_auto_schedule(halide_buffer_t *input, halide_buffer_t *output) { return stencil_chain(input, output); }

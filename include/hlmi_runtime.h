@@ -9,10 +9,15 @@
 #define HLMI_RUNTIME_H
 
 #include "hlmi_abi.h"
+#ifndef __cplusplus
+#include <stdbool.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+#ifndef HALIDE_HALIDERUNTIME_H /* the reference header declares this block itself (same signatures) */
 
 /* ---- error / print hooks -------------------------------------------------------------------
  * halide_error / halide_set_error_handler: src/runtime/HalideRuntime.h:192-195;
@@ -60,9 +65,10 @@ int halide_device_wrap_native(void *user_context, struct halide_buffer_t *buf, u
                               const struct halide_device_interface_t *device_interface);
 int halide_device_detach_native(void *user_context, struct halide_buffer_t *buf);
 void halide_device_release(void *user_context, const struct halide_device_interface_t *device_interface);
-/* src/runtime/HalideRuntime.h:2343 (bool there; int here is ABI-identical on x86-64);
- * tools/RunGenMain.cpp:608 calls it with (nullptr, true). */
-int halide_reuse_device_allocations(void *user_context, int flag);
+/* src/runtime/HalideRuntime.h:2343; tools/RunGenMain.cpp:608 calls it with (nullptr, true). */
+int halide_reuse_device_allocations(void *user_context, bool flag);
+
+#endif /* !HALIDE_HALIDERUNTIME_H */
 
 /* ---- the HIP device interface (mirrors HalideRuntimeCuda.h:21-82) ----------------------------- */
 const struct halide_device_interface_t *halide_hip_device_interface(void);
@@ -74,8 +80,10 @@ int halide_hip_release_unused_device_allocations(void *user_context);
 /* Device selection: src/runtime/HalideRuntime.h:1019-1026 (halide_set_gpu_device / HL_GPU_DEVICE);
  * -1 = "use HL_GPU_DEVICE or device 0".  The setting is per calling thread, so that one host
  * thread per GPU can drive its own device (the multi-GPU frame sharder does exactly that). */
+#ifndef HALIDE_HALIDERUNTIME_H
 void halide_set_gpu_device(int n);
 int halide_get_gpu_device(void *user_context);
+#endif
 /* Stream override (mirrors halide_set_cuda_get_stream, HalideRuntimeCuda.h:76-82, simplified to a
  * per-thread value): all work of subsequent calls on this thread is enqueued on `stream`
  * (a hipStream_t); NULL restores the library's own per-device stream. */

@@ -84,17 +84,18 @@ float oracle_halide_pow(float x, float y) { return o_halide_pow(x, y); }
 float oracle_fast_exp(float x) { return o_fast_exp(x); }
 
 /* Full pipeline.  in/out: planar u16 [3][H][W] with row stride `in_sy`/`out_sy` and plane stride
- * `in_sc`/`out_sc` (elements).  J = pyramid_levels (8 in the reference build, :10), levels = K.
+ * `in_sc`/`out_sc` (elements); (X0, Y0) = dim[0].min, dim[1].min of both buffers, i.e. the absolute
+ * coordinate of element [0][0] (the pyramids are functions of absolute coordinates).  J = pyramid_levels (8 in the reference build, :10), levels = K.
  * If dbg_level >= 0, additionally copies outGPyramid[dbg_level] restricted to R_j into dbg (row-major,
  * width = R_j extent) — used by the tests to localise a GPU mismatch; pass -1/NULL otherwise.
  * Returns 0, or -1 on bad arguments. */
-int oracle_local_laplacian(const uint16_t *in, int W, int H, int in_sy, int in_sc, int J, int levels, float alpha,
+int oracle_local_laplacian(const uint16_t *in, int W, int H, int in_sy, int in_sc, int X0, int Y0, int J, int levels, float alpha,
                            float beta, uint16_t *out, int out_sy, int out_sc, int dbg_level, float *dbg) {
     if (J < 1 || J > LL_MAXJ || levels < 2 || W < 1 || H < 1) return -1;
     const int K = levels;
     int Rx0[LL_MAXJ], Rx1[LL_MAXJ], Ry0[LL_MAXJ], Ry1[LL_MAXJ];
     int Gx0[LL_MAXJ], Gx1[LL_MAXJ], Gy0[LL_MAXJ], Gy1[LL_MAXJ];
-    Rx0[0] = 0, Rx1[0] = W - 1, Ry0[0] = 0, Ry1[0] = H - 1;
+    Rx0[0] = X0, Rx1[0] = X0 + W - 1, Ry0[0] = Y0, Ry1[0] = Y0 + H - 1;
     for (int j = 0; j + 1 < J; j++) {
         Rx0[j + 1] = o_fdiv(Rx0[j] - 1, 2), Rx1[j + 1] = o_fdiv(Rx1[j] + 1, 2);
         Ry0[j + 1] = o_fdiv(Ry0[j] - 1, 2), Ry1[j + 1] = o_fdiv(Ry1[j] + 1, 2);
@@ -117,9 +118,9 @@ int oracle_local_laplacian(const uint16_t *in, int W, int H, int in_sy, int in_s
     plane_alloc(&gray, Gx0[0], Gx1[0], Gy0[0], Gy1[0]);
 #pragma omp parallel for schedule(static)
     for (int y = gray.y0; y <= gray.y1; y++) {
-        int yc = o_clampi(y, 0, H - 1);
+        int yc = o_clampi(y, Y0, Y0 + H - 1) - Y0;
         for (int x = gray.x0; x <= gray.x1; x++) {
-            int xc = o_clampi(x, 0, W - 1);
+            int xc = o_clampi(x, X0, X0 + W - 1) - X0;
             size_t o = (size_t)yc * (size_t)in_sy + (size_t)xc;
             float f0 = (float)in[o] * r65535, f1 = (float)in[o + (size_t)in_sc] * r65535,
                   f2 = (float)in[o + 2 * (size_t)in_sc] * r65535;
@@ -198,7 +199,7 @@ int oracle_local_laplacian(const uint16_t *in, int W, int H, int in_sy, int in_s
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < H; y++) {
         for (int x = 0; x < W; x++) {
-            float og = P(&outG[0], x, y) + eps, gr = P(&gray, x, y) + eps;
+            float og = P(&outG[0], X0 + x, Y0 + y) + eps, gr = P(&gray, X0 + x, Y0 + y) + eps;
             for (int c = 0; c < 3; c++) {
                 float v = ((float)in[(size_t)y * (size_t)in_sy + (size_t)x + (size_t)c * (size_t)in_sc] * og) / gr;
                 out[(size_t)y * (size_t)out_sy + (size_t)x + (size_t)c * (size_t)out_sc] =

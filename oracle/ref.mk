@@ -1,3 +1,23 @@
-# oracle/ref.mk — builds oracle/_ref/* from reference sources where they lie. See oracle/Makefile.
-all:
-	@true
+# oracle/ref.mk — TEST INFRASTRUCTURE.  Compiles the REFERENCE's own test/driver sources from where
+# they lie under $(REF) (never copied), unmodified, against OUR library + the stand-in generated headers
+# in include/aot/.  Outputs go to oracle/_ref/ only (git-ignored; they travel to the GPU box).
+# These binaries are the drop-in proof: a driver written for the reference's AOT objects runs on libhlmi.so.
+CXX      ?= g++
+RT       := $(REF)/src/runtime
+TOOLS    := $(REF)/tools
+OUTDIR   := $(ROOT)/oracle/_ref
+LIBDIR   := $(ROOT)/halide_amd/lib
+CXXFLAGS := -std=c++17 -O2 -fopenmp -DHALIDE_NO_PNG -DHALIDE_NO_JPEG -I$(RT) -I$(TOOLS) -I$(ROOT)/include/aot
+LDFLAGS  := -L$(LIBDIR) -lhlmi -Wl,-rpath,'$$ORIGIN/../../halide_amd/lib' -lpthread -ldl
+
+TARGETS := $(OUTDIR)/blur_test $(OUTDIR)/local_laplacian_process
+
+all: $(TARGETS)
+
+# apps/blur/test.cpp: compares halide_blur() with its own scalar + SSE2 loops, prints "Success!"
+$(OUTDIR)/blur_test: $(REF)/apps/blur/test.cpp $(LIBDIR)/libhlmi.so
+	$(CXX) $(CXXFLAGS) -msse2 $< -o $@ $(LDFLAGS)
+
+# apps/local_laplacian/process.cpp: load image -> local_laplacian(+_auto_schedule) -> benchmark -> save
+$(OUTDIR)/local_laplacian_process: $(REF)/apps/local_laplacian/process.cpp $(LIBDIR)/libhlmi.so
+	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)

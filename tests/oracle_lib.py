@@ -11,6 +11,11 @@ import subprocess
 
 import numpy as np
 
+# The GPU box exposes 256 hardware threads; an OpenMP team that wide only adds fork/join + spin overhead for
+# the small parity cases, so cap the team (bench.py's cpu_baseline reports the count it actually used).
+os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 64)))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "lib", "liboracle.so")
 
@@ -36,8 +41,8 @@ for _name in ("oracle_halide_exp", "oracle_halide_log", "oracle_fast_exp"):
 _lib.oracle_halide_pow.argtypes = [C.c_float, C.c_float]
 _lib.oracle_halide_pow.restype = C.c_float
 _lib.oracle_ll_remap_lut.argtypes = [C.c_int, C.c_float, _f32p]
-_lib.oracle_local_laplacian.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
-                                        C.c_float, _u16p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+_lib.oracle_local_laplacian.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_float, C.c_float, _u16p, C.c_int, C.c_int, C.c_int, C.c_void_p]
 _lib.oracle_local_laplacian.restype = C.c_int
 
 
@@ -63,12 +68,41 @@ def ll_remap_lut(levels: int, alpha: float) -> np.ndarray:
     return lut
 
 
-def local_laplacian(inp: np.ndarray, levels: int, alpha: float, beta: float, J: int = 8) -> np.ndarray:
-    """inp: u16 array of shape (3, H, W) (planar). Returns the same shape."""
+def omp_threads() -> int:
+    return int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+
+
+def local_laplacian(inp: np.ndarray, levels: int, alpha: float, beta: float, J: int = 8, origin=(0, 0)) -> np.ndarray:
+    """inp: u16 array of shape (3, H, W) (planar). Returns the same shape.  `origin` = (min_x, min_y) of the
+    buffer in the pipeline's absolute coordinate system (the 2x-1 pyramid taps depend on it)."""
     inp = np.ascontiguousarray(inp, np.uint16)
     c, h, w = inp.shape
     assert c == 3
     out = np.zeros_like(inp)
-    r = _lib.oracle_local_laplacian(inp, w, h, w, w * h, J, levels, alpha, beta, out, w, w * h, -1, None)
+    r = _lib.oracle_local_laplacian(inp, w, h, w, w * h, int(origin[0]), int(origin[1]), J, levels, alpha, beta, out,
+                                    w, w * h, -1, None)
     assert r == 0
+    return out
+
+_lib.oracle_blur.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, _u16p, C.c_int]
+_lib.oracle_blur.restype = C.c_int
+
+
+def blur(inp: np.ndarray) -> np.ndarray:
+    """inp: u16 (H+2, W+2) -> (H, W)."""
+    inp = np.ascontiguousarray(inp, np.uint16)
+    h, w = inp.shape[0] - 2, inp.shape[1] - 2
+    out = np.zeros((h, w), np.uint16)
+    assert _lib.oracle_blur(inp, inp.shape[1], w, h, out, w) == 0
+    return out
+
+_lib.oracle_stencil_chain.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, C.c_int, _u16p, C.c_int]
+_lib.oracle_stencil_chain.restype = C.c_int
+
+
+def stencil_chain(inp: np.ndarray, stencils: int = 32) -> np.ndarray:
+    inp = np.ascontiguousarray(inp, np.uint16)
+    h, w = inp.shape
+    out = np.zeros_like(inp)
+    assert _lib.oracle_stencil_chain(inp, w, w, h, stencils, out, w) == 0
     return out

@@ -1,0 +1,81 @@
+"""blur 3x3 (BASELINE configs[0], the plumbing config).
+
+Reference: /root/reference/apps/blur/halide_blur_generator.cpp:39-40; golden behaviour:
+apps/blur/test.cpp:18-33 (scalar loop, `int` arithmetic on inputs `rand() & 0xfff`, :169) and :184-191
+(results must be identical)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def scalar_loop_of_test_cpp(inp):
+    """Restatement in numpy of apps/blur/test.cpp:18-33 — arithmetic in C `int`, store to u16."""
+    i = inp.astype(np.int64)
+    tmp = ((i[:, :-2] + i[:, 1:-1] + i[:, 2:]) // 3).astype(np.uint16).astype(np.int64)
+    return ((tmp[:-2] + tmp[1:-1] + tmp[2:]) // 3).astype(np.uint16)
+
+
+def test_oracle_equals_reference_scalar_loop_on_its_own_inputs(oracle):
+    rng = np.random.default_rng(0)
+    inp = (rng.integers(0, 1 << 31, (1922, 2568)) & 0xFFF).astype(np.uint16)  # test.cpp:162-169
+    assert np.array_equal(oracle.blur(inp), scalar_loop_of_test_cpp(inp))
+
+
+def test_oracle_wraps_mod_2_16_on_full_range_inputs(oracle):
+    # Halide semantics: u16 + u16 stays u16 (src/IR.h:29-47); RunGen's random fill is full-range
+    inp = np.array([[65535, 65535, 65535, 3], [1, 2, 3, 4], [60000, 30000, 10000, 7]], np.uint16)
+    bx = np.array([[((65535 * 3) & 0xFFFF) // 3, ((65535 * 2 + 3) & 0xFFFF) // 3], [2, 3],
+                   [(100000 & 0xFFFF) // 3, 40007 // 3]], np.uint16)
+    want = (((bx[0].astype(np.int64) + bx[1] + bx[2]) & 0xFFFF) // 3).astype(np.uint16)
+    assert np.array_equal(oracle.blur(inp), want[None, :])
+    rng = np.random.default_rng(1)
+    big = rng.integers(0, 65536, (300, 200), dtype=np.uint16)
+    a = big.astype(np.uint32)
+    bxx = (((a[:, :-2] + a[:, 1:-1] + a[:, 2:]) & 0xFFFF) // 3)
+    by = (((bxx[:-2] + bxx[1:-1] + bxx[2:]) & 0xFFFF) // 3).astype(np.uint16)
+    assert np.array_equal(oracle.blur(big), by)
+
+
+def test_bounds_query_grows_input_by_two(hl):
+    out = hl.Buffer(np.zeros((2560, 1536), np.uint16)).set_min(5, 7)
+    q = hl.Buffer.bounds_query(np.uint16, 2)
+    hl.halide_blur(q, out)
+    assert q.mins == [5, 7] and q.extents == [1538, 2562] and q.dim(0).stride == 1 and q.dim(1).stride == 1538
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,full_range", [(1536, 2560, False), (1536, 2560, True), (1, 1, True), (3, 5, True),
+                                            (255, 33, True), (257, 31, False), (2560, 1920, False)])
+def test_hip_matches_oracle(hl, oracle, w, h, full_range):
+    rng = np.random.default_rng(w * 7 + h)
+    inp = rng.integers(0, 65536 if full_range else 4096, (h + 2, w + 2), dtype=np.uint16)
+    a, o = hl.Buffer(inp), hl.Buffer(np.zeros((h, w), np.uint16))
+    hl.halide_blur(a, o)
+    assert np.array_equal(o.numpy(), oracle.blur(inp))
+
+
+@pytest.mark.gpu
+def test_hip_input_larger_than_needed_and_offset_output(hl, oracle):
+    """test.cpp passes a 2568x1922 input for a 2560x1920 output (:137, :162-163): extra columns are ignored;
+    a non-zero output min selects the window."""
+    rng = np.random.default_rng(3)
+    inp = rng.integers(0, 65536, (120, 200), dtype=np.uint16)
+    a = hl.Buffer(inp)
+    o = hl.Buffer(np.zeros((50, 64), np.uint16)).set_min(10, 20)
+    hl.halide_blur(a, o)
+    assert np.array_equal(o.numpy(), oracle.blur(inp[20:20 + 52, 10:10 + 66]))
+
+
+@pytest.mark.gpu
+def test_reference_blur_test_cpp_runs_unmodified_against_libhlmi():
+    """oracle/_ref/blur_test = /root/reference/apps/blur/test.cpp compiled unmodified against libhlmi.so;
+    it aborts on any difference between its scalar loop, its SSE2 loop and halide_blur()."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "blur_test")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/blur_test not built (reference tree was absent at build time)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Success!" in r.stdout, r.stdout + r.stderr

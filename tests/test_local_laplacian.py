@@ -194,20 +194,24 @@ def test_hip_extreme_inputs(hl, oracle):
 
 
 @pytest.mark.gpu
-def test_hip_padded_strides_and_nonzero_min(hl, oracle):
-    """Row padding (stride[1] > extent[0]) and min != 0 must not change results: the pipeline is
-    translation-covariant only through absolute coordinates (2x-1 taps), so compare against the oracle
-    on an image embedded at an EVEN offset (phase preserved) and check padding bytes stay untouched."""
+@pytest.mark.parametrize("mx,my", [(128, 256), (17, 33), (-5, -130)])
+def test_hip_padded_strides_and_nonzero_min(hl, oracle, mx, my):
+    """Row padding (stride[1] > extent[0]) must not matter and padding bytes must stay untouched; a
+    non-zero min shifts the ABSOLUTE coordinates the 2x-1 pyramid taps are taken at, so results are
+    translation-invariant only for shifts that are multiples of 2^(J-1) = 128 — for other mins compare
+    against the oracle evaluated at the same origin."""
     w, h = 150, 90
     inp = _rand_image(w, h, seed=21)
     big_in = np.zeros((3, h + 4, w + 10), np.uint16)
     big_in[:, :h, :w] = inp
     big_out = np.full((3, h + 2, w + 6), 0xABCD, np.uint16)
-    a = hl.Buffer(big_in[:, :h, :w]).set_min(16, 32, 0)
-    o = hl.Buffer(big_out[:, :h, :w]).set_min(16, 32, 0)
+    a = hl.Buffer(big_in[:, :h, :w]).set_min(mx, my, 0)
+    o = hl.Buffer(big_out[:, :h, :w]).set_min(mx, my, 0)
     hl.local_laplacian(a, 8, 1.0 / 7, 1.0, o)
     o.copy_to_host()
-    want = oracle.local_laplacian(inp, 8, 1.0 / 7, 1.0)
+    want = oracle.local_laplacian(inp, 8, 1.0 / 7, 1.0, origin=(mx, my))
+    if (mx, my) == (128, 256):
+        assert np.array_equal(want, oracle.local_laplacian(inp, 8, 1.0 / 7, 1.0))
     assert np.array_equal(big_out[:, :h, :w], want)
     assert np.all(big_out[:, h:, :] == 0xABCD) and np.all(big_out[:, :, w:] == 0xABCD)
 
