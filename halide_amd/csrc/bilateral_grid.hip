@@ -1,0 +1,197 @@
+// bilateral_grid.hip — gfx950 implementation of the reference's bilateral_grid AOT pipeline.
+//
+// Algorithm: /root/reference/apps/bilateral_grid/bilateral_grid_generator.cpp:14-67 (s_sigma = 8, :8);
+// boundary: `int bilateral_grid(halide_buffer_t *input, float r_sigma, halide_buffer_t *bilateral_grid)`
+// (:10-12, :203).  HBM-bound at 8 B/px (4 read + 4 written); the grid (~3 MB at 1080p) lives in L2/MALL.
+//
+// Kernels (same decomposition as the reference's GPU schedule, :85-119):
+//   bg_histogram_blurz  one thread per grid cell: zero an LDS histogram, accumulate its 8x8 pixels SERIALLY in
+//                       RDom order (float sums are order-sensitive, :28-29), blur in z, write float2 {value, weight}
+//   bg_blurx, bg_blury  5-tap [1 4 6 4 1], left-to-right association (:38-47)
+//   bg_slice            trilinear lerp x->y->z of both channels, divide (:50-67)
+// Grid layout in HBM: float2 G[z][y][x] (c fastest), x,y covering the cells the output region touches (+2 halo
+// for the pre-blur stages), z in [0, zmax+1] with zmax = int(1/r_sigma + 0.5).
+#include "hlmi_device_math.h"
+#include "hlmi_internal.h"
+
+using namespace hlmi;
+
+namespace {
+
+constexpr int S = 8;  // s_sigma
+
+struct BGeom {
+    int ix0, ix1, iy0, iy1;  // clamp box of the input (absolute)
+    int gx0, gy0;            // absolute cell coordinate of blury's x=0 / y=0
+    int GX, GY, HX, HY;      // blury extents; histogram/blurz extents (GX+4, GY+4)
+    int ZH, ZD;              // histogram bins, blurred planes
+    float inv_r;
+};
+
+__device__ __forceinline__ float blur5(float a, float b, float c, float d, float e) {
+    return (((a + b * 4.0f) + c * 6.0f) + d * 4.0f) + e;
+}
+
+__global__ void bg_histogram_blurz(const float *__restrict__ in, long in_sy, BGeom g, float2 *__restrict__ bz) {
+    extern __shared__ float hist[];  // [ZH][2][T]
+    const int T = blockDim.x, t = threadIdx.x;
+    const int cx = blockIdx.x * T + t, cy = blockIdx.y;
+    for (int i = t; i < g.ZH * 2 * T; i += T) hist[i] = 0.0f;
+    __syncthreads();
+    const bool active = cx < g.HX;
+    if (active) {
+        const int gx = g.gx0 - 2 + cx, gy = g.gy0 - 2 + cy;
+#pragma unroll 1
+        for (int ry = 0; ry < S; ry++) {
+            const int py = dev::clampi(gy * S + ry - S / 2, g.iy0, g.iy1) - g.iy0;
+            const float *row = in + (long)py * in_sy;
+#pragma unroll
+            for (int rx = 0; rx < S; rx++) {
+                const int px = dev::clampi(gx * S + rx - S / 2, g.ix0, g.ix1) - g.ix0;
+                float val = dev::clampf(row[px], 0.0f, 1.0f);
+                int zi = (int)(val * g.inv_r + 0.5f);
+                float *h = &hist[(zi * 2) * T + t];
+                h[0] = h[0] + val;
+                h[T] = h[T] + 1.0f;
+            }
+        }
+        const size_t plane = (size_t)g.HX * g.HY;
+        for (int z = 0; z < g.ZD; z++) {
+            float v[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                auto H = [&](int zz) -> float { return (zz >= 0 && zz < g.ZH) ? hist[(zz * 2 + c) * T + t] : 0.0f; };
+                v[c] = blur5(H(z - 2), H(z - 1), H(z), H(z + 1), H(z + 2));
+            }
+            bz[(size_t)z * plane + (size_t)cy * g.HX + cx] = make_float2(v[0], v[1]);
+        }
+    }
+}
+
+// blurx: out[z][y][x] (GX wide) from bz (HX wide), y over HY
+__global__ void bg_blurx(const float2 *__restrict__ bz, BGeom g, float2 *__restrict__ bx) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, z = blockIdx.z;
+    if (x >= g.GX) return;
+    const float2 *s = bz + ((size_t)z * g.HY + y) * g.HX + x;
+    float2 a = s[0], b = s[1], c = s[2], d = s[3], e = s[4];
+    bx[((size_t)z * g.HY + y) * g.GX + x] = make_float2(blur5(a.x, b.x, c.x, d.x, e.x), blur5(a.y, b.y, c.y, d.y, e.y));
+}
+
+__global__ void bg_blury(const float2 *__restrict__ bx, BGeom g, float2 *__restrict__ by) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, z = blockIdx.z;
+    if (x >= g.GX) return;
+    const float2 *s = bx + ((size_t)z * g.HY + y) * g.GX + x;
+    float2 a = s[0], b = s[g.GX], c = s[2 * g.GX], d = s[3 * g.GX], e = s[4 * g.GX];
+    by[((size_t)z * g.GY + y) * g.GX + x] = make_float2(blur5(a.x, b.x, c.x, d.x, e.x), blur5(a.y, b.y, c.y, d.y, e.y));
+}
+
+__device__ __forceinline__ float2 lerp2(float2 a, float2 b, float w) {
+    return make_float2(dev::lerpf(a.x, b.x, w), dev::lerpf(a.y, b.y, w));
+}
+
+__global__ __launch_bounds__(256) void bg_slice(const float *__restrict__ in, long in_sy, BGeom g, const float2 *__restrict__ by,
+                                               float *__restrict__ out, long out_sy, int ox0, int oy0, int ow) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= ow) return;
+    const int ax = ox0 + x, ay = oy0 + y;
+    float val = dev::clampf(in[(long)(ay - g.iy0) * in_sy + (ax - g.ix0)], 0.0f, 1.0f);
+    float zv = val * g.inv_r;
+    int zi = (int)zv;
+    float zf = zv - (float)zi;
+    float xf = (float)dev::fmod8(ax) * 0.125f, yf = (float)dev::fmod8(ay) * 0.125f;
+    int xi = dev::fdiv8(ax) - g.gx0, yi = dev::fdiv8(ay) - g.gy0;
+    const size_t plane = (size_t)g.GX * g.GY;
+    const float2 *p0 = by + (size_t)zi * plane + (size_t)yi * g.GX + xi;
+    const float2 *p1 = p0 + plane;
+    float2 a = lerp2(lerp2(p0[0], p0[1], xf), lerp2(p0[g.GX], p0[g.GX + 1], xf), yf);
+    float2 b = lerp2(lerp2(p1[0], p1[1], xf), lerp2(p1[g.GX], p1[g.GX + 1], xf), yf);
+    float2 r = lerp2(a, b, zf);
+    out[(long)y * out_sy + x] = r.x / r.y;
+}
+
+const int64_t e0 = 0, ew = 1536, eh = 2560;
+const int64_t *const est[4] = {&e0, &ew, &e0, &eh};
+const halide_scalar_value_t est_rs = [] { halide_scalar_value_t v{}; v.u.f32 = 0.1f; return v; }();
+const halide_type_t ty_f32 = {(decltype(halide_type_t::code))2, 32, 0};
+// estimates: generator :73-81
+const halide_filter_argument_t bg_args[3] = {
+    {"input", halide_argument_kind_input_buffer, 2, ty_f32, nullptr, nullptr, nullptr, nullptr, est},
+    {"r_sigma", halide_argument_kind_input_scalar, 0, ty_f32, nullptr, nullptr, nullptr, &est_rs, nullptr},
+    {"bilateral_grid", halide_argument_kind_output_buffer, 2, ty_f32, nullptr, nullptr, nullptr, nullptr, est},
+};
+const halide_filter_metadata_t bg_md = {1, 3, bg_args, kTargetString, "bilateral_grid"};
+
+}  // namespace
+
+extern "C" int bilateral_grid(halide_buffer_t *input, float r_sigma, halide_buffer_t *output) {
+    void *uc = nullptr;
+    BufArg args[2] = {{"input", input, T_F32, 2, false}, {"bilateral_grid", output, T_F32, 2, true}};
+    int r = check_not_null(uc, args, 2);
+    if (r) return r;
+    if ((r = check_type_and_dims(uc, args, 2))) return r;
+    if (any_bounds_query(args, 2)) {
+        // the unclamped `input(x, y)` of the slicing stage (:50) needs the output's region; histogram taps are clamped
+        int mins[2] = {output->dim[0].min, output->dim[1].min}, ext[2] = {output->dim[0].extent, output->dim[1].extent};
+        answer_query(input, mins, ext);
+        answer_query(output, mins, ext);
+        return 0;
+    }
+    if ((r = check_shape(uc, args[0])) || (r = check_shape(uc, args[1]))) return r;
+    const int ow = output->dim[0].extent, oh = output->dim[1].extent;
+    const int ox0 = output->dim[0].min, oy0 = output->dim[1].min;
+    if ((r = check_covers(uc, args[0], 0, ox0, ow)) || (r = check_covers(uc, args[0], 1, oy0, oh))) return r;
+
+    BGeom g;
+    g.inv_r = 1.0f / r_sigma;
+    const float zm = 1.0f * g.inv_r + 0.5f;
+    if (!(zm >= 0.0f && zm < 8192.0f)) {
+        return report(uc, halide_error_code_param_too_small,
+                      "Parameter r_sigma is %g: the grid would need %g range bins (supported: r_sigma >= 1/8191)", r_sigma, zm);
+    }
+    const int zmax = (int)zm;
+    g.ZH = zmax + 1, g.ZD = zmax + 2;
+
+    DeviceCtx ctx;
+    if ((r = acquire_device(uc, &ctx))) return r;
+    if ((r = input_to_device(uc, ctx, args[0]))) return r;
+    if ((r = output_on_device(uc, ctx, args[1]))) return r;
+    if (ow == 0 || oh == 0) {
+        mark_output_written(output);
+        return 0;
+    }
+    g.ix0 = input->dim[0].min, g.ix1 = g.ix0 + input->dim[0].extent - 1;
+    g.iy0 = input->dim[1].min, g.iy1 = g.iy0 + input->dim[1].extent - 1;
+    g.gx0 = floor_div(ox0, S), g.gy0 = floor_div(oy0, S);
+    g.GX = floor_div(ox0 + ow - 1, S) + 1 - g.gx0 + 1, g.GY = floor_div(oy0 + oh - 1, S) + 1 - g.gy0 + 1;
+    g.HX = g.GX + 4, g.HY = g.GY + 4;
+
+    auto al = [](size_t n) { return (n + 63) & ~(size_t)63; };
+    const size_t n_bz = al((size_t)g.HX * g.HY * g.ZD), n_bx = al((size_t)g.GX * g.HY * g.ZD), n_by = al((size_t)g.GX * g.GY * g.ZD);
+    void *ws = nullptr;
+    if ((r = get_workspace(uc, ctx, (n_bz + n_bx + n_by) * sizeof(float2), &ws))) return r;
+    float2 *bz = (float2 *)ws, *bx = bz + n_bz, *by = bx + n_bx;
+
+    const float *din = dev_ptr<float>(input);
+    const long in_sy = input->dim[1].stride, out_sy = output->dim[1].stride;
+    hipStream_t st = ctx.stream;
+    {
+        int T = 64;
+        while (T > 1 && (size_t)g.ZH * 2 * T * sizeof(float) > 65536) T >>= 1;
+        size_t sh = (size_t)g.ZH * 2 * T * sizeof(float);
+        HLMI_LAUNCH(uc, "bg_histogram_blurz", st, bg_histogram_blurz, dim3((g.HX + T - 1) / T, g.HY), dim3(T), sh, din, in_sy, g, bz);
+    }
+    HLMI_LAUNCH(uc, "bg_blurx", st, bg_blurx, dim3((g.GX + 63) / 64, g.HY, g.ZD), dim3(64), 0, bz, g, bx);
+    HLMI_LAUNCH(uc, "bg_blury", st, bg_blury, dim3((g.GX + 63) / 64, g.GY, g.ZD), dim3(64), 0, bx, g, by);
+    HLMI_LAUNCH(uc, "bg_slice", st, bg_slice, dim3((ow + 255) / 256, oh), dim3(256), 0, din, in_sy, g, by, dev_ptr<float>(output),
+                out_sy, ox0, oy0, ow);
+    mark_output_written(output);
+    return 0;
+}
+
+extern "C" int bilateral_grid_argv(void **a) {
+    return bilateral_grid((halide_buffer_t *)a[0], *(float *)a[1], (halide_buffer_t *)a[2]);
+}
+extern "C" const halide_filter_metadata_t *bilateral_grid_metadata(void) { return &bg_md; }
+extern "C" int bilateral_grid_auto_schedule(halide_buffer_t *input, float r_sigma, halide_buffer_t *output) {
+    return bilateral_grid(input, r_sigma, output);
+}

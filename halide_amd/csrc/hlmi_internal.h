@@ -114,6 +114,9 @@ int launch_failed(void *uc, const char *kernel);
 // (layout: src/runtime/HalideRuntime.h:1937-1975; contents as emitted by src/CodeGen_C.cpp:760-912)
 extern const char *const kTargetString;  // "x86-64-linux-hip-gfx950" (canonical-style target string)
 
+// conv_layer.hip: argument protocol shared by conv_layer and conv_layer_bf16
+int conv_check_args(void *uc, BufArg *args, int *CI, int *CO, int *W, int *H, int *N, bool *query);
+
 inline int floor_div(int a, int b) {  // b > 0 ; Halide integer division rounds toward -inf (src/IR.h:145-166)
     int q = a / b, r = a % b;
     return (r != 0 && r < 0) ? q - 1 : q;

@@ -1,0 +1,265 @@
+// nl_means.hip — gfx950 implementation of the reference's non-local-means AOT pipeline.
+//
+// Algorithm: /root/reference/apps/nl_means/nl_means_generator.cpp:24-63; boundary: `int nl_means(
+// halide_buffer_t *input, int32_t patch_size, int32_t search_area, float sigma, halide_buffer_t *non_local_means)`
+// (:9-14, :162).  This path is fp32-VALU/LDS bound (~2.4 kFLOP and 24 B per pixel), not HBM bound.
+//
+// Float sums are order-sensitive and the oracle fixes the order (d over channels, blur_d_y over y, blur_d
+// over x, 49-term weighted sum over the search window, x fastest) — so no running-sum box filters: every sum
+// is re-added in order from shared, deterministic partial results.
+//
+// Fast path (patch_size == search_area == 7, the reference's benchmark setting, :79-81): one workgroup owns a
+// 58 x 64 output tile, stages the (58+12) x (64+12) x 3 clamped input window in LDS once, then for each of the
+// 49 offsets (dy outer, dx inner):
+//   phase 1  thread <-> (column of the 64-wide blur_d_y tile, 16-row segment): walks down the column with the
+//            last 7 values of d in registers, writes blur_d_y to LDS
+//   phase 2  thread <-> (row, 15-px segment): walks along the row with the last 7 blur_d_y values in registers,
+//            w = fast_exp(blur_d * inv_sigma_sq), accumulates 4 sums per pixel in registers (60 VGPRs)
+// Odd LDS pitches (71, 65) keep the row-per-lane accesses of phase 2 conflict-free.
+// Any other (patch_size, search_area): a straightforward one-thread-per-pixel kernel from global memory.
+#include "hlmi_device_math.h"
+#include "hlmi_internal.h"
+
+using namespace hlmi;
+
+namespace {
+
+constexpr int P = 7, SA = 7, HALF = 3;
+constexpr int TW = 58, TH = 64;                  // output tile
+constexpr int IW = TW + 4 * HALF, IH = TH + 4 * HALF, IWP = 71;  // input window (halo 3 patch + 3 search), padded pitch
+constexpr int BWP = 65;                          // blur_d_y tile: TW + 6 = 64 columns, padded pitch
+constexpr int SEG = 15;                          // phase-2 x segments: 15,15,15,13
+constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)3 * IH * IWP + (size_t)TH * BWP);
+
+struct NGeom {
+    int ix0, ix1, iy0, iy1, ic0, ic1;  // clamp box of the input (absolute)
+    int ox0, oy0, ow, oh;              // output region (absolute origin, extents)
+    float inv;                         // -1 / (sigma*sigma*patch*patch)
+};
+
+__global__ __launch_bounds__(256) void nlm_7x7(const float *__restrict__ in, long in_sy, long in_sc, NGeom g,
+                                              float *__restrict__ out, long out_sy, long out_sc) {
+    extern __shared__ float lds[];
+    float *sin = lds;                       // [3][IH][IWP]
+    float *sbdy = lds + 3 * IH * IWP;       // [TH][BWP]
+    const int tid = threadIdx.x;
+    const int tx0 = g.ox0 + blockIdx.x * TW, ty0 = g.oy0 + blockIdx.y * TH;  // absolute coords of the tile
+
+    // stage the clamped input window (repeat_edge on x, y and c, generator :27)
+    for (int i = tid; i < 3 * IH * IW; i += 256) {
+        int c = i / (IH * IW), rem = i - c * (IH * IW), r = rem / IW, col = rem - r * IW;
+        int x = dev::clampi(tx0 - 2 * HALF + col, g.ix0, g.ix1) - g.ix0;
+        int y = dev::clampi(ty0 - 2 * HALF + r, g.iy0, g.iy1) - g.iy0;
+        int cc = dev::clampi(c, g.ic0, g.ic1) - g.ic0;
+        sin[(c * IH + r) * IWP + col] = in[(long)y * in_sy + x + (long)cc * in_sc];
+    }
+    __syncthreads();
+
+    // phase-1 role: column cx of the blur_d_y tile (abs x = tx0 - 3 + cx), rows [16*g1, 16*g1 + 16)
+    const int cx = tid & 63, g1 = tid >> 6;
+    // phase-2 role: row r2, pixels [SEG*s2, SEG*s2 + npx)
+    const int r2 = tid & 63, s2 = tid >> 6;
+    const int xb = s2 * SEG, npx = min(SEG, TW - xb);
+
+    float acc[SEG][4];
+#pragma unroll
+    for (int j = 0; j < SEG; j++) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f;
+
+#pragma unroll 1
+    for (int dy = -HALF; dy <= HALF; dy++) {
+#pragma unroll 1
+        for (int dx = -HALF; dx <= HALF; dx++) {
+            // ---- phase 1: d -> blur_d_y
+            {
+                const int col = cx + HALF;            // window column of abs x
+                const int row0 = 16 * g1 + HALF;      // window row of abs y = ty0 + 16*g1 - 3
+                float dwin[7];
+#pragma unroll
+                for (int i = 0; i < 16 + 6; i++) {
+                    const int r = row0 + i;
+                    float d = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        float t = sin[(c * IH + r) * IWP + col] - sin[(c * IH + r + dy) * IWP + col + dx];
+                        d = d + t * t;
+                    }
+                    if (i < 7) {
+                        dwin[i] = d;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 6; q++) dwin[q] = dwin[q + 1];
+                        dwin[6] = d;
+                    }
+                    if (i >= 6) {
+                        float s = 0.0f;
+#pragma unroll
+                        for (int q = 0; q < 7; q++) s = s + dwin[q];
+                        sbdy[(16 * g1 + i - 6) * BWP + cx] = s;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- phase 2: blur_d, weight, accumulate
+            {
+                const float *brow = sbdy + r2 * BWP + xb;
+                float bwin[7];
+#pragma unroll
+                for (int q = 0; q < 6; q++) bwin[q] = brow[q];
+#pragma unroll
+                for (int j = 0; j < SEG; j++) {
+                    if (j < npx) {
+                        bwin[6] = brow[j + 6];
+                        float s = 0.0f;
+#pragma unroll
+                        for (int q = 0; q < 7; q++) s = s + bwin[q];
+                        float w = dev::fast_exp(s * g.inv);
+                        const int ir = r2 + 2 * HALF + dy, ic = xb + j + 2 * HALF + dx;
+#pragma unroll
+                        for (int c = 0; c < 3; c++) acc[j][c] = acc[j][c] + w * sin[(c * IH + ir) * IWP + ic];
+                        acc[j][3] = acc[j][3] + w * 1.0f;
+#pragma unroll
+                        for (int q = 0; q < 6; q++) bwin[q] = bwin[q + 1];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- normalise + store
+    const int Y = ty0 + r2 - g.oy0;
+    if (Y < g.oh) {
+#pragma unroll
+        for (int j = 0; j < SEG; j++) {
+            const int X = tx0 + xb + j - g.ox0;
+            if (j < npx && X < g.ow) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    out[(long)Y * out_sy + X + (long)c * out_sc] = dev::clampf(acc[j][c] / acc[j][3], 0.0f, 1.0f);
+                }
+            }
+        }
+    }
+}
+
+// generic (patch, search): one thread per pixel, everything from (L2-resident) global memory, same sum orders
+__global__ __launch_bounds__(256) void nlm_generic(const float *__restrict__ in, long in_sy, long in_sc, NGeom g, int patch,
+                                                  int search, float *__restrict__ out, long out_sy, long out_sc) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= g.ow) return;
+    const int X = g.ox0 + x, Y = g.oy0 + y;
+    const int p0 = -(patch / 2), s0 = -(search / 2);
+    auto IN = [&](int ax, int ay, int c) -> float {
+        int xx = dev::clampi(ax, g.ix0, g.ix1) - g.ix0, yy = dev::clampi(ay, g.iy0, g.iy1) - g.iy0;
+        int cc = dev::clampi(c, g.ic0, g.ic1) - g.ic0;
+        return in[(long)yy * in_sy + xx + (long)cc * in_sc];
+    };
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int sy = s0; sy < s0 + search; sy++) {
+        for (int sx = s0; sx < s0 + search; sx++) {
+            float bd = 0.0f;
+            for (int px = p0; px < p0 + patch; px++) {
+                float bdy = 0.0f;
+                for (int py = p0; py < p0 + patch; py++) {
+                    float d = 0.0f;
+                    for (int c = 0; c < 3; c++) {
+                        float t = IN(X + px, Y + py, c) - IN(X + px + sx, Y + py + sy, c);
+                        d = d + t * t;
+                    }
+                    bdy = bdy + d;
+                }
+                bd = bd + bdy;
+            }
+            float w = dev::fast_exp(bd * g.inv);
+            for (int c = 0; c < 3; c++) acc[c] = acc[c] + w * IN(X + sx, Y + sy, c);
+            acc[3] = acc[3] + w * 1.0f;
+        }
+    }
+    for (int c = 0; c < 3; c++) out[(long)y * out_sy + x + (long)c * out_sc] = dev::clampf(acc[c] / acc[3], 0.0f, 1.0f);
+}
+
+const int64_t e0 = 0, ew = 1536, eh = 2560, ec = 3;
+const int64_t *const est[6] = {&e0, &ew, &e0, &eh, &e0, &ec};
+const halide_scalar_value_t est7 = [] { halide_scalar_value_t v{}; v.u.i32 = 7; return v; }();
+const halide_scalar_value_t est_sigma = [] { halide_scalar_value_t v{}; v.u.f32 = 0.12f; return v; }();
+const halide_type_t ty_f32 = {(decltype(halide_type_t::code))2, 32, 0};
+const halide_type_t ty_i32 = {(decltype(halide_type_t::code))0, 32, 0};
+// estimates: generator :76-82
+const halide_filter_argument_t nlm_args[5] = {
+    {"input", halide_argument_kind_input_buffer, 3, ty_f32, nullptr, nullptr, nullptr, nullptr, est},
+    {"patch_size", halide_argument_kind_input_scalar, 0, ty_i32, nullptr, nullptr, nullptr, &est7, nullptr},
+    {"search_area", halide_argument_kind_input_scalar, 0, ty_i32, nullptr, nullptr, nullptr, &est7, nullptr},
+    {"sigma", halide_argument_kind_input_scalar, 0, ty_f32, nullptr, nullptr, nullptr, &est_sigma, nullptr},
+    {"non_local_means", halide_argument_kind_output_buffer, 3, ty_f32, nullptr, nullptr, nullptr, nullptr, est},
+};
+const halide_filter_metadata_t nlm_md = {1, 5, nlm_args, kTargetString, "nl_means"};
+
+}  // namespace
+
+extern "C" int nl_means(halide_buffer_t *input, int32_t patch_size, int32_t search_area, float sigma,
+                        halide_buffer_t *output) {
+    void *uc = nullptr;
+    BufArg args[2] = {{"input", input, T_F32, 3, false}, {"non_local_means", output, T_F32, 3, true}};
+    int r = check_not_null(uc, args, 2);
+    if (r) return r;
+    if ((r = check_type_and_dims(uc, args, 2))) return r;
+    if (any_bounds_query(args, 2)) {
+        // all input taps are clamped (:27); propose the output's x/y region and the 3 channels the algorithm names.
+        // The output's channel dimension is pinned to [0, 3) (:68).
+        int mins[3] = {output->dim[0].min, output->dim[1].min, 0}, ext[3] = {output->dim[0].extent, output->dim[1].extent, 3};
+        answer_query(input, mins, ext);
+        answer_query(output, mins, ext);
+        return 0;
+    }
+    if ((r = check_shape(uc, args[0])) || (r = check_shape(uc, args[1]))) return r;
+    if ((r = check_equal(uc, "non_local_means.min.2", output->dim[2].min, "0", 0))) return r;
+    if ((r = check_equal(uc, "non_local_means.extent.2", output->dim[2].extent, "3", 3))) return r;
+    if (patch_size < 1 || search_area < 1) {
+        return report(uc, halide_error_code_param_too_small, "Parameters patch_size (%d) and search_area (%d) must be >= 1",
+                      patch_size, search_area);
+    }
+    const int ow = output->dim[0].extent, oh = output->dim[1].extent;
+    if (ow > 0 && oh > 0 && (input->dim[0].extent < 1 || input->dim[1].extent < 1 || input->dim[2].extent < 1)) {
+        return report(uc, halide_error_code_access_out_of_bounds, "Input buffer input is empty but is accessed (clamped)");
+    }
+    DeviceCtx ctx;
+    if ((r = acquire_device(uc, &ctx))) return r;
+    if ((r = input_to_device(uc, ctx, args[0]))) return r;
+    if ((r = output_on_device(uc, ctx, args[1]))) return r;
+    if (ow == 0 || oh == 0) {
+        mark_output_written(output);
+        return 0;
+    }
+    NGeom g;
+    g.ix0 = input->dim[0].min, g.ix1 = g.ix0 + input->dim[0].extent - 1;
+    g.iy0 = input->dim[1].min, g.iy1 = g.iy0 + input->dim[1].extent - 1;
+    g.ic0 = input->dim[2].min, g.ic1 = g.ic0 + input->dim[2].extent - 1;
+    g.ox0 = output->dim[0].min, g.oy0 = output->dim[1].min, g.ow = ow, g.oh = oh;
+    g.inv = -1.0f / (((sigma * sigma) * (float)patch_size) * (float)patch_size);
+    const float *din = dev_ptr<float>(input);
+    float *dout = dev_ptr<float>(output);
+    const long in_sy = input->dim[1].stride, in_sc = input->dim[2].stride;
+    const long out_sy = output->dim[1].stride, out_sc = output->dim[2].stride;
+    if (patch_size == P && search_area == SA) {
+        static bool attr_set[64] = {false};
+        if (!attr_set[ctx.device]) {
+            HLMI_HIP(uc, hipFuncSetAttribute((const void *)nlm_7x7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+            attr_set[ctx.device] = true;
+        }
+        dim3 grid((ow + TW - 1) / TW, (oh + TH - 1) / TH);
+        HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, nlm_7x7, grid, dim3(256), LDS_BYTES, din, in_sy, in_sc, g, dout, out_sy, out_sc);
+    } else {
+        HLMI_LAUNCH(uc, "nlm_generic", ctx.stream, nlm_generic, dim3((ow + 255) / 256, oh), dim3(256), 0, din, in_sy, in_sc, g,
+                    patch_size, search_area, dout, out_sy, out_sc);
+    }
+    mark_output_written(output);
+    return 0;
+}
+
+extern "C" int nl_means_argv(void **a) {
+    return nl_means((halide_buffer_t *)a[0], *(int32_t *)a[1], *(int32_t *)a[2], *(float *)a[3], (halide_buffer_t *)a[4]);
+}
+extern "C" const halide_filter_metadata_t *nl_means_metadata(void) { return &nlm_md; }
+extern "C" int nl_means_auto_schedule(halide_buffer_t *input, int32_t patch_size, int32_t search_area, float sigma,
+                                      halide_buffer_t *output) {
+    return nl_means(input, patch_size, search_area, sigma, output);
+}

@@ -63,7 +63,8 @@ HLMI_DECLARE_AUX(stencil_chain)
 
 /* apps/conv_layer/conv_layer_generator.cpp:9-12,207 — f32 input [CI,W+2,H+2,N], filter [CO,3,3,CI],
  * bias [CO], relu [CO,W,H,N] (c fastest).  The reference pins N=5, CI=CO=128, W=100, H=80 (:15,35-50);
- * this entry point accepts any N,W,H with CI, CO multiples of 32 (superset). */
+ * this entry point accepts any N, W, H with CI a multiple of 32 and CO a multiple of 128 (superset), dense
+ * strides and zero mins as the generator pins them.  Exact f32: a k-ordered fma chain on the f32 matrix cores. */
 int conv_layer(struct halide_buffer_t *input, struct halide_buffer_t *filter, struct halide_buffer_t *bias,
                struct halide_buffer_t *relu);
 HLMI_DECLARE_AUX(conv_layer)

@@ -106,3 +106,42 @@ def stencil_chain(inp: np.ndarray, stencils: int = 32) -> np.ndarray:
     out = np.zeros_like(inp)
     assert _lib.oracle_stencil_chain(inp, w, w, h, stencils, out, w) == 0
     return out
+
+_lib.oracle_bilateral_grid.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _f32p, C.c_int]
+_lib.oracle_bilateral_grid.restype = C.c_int
+
+
+def bilateral_grid(inp: np.ndarray, r_sigma: float, origin=(0, 0)) -> np.ndarray:
+    inp = np.ascontiguousarray(inp, np.float32)
+    h, w = inp.shape
+    out = np.zeros_like(inp)
+    assert _lib.oracle_bilateral_grid(inp, w, h, w, int(origin[0]), int(origin[1]), r_sigma, out, w) == 0
+    return out
+
+_lib.oracle_nl_means.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _f32p, C.c_int,
+                                 C.c_int]
+_lib.oracle_nl_means.restype = C.c_int
+
+
+def nl_means(inp: np.ndarray, patch: int, search: int, sigma: float) -> np.ndarray:
+    """inp: f32 (3, H, W) planar."""
+    inp = np.ascontiguousarray(inp, np.float32)
+    c, h, w = inp.shape
+    assert c == 3
+    out = np.zeros_like(inp)
+    assert _lib.oracle_nl_means(inp, w, h, w, w * h, patch, search, sigma, out, w, w * h) == 0
+    return out
+
+_lib.oracle_conv_layer.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+_lib.oracle_conv_layer.restype = C.c_int
+
+
+def conv_layer(inp: np.ndarray, filt: np.ndarray, bias: np.ndarray) -> np.ndarray:
+    """inp: (N, H+2, W+2, CI); filt: (CI, 3, 3, CO) [= halide (CO, kx, ky, CI) reversed]; bias: (CO,) -> (N, H, W, CO)."""
+    inp, filt, bias = (np.ascontiguousarray(a, np.float32) for a in (inp, filt, bias))
+    n, hp, wp, ci = inp.shape
+    co = bias.shape[0]
+    assert filt.shape == (ci, 3, 3, co)
+    out = np.zeros((n, hp - 2, wp - 2, co), np.float32)
+    assert _lib.oracle_conv_layer(inp, filt, bias, out, ci, co, wp - 2, hp - 2, n) == 0
+    return out
