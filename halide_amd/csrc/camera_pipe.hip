@@ -1,0 +1,285 @@
+// camera_pipe.hip — gfx950 implementation of the reference's camera_pipe AOT pipeline (raw Bayer -> RGB8).
+//
+// Algorithm: /root/reference/apps/camera_pipe/camera_pipe_generator.cpp — shift (16,12) :406-413, hot-pixel
+// suppression :240-250, deinterleave :252-263, Demosaic :47-152, colour matrix (Q8.8) :265-299, tone curve LUT
+// :301-366, 1-2-1 unsharp mask :368-404.  Boundary: `int camera_pipe(input, matrix_3200, matrix_7000, color_temp,
+// gamma, contrast, sharpen_strength, blackLevel, whiteLevel, processed)` (:219-228, :622).
+// All per-pixel stages are integer (u16/i16/i32/u8 with the reference's wrap / floor-division rules) and therefore
+// exact; only the 12 matrix coefficients and the 1024-entry curve are float set-up work (cp_setup kernel).
+// HBM: 2 B read + 3 B written per output pixel; v1 materialises the curved u8 planes once (3+3 B/px extra).
+//   cp_setup    1 block: colour matrix, tone curve, sharpen strength
+//   cp_demosaic one thread per Bayer quad: 10x10 raw window -> hot-pixel clamp -> 3x3x4 deinterleaved values in
+//               registers -> demosaic 4 pixels -> matrix -> curve -> u8 planes on [-1, W] x [-1, H]
+//   cp_sharpen  one thread per output pixel, 3 channels
+#include "hlmi_device_math.h"
+#include "hlmi_internal.h"
+
+using namespace hlmi;
+
+namespace {
+
+struct CPSetup {          // lives in the scratch arena, written by cp_setup
+    int16_t matrix[12];   // [row c][col j] = matrix(j, c)
+    uint8_t strength_x32;
+    uint8_t pad[7];
+    uint8_t curve[1024];
+};
+
+__global__ void cp_setup(const float *__restrict__ m3200, long m3_sy, const float *__restrict__ m7000, long m7_sy,
+                         float color_temp, float gamma, float contrast, float sharpen_strength, int blackLevel, int whiteLevel,
+                         CPSetup *__restrict__ s) {
+    const int t = threadIdx.x;
+    if (t < 12) {
+        const float k1 = 1.0f / 3200, k2 = 1.0f / 7000;
+        const float inv_den = 1.0f / (k2 - k1);
+        float alpha = (1.0f / color_temp - k1) * inv_den;
+        int c = t / 4, j = t - 4 * c;
+        float val = m3200[c * m3_sy + j] * alpha + m7000[c * m7_sy + j] * (1.0f - alpha);
+        s->matrix[t] = (int16_t)(val * 256.0f);
+    }
+    if (t == 12) s->strength_x32 = (uint8_t)dev::clampf(sharpen_strength * 32.0f, 0.0f, 255.0f);
+    if (t < 1024) {
+        const int minRaw = 0 + blackLevel, maxRaw = whiteLevel;
+        float invRange = 1.0f / (float)(maxRaw - minRaw);
+        float b = 2.0f - dev::halide_pow(2.0f, contrast * (1.0f / 100.0f));
+        float a = 2.0f - 2.0f * b;
+        float xf = dev::clampf((float)(t - minRaw) * invRange, 0.0f, 1.0f);
+        float g = dev::halide_pow(xf, 1.0f / gamma);
+        float z = g > 0.5f ? 1.0f - ((a * (1.0f - g)) * (1.0f - g) + b * (1.0f - g)) : (a * g) * g + b * g;
+        uint8_t val = (uint8_t)dev::clampf(z * 255.0f + 0.5f, 0.0f, 255.0f);
+        s->curve[t] = t <= minRaw ? (uint8_t)0 : (t > maxRaw ? (uint8_t)255 : val);
+    }
+}
+
+__device__ __forceinline__ uint16_t avg16(uint16_t a, uint16_t b) { return (uint16_t)(((uint32_t)a + b + 1u) >> 1); }
+__device__ __forceinline__ uint8_t avg8(uint8_t a, uint8_t b) { return (uint8_t)(((uint32_t)a + b + 1u) >> 1); }
+__device__ __forceinline__ uint16_t absd16(uint16_t a, uint16_t b) { return a > b ? (uint16_t)(a - b) : (uint16_t)(b - a); }
+__device__ __forceinline__ uint16_t u16(uint32_t v) { return (uint16_t)v; }
+
+// raw: pointer to shifted(0,0) = input(16,12) relative to the buffer's own min; cv: u8 planes [3][CH][CW] of curved on
+// [-1, W] x [-1, H]
+__global__ __launch_bounds__(256) void cp_demosaic(const uint16_t *__restrict__ raw, long in_sy, const CPSetup *__restrict__ s,
+                                                  uint8_t *__restrict__ cv, int CW, int CH, int nqx, int nqy) {
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x, qj = blockIdx.y;
+    if (qi >= nqx) return;
+    const int qx = qi - 1, qy = qj - 1;  // quads start at fdiv(-1, 2) = -1
+    // 10x10 raw window, origin (2qx-4, 2qy-4)
+    uint16_t R[10][10];
+    const uint16_t *base = raw + (long)(2 * qy - 4) * in_sy + (2 * qx - 4);
+#pragma unroll
+    for (int j = 0; j < 10; j++)
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            // only the plus-shaped footprint of the 6x6 centre is ever used; skip the 2x2 corners
+            bool used = !((i < 2 || i > 7) && (j < 2 || j > 7));
+            R[j][i] = used ? base[(long)j * in_sy + i] : (uint16_t)0;
+        }
+    // hot-pixel suppression (:240-250) + deinterleave (:252-263): D[c][dy+1][dx+1]
+    uint16_t D[4][3][3];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) {
+                const int i = 2 * (dx - 1) + (c & 1) + 4, j = 2 * (dy - 1) + (c >> 1) + 4;
+                uint16_t a = max(max(R[j][i - 2], R[j][i + 2]), max(R[j - 2][i], R[j + 2][i]));
+                D[c][dy][dx] = min(R[j][i], a);
+            }
+#define G_GR(dx, dy) D[0][(dy) + 1][(dx) + 1]
+#define R_R(dx, dy) D[1][(dy) + 1][(dx) + 1]
+#define B_B(dx, dy) D[2][(dy) + 1][(dx) + 1]
+#define G_GB(dx, dy) D[3][(dy) + 1][(dx) + 1]
+    auto g_r = [&](int dx, int dy) -> uint16_t {
+        uint16_t gv = avg16(G_GB(dx, dy - 1), G_GB(dx, dy)), gvd = absd16(G_GB(dx, dy - 1), G_GB(dx, dy));
+        uint16_t gh = avg16(G_GR(dx + 1, dy), G_GR(dx, dy)), ghd = absd16(G_GR(dx + 1, dy), G_GR(dx, dy));
+        return ghd < gvd ? gh : gv;
+    };
+    auto g_b = [&](int dx, int dy) -> uint16_t {
+        uint16_t gv = avg16(G_GR(dx, dy + 1), G_GR(dx, dy)), gvd = absd16(G_GR(dx, dy + 1), G_GR(dx, dy));
+        uint16_t gh = avg16(G_GB(dx - 1, dy), G_GB(dx, dy)), ghd = absd16(G_GB(dx - 1, dy), G_GB(dx, dy));
+        return ghd < gvd ? gh : gv;
+    };
+    const uint16_t gr00 = g_r(0, 0), grm0 = g_r(-1, 0), gr01 = g_r(0, 1), grm1 = g_r(-1, 1);
+    const uint16_t gb00 = g_b(0, 0), gb0m = g_b(0, -1), gb10 = g_b(1, 0), gb1m = g_b(1, -1);
+
+    uint16_t px[4][3];  // [site: gr, r, b, gb][r, g, b]
+    // green-red site (even, even)
+    px[0][1] = G_GR(0, 0);
+    px[0][0] = u16(u16(G_GR(0, 0) - avg16(gr00, grm0)) + avg16(R_R(-1, 0), R_R(0, 0)));
+    px[0][2] = u16(u16(G_GR(0, 0) - avg16(gb00, gb0m)) + avg16(B_B(0, 0), B_B(0, -1)));
+    // red site (odd, even)
+    px[1][0] = R_R(0, 0);
+    px[1][1] = gr00;
+    {
+        uint16_t bp = u16(u16(gr00 - avg16(gb00, gb1m)) + avg16(B_B(0, 0), B_B(1, -1)));
+        uint16_t bpd = absd16(B_B(0, 0), B_B(1, -1));
+        uint16_t bn = u16(u16(gr00 - avg16(gb10, gb0m)) + avg16(B_B(1, 0), B_B(0, -1)));
+        uint16_t bnd = absd16(B_B(1, 0), B_B(0, -1));
+        px[1][2] = bpd < bnd ? bp : bn;
+    }
+    // blue site (even, odd)
+    px[2][2] = B_B(0, 0);
+    px[2][1] = gb00;
+    {
+        uint16_t rp = u16(u16(gb00 - avg16(gr00, grm1)) + avg16(R_R(0, 0), R_R(-1, 1)));
+        uint16_t rpd = absd16(R_R(0, 0), R_R(-1, 1));
+        uint16_t rn = u16(u16(gb00 - avg16(grm0, gr01)) + avg16(R_R(-1, 0), R_R(0, 1)));
+        uint16_t rnd = absd16(R_R(-1, 0), R_R(0, 1));
+        px[2][0] = rpd < rnd ? rp : rn;
+    }
+    // green-blue site (odd, odd)
+    px[3][1] = G_GB(0, 0);
+    px[3][0] = u16(u16(G_GB(0, 0) - avg16(gr00, gr01)) + avg16(R_R(0, 0), R_R(0, 1)));
+    px[3][2] = u16(u16(G_GB(0, 0) - avg16(gb00, gb10)) + avg16(B_B(0, 0), B_B(1, 0)));
+#undef G_GR
+#undef R_R
+#undef B_B
+#undef G_GB
+    // colour matrix (Q8.8, floor /256) + tone curve -> u8, store to the curved planes
+    const size_t plane = (size_t)CW * CH;
+#pragma unroll
+    for (int site = 0; site < 4; site++) {
+        const int X = 2 * qx + (site & 1), Y = 2 * qy + (site >> 1);
+        const int cxx = X + 1, cyy = Y + 1;
+        if (cxx < 0 || cxx >= CW || cyy < 0 || cyy >= CH) continue;
+        const int32_t ir = (int16_t)px[site][0], ig = (int16_t)px[site][1], ib = (int16_t)px[site][2];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int16_t *m = &s->matrix[4 * c];
+            int32_t v = (((int32_t)m[3] + (int32_t)m[0] * ir) + (int32_t)m[1] * ig) + (int32_t)m[2] * ib;
+            int16_t cc = (int16_t)(v >> 8);
+            cv[(size_t)c * plane + (size_t)cyy * CW + cxx] = s->curve[dev::clampi(cc, 0, 1023)];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cp_sharpen(const uint8_t *__restrict__ cv, int CW, int CH, const CPSetup *__restrict__ s,
+                                                 uint8_t *__restrict__ out, long out_sy, long out_sc, int W, int H) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int16_t strength = (int16_t)s->strength_x32;
+    const size_t plane = (size_t)CW * CH;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const uint8_t *p = cv + (size_t)c * plane + (size_t)(y + 1) * CW + (x + 1);
+        uint8_t uy[3];
+#pragma unroll
+        for (int d = -1; d <= 1; d++) uy[d + 1] = avg8(avg8(p[d - CW], p[d + CW]), p[d]);
+        uint8_t unsharp = avg8(avg8(uy[0], uy[2]), uy[1]);
+        int16_t mask = (int16_t)((int16_t)p[0] - (int16_t)unsharp);
+        int16_t prod = (int16_t)(mask * strength);      // int16 (x) uint8 -> int16, wraps (src/IROperator.cpp:769-816)
+        int16_t q = (int16_t)(prod >> 5);               // floor division by 32
+        int16_t v = (int16_t)((int16_t)p[0] + q);
+        out[(long)y * out_sy + x + (long)c * out_sc] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}
+
+const halide_type_t ty_u16 = {(decltype(halide_type_t::code))1, 16, 0};
+const halide_type_t ty_u8 = {(decltype(halide_type_t::code))1, 8, 0};
+const halide_type_t ty_f32 = {(decltype(halide_type_t::code))2, 32, 0};
+const halide_type_t ty_i32 = {(decltype(halide_type_t::code))0, 32, 0};
+const int64_t e0 = 0, e2592 = 2592, e1968 = 1968, e4 = 4, e3 = 3;
+const int64_t *const est_in[4] = {&e0, &e2592, &e0, &e1968};
+const int64_t *const est_m[4] = {&e0, &e4, &e0, &e3};
+const int64_t *const est_out[6] = {&e0, &e2592, &e0, &e1968, &e0, &e3};
+halide_scalar_value_t fval(float f) { halide_scalar_value_t v{}; v.u.f32 = f; return v; }
+halide_scalar_value_t ival(int i) { halide_scalar_value_t v{}; v.u.i32 = i; return v; }
+const halide_scalar_value_t est_ct = fval(3700), est_gamma = fval(2.0f), est_contrast = fval(50), est_sharp = fval(1.0f),
+                            est_black = ival(25), est_white = ival(1023);
+// estimates: generator :430-439
+const halide_filter_argument_t cp_args[10] = {
+    {"input", halide_argument_kind_input_buffer, 2, ty_u16, nullptr, nullptr, nullptr, nullptr, est_in},
+    {"matrix_3200", halide_argument_kind_input_buffer, 2, ty_f32, nullptr, nullptr, nullptr, nullptr, est_m},
+    {"matrix_7000", halide_argument_kind_input_buffer, 2, ty_f32, nullptr, nullptr, nullptr, nullptr, est_m},
+    {"color_temp", halide_argument_kind_input_scalar, 0, ty_f32, nullptr, nullptr, nullptr, &est_ct, nullptr},
+    {"gamma", halide_argument_kind_input_scalar, 0, ty_f32, nullptr, nullptr, nullptr, &est_gamma, nullptr},
+    {"contrast", halide_argument_kind_input_scalar, 0, ty_f32, nullptr, nullptr, nullptr, &est_contrast, nullptr},
+    {"sharpen_strength", halide_argument_kind_input_scalar, 0, ty_f32, nullptr, nullptr, nullptr, &est_sharp, nullptr},
+    {"blackLevel", halide_argument_kind_input_scalar, 0, ty_i32, nullptr, nullptr, nullptr, &est_black, nullptr},
+    {"whiteLevel", halide_argument_kind_input_scalar, 0, ty_i32, nullptr, nullptr, nullptr, &est_white, nullptr},
+    {"processed", halide_argument_kind_output_buffer, 3, ty_u8, nullptr, nullptr, nullptr, nullptr, est_out},
+};
+const halide_filter_metadata_t cp_md = {1, 10, cp_args, kTargetString, "camera_pipe"};
+
+}  // namespace
+
+extern "C" int camera_pipe(halide_buffer_t *input, halide_buffer_t *matrix_3200, halide_buffer_t *matrix_7000, float color_temp,
+                           float gamma, float contrast, float sharpen_strength, int32_t blackLevel, int32_t whiteLevel,
+                           halide_buffer_t *processed) {
+    void *uc = nullptr;
+    BufArg args[4] = {{"input", input, T_U16, 2, false}, {"matrix_3200", matrix_3200, T_F32, 2, false},
+                      {"matrix_7000", matrix_7000, T_F32, 2, false}, {"processed", processed, T_U8, 3, true}};
+    int r = check_not_null(uc, args, 4);
+    if (r) return r;
+    if ((r = check_type_and_dims(uc, args, 4))) return r;
+    // footprint of a W x H output (no boundary condition anywhere in the pipeline): sharpen +-1 px, demosaic +-1 Bayer
+    // quad, hot-pixel +-2 raw px, all after the (16, 12) shift  =>  x in [ox+10, ox+W+21], y in [oy+6, oy+H+17]
+    const int W = processed->dim[0].extent, H = processed->dim[1].extent;
+    const int ox = processed->dim[0].min, oy = processed->dim[1].min;
+    if (any_bounds_query(args, 4)) {
+        int imin[2] = {ox + 10, oy + 6}, iext[2] = {W + 12, H + 12};
+        int mmin[2] = {0, 0}, mext[2] = {4, 3};
+        int omin[3] = {ox, oy, 0}, oext[3] = {W, H, 3};
+        answer_query(input, imin, iext);
+        answer_query(matrix_3200, mmin, mext);
+        answer_query(matrix_7000, mmin, mext);
+        answer_query(processed, omin, oext);
+        return 0;
+    }
+    for (int i = 0; i < 4; i++)
+        if ((r = check_shape(uc, args[i]))) return r;
+    if ((r = check_equal(uc, "processed.min.2", processed->dim[2].min, "0", 0))) return r;          // bound(c, 0, 3), :454
+    if ((r = check_equal(uc, "processed.extent.2", processed->dim[2].extent, "3", 3))) return r;
+    if ((ox & 1) || (oy & 1)) {
+        return report(uc, halide_error_code_constraint_violated,
+                      "Constraint violated: processed.min.0 (%d) and processed.min.1 (%d) must be even (Bayer phase)", ox, oy);
+    }
+    if (W > 0 && H > 0) {
+        if ((r = check_covers(uc, args[0], 0, ox + 10, W + 12)) || (r = check_covers(uc, args[0], 1, oy + 6, H + 12))) return r;
+    }
+    for (int i = 1; i <= 2; i++) {
+        if ((r = check_covers(uc, args[i], 0, 0, 4)) || (r = check_covers(uc, args[i], 1, 0, 3))) return r;
+    }
+    DeviceCtx ctx;
+    if ((r = acquire_device(uc, &ctx))) return r;
+    for (int i = 0; i < 3; i++)
+        if ((r = input_to_device(uc, ctx, args[i]))) return r;
+    if ((r = output_on_device(uc, ctx, args[3]))) return r;
+    if (W == 0 || H == 0) {
+        mark_output_written(processed);
+        return 0;
+    }
+    const int CW = W + 2, CH = H + 2;
+    const size_t setup_bytes = (sizeof(CPSetup) + 255) & ~(size_t)255;
+    void *ws = nullptr;
+    if ((r = get_workspace(uc, ctx, setup_bytes + (size_t)3 * CW * CH + 256, &ws))) return r;
+    CPSetup *setup = (CPSetup *)ws;
+    uint8_t *cv = (uint8_t *)ws + setup_bytes;
+    hipStream_t st = ctx.stream;
+    const float *m3 = dev_ptr<float>(matrix_3200) - ((long)matrix_3200->dim[1].min * matrix_3200->dim[1].stride + matrix_3200->dim[0].min);
+    const float *m7 = dev_ptr<float>(matrix_7000) - ((long)matrix_7000->dim[1].min * matrix_7000->dim[1].stride + matrix_7000->dim[0].min);
+    HLMI_LAUNCH(uc, "cp_setup", st, cp_setup, dim3(1), dim3(1024), 0, m3, (long)matrix_3200->dim[1].stride, m7,
+                (long)matrix_7000->dim[1].stride, color_temp, gamma, contrast, sharpen_strength, blackLevel, whiteLevel, setup);
+    // shifted(x, y) = input(x + 16, y + 12) in ABSOLUTE coordinates; output pixel (ox, oy) is X = 0 of the kernels
+    const long in_sy = input->dim[1].stride;
+    const uint16_t *raw = dev_ptr<uint16_t>(input) + (long)(oy + 12 - input->dim[1].min) * in_sy + (ox + 16 - input->dim[0].min);
+    const int nqx = floor_div(W, 2) + 2, nqy = floor_div(H, 2) + 2;
+    HLMI_LAUNCH(uc, "cp_demosaic", st, cp_demosaic, dim3((nqx + 255) / 256, nqy), dim3(256), 0, raw, in_sy, setup, cv, CW, CH, nqx, nqy);
+    HLMI_LAUNCH(uc, "cp_sharpen", st, cp_sharpen, dim3((W + 255) / 256, H), dim3(256), 0, cv, CW, CH, setup, dev_ptr<uint8_t>(processed),
+                (long)processed->dim[1].stride, (long)processed->dim[2].stride, W, H);
+    mark_output_written(processed);
+    return 0;
+}
+
+extern "C" int camera_pipe_argv(void **a) {
+    return camera_pipe((halide_buffer_t *)a[0], (halide_buffer_t *)a[1], (halide_buffer_t *)a[2], *(float *)a[3], *(float *)a[4],
+                       *(float *)a[5], *(float *)a[6], *(int32_t *)a[7], *(int32_t *)a[8], (halide_buffer_t *)a[9]);
+}
+extern "C" const halide_filter_metadata_t *camera_pipe_metadata(void) { return &cp_md; }
+extern "C" int camera_pipe_auto_schedule(halide_buffer_t *input, halide_buffer_t *matrix_3200, halide_buffer_t *matrix_7000,
+                                         float color_temp, float gamma, float contrast, float sharpen_strength,
+                                         int32_t blackLevel, int32_t whiteLevel, halide_buffer_t *processed) {
+    return camera_pipe(input, matrix_3200, matrix_7000, color_temp, gamma, contrast, sharpen_strength, blackLevel, whiteLevel,
+                       processed);
+}

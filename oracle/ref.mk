@@ -10,7 +10,8 @@ LIBDIR   := $(ROOT)/halide_amd/lib
 CXXFLAGS := -std=c++17 -O2 -fopenmp -DHALIDE_NO_PNG -DHALIDE_NO_JPEG -I$(RT) -I$(TOOLS) -I$(ROOT)/include/aot
 LDFLAGS  := -L$(LIBDIR) -lhlmi -Wl,-rpath,'$$ORIGIN/../../halide_amd/lib' -lpthread -ldl
 
-TARGETS := $(OUTDIR)/blur_test $(OUTDIR)/local_laplacian_process
+TARGETS := $(OUTDIR)/blur_test $(OUTDIR)/local_laplacian_process $(OUTDIR)/bilateral_grid_filter \
+           $(OUTDIR)/nl_means_process $(OUTDIR)/stencil_chain_process $(OUTDIR)/conv_layer_process $(OUTDIR)/camera_pipe_process
 
 all: $(TARGETS)
 
@@ -20,4 +21,16 @@ $(OUTDIR)/blur_test: $(REF)/apps/blur/test.cpp $(LIBDIR)/libhlmi.so
 
 # apps/local_laplacian/process.cpp: load image -> local_laplacian(+_auto_schedule) -> benchmark -> save
 $(OUTDIR)/local_laplacian_process: $(REF)/apps/local_laplacian/process.cpp $(LIBDIR)/libhlmi.so
+	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)
+
+# the other app drivers, same recipe (apps/<app>/{filter,process}.cpp, unmodified)
+$(OUTDIR)/bilateral_grid_filter: $(REF)/apps/bilateral_grid/filter.cpp $(LIBDIR)/libhlmi.so
+	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)
+$(OUTDIR)/nl_means_process: $(REF)/apps/nl_means/process.cpp $(LIBDIR)/libhlmi.so
+	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)
+$(OUTDIR)/stencil_chain_process: $(REF)/apps/stencil_chain/process.cpp $(LIBDIR)/libhlmi.so
+	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)
+$(OUTDIR)/conv_layer_process: $(REF)/apps/conv_layer/process.cpp $(LIBDIR)/libhlmi.so
+	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)
+$(OUTDIR)/camera_pipe_process: $(REF)/apps/camera_pipe/process.cpp $(LIBDIR)/libhlmi.so
 	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)

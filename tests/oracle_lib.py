@@ -145,3 +145,29 @@ def conv_layer(inp: np.ndarray, filt: np.ndarray, bias: np.ndarray) -> np.ndarra
     out = np.zeros((n, hp - 2, wp - 2, co), np.float32)
     assert _lib.oracle_conv_layer(inp, filt, bias, out, ci, co, wp - 2, hp - 2, n) == 0
     return out
+
+_i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
+_lib.oracle_camera_pipe.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_float, C.c_float, C.c_float, C.c_float,
+                                    C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.c_int]
+_lib.oracle_camera_pipe.restype = C.c_int
+_lib.oracle_camera_pipe_setup.argtypes = [_f32p, _f32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _i16p,
+                                          _u8p, _u8p]
+
+
+def camera_pipe(raw: np.ndarray, m3200: np.ndarray, m7000: np.ndarray, color_temp, gamma, contrast, sharpen, black, white,
+                out_w: int, out_h: int) -> np.ndarray:
+    """raw: u16 (H_in, W_in); matrices f32 (3, 4); returns u8 (3, out_h, out_w)."""
+    raw = np.ascontiguousarray(raw, np.uint16)
+    m3200, m7000 = np.ascontiguousarray(m3200, np.float32), np.ascontiguousarray(m7000, np.float32)
+    out = np.zeros((3, out_h, out_w), np.uint8)
+    r = _lib.oracle_camera_pipe(raw, raw.shape[1], raw.shape[0], raw.shape[1], m3200, m7000, color_temp, gamma, contrast,
+                                sharpen, black, white, out, out_w, out_h, out_w, out_w * out_h)
+    assert r == 0, r
+    return out
+
+
+def camera_pipe_setup(m3200, m7000, color_temp, gamma, contrast, sharpen, black, white):
+    matrix, curve, s = np.zeros(12, np.int16), np.zeros(1024, np.uint8), np.zeros(1, np.uint8)
+    _lib.oracle_camera_pipe_setup(np.ascontiguousarray(m3200, np.float32), np.ascontiguousarray(m7000, np.float32), color_temp,
+                                  gamma, contrast, sharpen, black, white, matrix, curve, s)
+    return matrix.reshape(3, 4), curve, int(s[0])

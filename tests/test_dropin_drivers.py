@@ -62,3 +62,92 @@ def test_local_laplacian_process_cpp(tmp_path, oracle):
     inp16 = img8.astype(np.uint16) * 0x0101  # load_and_convert_image u8 -> u16 (tools/halide_image_io.h:194-196)
     want = oracle.local_laplacian(inp16, 8, float(np.float32(1.0) / np.float32(7)), 1.0)
     assert np.array_equal(got, want)
+
+
+def write_pgm(path, img, maxval):  # img: (H, W)
+    h, w = img.shape
+    with open(path, "wb") as f:
+        f.write(b"P5\n%d %d\n%d\n" % (w, h, maxval))
+        f.write(np.ascontiguousarray(img.astype(">u2" if maxval > 255 else np.uint8)).tobytes())
+
+
+def _quantise(out_f32, maxval):
+    # convert_and_save_image: float -> uint: lround(v * maxval) (tools/halide_image_io.h:180-182, :232-234)
+    return np.floor(out_f32.astype(np.float32) * np.float32(maxval) + np.float32(0.5)).astype(np.uint16)
+
+
+def _scene8(w, h, seed, ch):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = (np.sin(xx / 19.0 + seed) + np.cos(yy / 13.0) + 2.2) / 4.4
+    img = np.stack([base * (255 - 20 * c) for c in range(ch)]) + rng.normal(0, 7, (ch, h, w))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def _maxval(path):
+    with open(path, "rb") as f:
+        head = f.read(64).split()
+    return int(head[3])
+
+
+@pytest.mark.gpu
+def test_bilateral_grid_filter_cpp(tmp_path, oracle):
+    exe = _exe("bilateral_grid_filter")
+    img8 = _scene8(320, 200, 1, 1)[0]
+    src, dst = str(tmp_path / "in.pgm"), str(tmp_path / "out.pgm")
+    write_pgm(src, img8, 255)
+    r = subprocess.run([exe, src, dst, "0.1", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Success!" in r.stdout, r.stdout + r.stderr
+    got = read_pnm16(dst)[0]
+    inp = img8.astype(np.float32) / np.float32(255.0)  # u8 -> float (tools/halide_image_io.h:610-612)
+    want = oracle.bilateral_grid(inp, float(np.float32(0.1)))
+    assert np.array_equal(got, _quantise(want, _maxval(dst)))
+
+
+@pytest.mark.gpu
+def test_nl_means_process_cpp(tmp_path, oracle):
+    exe = _exe("nl_means_process")
+    img8 = _scene8(192, 120, 2, 3)
+    src, dst = str(tmp_path / "in.ppm"), str(tmp_path / "out.ppm")
+    write_ppm8(src, img8)
+    r = subprocess.run([exe, src, "7", "7", "0.12", "2", dst], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Success!" in r.stdout, r.stdout + r.stderr
+    got = read_pnm16(dst)
+    inp = img8.astype(np.float32) / np.float32(255.0)
+    want = oracle.nl_means(inp, 7, 7, float(np.float32(0.12)))
+    assert np.array_equal(got, _quantise(want, _maxval(dst)))
+
+
+@pytest.mark.gpu
+def test_stencil_chain_process_cpp(tmp_path, oracle):
+    exe = _exe("stencil_chain_process")
+    img8 = _scene8(256, 160, 3, 3)
+    src, dst = str(tmp_path / "in.ppm"), str(tmp_path / "out.pgm")
+    write_ppm8(src, img8)
+    r = subprocess.run([exe, src, "3", dst], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Success!" in r.stdout, r.stdout + r.stderr
+    got = read_pnm16(dst)[0]
+    red16 = img8[0].astype(np.uint16) * 0x0101  # process.cpp:26 takes channel 0 of the u16 conversion
+    assert np.array_equal(got, oracle.stencil_chain(red16))
+
+
+@pytest.mark.gpu
+def test_conv_layer_process_cpp():
+    exe = _exe("conv_layer_process")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Success!" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_camera_pipe_process_cpp(tmp_path, oracle):
+    exe = _exe("camera_pipe_process")
+    from test_camera_pipe import M3200, M7000, _raw
+    raw = _raw(352, 280, seed=6)
+    src, dst = str(tmp_path / "raw.pgm"), str(tmp_path / "out.ppm")
+    write_pgm(src, raw, 65535)
+    r = subprocess.run([exe, src, "3700", "2.0", "50", "1.0", "2", dst], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Success!" in r.stdout, r.stdout + r.stderr
+    got = read_pnm16(dst)
+    ow, oh = ((352 - 32) // 32) * 32, ((280 - 24) // 32) * 32  # process.cpp:34
+    want = oracle.camera_pipe(raw, M3200, M7000, 3700.0, 2.0, 50.0, 1.0, 25, 1023, ow, oh)
+    assert np.array_equal(got, want)
