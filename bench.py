@@ -137,9 +137,9 @@ def main():
         dom = max(per_frame, key=per_frame.get)
         dom_rec = next(k for k in kernels if k["name"] == dom)
         # algorithmic bytes per launch of each full-resolution kernel:
-        #   ll_level0_down: read u16x3 (6 B/px) + write 9 quarter-res f32 planes (9 B/px)  = 15 B/px
-        #   ll_level0_up  : read u16x3 (6) + 2 selected quarter-res planes (2) + outG1 (1) + write u16x3 (6) = 15 B/px
-        alg_bytes = {"ll_level0_down": 15, "ll_level0_up": 15}.get(dom, ALG_BYTES_PER_PX) * W * H
+        #   ll_down0: read u16x3 (6 B/px) + write 9 quarter-res f32 planes (9 B/px)  = 15 B/px
+        #   ll_up0  : read u16x3 (6) + 2 selected quarter-res planes (2) + outG1 (1) + write u16x3 (6) = 15 B/px
+        alg_bytes = {"ll_down0": 15, "ll_up0": 15}.get(dom, ALG_BYTES_PER_PX) * W * H
         achieved = alg_bytes / (dom_rec["avg_ms"] * 1e-3) / 1e9
         result = {
             "metric": "megapixels/sec local_laplacian 8-level fp32 4K",

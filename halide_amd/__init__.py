@@ -329,6 +329,21 @@ def local_laplacian(input, levels, alpha, beta, output) -> int:
     return _check(_ll(_as_ptr(input), int(levels), float(alpha), float(beta), _as_ptr(output)))
 
 
+def debug_local_laplacian_outg(level: int) -> np.ndarray:
+    """Test hook: outGPyramid[level] (restricted to the region R_level) of this thread's last
+    local_laplacian call, as an (rh, rw) float32 array."""
+    fn = lib.hlmi_debug_local_laplacian_outg
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    rw, rh = C.c_int(0), C.c_int(0)
+    if fn(level, None, 0, C.byref(rw), C.byref(rh)) != 0:
+        raise HalideError(-1, "no local_laplacian call to inspect")
+    out = np.zeros((rh.value, rw.value), np.float32)
+    if fn(level, out.ctypes.data_as(C.c_void_p), out.size, None, None) != 0:
+        raise HalideError(-1, "debug copy failed")
+    return out
+
+
 def bilateral_grid(input, r_sigma, output) -> int:
     return _check(_bg(_as_ptr(input), float(r_sigma), _as_ptr(output)))
 

@@ -7,36 +7,58 @@
 // Layout in HBM.  All Funcs of the reference are total functions on Z^2 and only the input is
 // edge-clamped (:28), so level j must be known a few pixels OUTSIDE ceil(W/2^j).  Because the clamp
 // makes level 0 constant beyond the image edge, level j is constant beyond
-//     lo_{j+1} = floor((lo_j - 2)/2),   hi_{j+1} = ceil((hi_j + 1)/2)      (lo_0, hi_0 = input min/max)
-// so each level is stored on [lo_j, hi_j]^2 only and reads are clamped to that box — bit-identical
-// to evaluating on the unbounded regions the reference's bounds inference demands.
-//   level j (1..7):  float G[j][K+1][h_j][w_j]  — planes 0..K-1 = gPyramid[j](.,.,k), plane K = inGPyramid[j]
-//                    float OUT[j][h_j][w_j]     — outGPyramid[j] on R_j
-//   remap LUT: 2*(K-1)*256+1 floats, built on the device by ll_remap_lut.
-// Launch chain (v1, one frame): lut, level0->1 (LDS tiled), 6x generic down, top, 6x generic up,
-// level-0 collapse+recolour = 16 launches on one stream.
+//     lo_{j+1} = floor((lo_j - 2)/2),   hi_{j+1} = floor((hi_j + 2)/2)      (lo_0, hi_0 = input min/max)
+// so each level is stored on a box [so_j, hi_j] x [loy_j, hiy_j] (so_j <= lo_j, see below) and reads are
+// clamped to that box — bit-identical to evaluating on the unbounded regions the reference's bounds
+// inference demands.
+//   level j (1..7):  float G[j][K+1][h_j][ws_j] — planes 0..K-1 = gPyramid[j](.,.,k), plane K = inGPyramid[j]
+//                    float OUT[j][h_j][ws_j]    — outGPyramid[j] on R_j
+//   row stride ws_j = w_j rounded up to 4 floats, plane stride a multiple of 4 floats: every row starts
+//   16-byte aligned.  The storage origin so_j is chosen (one column left of lo_j when necessary) so that the
+//   4-column groups the down-sampling waves load and the 2-column groups they store are naturally aligned.
+//
+// Kernels (one frame = 1 + 1 + 6 + 1 + 6 + 1 launches on one stream):
+//   ll_remap_lut   remap LUT (generator :23-25)
+//   ll_down0       level 0 -> 1, all K+1 planes; gray and gPyramid[0] never touch memory.  One WAVE owns a
+//                  strip of 126 level-1 columns x TY rows: each lane holds 4 adjacent level-0 columns, streams
+//                  down the rows with the vertical 1-3-3-1 window in registers (2 rows of state per plane),
+//                  exchanges the two edge columns with its neighbour lanes by DPP wave shifts for the
+//                  horizontal 1-3-3-1, and stores float2.  HBM-bound by design: 6 B/px read, 9 B/px written.
+//   ll_down_strip  level j -> j+1 (j >= 1), same wave-strip scheme, one plane per wave, float4 loads.
+//   ll_top, ll_up  outGPyramid[J-1], outGPyramid[j] (1 <= j <= J-2): pointwise, data-dependent plane gathers.
+//   ll_up0         outGPyramid[0] + recolour + u16 store, 2 columns per lane, LUT in LDS.
 #include "hlmi_device_math.h"
 #include "hlmi_internal.h"
+
+#include <atomic>
+#include <stdlib.h>
 
 using namespace hlmi;
 
 namespace {
 
-constexpr int J = 8;        // pyramid_levels (local_laplacian_generator.cpp:10)
-constexpr int MAX_K = 32;   // largest `levels` the LUT sizing below admits
+constexpr int J = 8;         // pyramid_levels (local_laplacian_generator.cpp:10)
+constexpr int MAX_K = 32;    // largest `levels` the LUT sizing below admits
+constexpr int STRIP = 126;   // level-(j+1) columns one wave produces per row (lanes 0..62 store a float2)
+constexpr int KCH = 8;       // planes of gPyramid one ll_down0 pass keeps in registers
 
 struct Level {
-    int lox, loy, w, h;     // stored box: x in [lox, lox+w-1]
-    int rx0, rx1, ry0, ry1; // R_j: region of outGPyramid[j] that is needed
-    float *g;               // (K+1) planes
-    float *out;             // outGPyramid[j]
+    int lox, loy;            // absolute coordinates of storage element [0][0]
+    int w, h;                // valid extent; reads clamp to [0,w-1] x [0,h-1] (storage coordinates)
+    int ws;                  // row stride in floats (multiple of 4)
+    size_t ps;               // plane stride in floats (multiple of 4)
+    int rx0, rx1, ry0, ry1;  // R_j: region of outGPyramid[j] that is needed (absolute)
+    float *g;                // (K+1) planes
+    float *out;              // outGPyramid[j]
+    // how level j is produced from level j-1 by the strip kernels
+    bool odd;                // lane's source columns are 2P-1..2P+2 (odd source origin) instead of 2P-2..2P+1
+    int nsx;                 // strips per row
 };
 
 struct Geometry {
-    int K, half;            // levels, (K-1)*256
+    int K, half;             // levels, (K-1)*256
     float Km1, inv_Km1;
-    int ix0, ix1, iy0, iy1; // clamp box of the input (absolute coordinates)
-    int ic0, ic1;           // channel clamp box
+    int ix0, ix1, iy0, iy1;  // clamp box of the input (absolute coordinates)
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -52,190 +74,432 @@ __device__ __forceinline__ float down4(float a, float b, float c, float d) {
     return ((a + 3.0f * (b + c)) + d) * 0.125f;  // (:270-271), "/ 8.0f" == "* 0.125f"
 }
 
-__device__ __forceinline__ float gray_of(const uint16_t *in, long sy, long sc, int x, int y, const Geometry &gm) {
-    // clamped(x,y,c) / 65535.0f -> * (1/65535.0f); gray = 0.299 f0 + 0.587 f1 + 0.114 f2  (:28-36)
-    int xc = dev::clampi(x, gm.ix0, gm.ix1) - gm.ix0, yc = dev::clampi(y, gm.iy0, gm.iy1) - gm.iy0;
-    const float r = 1.0f / 65535.0f;
-    long o = (long)yc * sy + xc;
-    int c0 = dev::clampi(0, gm.ic0, gm.ic1) - gm.ic0, c1 = dev::clampi(1, gm.ic0, gm.ic1) - gm.ic0,
-        c2 = dev::clampi(2, gm.ic0, gm.ic1) - gm.ic0;
-    float f0 = (float)in[o + c0 * sc] * r, f1 = (float)in[o + c1 * sc] * r, f2 = (float)in[o + c2 * sc] * r;
+// gray = 0.299 f0 + 0.587 f1 + 0.114 f2, f = u16 / 65535.0f -> * (1/65535.0f)   (:28-36)
+__device__ __forceinline__ float gray_from(uint16_t r, uint16_t g, uint16_t b) {
+    const float s = 1.0f / 65535.0f;
+    float f0 = (float)r * s, f1 = (float)g * s, f2 = (float)b * s;
     return (0.299f * f0 + 0.587f * f1) + 0.114f * f2;
 }
-
-// gPyramid[0](x,y,k) = beta*(gray - level) + level + remap(idx - 256*k)   (:41-44)
-__device__ __forceinline__ float g0_of(float gray, int idx, int k, float beta, float inv_Km1, const float *lut, int half) {
-    float level = (float)k * inv_Km1;
-    return (beta * (gray - level) + level) + lut[idx - 256 * k + half];
-}
 __device__ __forceinline__ int idx_of(float gray, float Km1, int half) {
-    return dev::clampi((int)((gray * Km1) * 256.0f), 0, half);
+    return dev::clampi((int)((gray * Km1) * 256.0f), 0, half);  // (:42-43)
+}
+// gPyramid[0](x,y,k) = beta*(gray - level) + level + remap(idx - 256*k)   (:41-44); `l` = remap value
+__device__ __forceinline__ float g0_val(float gray, float level, float beta, float l) {
+    return (beta * (gray - level) + level) + l;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// level 0 -> level 1: gray + gPyramid[0] are never materialised (the reference's CPU schedule does the
-// same, :184-188).  One workgroup produces a TX x TY tile of all K+1 planes of level 1.
-constexpr int TX = 64, TY = 8, GW = 2 * TX + 2, GH = 2 * TY + 2, KC = 5;
-
-template<bool LUT_IN_LDS>
-__global__ __launch_bounds__(256) void ll_level0_down(const uint16_t *__restrict__ in, long in_sy, long in_sc,
-                                                     Geometry gm, float beta, const float *__restrict__ lut_g,
-                                                     float *__restrict__ g1, int lox, int loy, int w1, int h1) {
-    extern __shared__ float smem[];
-    float *sgray = smem;                       // GH*GW
-    float *sdy = smem + GH * GW;               // KC*TY*GW
-    float *slut = sdy + KC * TY * GW;          // 2*half+1 (only if LUT_IN_LDS)
-    uint16_t *sidx = (uint16_t *)(slut + (LUT_IN_LDS ? 2 * gm.half + 1 : 0));  // GH*GW, idx <= 31*256
-    const int tid = threadIdx.x;
-    const int X0 = lox + blockIdx.x * TX, Y0 = loy + blockIdx.y * TY;  // level-1 coords of the tile origin
-    const int gx0 = 2 * X0 - 1, gy0 = 2 * Y0 - 1;                      // level-0 coords of the window origin
-
-    if (LUT_IN_LDS) {
-        for (int i = tid; i <= 2 * gm.half; i += 256) slut[i] = lut_g[i];
+// ---- lane <-> lane exchange: DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1), with a
+// ds_bpermute fallback chosen at run time if the probe kernel below disagrees with the DPP result.
+template<bool DPP>
+__device__ __forceinline__ float lane_prev(float v) {  // value held by lane-1 (undefined for lane 0)
+    if (DPP) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+    } else {
+        return __shfl_up(v, 1, 64);
     }
-    for (int i = tid; i < GH * GW; i += 256) {
-        int r = i / GW, c = i - r * GW;
-        float gr = gray_of(in, in_sy, in_sc, gx0 + c, gy0 + r, gm);
-        sgray[i] = gr;
-        sidx[i] = (uint16_t)idx_of(gr, gm.Km1, gm.half);
+}
+template<bool DPP>
+__device__ __forceinline__ float lane_next(float v) {  // value held by lane+1 (undefined for lane 63)
+    if (DPP) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+    } else {
+        return __shfl_down(v, 1, 64);
     }
-    __syncthreads();
-    const float *lut = LUT_IN_LDS ? slut : lut_g;
-    const size_t plane = (size_t)w1 * h1;
+}
+__global__ void ll_dpp_probe(int *ok) {
+    float v = (float)threadIdx.x;
+    float p = lane_prev<true>(v), n = lane_next<true>(v);
+    bool good = (threadIdx.x == 0 || p == v - 1.0f) && (threadIdx.x == 63 || n == v + 1.0f);
+    unsigned long long m = __ballot(good);
+    if (threadIdx.x == 0) *ok = (m == ~0ull) ? 1 : 0;
+}
 
-    for (int k0 = 0; k0 <= gm.K; k0 += KC) {
-        const int nk = min(KC, gm.K + 1 - k0);
-        // phase 1: vertical 1-3-3-1 on columns; thread <-> (plane kk, column c), walks the TY outputs
-        for (int it = tid; it < nk * GW; it += 256) {
-            int kk = it / GW, c = it - kk * GW;
-            int k = k0 + kk;
-            bool is_in = (k == gm.K);  // plane K: inGPyramid, gPyramid[0] replaced by gray itself (:58)
-            float v0, v1, v2, v3;
-            auto eval = [&](int r) -> float {
-                float gr = sgray[r * GW + c];
-                return is_in ? gr : g0_of(gr, sidx[r * GW + c], k, beta, gm.inv_Km1, lut, gm.half);
-            };
-            v0 = eval(0);
-            v1 = eval(1);
-#pragma unroll
-            for (int t = 0; t < TY; t++) {
-                v2 = eval(2 * t + 2);
-                v3 = eval(2 * t + 3);
-                sdy[(kk * TY + t) * GW + c] = down4(v0, v1, v2, v3);
-                v0 = v2;
-                v1 = v3;
-            }
-        }
-        __syncthreads();
-        // phase 2: horizontal 1-3-3-1, write level 1
-        for (int it = tid; it < nk * TY * TX; it += 256) {
-            int x = it % TX, t = (it / TX) % TY, kk = it / (TX * TY);
-            int ox = X0 + x - lox, oy = Y0 + t - loy;
-            if (ox < w1 && oy < h1) {
-                const float *d = &sdy[(kk * TY + t) * GW + 2 * x];
-                g1[(size_t)(k0 + kk) * plane + (size_t)oy * w1 + ox] = down4(d[0], d[1], d[2], d[3]);
-            }
-        }
-        __syncthreads();
+// Horizontal 1-3-3-1 of one output row.  dy[0..3] = vertical results of the lane's 4 adjacent source
+// columns q0..q0+3.  Returns the two outputs at destination columns (P, P+1), valid for lanes 0..62.
+//   !ODD: q0 = 2P-2: out(P-1) = f(left, dy0, dy1, dy2) and out(P) = f(dy1, dy2, dy3, right) are computed
+//         here, out(P+1) is the next lane's out(P-1)
+//    ODD: q0 = 2P-1: out(P) = f(dy0..dy3), out(P+1) = f(dy2, dy3, next.dy0, next.dy1)
+template<bool ODD, bool DPP>
+__device__ __forceinline__ float2 hpair(const float (&dy)[4]) {
+    if (!ODD) {
+        float left = lane_prev<DPP>(dy[3]);
+        float right = lane_next<DPP>(dy[0]);
+        float o0 = down4(left, dy[0], dy[1], dy[2]);
+        float o1 = down4(dy[1], dy[2], dy[3], right);
+        float o2 = lane_next<DPP>(o0);
+        return make_float2(o1, o2);
+    } else {
+        float r0 = lane_next<DPP>(dy[0]), r1 = lane_next<DPP>(dy[1]);
+        float o0 = down4(dy[0], dy[1], dy[2], dy[3]);
+        float o1 = down4(dy[2], dy[3], r0, r1);
+        return make_float2(o0, o1);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// generic level j -> j+1 (j >= 1): one thread per output element of one plane; 16 clamped taps
-__global__ __launch_bounds__(256) void ll_down(const float *__restrict__ src, int slox, int sloy, int sw, int sh,
-                                               float *__restrict__ dst, int dlox, int dloy, int dw, int dh) {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= dw) return;
-    const float *s = src + (size_t)blockIdx.z * sw * sh;
-    int X = dlox + x, Y = dloy + y;
-    int c[4], r[4];
+// Clamped 4-column groups.  A lane needs source columns o..o+3 (storage coordinates, o a multiple of 4 by
+// construction) clamped to [0, w-1].  It always loads the ALIGNED quad at oq = clamp(o, 0, (w-1) & ~3) and,
+// only in waves that touch an edge (wave-uniform branch), picks element sel[i] = clamp(o+i, 0, w-1) - oq of
+// that quad for column i.  Memory-safe when the row is readable up to ((w-1)|3), which the padded level
+// rows always are and the input is when its width is a multiple of 4.
+struct QuadSel {
+    int oq;        // storage column of the quad that is loaded
+    int sel[4];    // which of its elements column i takes
+    bool plain;    // sel == {0,1,2,3}
+};
+__device__ __forceinline__ QuadSel quad_sel(int o, int w) {
+    QuadSel q;
+    q.oq = dev::clampi(o, 0, (w - 1) & ~3);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        c[i] = dev::clampi(2 * X - 1 + i - slox, 0, sw - 1);
-        r[i] = dev::clampi(2 * Y - 1 + i - sloy, 0, sh - 1);
-    }
-    float dy[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        dy[i] = down4(s[(size_t)r[0] * sw + c[i]], s[(size_t)r[1] * sw + c[i]], s[(size_t)r[2] * sw + c[i]],
-                      s[(size_t)r[3] * sw + c[i]]);
-    }
-    dst[(size_t)blockIdx.z * dw * dh + (size_t)y * dw + x] = down4(dy[0], dy[1], dy[2], dy[3]);
+    for (int i = 0; i < 4; i++) q.sel[i] = dev::clampi(o + i, 0, w - 1) - q.oq;
+    q.plain = (o >= 0) && (o + 3 <= w - 1);
+    return q;
+}
+template<typename T>
+__device__ __forceinline__ T pick4(T x, T y, T z, T w, int s) {
+    T lo = (s & 1) ? y : x, hi = (s & 1) ? w : z;
+    return (s & 2) ? hi : lo;
 }
 
-// upsample(f)(X,Y) (:276-282) of a stored level plane `f` (origin lox/loy, width w)
-__device__ __forceinline__ float up_at(const float *__restrict__ f, int lox, int loy, int w, int X, int Y) {
+// ---------------------------------------------------------------------------------------------------
+// level 0 -> level 1
+struct Raw {
+    ushort4 c0, c1, c2;  // the lane's 4 columns of the three (clamped) colour channels of one input row
+};
+struct Levels {
+    float v[MAX_K];      // level_k = k * (1 / (levels - 1))  (:41), kernel-argument (scalar) operands
+};
+
+template<bool VEC>
+__device__ __forceinline__ void load_raw(Raw &r, const uint16_t *__restrict__ rp, long co0, long co1, long co2,
+                                         int oq, const int (&xo)[4]) {
+    if (VEC) {
+        r.c0 = *reinterpret_cast<const ushort4 *>(rp + co0 + oq);
+        r.c1 = *reinterpret_cast<const ushort4 *>(rp + co1 + oq);
+        r.c2 = *reinterpret_cast<const ushort4 *>(rp + co2 + oq);
+    } else {
+        r.c0 = make_ushort4(rp[co0 + xo[0]], rp[co0 + xo[1]], rp[co0 + xo[2]], rp[co0 + xo[3]]);
+        r.c1 = make_ushort4(rp[co1 + xo[0]], rp[co1 + xo[1]], rp[co1 + xo[2]], rp[co1 + xo[3]]);
+        r.c2 = make_ushort4(rp[co2 + xo[0]], rp[co2 + xo[1]], rp[co2 + xo[2]], rp[co2 + xo[3]]);
+    }
+}
+
+// 165 VGPRs: 3 waves/SIMD; the scalar-load variant (odd strides / widths) needs more and is not the fast path
+#ifndef LL_D0_WAVES
+#define LL_D0_WAVES 3
+#endif
+template<bool ODD, bool DPP, bool VEC, bool LUT_LDS>
+__global__ __launch_bounds__(128, VEC ? LL_D0_WAVES : 2) void ll_down0(const uint16_t *__restrict__ in, long in_sy, long co0,
+                                                             long co1, long co2, Geometry gm, Levels lev, float beta,
+                                                             const float *__restrict__ lut_g, float *__restrict__ g1,
+                                                             int Xs, int loy1, int w1, int h1, int ws1, size_t ps1,
+                                                             int nsx, int nunits, int TY) {
+    extern __shared__ float slut[];
+    if (LUT_LDS) {
+        for (int i = threadIdx.x; i <= 2 * gm.half; i += 128) slut[i] = lut_g[i];
+        __syncthreads();
+    }
+    const float *lut = LUT_LDS ? slut : lut_g;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> scalar control flow
+    const int unit = blockIdx.x * 2 + wave;
+    if (unit >= nunits) return;
+    const int lane = threadIdx.x & 63;
+    const int sx = unit % nsx, sy = unit / nsx;
+    const int off = STRIP * sx + 2 * lane;        // destination storage column of the lane's pair
+    const int P = Xs + off;                       // absolute level-1 column of the pair
+    const int q0 = ODD ? 2 * P - 1 : 2 * P - 2;   // absolute level-0 column of the lane's first source column
+    const int iw = gm.ix1 - gm.ix0 + 1, ih = gm.iy1 - gm.iy0;
+    const QuadSel qs = quad_sel(q0 - gm.ix0, iw);
+    int xo[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) xo[i] = qs.oq + qs.sel[i];
+    const bool edge_wave = VEC && __any(!qs.plain);
+    const bool store_ok = (lane < 63) && (off < w1);
+    const int t0 = sy * TY, t1 = min(t0 + TY, h1) - 1;  // level-1 storage rows of this unit
+
+    auto row_ptr = [&](int y_abs) -> const uint16_t * {
+        return in + (long)(dev::clampi(y_abs - gm.iy0, 0, ih)) * in_sy;
+    };
+
+    for (int kb = 0; kb < gm.K; kb += KCH) {
+        const int nk = min(KCH, gm.K - kb);
+        const bool with_in = (kb == 0);  // plane K (inGPyramid[1], :58-61) rides along with the first chunk
+        const int lbase = gm.half - 256 * (kb + KCH - 1);  // lut index of plane kb+7 is idx + lbase (< 0 only if unused)
+
+        float a[KCH + 1][4], b[KCH + 1][4];
+        // gray and LUT position of the lane's 4 pixels of one input row
+        auto gray_row = [&](const Raw &r, float (&gr)[4], int (&li)[4]) {
+            const uint16_t rr[4] = {r.c0.x, r.c0.y, r.c0.z, r.c0.w};
+            const uint16_t gg[4] = {r.c1.x, r.c1.y, r.c1.z, r.c1.w};
+            const uint16_t bb[4] = {r.c2.x, r.c2.y, r.c2.z, r.c2.w};
+            float g[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) g[i] = gray_from(rr[i], gg[i], bb[i]);
+            if (edge_wave) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) gr[i] = pick4(g[0], g[1], g[2], g[3], qs.sel[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) gr[i] = g[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) li[i] = idx_of(gr[i], gm.Km1, gm.half) + lbase;
+        };
+        // gPyramid[0](., ., kb+kk) (kk < KCH) or gray itself (kk == KCH: the inGPyramid plane)
+        auto plane_val = [&](int kk, float gr, int li) -> float {
+            return kk < KCH ? g0_val(gr, lev.v[kb + (kk < KCH ? kk : 0)], beta, lut[li + 256 * (KCH - 1 - kk)]) : gr;
+        };
+
+        const int T0 = loy1 + t0;
+        {
+            Raw ra, rb;
+            load_raw<VEC>(ra, row_ptr(2 * T0 - 1), co0, co1, co2, qs.oq, xo);
+            load_raw<VEC>(rb, row_ptr(2 * T0), co0, co1, co2, qs.oq, xo);
+            float gra[4], grb[4];
+            int la[4], lb[4];
+            gray_row(ra, gra, la);
+            gray_row(rb, grb, lb);
+#pragma unroll
+            for (int kk = 0; kk <= KCH; kk++) {
+                if (kk < KCH ? (kk < nk) : with_in) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        a[kk][i] = plane_val(kk, gra[i], la[i]);
+                        b[kk][i] = plane_val(kk, grb[i], lb[i]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        Raw rc, rd;
+        load_raw<VEC>(rc, row_ptr(2 * T0 + 1), co0, co1, co2, qs.oq, xo);
+        load_raw<VEC>(rd, row_ptr(2 * T0 + 2), co0, co1, co2, qs.oq, xo);
+        for (int t = t0; t <= t1; t++) {
+            const int T = loy1 + t;
+            Raw nc = rc, nd = rd;
+            if (t < t1) {  // prefetch the next two input rows while this pair is being reduced
+                load_raw<VEC>(nc, row_ptr(2 * T + 3), co0, co1, co2, qs.oq, xo);
+                load_raw<VEC>(nd, row_ptr(2 * T + 4), co0, co1, co2, qs.oq, xo);
+            }
+            float grc[4], grd[4];
+            int lc[4], ld[4];
+            gray_row(rc, grc, lc);
+            gray_row(rd, grd, ld);
+            float *drow = g1 + (size_t)t * ws1 + off;
+#pragma unroll
+            for (int kk = 0; kk <= KCH; kk++) {
+                if (kk < KCH ? (kk < nk) : with_in) {
+                    float dy[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        float cv = plane_val(kk, grc[i], lc[i]), dv = plane_val(kk, grd[i], ld[i]);
+                        dy[i] = down4(a[kk][i], b[kk][i], cv, dv);
+                        a[kk][i] = cv;
+                        b[kk][i] = dv;
+                    }
+                    float2 o = hpair<ODD, DPP>(dy);
+                    const int plane = (kk < KCH) ? kb + kk : gm.K;
+                    if (store_ok) *reinterpret_cast<float2 *>(drow + (size_t)plane * ps1) = o;
+                }
+                // keep the planes sequential: hoisting all 64 LUT reads of a row pair costs 64 VGPRs
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            rc = nc;
+            rd = nd;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// level j -> j+1 (j >= 1): one wave = (strip of 126 destination columns, TY rows, one plane)
+template<bool ODD, bool DPP>
+__global__ __launch_bounds__(256) void ll_down_strip(const float *__restrict__ src, int slox, int sloy, int sw, int sh,
+                                                     int sws, size_t sps, float *__restrict__ dst, int Xs, int dloy,
+                                                     int dw, int dh, int dws, size_t dps, int nsx, int nsy, int nunits,
+                                                     int TY) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int unit = blockIdx.x * 4 + wave;
+    if (unit >= nunits) return;
+    const int lane = threadIdx.x & 63;
+    const int sx = unit % nsx, rest = unit / nsx, sy = rest % nsy, plane = rest / nsy;
+    const int off = STRIP * sx + 2 * lane;
+    const int P = Xs + off;
+    const QuadSel qs = quad_sel((ODD ? 2 * P - 1 : 2 * P - 2) - slox, sw);
+    const bool edge_wave = __any(!qs.plain);
+    const bool store_ok = (lane < 63) && (off < dw);
+    const int t0 = sy * TY, t1 = min(t0 + TY, dh) - 1;
+    const float *sp = src + (size_t)plane * sps + qs.oq;
+    float *dp = dst + (size_t)plane * dps + off;
+    auto row = [&](int y_abs) -> float4 {
+        float4 v = *reinterpret_cast<const float4 *>(sp + (size_t)dev::clampi(y_abs - sloy, 0, sh - 1) * sws);
+        if (edge_wave) {
+            v = make_float4(pick4(v.x, v.y, v.z, v.w, qs.sel[0]), pick4(v.x, v.y, v.z, v.w, qs.sel[1]),
+                            pick4(v.x, v.y, v.z, v.w, qs.sel[2]), pick4(v.x, v.y, v.z, v.w, qs.sel[3]));
+        }
+        return v;
+    };
+    const int T0 = dloy + t0;
+    float4 a = row(2 * T0 - 1), b = row(2 * T0), c = row(2 * T0 + 1), d = row(2 * T0 + 2);
+    for (int t = t0; t <= t1; t++) {
+        const int T = dloy + t;
+        float4 nc = c, nd = d;
+        if (t < t1) {
+            nc = row(2 * T + 3);
+            nd = row(2 * T + 4);
+        }
+        float dy[4] = {down4(a.x, b.x, c.x, d.x), down4(a.y, b.y, c.y, d.y), down4(a.z, b.z, c.z, d.z),
+                       down4(a.w, b.w, c.w, d.w)};
+        float2 o = hpair<ODD, DPP>(dy);
+        if (store_ok) *reinterpret_cast<float2 *>(dp + (size_t)t * dws) = o;
+        a = c, b = d, c = nc, d = nd;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// upsample(f)(X,Y) (:276-282) of a stored level plane `f` (origin lox/loy, row stride ws)
+__device__ __forceinline__ float up_at(const float *__restrict__ f, int lox, int loy, int ws, int X, int Y) {
     int xa = dev::fdiv2(X + 1) - lox, xb = dev::fdiv2(X - 1) - lox;
     int ya = dev::fdiv2(Y + 1) - loy, yb = dev::fdiv2(Y - 1) - loy;
     float wx = (float)(dev::fmod2(X) * 2 + 1) * 0.25f, wy = (float)(dev::fmod2(Y) * 2 + 1) * 0.25f;
-    float ua = dev::lerpf(f[(size_t)ya * w + xa], f[(size_t)ya * w + xb], wx);
-    float ub = dev::lerpf(f[(size_t)yb * w + xa], f[(size_t)yb * w + xb], wx);
+    float ua = dev::lerpf(f[(size_t)ya * ws + xa], f[(size_t)ya * ws + xb], wx);
+    float ub = dev::lerpf(f[(size_t)yb * ws + xa], f[(size_t)yb * ws + xb], wx);
     return dev::lerpf(ua, ub, wy);
 }
 
 // outGPyramid[J-1] = outLPyramid[J-1] (:76, :63-72 with lPyramid[J-1] = gPyramid[J-1], :51)
-__global__ void ll_top(const float *__restrict__ g, int w, int h, int lox, int loy, int rx0, int ry0, int rw, int rh,
-                       int K, float Km1, float *__restrict__ out) {
+__global__ void ll_top(const float *__restrict__ g, int ws, size_t ps, int lox, int loy, int rx0, int ry0, int rw,
+                       int rh, int K, float Km1, float *__restrict__ out) {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= rw || y >= rh) return;
-    size_t o = (size_t)(ry0 + y - loy) * w + (rx0 + x - lox), plane = (size_t)w * h;
-    float level = g[(size_t)K * plane + o] * Km1;
+    size_t o = (size_t)(ry0 + y - loy) * ws + (rx0 + x - lox);
+    float level = g[(size_t)K * ps + o] * Km1;
     int li = dev::clampi((int)level, 0, K - 2);
     float lf = level - (float)li;
-    out[o] = (1.0f - lf) * g[(size_t)li * plane + o] + lf * g[(size_t)(li + 1) * plane + o];
+    out[o] = (1.0f - lf) * g[(size_t)li * ps + o] + lf * g[(size_t)(li + 1) * ps + o];
 }
 
 // outGPyramid[j] = upsample(outGPyramid[j+1]) + outLPyramid[j], 1 <= j <= J-2 (:50-54, :63-79)
-__global__ __launch_bounds__(256) void ll_up(const float *__restrict__ g, int w, int h, int lox, int loy,
-                                             const float *__restrict__ gc, const float *__restrict__ outc, int cw,
-                                             int ch, int clox, int cloy, int rx0, int ry0, int rw, int rh, int K,
+__global__ __launch_bounds__(256) void ll_up(const float *__restrict__ g, int ws, size_t ps, int lox, int loy,
+                                             const float *__restrict__ gc, const float *__restrict__ outc, int cws,
+                                             size_t cps, int clox, int cloy, int rx0, int ry0, int rw, int rh, int K,
                                              float Km1, float *__restrict__ out) {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= rw || y >= rh) return;
     int X = rx0 + x, Y = ry0 + y;
-    size_t o = (size_t)(Y - loy) * w + (X - lox), plane = (size_t)w * h, cplane = (size_t)cw * ch;
-    float level = g[(size_t)K * plane + o] * Km1;
+    size_t o = (size_t)(Y - loy) * ws + (X - lox);
+    float level = g[(size_t)K * ps + o] * Km1;
     int li = dev::clampi((int)level, 0, K - 2);
     float lf = level - (float)li;
-    float l0 = g[(size_t)li * plane + o] - up_at(gc + (size_t)li * cplane, clox, cloy, cw, X, Y);
-    float l1 = g[(size_t)(li + 1) * plane + o] - up_at(gc + (size_t)(li + 1) * cplane, clox, cloy, cw, X, Y);
+    float l0 = g[(size_t)li * ps + o] - up_at(gc + (size_t)li * cps, clox, cloy, cws, X, Y);
+    float l1 = g[(size_t)(li + 1) * ps + o] - up_at(gc + (size_t)(li + 1) * cps, clox, cloy, cws, X, Y);
     float outL = (1.0f - lf) * l0 + lf * l1;
-    out[o] = up_at(outc, clox, cloy, cw, X, Y) + outL;
+    out[o] = up_at(outc, clox, cloy, cws, X, Y) + outL;
 }
 
+// ---------------------------------------------------------------------------------------------------
 // level 0: outGPyramid[0], colour, u16 (:63-87).  gray / gPyramid[0] recomputed pointwise.
-template<bool LUT_IN_LDS>
-__global__ __launch_bounds__(256) void ll_level0_up(const uint16_t *__restrict__ in, long in_sy, long in_sc, Geometry gm,
-                                                   float beta, const float *__restrict__ lut_g,
-                                                   const float *__restrict__ g1, const float *__restrict__ out1, int w1,
-                                                   int h1, int lox1, int loy1, uint16_t *__restrict__ out, long out_sy,
-                                                   long out_sc, int ox0, int oy0, int ow, int oh, int oc0, int nc) {
+// Workgroup = 4 waves as 2 x 2; a wave covers 128 columns x RU rows, a lane 2 adjacent columns.
+struct Up0Args {
+    const uint16_t *in;
+    long in_sy;
+    long gco[3];             // clamped channel offsets feeding `gray`
+    long cco[3];             // channel offsets of the (unclamped) colour read, per output channel
+    const float *lut_g, *g1, *out1;
+    int lox1, loy1, ws1;
+    size_t ps1;
+    uint16_t *out;
+    long out_sy, out_sc;
+    int ox0, oy0, ow, oh, nc, RU;
+    int same_ch;             // the colour channels are exactly the gray channels: load once
+    float beta;
+};
+
+template<bool VEC, bool LUT_LDS>
+__global__ __launch_bounds__(256) void ll_up0(Up0Args p, Geometry gm) {
     extern __shared__ float slut[];
-    if (LUT_IN_LDS) {
-        for (int i = threadIdx.x; i <= 2 * gm.half; i += 256) slut[i] = lut_g[i];
+    if (LUT_LDS) {
+        for (int i = threadIdx.x; i <= 2 * gm.half; i += 256) slut[i] = p.lut_g[i];
         __syncthreads();
     }
-    const float *lut = LUT_IN_LDS ? slut : lut_g;
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= ow) return;
-    int X = ox0 + x, Y = oy0 + y;
-    float gray = gray_of(in, in_sy, in_sc, X, Y, gm);
-    float level = gray * gm.Km1;
-    int li = dev::clampi((int)level, 0, gm.K - 2);
-    float lf = level - (float)li;
-    int idx = idx_of(gray, gm.Km1, gm.half);
-    size_t plane1 = (size_t)w1 * h1;
-    float l0 = g0_of(gray, idx, li, beta, gm.inv_Km1, lut, gm.half) - up_at(g1 + (size_t)li * plane1, lox1, loy1, w1, X, Y);
-    float l1 = g0_of(gray, idx, li + 1, beta, gm.inv_Km1, lut, gm.half) -
-               up_at(g1 + (size_t)(li + 1) * plane1, lox1, loy1, w1, X, Y);
-    float outL = (1.0f - lf) * l0 + lf * l1;
-    float og = (up_at(out1, lox1, loy1, w1, X, Y) + outL) + 0.01f;
-    float gr = gray + 0.01f;
-    long io = (long)(Y - gm.iy0) * in_sy + (X - gm.ix0), oo = (long)y * out_sy + x;
-    for (int c = 0; c < nc; c++) {
-        // color = input * (outG0 + eps) / (gray + eps); input is the UNclamped input here (:84)
-        float v = ((float)in[io + (long)(oc0 + c - gm.ic0) * in_sc] * og) / gr;
-        out[oo + (long)c * out_sc] = (uint16_t)dev::clampf(v, 0.0f, 65535.0f);
+    const float *lut = LUT_LDS ? slut : p.lut_g;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 256 + (wave & 1) * 128 + 2 * lane;  // output storage column of the lane's pair
+    const int y0 = blockIdx.y * (2 * p.RU) + (wave >> 1) * p.RU;
+    if (x >= p.ow || y0 >= p.oh) return;
+    const int npx = min(2, p.ow - x);
+    const int y1 = min(y0 + p.RU, p.oh);
+    const int X = p.ox0 + x;
+    const bool vec = VEC && npx == 2;
+    for (int y = y0; y < y1; y++) {
+        const int Y = p.oy0 + y;
+        const uint16_t *ip = p.in + (long)(Y - gm.iy0) * p.in_sy + (X - gm.ix0);
+        uint16_t *op = p.out + (long)y * p.out_sy + x;
+        uint16_t gch[3][2], cch[3][2];
+        if (vec) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                ushort2 v = *reinterpret_cast<const ushort2 *>(ip + p.gco[c]);
+                gch[c][0] = v.x, gch[c][1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                gch[c][0] = ip[p.gco[c]];
+                gch[c][1] = npx == 2 ? ip[p.gco[c] + 1] : gch[c][0];
+            }
+        }
+        if (p.same_ch) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) cch[c][0] = gch[c][0], cch[c][1] = gch[c][1];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                if (c < p.nc) {
+                    cch[c][0] = ip[p.cco[c]];
+                    cch[c][1] = npx == 2 ? ip[p.cco[c] + 1] : cch[c][0];
+                } else {
+                    cch[c][0] = cch[c][1] = 0;
+                }
+            }
+        }
+        uint16_t res[3][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int Xi = X + i;
+            float gray = gray_from(gch[0][i], gch[1][i], gch[2][i]);
+            float level = gray * gm.Km1;
+            int li = dev::clampi((int)level, 0, gm.K - 2);
+            float lf = level - (float)li;
+            int idx = idx_of(gray, gm.Km1, gm.half);
+            const float *lp = lut + (idx - 256 * li + gm.half);
+            float lev0 = (float)li * gm.inv_Km1, lev1 = (float)(li + 1) * gm.inv_Km1;
+            const float *gp = p.g1 + (size_t)li * p.ps1;
+            float l0 = g0_val(gray, lev0, p.beta, lp[0]) - up_at(gp, p.lox1, p.loy1, p.ws1, Xi, Y);
+            float l1 = g0_val(gray, lev1, p.beta, lp[-256]) - up_at(gp + p.ps1, p.lox1, p.loy1, p.ws1, Xi, Y);
+            float outL = (1.0f - lf) * l0 + lf * l1;
+            float og = (up_at(p.out1, p.lox1, p.loy1, p.ws1, Xi, Y) + outL) + 0.01f;
+            float gr = gray + 0.01f;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                // color = input * (outG0 + eps) / (gray + eps); input is the UNclamped input here (:84)
+                float v = ((float)cch[c][i] * og) / gr;
+                res[c][i] = (uint16_t)dev::clampf(v, 0.0f, 65535.0f);
+            }
+        }
+        if (vec) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                if (c < p.nc) *reinterpret_cast<ushort2 *>(op + (long)c * p.out_sc) = make_ushort2(res[c][0], res[c][1]);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                if (c < p.nc) {
+                    op[(long)c * p.out_sc] = res[c][0];
+                    if (npx == 2) op[(long)c * p.out_sc + 1] = res[c][1];
+                }
+            }
+        }
     }
 }
 
@@ -256,6 +520,40 @@ const halide_filter_argument_t ll_args[5] = {
     {"output", halide_argument_kind_output_buffer, 3, ty_u16, nullptr, nullptr, nullptr, nullptr, buf_est},
 };
 const halide_filter_metadata_t ll_md = {1, 5, ll_args, kTargetString, "local_laplacian"};
+
+// ---- run-time switches (all default to the fast path; the env overrides exist for A/B measurements)
+int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+
+// 1 = DPP wave shifts verified on this device, 0 = use ds_bpermute shuffles
+std::atomic<int> g_dpp_state{-1};
+int dpp_usable(void *uc, const DeviceCtx &ctx, int *out) {
+    int s = g_dpp_state.load();
+    if (s < 0) {
+        if (env_int("HLMI_LL_NO_DPP", 0)) {
+            s = 0;
+        } else {
+            int *flag = nullptr;
+            HLMI_HIP(uc, hipMalloc(&flag, sizeof(int)));
+            HLMI_HIP(uc, hipMemsetAsync(flag, 0, sizeof(int), ctx.stream));
+            hipLaunchKernelGGL(ll_dpp_probe, dim3(1), dim3(64), 0, ctx.stream, flag);
+            int h = 0;
+            HLMI_HIP(uc, hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, ctx.stream));
+            HLMI_HIP(uc, hipStreamSynchronize(ctx.stream));
+            HLMI_HIP(uc, hipFree(flag));
+            s = h ? 1 : 0;
+        }
+        g_dpp_state.store(s);
+    }
+    *out = s;
+    return 0;
+}
+
+// last call's level table, for hlmi_debug_local_laplacian_outg (tests only)
+thread_local Level t_dbg_lv[J];
+thread_local hipStream_t t_dbg_stream = nullptr;
 
 }  // namespace
 
@@ -282,6 +580,10 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
                       "Parameter levels is %d but must be in [2, %d]", levels, MAX_K);
     }
     const int ow = output->dim[0].extent, oh = output->dim[1].extent, nc = output->dim[2].extent;
+    if (nc > 3) {
+        // `color` is defined for c in [0,3) only (:84 reads input(x,y,c), whose extent the check above bounds)
+        return report(uc, halide_error_code_constraint_violated, "Output buffer output has %d channels, at most 3 supported", nc);
+    }
 
     DeviceCtx ctx;
     if ((r = acquire_device(uc, &ctx))) return r;
@@ -291,6 +593,8 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         mark_output_written(output);
         return 0;
     }
+    int use_dpp = 0;
+    if ((r = dpp_usable(uc, ctx, &use_dpp))) return r;
 
     Geometry gm;
     gm.K = levels;
@@ -299,25 +603,37 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     gm.inv_Km1 = 1.0f / gm.Km1;
     gm.ix0 = input->dim[0].min, gm.ix1 = gm.ix0 + input->dim[0].extent - 1;
     gm.iy0 = input->dim[1].min, gm.iy1 = gm.iy0 + input->dim[1].extent - 1;
-    gm.ic0 = input->dim[2].min, gm.ic1 = gm.ic0 + input->dim[2].extent - 1;
+    const int ic0 = input->dim[2].min, ic1 = ic0 + input->dim[2].extent - 1;
 
-    // per-level boxes
+    // per-level boxes.  lo/hi: beyond them the level is constant; so: storage origin (<= lo) whose parity
+    // makes the strip kernels' 16-byte loads / 8-byte stores aligned (see ll_down0 / hpair).
     Level lv[J];
-    int lox = gm.ix0, hix = gm.ix1, loy = gm.iy0, hiy = gm.iy1;
+    int lox = gm.ix0, hix = gm.ix1, loy = gm.iy0, hiy = gm.iy1, so = gm.ix0;
     int rx0 = output->dim[0].min, rx1 = rx0 + ow - 1, ry0 = output->dim[1].min, ry1 = ry0 + oh - 1;
     size_t ws_floats = (size_t)(2 * gm.half + 1 + 63) & ~(size_t)63;
-    size_t off[J], off_out[J];
+    size_t off_g[J], off_out[J];
     for (int j = 0; j < J; j++) {
-        lv[j].lox = lox, lv[j].loy = loy, lv[j].w = hix - lox + 1, lv[j].h = hiy - loy + 1;
-        lv[j].rx0 = rx0, lv[j].rx1 = rx1, lv[j].ry0 = ry0, lv[j].ry1 = ry1;
+        Level &L = lv[j];
+        L.lox = so, L.loy = loy, L.w = hix - so + 1, L.h = hiy - loy + 1;
+        L.ws = (L.w + 3) & ~3;
+        L.ps = ((size_t)L.ws * L.h + 3) & ~(size_t)3;
+        L.rx0 = rx0, L.rx1 = rx1, L.ry0 = ry0, L.ry1 = ry1;
         if (j >= 1) {
-            off[j] = ws_floats;
-            ws_floats += ((size_t)(levels + 1) * lv[j].w * lv[j].h + 63) & ~(size_t)63;
+            off_g[j] = ws_floats;
+            ws_floats += ((size_t)(levels + 1) * L.ps + 63) & ~(size_t)63;
             off_out[j] = ws_floats;
-            ws_floats += ((size_t)lv[j].w * lv[j].h + 63) & ~(size_t)63;
+            ws_floats += (L.ps + 63) & ~(size_t)63;
         }
+        // next level
+        const bool odd = (so & 1) != 0;
+        const int par = odd ? (floor_div(so + 1, 2) & 1) : ((floor_div(so, 2) + 1) & 1);
         lox = floor_div(lox - 2, 2), hix = floor_div(hix + 2, 2);
         loy = floor_div(loy - 2, 2), hiy = floor_div(hiy + 2, 2);
+        so = lox - ((lox - par) & 1);
+        if (j + 1 < J) {
+            lv[j + 1].odd = odd;
+            lv[j + 1].nsx = (hix - so + 1 + STRIP - 1) / STRIP;
+        }
         rx0 = floor_div(rx0 - 1, 2), rx1 = floor_div(rx1 + 1, 2);
         ry0 = floor_div(ry0 - 1, 2), ry1 = floor_div(ry1 + 1, 2);
     }
@@ -325,57 +641,108 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     if ((r = get_workspace(uc, ctx, ws_floats * sizeof(float), &ws))) return r;
     float *wsf = (float *)ws;
     float *lut = wsf;
-    for (int j = 1; j < J; j++) lv[j].g = wsf + off[j], lv[j].out = wsf + off_out[j];
+    for (int j = 1; j < J; j++) lv[j].g = wsf + off_g[j], lv[j].out = wsf + off_out[j];
+    lv[0].g = lv[0].out = nullptr;
+    for (int j = 0; j < J; j++) t_dbg_lv[j] = lv[j];
+    t_dbg_stream = ctx.stream;
 
     const uint16_t *din = dev_ptr<uint16_t>(input);
     uint16_t *dout = dev_ptr<uint16_t>(output);
     const long in_sy = input->dim[1].stride, in_sc = input->dim[2].stride;
     const long out_sy = output->dim[1].stride, out_sc = output->dim[2].stride;
+    // clamped channels feeding `gray` (repeat_edge clamps the channel coordinate too, :28)
+    long gco[3];
+    for (int c = 0; c < 3; c++) gco[c] = (long)((c < ic0 ? ic0 : (c > ic1 ? ic1 : c)) - ic0) * in_sc;
     hipStream_t st = ctx.stream;
-    const bool lut_lds = levels <= 15;  // LUT + tile must fit the default 64 KB dynamic-LDS window
+    const bool lut_lds = levels <= 15;  // LUT must fit the default 64 KB dynamic-LDS window
     const int nlut = 2 * gm.half + 1;
+    const size_t lut_sh = lut_lds ? sizeof(float) * nlut : 0;
 
     HLMI_LAUNCH(uc, "ll_remap_lut", st, ll_remap_lut, dim3((nlut + 255) / 256), dim3(256), 0, lut, gm.half, alpha);
     {
-        dim3 grid((lv[1].w + TX - 1) / TX, (lv[1].h + TY - 1) / TY);
-        size_t sh = sizeof(float) * (GH * GW + KC * TY * GW + (lut_lds ? nlut : 0)) + sizeof(uint16_t) * GH * GW;
-        if (lut_lds) {
-            HLMI_LAUNCH(uc, "ll_level0_down", st, ll_level0_down<true>, grid, dim3(256), sh, din, in_sy, in_sc, gm, beta,
-                        lut, lv[1].g, lv[1].lox, lv[1].loy, lv[1].w, lv[1].h);
-        } else {
-            HLMI_LAUNCH(uc, "ll_level0_down", st, ll_level0_down<false>, grid, dim3(256), sh, din, in_sy, in_sc, gm, beta,
-                        lut, lv[1].g, lv[1].lox, lv[1].loy, lv[1].w, lv[1].h);
+        const Level &d = lv[1];
+        const int TY = max(1, env_int("HLMI_LL_TY0", 8));
+        const int nsy = (d.h + TY - 1) / TY, nunits = d.nsx * nsy;
+        const int iw = gm.ix1 - gm.ix0 + 1;
+        const bool vec = ((uintptr_t)din % 8 == 0) && in_sy % 4 == 0 && gco[0] % 4 == 0 && gco[1] % 4 == 0 &&
+                         gco[2] % 4 == 0 && iw % 4 == 0 && !env_int("HLMI_LL_NO_VEC", 0);
+        Levels lev;
+        for (int k = 0; k < MAX_K; k++) lev.v[k] = (float)k * gm.inv_Km1;
+        const int variant = (d.odd ? 8 : 0) | (use_dpp ? 4 : 0) | (vec ? 2 : 0) | (lut_lds ? 1 : 0);
+        dim3 grid((nunits + 1) / 2), block(128);
+#define LL_D0(O, D, V, L)                                                                                           \
+    case ((O ? 8 : 0) | (D ? 4 : 0) | (V ? 2 : 0) | (L ? 1 : 0)):                                                    \
+        HLMI_LAUNCH(uc, "ll_down0", st, (ll_down0<O, D, V, L>), grid, block, lut_sh, din, in_sy, gco[0], gco[1],     \
+                    gco[2], gm, lev, beta, lut, d.g, d.lox, d.loy, d.w, d.h, d.ws, d.ps, d.nsx, nunits, TY);              \
+        break;
+        switch (variant) {
+            LL_D0(false, false, false, false) LL_D0(false, false, false, true) LL_D0(false, false, true, false)
+            LL_D0(false, false, true, true) LL_D0(false, true, false, false) LL_D0(false, true, false, true)
+            LL_D0(false, true, true, false) LL_D0(false, true, true, true) LL_D0(true, false, false, false)
+            LL_D0(true, false, false, true) LL_D0(true, false, true, false) LL_D0(true, false, true, true)
+            LL_D0(true, true, false, false) LL_D0(true, true, false, true) LL_D0(true, true, true, false)
+            LL_D0(true, true, true, true)
         }
+#undef LL_D0
     }
     for (int j = 1; j + 1 < J; j++) {
-        dim3 grid((lv[j + 1].w + 255) / 256, lv[j + 1].h, levels + 1);
-        HLMI_LAUNCH(uc, "ll_down", st, ll_down, grid, dim3(256), 0, lv[j].g, lv[j].lox, lv[j].loy, lv[j].w, lv[j].h,
-                    lv[j + 1].g, lv[j + 1].lox, lv[j + 1].loy, lv[j + 1].w, lv[j + 1].h);
+        const Level &s = lv[j], &d = lv[j + 1];
+        // enough waves to fill the chip on the big levels, short strips on the small ones
+        const long work = (long)d.nsx * d.h * (levels + 1);
+        int TY = env_int("HLMI_LL_TYB", 0);
+        if (TY <= 0) TY = (int)(work / 2048 < 2 ? 2 : (work / 2048 > 16 ? 16 : work / 2048));
+        const int nsy = (d.h + TY - 1) / TY, nunits = d.nsx * nsy * (levels + 1);
+        dim3 grid((nunits + 3) / 4), block(256);
+#define LL_DS(O, D)                                                                                                 \
+    HLMI_LAUNCH(uc, "ll_down_strip", st, (ll_down_strip<O, D>), grid, block, 0, s.g, s.lox, s.loy, s.w, s.h, s.ws,   \
+                s.ps, d.g, d.lox, d.loy, d.w, d.h, d.ws, d.ps, d.nsx, nsy, nunits, TY)
+        if (d.odd) {
+            if (use_dpp) LL_DS(true, true); else LL_DS(true, false);
+        } else {
+            if (use_dpp) LL_DS(false, true); else LL_DS(false, false);
+        }
+#undef LL_DS
     }
     {
         const Level &t = lv[J - 1];
         int rw = t.rx1 - t.rx0 + 1, rh = t.ry1 - t.ry0 + 1;
-        HLMI_LAUNCH(uc, "ll_top", st, ll_top, dim3((rw + 63) / 64, rh), dim3(64), 0, t.g, t.w, t.h, t.lox, t.loy, t.rx0,
+        HLMI_LAUNCH(uc, "ll_top", st, ll_top, dim3((rw + 63) / 64, rh), dim3(64), 0, t.g, t.ws, t.ps, t.lox, t.loy, t.rx0,
                     t.ry0, rw, rh, levels, gm.Km1, t.out);
     }
     for (int j = J - 2; j >= 1; j--) {
         const Level &a = lv[j], &c = lv[j + 1];
         int rw = a.rx1 - a.rx0 + 1, rh = a.ry1 - a.ry0 + 1;
-        HLMI_LAUNCH(uc, "ll_up", st, ll_up, dim3((rw + 255) / 256, rh), dim3(256), 0, a.g, a.w, a.h, a.lox, a.loy, c.g,
-                    c.out, c.w, c.h, c.lox, c.loy, a.rx0, a.ry0, rw, rh, levels, gm.Km1, a.out);
+        HLMI_LAUNCH(uc, "ll_up", st, ll_up, dim3((rw + 255) / 256, rh), dim3(256), 0, a.g, a.ws, a.ps, a.lox, a.loy, c.g,
+                    c.out, c.ws, c.ps, c.lox, c.loy, a.rx0, a.ry0, rw, rh, levels, gm.Km1, a.out);
     }
     {
-        dim3 grid((ow + 255) / 256, oh);
-        size_t sh = lut_lds ? sizeof(float) * nlut : 0;
         const Level &c = lv[1];
-        if (lut_lds) {
-            HLMI_LAUNCH(uc, "ll_level0_up", st, ll_level0_up<true>, grid, dim3(256), sh, din, in_sy, in_sc, gm, beta, lut,
-                        c.g, c.out, c.w, c.h, c.lox, c.loy, dout, out_sy, out_sc, output->dim[0].min, output->dim[1].min,
-                        ow, oh, output->dim[2].min, nc);
+        Up0Args p;
+        p.in = din, p.in_sy = in_sy;
+        const int oc0 = output->dim[2].min;
+        bool same = (nc == 3);
+        for (int ch = 0; ch < 3; ch++) {
+            p.gco[ch] = gco[ch];
+            p.cco[ch] = ch < nc ? (long)(oc0 + ch - ic0) * in_sc : 0;
+            if (p.cco[ch] != p.gco[ch]) same = false;
+        }
+        p.same_ch = same ? 1 : 0;
+        p.lut_g = lut, p.g1 = c.g, p.out1 = c.out;
+        p.lox1 = c.lox, p.loy1 = c.loy, p.ws1 = c.ws, p.ps1 = c.ps;
+        p.out = dout, p.out_sy = out_sy, p.out_sc = out_sc;
+        p.ox0 = output->dim[0].min, p.oy0 = output->dim[1].min, p.ow = ow, p.oh = oh, p.nc = nc;
+        p.RU = max(1, env_int("HLMI_LL_RU", 8));
+        p.beta = beta;
+        bool vec = ((uintptr_t)din % 4 == 0) && ((uintptr_t)dout % 4 == 0) && in_sy % 2 == 0 && out_sy % 2 == 0 &&
+                   out_sc % 2 == 0 && ((p.ox0 - gm.ix0) % 2 == 0) && !env_int("HLMI_LL_NO_VEC", 0);
+        for (int ch = 0; ch < 3; ch++) vec = vec && p.gco[ch] % 2 == 0 && p.cco[ch] % 2 == 0;
+        dim3 grid((ow + 255) / 256, (oh + 2 * p.RU - 1) / (2 * p.RU)), block(256);
+        if (vec) {
+            if (lut_lds) HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0<true, true>), grid, block, lut_sh, p, gm);
+            else HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0<true, false>), grid, block, lut_sh, p, gm);
         } else {
-            HLMI_LAUNCH(uc, "ll_level0_up", st, ll_level0_up<false>, grid, dim3(256), sh, din, in_sy, in_sc, gm, beta, lut,
-                        c.g, c.out, c.w, c.h, c.lox, c.loy, dout, out_sy, out_sc, output->dim[0].min, output->dim[1].min,
-                        ow, oh, output->dim[2].min, nc);
+            if (lut_lds) HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0<false, true>), grid, block, lut_sh, p, gm);
+            else HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0<false, false>), grid, block, lut_sh, p, gm);
         }
     }
     mark_output_written(output);
@@ -390,4 +757,23 @@ extern "C" const halide_filter_metadata_t *local_laplacian_metadata(void) { retu
 extern "C" int local_laplacian_auto_schedule(halide_buffer_t *input, int32_t levels, float alpha, float beta,
                                              halide_buffer_t *output) {
     return local_laplacian(input, levels, alpha, beta, output);
+}
+
+// Test hook (tests/ only; not part of the reference ABI): copies outGPyramid[level] of the calling thread's
+// LAST local_laplacian call, restricted to R_level, to `dst` (row-major, rw x rh floats); returns 0, or -1.
+extern "C" int hlmi_debug_local_laplacian_outg(int level, float *dst, int cap_floats, int *rw_out, int *rh_out) {
+    if (level < 1 || level >= J || !t_dbg_lv[level].out) return -1;
+    const Level &L = t_dbg_lv[level];
+    int rw = L.rx1 - L.rx0 + 1, rh = L.ry1 - L.ry0 + 1;
+    if (rw_out) *rw_out = rw;
+    if (rh_out) *rh_out = rh;
+    if (!dst) return 0;
+    if ((long)rw * rh > cap_floats) return -1;
+    if (hipStreamSynchronize(t_dbg_stream) != hipSuccess) return -1;
+    const float *src = L.out + (size_t)(L.ry0 - L.loy) * L.ws + (L.rx0 - L.lox);
+    if (hipMemcpy2D(dst, sizeof(float) * rw, src, sizeof(float) * L.ws, sizeof(float) * rw, rh, hipMemcpyDeviceToHost) !=
+        hipSuccess) {
+        return -1;
+    }
+    return 0;
 }

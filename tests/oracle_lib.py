@@ -84,6 +84,23 @@ def local_laplacian(inp: np.ndarray, levels: int, alpha: float, beta: float, J: 
     assert r == 0
     return out
 
+
+
+def local_laplacian_outg(inp: np.ndarray, levels: int, alpha: float, beta: float, level: int, J: int = 8,
+                         origin=(0, 0)) -> np.ndarray:
+    """outGPyramid[level] on its required region R_level, as an (rh, rw) float32 array (debug aid)."""
+    inp = np.ascontiguousarray(inp, np.uint16)
+    c, h, w = inp.shape
+    x0, x1, y0, y1 = origin[0], origin[0] + w - 1, origin[1], origin[1] + h - 1
+    for _ in range(level):
+        x0, x1, y0, y1 = (x0 - 1) // 2, (x1 + 1) // 2, (y0 - 1) // 2, (y1 + 1) // 2
+    dbg = np.zeros((y1 - y0 + 1, x1 - x0 + 1), np.float32)
+    out = np.zeros_like(inp)
+    r = _lib.oracle_local_laplacian(inp, w, h, w, w * h, int(origin[0]), int(origin[1]), J, levels, alpha, beta, out,
+                                    w, w * h, level, dbg.ctypes.data_as(C.c_void_p))
+    assert r == 0
+    return dbg
+
 _lib.oracle_blur.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, _u16p, C.c_int]
 _lib.oracle_blur.restype = C.c_int
 

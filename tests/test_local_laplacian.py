@@ -173,6 +173,27 @@ def test_hip_matches_oracle(hl, oracle, w, h, levels, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("w,h,origin", [(640, 480, (0, 0)), (1000, 300, (0, 0)), (301, 203, (17, 33)), (150, 90, (-6, 2))])
+def test_hip_pyramid_levels_match_oracle(hl, oracle, w, h, origin):
+    """Every outGPyramid level (coarse to fine) must be bit-identical to the oracle's: localises a mismatch
+    to the down chain (level 7 wrong), one up step, or the final recolouring."""
+    inp = _rand_image(w, h, seed=w + h, kind="smooth")
+    a = hl.Buffer(inp).set_min(origin[0], origin[1], 0)
+    o = hl.Buffer(np.zeros_like(inp)).set_min(origin[0], origin[1], 0)
+    hl.local_laplacian(a, 8, 1.0 / 7, 1.0, o)
+    bad = []
+    for level in range(7, 0, -1):
+        got = hl.debug_local_laplacian_outg(level)
+        want = oracle.local_laplacian_outg(inp, 8, 1.0 / 7, 1.0, level, origin=origin)
+        assert got.shape == want.shape
+        if not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
+            ys, xs = np.nonzero(got.view(np.uint32) != want.view(np.uint32))
+            bad.append((level, len(ys), int(xs.min()), int(xs.max()), int(ys.min()), int(ys.max())))
+    assert not bad, f"(level, #bad, xmin, xmax, ymin, ymax): {bad}"
+    assert np.array_equal(o.numpy(), oracle.local_laplacian(inp, 8, 1.0 / 7, 1.0, origin=origin))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("alpha,beta", [(0.0, 1.0), (1.0, 1.0), (0.4, 0.0), (-0.3, 1.7), (2.0, 0.5)])
 def test_hip_matches_oracle_parameter_sweep(hl, oracle, alpha, beta):
     inp = _rand_image(301, 203, seed=5, kind="smooth")
