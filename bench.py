@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("HLMI_BENCH_STREAMS", "1")),
+                    help="HIP streams the frames of a step are spread over (independent frames may overlap)")
     args = ap.parse_args()
 
     import numpy as np
@@ -86,16 +88,25 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # --- synthetic frames, resident in HBM before the timed region
-    frames = [synth_frame(1000 * rank + i) for i in range(FRAMES_PER_STEP)]
+    from halide_amd import sharding
+    # the step's batch is world * FRAMES_PER_STEP frames; rank r owns frames r, r+world, ... (weak scaling)
+    mine = sharding.shard(world * FRAMES_PER_STEP, rank, world)
+    frames = [synth_frame(i) for i in mine]
     ins = [hl.Buffer(f) for f in frames]
     outs = [hl.Buffer(np.zeros_like(f)) for f in frames]
     for a, o in zip(ins, outs):  # first call uploads the input and allocates the output on the device
         hl.local_laplacian(a, LEVELS, ALPHA, BETA, o)
     outs[-1].device_sync()
 
+    streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else []
+
     def step():
-        for a, o in zip(ins, outs):
+        for i, (a, o) in enumerate(zip(ins, outs)):
+            if streams:  # frame i is enqueued on stream i % n: its kernels may overlap the neighbours' launch gaps
+                hl.set_stream(streams[i % len(streams)].cuda_stream)
             hl.local_laplacian(a, LEVELS, ALPHA, BETA, o)
+        if streams:
+            hl.set_stream(None)
 
     def barrier():
         torch.cuda.synchronize()
@@ -111,10 +122,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.max_over_ranks(elapsed, dist, "cuda")
 
     # --- per-kernel durations, HIP events on the launch stream, separate untimed pass
     hl.kernel_timing_reset()
@@ -130,17 +138,21 @@ def main():
         px_per_step = world * FRAMES_PER_STEP * W * H
         value = px_per_step * args.steps / elapsed / 1e6
         frame_ms = elapsed / (args.steps * FRAMES_PER_STEP) * 1e3
-        # dominant kernel = largest share of the summed kernel time per frame
-        per_frame = {}
-        for k in kernels:
-            per_frame[k["name"]] = per_frame.get(k["name"], 0.0) + k["total_ms"] / (3 * FRAMES_PER_STEP)
-        dom = max(per_frame, key=per_frame.get)
-        dom_rec = next(k for k in kernels if k["name"] == dom)
-        # algorithmic bytes per launch of each full-resolution kernel:
-        #   ll_down0: read u16x3 (6 B/px) + write 9 quarter-res f32 planes (9 B/px)  = 15 B/px
-        #   ll_up0  : read u16x3 (6) + 2 selected quarter-res planes (2) + outG1 (1) + write u16x3 (6) = 15 B/px
-        alg_bytes = {"ll_down0": 15, "ll_up0": 15}.get(dom, ALG_BYTES_PER_PX) * W * H
+        # per-launch view: every launch of the chain is reported under its own name (ll_down_strip:1 ... ll_up:6 ...)
+        per_frame = {k["name"]: k["total_ms"] / (3 * FRAMES_PER_STEP) for k in kernels}
+        # dominant kernel = the launch with the longest average duration; its ALGORITHMIC bytes (compulsory reads +
+        # writes of that launch, declared next to the launch in halide_amd/csrc/local_laplacian.hip)
+        dom_rec = max(kernels, key=lambda k: k["avg_ms"])
+        dom = dom_rec["name"]
+        alg_bytes = dom_rec.get("alg_bytes") or ALG_BYTES_PER_PX * W * H
         achieved = alg_bytes / (dom_rec["avg_ms"] * 1e-3) / 1e9
+        # measured HBM traffic of that kernel (rocprofv3 PMC passes, FETCH_SIZE corrected x2 as
+        # MI355X_MICROARCH.md prescribes for wide coalesced reads + WRITE_SIZE), committed under profiles/
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("bytes_per_launch", {}).get(dom)
         result = {
             "metric": "megapixels/sec local_laplacian 8-level fp32 4K",
             "value": round(value, 2), "unit": "Mpx/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -148,10 +160,12 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "apps/local_laplacian J=8 levels=8 alpha=1/7 beta=1, u16 RGB planar 3840x2160",
                        "frames_per_step_per_gpu": FRAMES_PER_STEP, "frame_ms": round(frame_ms, 4),
+                       "streams_per_gpu": max(1, args.streams),
                        "boundary": "C ABI local_laplacian(halide_buffer_t*,int32,float,float,halide_buffer_t*)",
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "alg_bytes_per_launch": int(alg_bytes),
                          "kernel_avg_ms": round(dom_rec["avg_ms"], 5),
                          "pipeline_alg_bytes_per_frame": ALG_BYTES_PER_PX * W * H,
                          "pipeline_frac": round(ALG_BYTES_PER_PX * W * H / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

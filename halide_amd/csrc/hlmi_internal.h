@@ -90,6 +90,8 @@ inline T *dev_ptr(const halide_buffer_t *b) { return reinterpret_cast<T *>((uint
 bool timing_enabled();
 void timing_begin(const char *name, hipStream_t s);
 void timing_end(hipStream_t s);
+// declares the ALGORITHMIC bytes (compulsory reads + writes) of the next timed launch of this thread
+void timing_note_bytes(double bytes);
 struct ScopedKernelTimer {
     hipStream_t s;
     bool on;

@@ -41,6 +41,7 @@ constexpr int J = 8;         // pyramid_levels (local_laplacian_generator.cpp:10
 constexpr int MAX_K = 32;    // largest `levels` the LUT sizing below admits
 constexpr int STRIP = 126;   // level-(j+1) columns one wave produces per row (lanes 0..62 store a float2)
 constexpr int KCH = 8;       // planes of gPyramid one ll_down0 pass keeps in registers
+constexpr int D0_THREADS = 256;  // ll_down0 workgroup: one wave per SIMD, two workgroups per CU (242 VGPRs)
 
 struct Level {
     int lox, loy;            // absolute coordinates of storage element [0][0]
@@ -70,6 +71,14 @@ __global__ void ll_remap_lut(float *lut, int half, float alpha) {
     lut[i] = (alpha * fx) * dev::halide_exp(((-fx) * fx) * 0.5f);
 }
 
+// Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, observed, speed only).  This
+// remap hands every XCD a CONTIGUOUS range of logical blocks, so that neighbouring work units (which share
+// halo rows) run on the same XCD and find each other's rows in its L2.
+__device__ __forceinline__ int xcd_block() {
+    const int nb8 = gridDim.x >> 3, b = blockIdx.x;
+    return (b < (nb8 << 3)) ? (b & 7) * nb8 + (b >> 3) : b;
+}
+
 __device__ __forceinline__ float down4(float a, float b, float c, float d) {
     return ((a + 3.0f * (b + c)) + d) * 0.125f;  // (:270-271), "/ 8.0f" == "* 0.125f"
 }
@@ -84,31 +93,23 @@ __device__ __forceinline__ int idx_of(float gray, float Km1, int half) {
     return dev::clampi((int)((gray * Km1) * 256.0f), 0, half);  // (:42-43)
 }
 // gPyramid[0](x,y,k) = beta*(gray - level) + level + remap(idx - 256*k)   (:41-44); `l` = remap value
+// B1: beta == 1.0f exactly, and 1.0f * x == x bit for bit, so the multiply is skipped
+template<bool B1 = false>
 __device__ __forceinline__ float g0_val(float gray, float level, float beta, float l) {
-    return (beta * (gray - level) + level) + l;
+    return B1 ? ((gray - level) + level) + l : (beta * (gray - level) + level) + l;
 }
 
-// ---- lane <-> lane exchange: DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1), with a
-// ds_bpermute fallback chosen at run time if the probe kernel below disagrees with the DPP result.
-template<bool DPP>
-__device__ __forceinline__ float lane_prev(float v) {  // value held by lane-1 (undefined for lane 0)
-    if (DPP) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
-    } else {
-        return __shfl_up(v, 1, 64);
-    }
+// ---- lane <-> lane exchange: DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1; gfx9-family only,
+// verified on gfx950 by ll_dpp_probe, which tests/ run through hlmi_debug_dpp_probe).
+__device__ __forceinline__ float lane_prev(float v) {  // value held by lane-1 (0 for lane 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
-template<bool DPP>
-__device__ __forceinline__ float lane_next(float v) {  // value held by lane+1 (undefined for lane 63)
-    if (DPP) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
-    } else {
-        return __shfl_down(v, 1, 64);
-    }
+__device__ __forceinline__ float lane_next(float v) {  // value held by lane+1 (0 for lane 63)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 __global__ void ll_dpp_probe(int *ok) {
     float v = (float)threadIdx.x;
-    float p = lane_prev<true>(v), n = lane_next<true>(v);
+    float p = lane_prev(v), n = lane_next(v);
     bool good = (threadIdx.x == 0 || p == v - 1.0f) && (threadIdx.x == 63 || n == v + 1.0f);
     unsigned long long m = __ballot(good);
     if (threadIdx.x == 0) *ok = (m == ~0ull) ? 1 : 0;
@@ -119,17 +120,17 @@ __global__ void ll_dpp_probe(int *ok) {
 //   !ODD: q0 = 2P-2: out(P-1) = f(left, dy0, dy1, dy2) and out(P) = f(dy1, dy2, dy3, right) are computed
 //         here, out(P+1) is the next lane's out(P-1)
 //    ODD: q0 = 2P-1: out(P) = f(dy0..dy3), out(P+1) = f(dy2, dy3, next.dy0, next.dy1)
-template<bool ODD, bool DPP>
+template<bool ODD>
 __device__ __forceinline__ float2 hpair(const float (&dy)[4]) {
     if (!ODD) {
-        float left = lane_prev<DPP>(dy[3]);
-        float right = lane_next<DPP>(dy[0]);
+        float left = lane_prev(dy[3]);
+        float right = lane_next(dy[0]);
         float o0 = down4(left, dy[0], dy[1], dy[2]);
         float o1 = down4(dy[1], dy[2], dy[3], right);
-        float o2 = lane_next<DPP>(o0);
+        float o2 = lane_next(o0);
         return make_float2(o1, o2);
     } else {
-        float r0 = lane_next<DPP>(dy[0]), r1 = lane_next<DPP>(dy[1]);
+        float r0 = lane_next(dy[0]), r1 = lane_next(dy[1]);
         float o0 = down4(dy[0], dy[1], dy[2], dy[3]);
         float o1 = down4(dy[2], dy[3], r0, r1);
         return make_float2(o0, o1);
@@ -185,26 +186,29 @@ __device__ __forceinline__ void load_raw(Raw &r, const uint16_t *__restrict__ rp
 }
 
 // 165 VGPRs: 3 waves/SIMD; the scalar-load variant (odd strides / widths) needs more and is not the fast path
-#ifndef LL_D0_WAVES
-#define LL_D0_WAVES 3
-#endif
-template<bool ODD, bool DPP, bool VEC, bool LUT_LDS>
-__global__ __launch_bounds__(128, VEC ? LL_D0_WAVES : 2) void ll_down0(const uint16_t *__restrict__ in, long in_sy, long co0,
-                                                             long co1, long co2, Geometry gm, Levels lev, float beta,
-                                                             const float *__restrict__ lut_g, float *__restrict__ g1,
-                                                             int Xs, int loy1, int w1, int h1, int ws1, size_t ps1,
-                                                             int nsx, int nunits, int TY) {
+// ABL != 0: ablation variants for timing experiments (HLMI_LL_ABL0), results are NOT valid:
+//   1 = no LUT reads, 2 = no stores, 4 = no input loads after the first row pair
+// Register budget: 72 (vertical window state) + 16 (double-buffered LUT values) + 32 (gray / LUT positions of this
+// and the next row pair) + 12 (raw input in flight) + 18 (results awaiting their stores) + temporaries: two waves per
+// SIMD (launch bound); the LUT reads of plane k+1 are issued before the arithmetic of plane k so that the LDS latency
+// hides inside the wave itself.
+template<bool ODD, bool VEC, bool LUT_LDS, bool B1, int ABL = 0>
+__global__ __launch_bounds__(D0_THREADS, 2) void ll_down0(const uint16_t *__restrict__ in, long in_sy, long co0, long co1,
+                                                   long co2, Geometry gm, Levels lev, float beta,
+                                                   const float *__restrict__ lut_g, float *__restrict__ g1, int Xs,
+                                                   int loy1, int w1, int h1, int ws1, size_t ps1, int nsx, int nsy,
+                                                   int nunits) {
     extern __shared__ float slut[];
     if (LUT_LDS) {
-        for (int i = threadIdx.x; i <= 2 * gm.half; i += 128) slut[i] = lut_g[i];
+        for (int i = threadIdx.x; i <= 2 * gm.half; i += D0_THREADS) slut[i] = lut_g[i];
         __syncthreads();
     }
     const float *lut = LUT_LDS ? slut : lut_g;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> scalar control flow
-    const int unit = blockIdx.x * 2 + wave;
+    const int unit = xcd_block() * (D0_THREADS / 64) + wave;
     if (unit >= nunits) return;
     const int lane = threadIdx.x & 63;
-    const int sx = unit % nsx, sy = unit / nsx;
+    const int sy = unit % nsy, sx = unit / nsy;   // sy fastest: an XCD walks down a strip, halo rows stay in its L2
     const int off = STRIP * sx + 2 * lane;        // destination storage column of the lane's pair
     const int P = Xs + off;                       // absolute level-1 column of the pair
     const int q0 = ODD ? 2 * P - 1 : 2 * P - 2;   // absolute level-0 column of the lane's first source column
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(128, VEC ? LL_D0_WAVES : 2) void ll_down0(const uin
     for (int i = 0; i < 4; i++) xo[i] = qs.oq + qs.sel[i];
     const bool edge_wave = VEC && __any(!qs.plain);
     const bool store_ok = (lane < 63) && (off < w1);
-    const int t0 = sy * TY, t1 = min(t0 + TY, h1) - 1;  // level-1 storage rows of this unit
+    const int t0 = (int)((long)sy * h1 / nsy), t1 = (int)((long)(sy + 1) * h1 / nsy) - 1;  // level-1 storage rows
 
     auto row_ptr = [&](int y_abs) -> const uint16_t * {
         return in + (long)(dev::clampi(y_abs - gm.iy0, 0, ih)) * in_sy;
@@ -225,8 +229,17 @@ __global__ __launch_bounds__(128, VEC ? LL_D0_WAVES : 2) void ll_down0(const uin
         const int nk = min(KCH, gm.K - kb);
         const bool with_in = (kb == 0);  // plane K (inGPyramid[1], :58-61) rides along with the first chunk
         const int lbase = gm.half - 256 * (kb + KCH - 1);  // lut index of plane kb+7 is idx + lbase (< 0 only if unused)
+        float level[KCH];                // level_k of this chunk's planes, pinned in scalar registers
+#pragma unroll
+        for (int kk = 0; kk < KCH; kk++) {
+            level[kk] = lev.v[kb + kk];
+            asm volatile("" : "+s"(level[kk]));
+        }
 
-        float a[KCH + 1][4], b[KCH + 1][4];
+        // vertical-window state: two row pairs' worth of planes, ping-ponged between (a, b) and (a2, b2) so that
+        // neither the state nor the prefetched input rows are ever copied between registers (a copy at the loop
+        // back-edge would force s_waitcnt vmcnt(0), i.e. a wait for this iteration's STORES, every iteration)
+        float a[KCH + 1][4], b[KCH + 1][4], a2[KCH + 1][4], b2[KCH + 1][4];
         // gray and LUT position of the lane's 4 pixels of one input row
         auto gray_row = [&](const Raw &r, float (&gr)[4], int (&li)[4]) {
             const uint16_t rr[4] = {r.c0.x, r.c0.y, r.c0.z, r.c0.w};
@@ -245,9 +258,36 @@ __global__ __launch_bounds__(128, VEC ? LL_D0_WAVES : 2) void ll_down0(const uin
 #pragma unroll
             for (int i = 0; i < 4; i++) li[i] = idx_of(gr[i], gm.Km1, gm.half) + lbase;
         };
-        // gPyramid[0](., ., kb+kk) (kk < KCH) or gray itself (kk == KCH: the inGPyramid plane)
-        auto plane_val = [&](int kk, float gr, int li) -> float {
-            return kk < KCH ? g0_val(gr, lev.v[kb + (kk < KCH ? kk : 0)], beta, lut[li + 256 * (KCH - 1 - kk)]) : gr;
+        // remap values of plane kb+kk for the 8 pixels of a row pair
+        auto lut_issue = [&](int kk, const int (&l0)[4], const int (&l1)[4], float (&dst)[8]) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                dst[i] = (ABL & 1) ? __int_as_float(l0[i]) : lut[l0[i] + 256 * (KCH - 1 - kk)];
+                dst[4 + i] = (ABL & 1) ? __int_as_float(l1[i]) : lut[l1[i] + 256 * (KCH - 1 - kk)];
+            }
+        };
+        // Walk the planes of one row pair (r0 = gray/positions of the first row, r1 of the second).  F(kk, i, v0, v1)
+        // receives, for plane slot kk and column i, the gPyramid[0] (or gray, slot KCH) values of the two rows;
+        // G(kk) runs once per plane after its four columns.
+        auto for_planes = [&](const float (&g0r)[4], const int (&l0)[4], const float (&g1r)[4], const int (&l1)[4],
+                              auto &&F, auto &&G) {
+            float lv[2][8];
+            lut_issue(0, l0, l1, lv[0]);
+#pragma unroll
+            for (int kk = 0; kk <= KCH; kk++) {
+                if (kk + 1 < KCH && kk + 1 < nk) lut_issue(kk + 1, l0, l1, lv[(kk + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk < KCH ? (kk < nk) : with_in) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        float v0 = kk < KCH ? g0_val<B1>(g0r[i], level[kk < KCH ? kk : 0], beta, lv[kk & 1][i]) : g0r[i];
+                        float v1 = kk < KCH ? g0_val<B1>(g1r[i], level[kk < KCH ? kk : 0], beta, lv[kk & 1][4 + i]) : g1r[i];
+                        F(kk, i, v0, v1);
+                    }
+                    G(kk);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         };
 
         const int T0 = loy1 + t0;
@@ -259,75 +299,102 @@ __global__ __launch_bounds__(128, VEC ? LL_D0_WAVES : 2) void ll_down0(const uin
             int la[4], lb[4];
             gray_row(ra, gra, la);
             gray_row(rb, grb, lb);
-#pragma unroll
-            for (int kk = 0; kk <= KCH; kk++) {
-                if (kk < KCH ? (kk < nk) : with_in) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        a[kk][i] = plane_val(kk, gra[i], la[i]);
-                        b[kk][i] = plane_val(kk, grb[i], lb[i]);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for_planes(gra, la, grb, lb, [&](int kk, int i, float v0, float v1) { a[kk][i] = v0, b[kk][i] = v1; },
+                       [&](int) {});
         }
+        // One output row.  VMEM loads and stores share one in-order-per-type counter (vmcnt) and may complete out of
+        // order with respect to EACH OTHER, so waiting for a load means waiting until every store issued before the
+        // wait has been acknowledged as well.  The step is therefore ordered so that the only wait sits where all
+        // pending VMEM operations are one full step old:
+        //   1. arithmetic of all planes (row pair prepared by the previous step), results kept in registers
+        //   2. wait for the NEXT row pair's raw input (issued at the end of the previous step) -> gray / LUT positions
+        //   3. this row's stores, back to back          4. loads of the row pair after next
+        struct RowPair {
+            float g0[4], g1[4];  // gray of the two input rows (LUT positions are recomputed from them: 8 VGPRs less)
+        };
         Raw rc, rd;
-        load_raw<VEC>(rc, row_ptr(2 * T0 + 1), co0, co1, co2, qs.oq, xo);
-        load_raw<VEC>(rd, row_ptr(2 * T0 + 2), co0, co1, co2, qs.oq, xo);
-        for (int t = t0; t <= t1; t++) {
+        auto lut_pos = [&](const float (&g)[4], int (&l)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) l[i] = idx_of(g[i], gm.Km1, gm.half) + lbase;
+        };
+        float2 *stage = reinterpret_cast<float2 *>(slut + (LUT_LDS ? ((2 * gm.half + 1 + 1) & ~1) : 0)) + threadIdx.x;
+        auto step = [&](int t, const RowPair &cur, RowPair &nxt, float (&ia)[KCH + 1][4], float (&ib)[KCH + 1][4],
+                        float (&oa)[KCH + 1][4], float (&ob)[KCH + 1][4]) {
             const int T = loy1 + t;
-            Raw nc = rc, nd = rd;
-            if (t < t1) {  // prefetch the next two input rows while this pair is being reduced
-                load_raw<VEC>(nc, row_ptr(2 * T + 3), co0, co1, co2, qs.oq, xo);
-                load_raw<VEC>(nd, row_ptr(2 * T + 4), co0, co1, co2, qs.oq, xo);
+            int l0[4], l1[4];
+            lut_pos(cur.g0, l0);
+            lut_pos(cur.g1, l1);
+            float dy[4];
+            // results wait in LDS (one float2 slot per plane and lane) for the store batch at the end of the step
+            for_planes(cur.g0, l0, cur.g1, l1,
+                       [&](int kk, int i, float cv, float dv) {
+                           dy[i] = down4(ia[kk][i], ib[kk][i], cv, dv);
+                           oa[kk][i] = cv;
+                           ob[kk][i] = dv;
+                       },
+                       [&](int kk) { stage[kk * D0_THREADS] = hpair<ODD>(dy); });
+            if (t < t1) {
+                int unused[4];
+                gray_row(rc, nxt.g0, unused);
+                gray_row(rd, nxt.g1, unused);
             }
-            float grc[4], grd[4];
-            int lc[4], ld[4];
-            gray_row(rc, grc, lc);
-            gray_row(rd, grd, ld);
+            __builtin_amdgcn_sched_barrier(0);
             float *drow = g1 + (size_t)t * ws1 + off;
 #pragma unroll
             for (int kk = 0; kk <= KCH; kk++) {
                 if (kk < KCH ? (kk < nk) : with_in) {
-                    float dy[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        float cv = plane_val(kk, grc[i], lc[i]), dv = plane_val(kk, grd[i], ld[i]);
-                        dy[i] = down4(a[kk][i], b[kk][i], cv, dv);
-                        a[kk][i] = cv;
-                        b[kk][i] = dv;
-                    }
-                    float2 o = hpair<ODD, DPP>(dy);
                     const int plane = (kk < KCH) ? kb + kk : gm.K;
-                    if (store_ok) *reinterpret_cast<float2 *>(drow + (size_t)plane * ps1) = o;
+                    const float2 o = stage[kk * D0_THREADS];
+                    if ((ABL & 2) ? (store_ok && o.x == 12345.678f) : store_ok) {
+                        *reinterpret_cast<float2 *>(drow + (size_t)plane * ps1) = o;
+                    }
                 }
-                // keep the planes sequential: hoisting all 64 LUT reads of a row pair costs 64 VGPRs
-                __builtin_amdgcn_sched_barrier(0);
             }
-            rc = nc;
-            rd = nd;
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < t1 && !(ABL & 4)) {
+                load_raw<VEC>(rc, row_ptr(2 * T + 5), co0, co1, co2, qs.oq, xo);
+                load_raw<VEC>(rd, row_ptr(2 * T + 6), co0, co1, co2, qs.oq, xo);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        RowPair p0, p1;
+        load_raw<VEC>(rc, row_ptr(2 * T0 + 1), co0, co1, co2, qs.oq, xo);
+        load_raw<VEC>(rd, row_ptr(2 * T0 + 2), co0, co1, co2, qs.oq, xo);
+        {
+            int unused[4];
+            gray_row(rc, p0.g0, unused);
+            gray_row(rd, p0.g1, unused);
+        }
+        if (t0 < t1) {
+            load_raw<VEC>(rc, row_ptr(2 * T0 + 3), co0, co1, co2, qs.oq, xo);
+            load_raw<VEC>(rd, row_ptr(2 * T0 + 4), co0, co1, co2, qs.oq, xo);
+        }
+        for (int t = t0; t <= t1;) {
+            step(t, p0, p1, a, b, a2, b2);
+            if (++t > t1) break;
+            step(t, p1, p0, a2, b2, a, b);
+            ++t;
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // level j -> j+1 (j >= 1): one wave = (strip of 126 destination columns, TY rows, one plane)
-template<bool ODD, bool DPP>
+template<bool ODD>
 __global__ __launch_bounds__(256) void ll_down_strip(const float *__restrict__ src, int slox, int sloy, int sw, int sh,
                                                      int sws, size_t sps, float *__restrict__ dst, int Xs, int dloy,
-                                                     int dw, int dh, int dws, size_t dps, int nsx, int nsy, int nunits,
-                                                     int TY) {
+                                                     int dw, int dh, int dws, size_t dps, int nsx, int nsy, int nunits) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int unit = blockIdx.x * 4 + wave;
+    const int unit = xcd_block() * 4 + wave;
     if (unit >= nunits) return;
     const int lane = threadIdx.x & 63;
-    const int sx = unit % nsx, rest = unit / nsx, sy = rest % nsy, plane = rest / nsy;
+    const int sy = unit % nsy, rest = unit / nsy, sx = rest % nsx, plane = rest / nsx;
     const int off = STRIP * sx + 2 * lane;
     const int P = Xs + off;
     const QuadSel qs = quad_sel((ODD ? 2 * P - 1 : 2 * P - 2) - slox, sw);
     const bool edge_wave = __any(!qs.plain);
     const bool store_ok = (lane < 63) && (off < dw);
-    const int t0 = sy * TY, t1 = min(t0 + TY, dh) - 1;
+    const int t0 = (int)((long)sy * dh / nsy), t1 = (int)((long)(sy + 1) * dh / nsy) - 1;
     const float *sp = src + (size_t)plane * sps + qs.oq;
     float *dp = dst + (size_t)plane * dps + off;
     auto row = [&](int y_abs) -> float4 {
@@ -349,7 +416,7 @@ __global__ __launch_bounds__(256) void ll_down_strip(const float *__restrict__ s
         }
         float dy[4] = {down4(a.x, b.x, c.x, d.x), down4(a.y, b.y, c.y, d.y), down4(a.z, b.z, c.z, d.z),
                        down4(a.w, b.w, c.w, d.w)};
-        float2 o = hpair<ODD, DPP>(dy);
+        float2 o = hpair<ODD>(dy);
         if (store_ok) *reinterpret_cast<float2 *>(dp + (size_t)t * dws) = o;
         a = c, b = d, c = nc, d = nd;
     }
@@ -414,7 +481,9 @@ struct Up0Args {
     float beta;
 };
 
-template<bool VEC, bool LUT_LDS>
+// ABL != 0: ablation variants for timing experiments (HLMI_LL_ABLU), results NOT valid:
+//   1 = no level-1 gathers, 2 = no LUT reads, 4 = no division, 8 = no stores
+template<bool VEC, bool LUT_LDS, int ABL = 0>
 __global__ __launch_bounds__(256) void ll_up0(Up0Args p, Geometry gm) {
     extern __shared__ float slut[];
     if (LUT_LDS) {
@@ -474,22 +543,25 @@ __global__ __launch_bounds__(256) void ll_up0(Up0Args p, Geometry gm) {
             const float *lp = lut + (idx - 256 * li + gm.half);
             float lev0 = (float)li * gm.inv_Km1, lev1 = (float)(li + 1) * gm.inv_Km1;
             const float *gp = p.g1 + (size_t)li * p.ps1;
-            float l0 = g0_val(gray, lev0, p.beta, lp[0]) - up_at(gp, p.lox1, p.loy1, p.ws1, Xi, Y);
-            float l1 = g0_val(gray, lev1, p.beta, lp[-256]) - up_at(gp + p.ps1, p.lox1, p.loy1, p.ws1, Xi, Y);
+            float l0 = g0_val(gray, lev0, p.beta, (ABL & 2) ? lf : lp[0]) - ((ABL & 1) ? lev0 : up_at(gp, p.lox1, p.loy1, p.ws1, Xi, Y));
+            float l1 = g0_val(gray, lev1, p.beta, (ABL & 2) ? lf : lp[-256]) -
+                       ((ABL & 1) ? lev1 : up_at(gp + p.ps1, p.lox1, p.loy1, p.ws1, Xi, Y));
             float outL = (1.0f - lf) * l0 + lf * l1;
-            float og = (up_at(p.out1, p.lox1, p.loy1, p.ws1, Xi, Y) + outL) + 0.01f;
+            float og = (((ABL & 1) ? lf : up_at(p.out1, p.lox1, p.loy1, p.ws1, Xi, Y)) + outL) + 0.01f;
             float gr = gray + 0.01f;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 // color = input * (outG0 + eps) / (gray + eps); input is the UNclamped input here (:84)
-                float v = ((float)cch[c][i] * og) / gr;
+                float v = (ABL & 4) ? ((float)cch[c][i] * og) * gr : ((float)cch[c][i] * og) / gr;
                 res[c][i] = (uint16_t)dev::clampf(v, 0.0f, 65535.0f);
             }
         }
         if (vec) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                if (c < p.nc) *reinterpret_cast<ushort2 *>(op + (long)c * p.out_sc) = make_ushort2(res[c][0], res[c][1]);
+                if ((ABL & 8) ? (c < p.nc && res[c][0] == 12345) : (c < p.nc)) {
+                    *reinterpret_cast<ushort2 *>(op + (long)c * p.out_sc) = make_ushort2(res[c][0], res[c][1]);
+                }
             }
         } else {
 #pragma unroll
@@ -527,28 +599,14 @@ int env_int(const char *name, int dflt) {
     return (e && *e) ? atoi(e) : dflt;
 }
 
-// 1 = DPP wave shifts verified on this device, 0 = use ds_bpermute shuffles
-std::atomic<int> g_dpp_state{-1};
-int dpp_usable(void *uc, const DeviceCtx &ctx, int *out) {
-    int s = g_dpp_state.load();
-    if (s < 0) {
-        if (env_int("HLMI_LL_NO_DPP", 0)) {
-            s = 0;
-        } else {
-            int *flag = nullptr;
-            HLMI_HIP(uc, hipMalloc(&flag, sizeof(int)));
-            HLMI_HIP(uc, hipMemsetAsync(flag, 0, sizeof(int), ctx.stream));
-            hipLaunchKernelGGL(ll_dpp_probe, dim3(1), dim3(64), 0, ctx.stream, flag);
-            int h = 0;
-            HLMI_HIP(uc, hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, ctx.stream));
-            HLMI_HIP(uc, hipStreamSynchronize(ctx.stream));
-            HLMI_HIP(uc, hipFree(flag));
-            s = h ? 1 : 0;
-        }
-        g_dpp_state.store(s);
+int cu_count(int dev) {
+    static std::atomic<int> cached[64];
+    int c = cached[dev & 63].load();
+    if (c <= 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+        cached[dev & 63].store(c);
     }
-    *out = s;
-    return 0;
+    return c;
 }
 
 // last call's level table, for hlmi_debug_local_laplacian_outg (tests only)
@@ -593,8 +651,6 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         mark_output_written(output);
         return 0;
     }
-    int use_dpp = 0;
-    if ((r = dpp_usable(uc, ctx, &use_dpp))) return r;
 
     Geometry gm;
     gm.K = levels;
@@ -661,46 +717,68 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     HLMI_LAUNCH(uc, "ll_remap_lut", st, ll_remap_lut, dim3((nlut + 255) / 256), dim3(256), 0, lut, gm.half, alpha);
     {
         const Level &d = lv[1];
-        const int TY = max(1, env_int("HLMI_LL_TY0", 8));
-        const int nsy = (d.h + TY - 1) / TY, nunits = d.nsx * nsy;
+        // two waves per SIMD with (almost) equal row counts: the kernel is VALU-bound, so balance is what counts
+        const int target = env_int("HLMI_LL_UNITS0", 8 * cu_count(ctx.device));
+        const int nsy = max(1, min(max(target / d.nsx, (d.h + 63) / 64), max(1, d.h / 2)));
+        const int nunits = d.nsx * nsy;
         const int iw = gm.ix1 - gm.ix0 + 1;
         const bool vec = ((uintptr_t)din % 8 == 0) && in_sy % 4 == 0 && gco[0] % 4 == 0 && gco[1] % 4 == 0 &&
                          gco[2] % 4 == 0 && iw % 4 == 0 && !env_int("HLMI_LL_NO_VEC", 0);
         Levels lev;
         for (int k = 0; k < MAX_K; k++) lev.v[k] = (float)k * gm.inv_Km1;
-        const int variant = (d.odd ? 8 : 0) | (use_dpp ? 4 : 0) | (vec ? 2 : 0) | (lut_lds ? 1 : 0);
-        dim3 grid((nunits + 1) / 2), block(128);
-#define LL_D0(O, D, V, L)                                                                                           \
-    case ((O ? 8 : 0) | (D ? 4 : 0) | (V ? 2 : 0) | (L ? 1 : 0)):                                                    \
-        HLMI_LAUNCH(uc, "ll_down0", st, (ll_down0<O, D, V, L>), grid, block, lut_sh, din, in_sy, gco[0], gco[1],     \
-                    gco[2], gm, lev, beta, lut, d.g, d.lox, d.loy, d.w, d.h, d.ws, d.ps, d.nsx, nunits, TY);              \
+        const bool b1 = (beta == 1.0f);
+        const int variant = (d.odd ? 8 : 0) | (vec ? 4 : 0) | (lut_lds ? 2 : 0) | (b1 ? 1 : 0);
+        constexpr int WPB = D0_THREADS / 64;
+        dim3 grid((nunits + WPB - 1) / WPB), block(D0_THREADS);
+        const size_t d0_sh = (lut_lds ? sizeof(float) * ((nlut + 1) & ~1) : 0) + sizeof(float2) * D0_THREADS * (KCH + 1);
+        // algorithmic bytes: the input read once (u16 x 3 channels), the K+1 level-1 planes written once
+        const double d0_bytes = 6.0 * iw * (gm.iy1 - gm.iy0 + 1) + 4.0 * (levels + 1) * d.w * d.h;
+        auto launch_d0 = [&](auto kern) -> int {
+            timing_note_bytes(d0_bytes);
+            HLMI_LAUNCH(uc, "ll_down0", st, kern, grid, block, d0_sh, din, in_sy, gco[0], gco[1], gco[2], gm, lev, beta,
+                        lut, d.g, d.lox, d.loy, d.w, d.h, d.ws, d.ps, d.nsx, nsy, nunits);
+            return 0;
+        };
+#define LL_D0(O, V, L, B)                                             \
+    case ((O ? 8 : 0) | (V ? 4 : 0) | (L ? 2 : 0) | (B ? 1 : 0)):      \
+        r = launch_d0(&ll_down0<O, V, L, B>);                         \
         break;
-        switch (variant) {
-            LL_D0(false, false, false, false) LL_D0(false, false, false, true) LL_D0(false, false, true, false)
-            LL_D0(false, false, true, true) LL_D0(false, true, false, false) LL_D0(false, true, false, true)
-            LL_D0(false, true, true, false) LL_D0(false, true, true, true) LL_D0(true, false, false, false)
-            LL_D0(true, false, false, true) LL_D0(true, false, true, false) LL_D0(true, false, true, true)
-            LL_D0(true, true, false, false) LL_D0(true, true, false, true) LL_D0(true, true, true, false)
-            LL_D0(true, true, true, true)
+#define LL_D0A(A)                                                     \
+    case A:                                                           \
+        r = launch_d0(&ll_down0<false, true, true, true, A>);         \
+        break;
+        const int abl0 = env_int("HLMI_LL_ABL0", 0);
+        if (abl0 && variant == 7) {  // timing experiments on the main variant only
+            switch (abl0) { LL_D0A(1) LL_D0A(2) LL_D0A(3) LL_D0A(4) LL_D0A(6) LL_D0A(7) }
+        } else {
+            switch (variant) {
+                LL_D0(false, false, false, false) LL_D0(false, false, false, true) LL_D0(false, false, true, false)
+                LL_D0(false, false, true, true) LL_D0(false, true, false, false) LL_D0(false, true, false, true)
+                LL_D0(false, true, true, false) LL_D0(false, true, true, true) LL_D0(true, false, false, false)
+                LL_D0(true, false, false, true) LL_D0(true, false, true, false) LL_D0(true, false, true, true)
+                LL_D0(true, true, false, false) LL_D0(true, true, false, true) LL_D0(true, true, true, false)
+                LL_D0(true, true, true, true)
+            }
         }
 #undef LL_D0
+#undef LL_D0A
+        if (r) return r;
     }
     for (int j = 1; j + 1 < J; j++) {
         const Level &s = lv[j], &d = lv[j + 1];
         // enough waves to fill the chip on the big levels, short strips on the small ones
-        const long work = (long)d.nsx * d.h * (levels + 1);
-        int TY = env_int("HLMI_LL_TYB", 0);
-        if (TY <= 0) TY = (int)(work / 2048 < 2 ? 2 : (work / 2048 > 16 ? 16 : work / 2048));
-        const int nsy = (d.h + TY - 1) / TY, nunits = d.nsx * nsy * (levels + 1);
+        const int cols = d.nsx * (levels + 1);
+        const int target = env_int("HLMI_LL_UNITSB", 16 * cu_count(ctx.device));
+        const int nsy = max(1, min(max(target / cols, (d.h + 31) / 32), max(1, d.h / 2)));
+        const int nunits = cols * nsy;
         dim3 grid((nunits + 3) / 4), block(256);
-#define LL_DS(O, D)                                                                                                 \
-    HLMI_LAUNCH(uc, "ll_down_strip", st, (ll_down_strip<O, D>), grid, block, 0, s.g, s.lox, s.loy, s.w, s.h, s.ws,   \
-                s.ps, d.g, d.lox, d.loy, d.w, d.h, d.ws, d.ps, d.nsx, nsy, nunits, TY)
-        if (d.odd) {
-            if (use_dpp) LL_DS(true, true); else LL_DS(true, false);
-        } else {
-            if (use_dpp) LL_DS(false, true); else LL_DS(false, false);
-        }
+        char nm[32];
+        snprintf(nm, sizeof nm, "ll_down_strip:%d", j);
+        timing_note_bytes(4.0 * (levels + 1) * ((double)s.w * s.h + (double)d.w * d.h));
+#define LL_DS(O)                                                                                                 \
+    HLMI_LAUNCH(uc, nm, st, (ll_down_strip<O>), grid, block, 0, s.g, s.lox, s.loy, s.w, s.h, s.ws,   \
+                s.ps, d.g, d.lox, d.loy, d.w, d.h, d.ws, d.ps, d.nsx, nsy, nunits)
+        if (d.odd) LL_DS(true); else LL_DS(false);
 #undef LL_DS
     }
     {
@@ -712,7 +790,11 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     for (int j = J - 2; j >= 1; j--) {
         const Level &a = lv[j], &c = lv[j + 1];
         int rw = a.rx1 - a.rx0 + 1, rh = a.ry1 - a.ry0 + 1;
-        HLMI_LAUNCH(uc, "ll_up", st, ll_up, dim3((rw + 255) / 256, rh), dim3(256), 0, a.g, a.ws, a.ps, a.lox, a.loy, c.g,
+        char nm[32];
+        snprintf(nm, sizeof nm, "ll_up:%d", j);
+        // per output: 2 planes of g_j + inG_j read, outG_j written; per coarse pixel: 2 planes of g_{j+1} + outG_{j+1}
+        timing_note_bytes(4.0 * (4.0 * rw * rh + 3.0 * (c.rx1 - c.rx0 + 1) * (c.ry1 - c.ry0 + 1)));
+        HLMI_LAUNCH(uc, nm, st, ll_up, dim3((rw + 255) / 256, rh), dim3(256), 0, a.g, a.ws, a.ps, a.lox, a.loy, c.g,
                     c.out, c.ws, c.ps, c.lox, c.loy, a.rx0, a.ry0, rw, rh, levels, gm.Km1, a.out);
     }
     {
@@ -737,7 +819,18 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
                    out_sc % 2 == 0 && ((p.ox0 - gm.ix0) % 2 == 0) && !env_int("HLMI_LL_NO_VEC", 0);
         for (int ch = 0; ch < 3; ch++) vec = vec && p.gco[ch] % 2 == 0 && p.cco[ch] % 2 == 0;
         dim3 grid((ow + 255) / 256, (oh + 2 * p.RU - 1) / (2 * p.RU)), block(256);
-        if (vec) {
+        // input read + output written (u16 x nc channels), 2 selected planes of g_1 + outG_1 read
+        const double u0_bytes = 2.0 * (3 + nc) * ow * oh + 4.0 * 3.0 * (c.rx1 - c.rx0 + 1) * (c.ry1 - c.ry0 + 1);
+        timing_note_bytes(u0_bytes);
+        const int ablu = env_int("HLMI_LL_ABLU", 0);
+        if (ablu && vec && lut_lds) {
+#define LL_U0A(A)                                                                                      \
+    case A:                                                                                            \
+        HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0<true, true, A>), grid, block, lut_sh, p, gm);            \
+        break;
+            switch (ablu) { LL_U0A(1) LL_U0A(2) LL_U0A(3) LL_U0A(4) LL_U0A(7) LL_U0A(8) LL_U0A(15) }
+#undef LL_U0A
+        } else if (vec) {
             if (lut_lds) HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0<true, true>), grid, block, lut_sh, p, gm);
             else HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0<true, false>), grid, block, lut_sh, p, gm);
         } else {
@@ -757,6 +850,18 @@ extern "C" const halide_filter_metadata_t *local_laplacian_metadata(void) { retu
 extern "C" int local_laplacian_auto_schedule(halide_buffer_t *input, int32_t levels, float alpha, float beta,
                                              halide_buffer_t *output) {
     return local_laplacian(input, levels, alpha, beta, output);
+}
+
+// Test hook: runs the DPP wave-shift probe on the current device; 1 = wave_shr:1 / wave_shl:1 behave as the
+// strip kernels assume, 0 = they do not, < 0 = HIP error.
+extern "C" int hlmi_debug_dpp_probe(void) {
+    int *flag = nullptr, h = 0;
+    if (hipMalloc(&flag, sizeof(int)) != hipSuccess) return -1;
+    if (hipMemset(flag, 0, sizeof(int)) != hipSuccess) return -1;
+    hipLaunchKernelGGL(ll_dpp_probe, dim3(1), dim3(64), 0, 0, flag);
+    if (hipMemcpy(&h, flag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    (void)hipFree(flag);
+    return h;
 }
 
 // Test hook (tests/ only; not part of the reference ABI): copies outGPyramid[level] of the calling thread's

@@ -603,7 +603,10 @@ void mark_output_written(halide_buffer_t *b) {
 struct TimedLaunch {
     std::string name;
     hipEvent_t e0, e1;
+    double alg_bytes;  // algorithmic bytes of this launch (0 = not declared by the pipeline)
 };
+static thread_local double t_next_alg_bytes = 0;
+void timing_note_bytes(double bytes) { t_next_alg_bytes = bytes; }
 static std::atomic<int> g_timing{0};
 static std::mutex g_timing_mu;
 static std::vector<TimedLaunch> g_launches;
@@ -614,6 +617,8 @@ bool timing_enabled() { return g_timing.load(std::memory_order_relaxed) != 0; }
 void timing_begin(const char *name, hipStream_t s) {
     TimedLaunch t;
     t.name = name;
+    t.alg_bytes = t_next_alg_bytes;
+    t_next_alg_bytes = 0;
     if (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess) return;
     (void)hipEventRecord(t.e0, s);
     t_pending_e1 = t.e1;
@@ -937,7 +942,7 @@ size_t hlmi_kernel_timing_report(char *out, size_t cap) {
     std::lock_guard<std::mutex> lock(g_timing_mu);
     struct Agg {
         int calls = 0;
-        double ms = 0;
+        double ms = 0, bytes = 0;
     };
     std::vector<std::string> order;
     std::unordered_map<std::string, Agg> agg;
@@ -949,13 +954,15 @@ size_t hlmi_kernel_timing_report(char *out, size_t cap) {
         Agg &a = agg[t.name];
         a.calls++;
         a.ms += ms;
+        a.bytes += t.alg_bytes;
     }
     std::string s = "[";
     for (size_t i = 0; i < order.size(); i++) {
         const Agg &a = agg[order[i]];
         char line[256];
-        snprintf(line, sizeof line, "%s{\"name\":\"%s\",\"calls\":%d,\"total_ms\":%.6f,\"avg_ms\":%.6f}", i ? "," : "",
-                 order[i].c_str(), a.calls, a.ms, a.ms / (a.calls ? a.calls : 1));
+        snprintf(line, sizeof line,
+                 "%s{\"name\":\"%s\",\"calls\":%d,\"total_ms\":%.6f,\"avg_ms\":%.6f,\"alg_bytes\":%.0f}", i ? "," : "",
+                 order[i].c_str(), a.calls, a.ms, a.ms / (a.calls ? a.calls : 1), a.bytes / (a.calls ? a.calls : 1));
         s += line;
     }
     s += "]";

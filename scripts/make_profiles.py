@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Turn a gpurun_out/<tag>/ evidence directory (scripts/gpu_full.sh) into the tracked summaries under profiles/.
+
+    python scripts/make_profiles.py <tag> [<round-name>]
+
+Writes profiles/<round>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), profiles/<round>_bench.json,
+profiles/<round>_pmc_traffic.csv (FETCH_SIZE / WRITE_SIZE per kernel and grid, mean per dispatch, as reported, KB)
+and profiles/traffic.json: HBM bytes per launch of the local_laplacian kernels = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
+(FETCH_SIZE doubled: gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md §HBM for wide coalesced reads)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else tag
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+
+
+ks = glob.glob(os.path.join(src, "kt", "*kernel_stats.csv"))
+if ks:
+    with open(ks[0]) as f, open(os.path.join(dst, f"{rnd}_kernel_stats.csv"), "w") as g:
+        w = csv.writer(g)
+        for i, row in enumerate(csv.reader(f)):
+            if i:
+                row[0] = short(row[0])
+            w.writerow(row)
+for name in ("bench.json", "bench_2streams.json", "pytest_gpu.log", "rocminfo.txt"):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, f"{rnd}_{name}"))
+
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    for p in glob.glob(os.path.join(src, f"pmc_{ctr}", "*counter_collection.csv")):
+        for r in csv.DictReader(open(p)):
+            acc[(short(r["Kernel_Name"]), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+rows = []
+for (k, grid), v in sorted(acc.items(), key=lambda kv: -sum(kv[1].get("FETCH_SIZE", [0]))):
+    if k.startswith("__amd"):
+        continue
+    f = sum(v.get("FETCH_SIZE", [0])) / max(1, len(v.get("FETCH_SIZE", [])))
+    w = sum(v.get("WRITE_SIZE", [0])) / max(1, len(v.get("WRITE_SIZE", [])))
+    rows.append((k, grid, len(v.get("FETCH_SIZE", [])), round(f, 1), round(w, 1), int((2 * f + w) * 1024)))
+if rows:
+    with open(os.path.join(dst, f"{rnd}_pmc_traffic.csv"), "w") as g:
+        w = csv.writer(g)
+        w.writerow(["kernel", "grid_size", "dispatches", "FETCH_SIZE_KB_mean", "WRITE_SIZE_KB_mean", "hbm_bytes_2xfetch_plus_write"])
+        w.writerows(rows)
+    # name the launches the way libhlmi's timing report does: strips and ups by descending grid size
+    per = {}
+    strips = sorted([r for r in rows if r[0].startswith("ll_down_strip")], key=lambda r: -r[5])
+    for i, r in enumerate(strips):
+        per[f"ll_down_strip:{i + 1}"] = r[5]
+    ups = sorted([r for r in rows if r[0] == "ll_up"], key=lambda r: -r[5])
+    for i, r in enumerate(ups):
+        per[f"ll_up:{i + 1}"] = r[5]
+    for r in rows:
+        for base in ("ll_down0", "ll_up0", "ll_top", "ll_remap_lut"):
+            if r[0].startswith(base):
+                per[base] = r[5]
+    json.dump({"source": f"profiles/{rnd}_pmc_traffic.csv", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per dispatch",
+               "bytes_per_launch": per}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+print("wrote", sorted(os.listdir(dst)))

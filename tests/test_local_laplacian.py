@@ -147,6 +147,15 @@ def test_oracle_regression_digest(oracle):
 
 
 # ---------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_dpp_wave_shift_probe(hl):
+    """The strip kernels exchange edge columns between neighbouring lanes with DPP wave_shr:1 / wave_shl:1."""
+    import ctypes
+    fn = hl.lib.hlmi_debug_dpp_probe
+    fn.restype = ctypes.c_int
+    assert fn() == 1
+
+
 def _run_hip(hl, inp, levels, alpha, beta, out_arr=None):
     a = hl.Buffer(inp)
     o = hl.Buffer(np.zeros_like(inp) if out_arr is None else out_arr)

@@ -1,0 +1,75 @@
+"""N>1 path on CPU: frame sharding + the collectives the multi-GPU bench uses, world_size 2 over gloo.
+
+The GPU pipeline cannot run here, so the per-frame `process` of this test is the CPU oracle (test infrastructure);
+what is under test is the sharding/collective logic of halide_amd/sharding.py that bench.py drives with RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _frames(n):
+    rng = np.random.default_rng(42)
+    return [rng.integers(0, 65536, (34, 50), dtype=np.uint16) for _ in range(n)]
+
+
+def _worker(rank, world, port, n_frames, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import oracle_lib
+    from halide_amd import sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = _frames(n_frames)
+    mine = sharding.run_batch(frames, oracle_lib.blur, rank, world)
+    assert sorted(mine) == sharding.shard(n_frames, rank, world)
+    digests = sharding.gather_digests({i: sharding.digest64(v) for i, v in mine.items()}, n_frames, dist)
+    slowest = sharding.max_over_ranks(0.25 * (rank + 1), dist)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, digests, slowest))
+
+
+def test_shard_partitions_the_batch():
+    from halide_amd import sharding
+    for n in (0, 1, 5, 8, 33):
+        for world in (1, 2, 3, 8):
+            parts = [sharding.shard(n, r, world) for r in range(world)]
+            assert sorted(i for p in parts for i in p) == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard(4, 2, 2)
+
+
+def test_two_ranks_over_gloo_match_single_process():
+    import torch.multiprocessing as mp
+    import oracle_lib
+    from halide_amd import sharding
+    n_frames, world = 5, 2
+    want = [sharding.digest64(oracle_lib.blur(f)) for f in _frames(n_frames)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, digests, slowest in results:
+        assert digests == want          # every rank sees the digests of the whole batch
+        assert slowest == 0.5           # max over ranks of 0.25*(rank+1)
