@@ -82,6 +82,13 @@ __device__ __forceinline__ int xcd_block() {
 __device__ __forceinline__ float down4(float a, float b, float c, float d) {
     return ((a + 3.0f * (b + c)) + d) * 0.125f;  // (:270-271), "/ 8.0f" == "* 0.125f"
 }
+// The two passes of one level, with the vertical pass's "* 0.125f" deferred: scaling by a power of two commutes
+// with every rounding of the chain (no operand is anywhere near the subnormal range), so
+//   down4(down4(..), ..) == down4_tail(down4_raw(..), ..)   bit for bit, one multiply less per vertical result.
+__device__ __forceinline__ float down4_raw(float a, float b, float c, float d) { return (a + 3.0f * (b + c)) + d; }
+__device__ __forceinline__ float down4_tail(float a, float b, float c, float d) {
+    return ((a + 3.0f * (b + c)) + d) * 0.015625f;
+}
 
 // gray = 0.299 f0 + 0.587 f1 + 0.114 f2, f = u16 / 65535.0f -> * (1/65535.0f)   (:28-36)
 __device__ __forceinline__ float gray_from(uint16_t r, uint16_t g, uint16_t b) {
@@ -121,18 +128,18 @@ __global__ void ll_dpp_probe(int *ok) {
 //         here, out(P+1) is the next lane's out(P-1)
 //    ODD: q0 = 2P-1: out(P) = f(dy0..dy3), out(P+1) = f(dy2, dy3, next.dy0, next.dy1)
 template<bool ODD>
-__device__ __forceinline__ float2 hpair(const float (&dy)[4]) {
+__device__ __forceinline__ float2 hpair(const float (&dy)[4]) {  // dy = down4_raw results
     if (!ODD) {
         float left = lane_prev(dy[3]);
         float right = lane_next(dy[0]);
-        float o0 = down4(left, dy[0], dy[1], dy[2]);
-        float o1 = down4(dy[1], dy[2], dy[3], right);
+        float o0 = down4_tail(left, dy[0], dy[1], dy[2]);
+        float o1 = down4_tail(dy[1], dy[2], dy[3], right);
         float o2 = lane_next(o0);
         return make_float2(o1, o2);
     } else {
         float r0 = lane_next(dy[0]), r1 = lane_next(dy[1]);
-        float o0 = down4(dy[0], dy[1], dy[2], dy[3]);
-        float o1 = down4(dy[2], dy[3], r0, r1);
+        float o0 = down4_tail(dy[0], dy[1], dy[2], dy[3]);
+        float o1 = down4_tail(dy[2], dy[3], r0, r1);
         return make_float2(o0, o1);
     }
 }
@@ -192,7 +199,8 @@ __device__ __forceinline__ void load_raw(Raw &r, const uint16_t *__restrict__ rp
 // and the next row pair) + 12 (raw input in flight) + 18 (results awaiting their stores) + temporaries: two waves per
 // SIMD (launch bound); the LUT reads of plane k+1 are issued before the arithmetic of plane k so that the LDS latency
 // hides inside the wave itself.
-template<bool ODD, bool VEC, bool LUT_LDS, bool B1, int ABL = 0>
+// FULL: levels == KCH, one chunk with every plane slot live (no per-plane run-time guards)
+template<bool ODD, bool VEC, bool LUT_LDS, bool B1, int ABL = 0, bool FULL = false>
 __global__ __launch_bounds__(D0_THREADS, 2) void ll_down0(const uint16_t *__restrict__ in, long in_sy, long co0, long co1,
                                                    long co2, Geometry gm, Levels lev, float beta,
                                                    const float *__restrict__ lut_g, float *__restrict__ g1, int Xs,
@@ -225,9 +233,9 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down0(const uint16_t *__rest
         return in + (long)(dev::clampi(y_abs - gm.iy0, 0, ih)) * in_sy;
     };
 
-    for (int kb = 0; kb < gm.K; kb += KCH) {
-        const int nk = min(KCH, gm.K - kb);
-        const bool with_in = (kb == 0);  // plane K (inGPyramid[1], :58-61) rides along with the first chunk
+    for (int kb = 0; kb < (FULL ? KCH : gm.K); kb += KCH) {
+        const int nk = FULL ? KCH : min(KCH, gm.K - kb);
+        const bool with_in = FULL || (kb == 0);  // plane K (inGPyramid[1], :58-61) rides along with the first chunk
         const int lbase = gm.half - 256 * (kb + KCH - 1);  // lut index of plane kb+7 is idx + lbase (< 0 only if unused)
         float level[KCH];                // level_k of this chunk's planes, pinned in scalar registers
 #pragma unroll
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down0(const uint16_t *__rest
             // results wait in LDS (one float2 slot per plane and lane) for the store batch at the end of the step
             for_planes(cur.g0, l0, cur.g1, l1,
                        [&](int kk, int i, float cv, float dv) {
-                           dy[i] = down4(ia[kk][i], ib[kk][i], cv, dv);
+                           dy[i] = down4_raw(ia[kk][i], ib[kk][i], cv, dv);
                            oa[kk][i] = cv;
                            ob[kk][i] = dv;
                        },
@@ -414,8 +422,8 @@ __global__ __launch_bounds__(256) void ll_down_strip(const float *__restrict__ s
             nc = row(2 * T + 3);
             nd = row(2 * T + 4);
         }
-        float dy[4] = {down4(a.x, b.x, c.x, d.x), down4(a.y, b.y, c.y, d.y), down4(a.z, b.z, c.z, d.z),
-                       down4(a.w, b.w, c.w, d.w)};
+        float dy[4] = {down4_raw(a.x, b.x, c.x, d.x), down4_raw(a.y, b.y, c.y, d.y), down4_raw(a.z, b.z, c.z, d.z),
+                       down4_raw(a.w, b.w, c.w, d.w)};
         float2 o = hpair<ODD>(dy);
         if (store_ok) *reinterpret_cast<float2 *>(dp + (size_t)t * dws) = o;
         a = c, b = d, c = nc, d = nd;
@@ -571,6 +579,125 @@ __global__ __launch_bounds__(256) void ll_up0(Up0Args p, Geometry gm) {
                     if (npx == 2) op[(long)c * p.out_sc + 1] = res[c][1];
                 }
             }
+        }
+    }
+}
+
+// ---- ll_up0f: the same function as ll_up0<true, *> for the common geometry (even output origin and width,
+// three colour channels that are the gray channels, workspace offsets < 4 GB), restructured around what the
+// hardware charges for: instruction issue and gather instructions.
+//   * a wave's row Y is wave-uniform: row pointers, vertical weights and row parity live in scalar registers
+//   * every load is `scalar base + 32-bit lane offset` (no 64-bit vector address arithmetic)
+//   * the pair (X even, X+1) of a lane needs coarse columns c-1, c, c+1 (c = X/2): one 8-byte gather per
+//     (pixel, plane, coarse row) and one 12-byte gather per coarse row of outGPyramid[1] for the pair
+//   * lerp weights are the constants 1/4, 3/4 (:276-282 with x, y parity known), (1 - w) is exact
+//   * the three colour quotients share their denominator: one v_rcp_f32 + one Newton step, then the
+//     correctly-rounded refinement per numerator (div3_by below)
+struct __attribute__((packed, aligned(4))) F2U { float x, y; };
+struct __attribute__((packed, aligned(4))) F3U { float x, y, z; };
+template<typename T>
+__device__ __forceinline__ T ld_su(const void *sbase, uint32_t byte_off) {  // sbase wave-uniform
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(sbase) + byte_off);
+}
+
+// q[i] = n[i] / d, correctly rounded (identical to IEEE `/` up to the sign of a zero quotient, which the u16 cast
+// of the caller discards), for 0.005 <= d <= 4 and n[i] == 0 or
+// 2^-100 < |n[i]| < 2^100.  This is the refinement the compiler emits for `/` (rcp, Newton step, quotient, two
+// residual corrections) without v_div_scale / v_div_fmas' post-scale / v_div_fixup, which only act on operands
+// outside that range (denormal or huge quotients, infinities, NaNs); tests/test_local_laplacian.py checks it
+// against `/` on 2^26 random operand pairs of the range (hlmi_debug_div3_check).
+__device__ __forceinline__ void div3_by(const float (&n)[3], float d, float (&q)[3]) {
+    float r = __builtin_amdgcn_rcpf(d);
+    float e = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        float qq = n[i] * r;
+        float t = __builtin_fmaf(-d, qq, n[i]);
+        qq = __builtin_fmaf(t, r, qq);
+        t = __builtin_fmaf(-d, qq, n[i]);
+        q[i] = __builtin_fmaf(t, r, qq);
+    }
+}
+__global__ void ll_div3_check(const float *n, const float *d, int count, int *bad) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float nn[3] = {n[i], -n[i], n[i] * 3.0f}, q[3];
+    div3_by(nn, d[i], q);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float ref = nn[k] / d[i];  // a zero quotient may differ in sign (the u16 cast discards it): `==` accepts that
+        if (!(ref == q[k]) && !(ref != ref && q[k] != q[k])) atomicAdd(bad, 1);
+    }
+}
+
+template<bool LUT_LDS, bool B1>
+__global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
+    extern __shared__ float slut[];
+    if (LUT_LDS) {
+        for (int i = threadIdx.x; i <= 2 * gm.half; i += 256) slut[i] = p.lut_g[i];
+        __syncthreads();
+    }
+    const float *lut = LUT_LDS ? slut : p.lut_g;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 256 + (wave & 1) * 128 + 2 * lane;  // output storage column of the lane's pair
+    const int y0 = blockIdx.y * (2 * p.RU) + (wave >> 1) * p.RU;
+    if (y0 >= p.oh || x >= p.ow) return;
+    const int y1 = min(y0 + p.RU, p.oh);
+    const int X = p.ox0 + x;                                              // even
+    const uint32_t colb = (uint32_t)((X >> 1) - 1 - p.lox1) * 4u;         // coarse column c-1, bytes
+    const uint32_t inb = (uint32_t)(X - gm.ix0) * 2u, outb = (uint32_t)x * 2u;
+    const uint32_t psb = (uint32_t)p.ps1 * 4u;
+    auto hl0 = [](float rm, float r0) { return r0 * 0.75f + rm * 0.25f; };  // lerp(f[c], f[c-1], 1/4): X even
+    auto hl1 = [](float r0, float rp) { return rp * 0.25f + r0 * 0.75f; };  // lerp(f[c+1], f[c], 3/4): X odd
+    for (int y = y0; y < y1; y++) {
+        const int Y = p.oy0 + y;
+        const uint16_t *irow = p.in + (long)(Y - gm.iy0) * p.in_sy;
+        uint16_t *orow = p.out + (long)y * p.out_sy;
+        const ushort2 c0 = ld_su<ushort2>(irow + p.gco[0], inb), c1 = ld_su<ushort2>(irow + p.gco[1], inb),
+                      c2 = ld_su<ushort2>(irow + p.gco[2], inb);
+        const int ya = dev::fdiv2(Y + 1) - p.loy1, yb = dev::fdiv2(Y - 1) - p.loy1;
+        const float wy = dev::fmod2(Y) ? 0.75f : 0.25f, wy1 = 1.0f - wy;
+        const float *ga = p.g1 + (size_t)ya * p.ws1, *gb = p.g1 + (size_t)yb * p.ws1;
+        const float *oa = p.out1 + (size_t)ya * p.ws1, *ob = p.out1 + (size_t)yb * p.ws1;
+        auto vl = [&](float ua, float ub) { return ua * wy1 + ub * wy; };
+        const F3U OA = ld_su<F3U>(oa, colb), OB = ld_su<F3U>(ob, colb);
+        const float uo[2] = {vl(hl0(OA.x, OA.y), hl0(OB.x, OB.y)), vl(hl1(OA.y, OA.z), hl1(OB.y, OB.z))};
+        const uint16_t ch[3][2] = {{c0.x, c0.y}, {c1.x, c1.y}, {c2.x, c2.y}};
+        uint16_t res[3][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const float gray = gray_from(ch[0][i], ch[1][i], ch[2][i]);
+            const float level = gray * gm.Km1;
+            const int li = dev::clampi((int)level, 0, gm.K - 2);
+            const float lif = (float)li, lf = level - lif;
+            const int idx = dev::clampi((int)(level * 256.0f), 0, gm.half);
+            const float *lp = lut + (idx - 256 * li + gm.half);
+            const float lev0 = lif * gm.inv_Km1, lev1 = (lif + 1.0f) * gm.inv_Km1;
+            const uint32_t pb = (uint32_t)li * psb + colb + 4u * i;
+            const F2U A0 = ld_su<F2U>(ga, pb), B0 = ld_su<F2U>(gb, pb);
+            const F2U A1 = ld_su<F2U>(ga, pb + psb), B1v = ld_su<F2U>(gb, pb + psb);
+            float u0, u1;
+            if (i == 0) {
+                u0 = vl(hl0(A0.x, A0.y), hl0(B0.x, B0.y)), u1 = vl(hl0(A1.x, A1.y), hl0(B1v.x, B1v.y));
+            } else {
+                u0 = vl(hl1(A0.x, A0.y), hl1(B0.x, B0.y)), u1 = vl(hl1(A1.x, A1.y), hl1(B1v.x, B1v.y));
+            }
+            const float l0 = g0_val<B1>(gray, lev0, p.beta, lp[0]) - u0;
+            const float l1 = g0_val<B1>(gray, lev1, p.beta, lp[-256]) - u1;
+            const float outL = (1.0f - lf) * l0 + lf * l1;
+            const float og = (uo[i] + outL) + 0.01f;
+            const float gr = gray + 0.01f;
+            const float n[3] = {(float)ch[0][i] * og, (float)ch[1][i] * og, (float)ch[2][i] * og};
+            float q[3];
+            div3_by(n, gr, q);
+#pragma unroll
+            for (int c = 0; c < 3; c++) res[c][i] = (uint16_t)dev::clampf(q[c], 0.0f, 65535.0f);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            *reinterpret_cast<ushort2 *>(reinterpret_cast<char *>(orow + (long)c * p.out_sc) + outb) =
+                make_ushort2(res[c][0], res[c][1]);
         }
     }
 }
@@ -748,7 +875,10 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         r = launch_d0(&ll_down0<false, true, true, true, A>);         \
         break;
         const int abl0 = env_int("HLMI_LL_ABL0", 0);
-        if (abl0 && variant == 7) {  // timing experiments on the main variant only
+        if (!abl0 && levels == KCH && (variant & 7) == 7 && !env_int("HLMI_LL_NO_FULL", 0)) {
+            r = d.odd ? launch_d0(&ll_down0<true, true, true, true, 0, true>)
+                      : launch_d0(&ll_down0<false, true, true, true, 0, true>);
+        } else if (abl0 && variant == 7) {  // timing experiments on the main variant only
             switch (abl0) { LL_D0A(1) LL_D0A(2) LL_D0A(3) LL_D0A(4) LL_D0A(6) LL_D0A(7) }
         } else {
             switch (variant) {
@@ -823,7 +953,15 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         const double u0_bytes = 2.0 * (3 + nc) * ow * oh + 4.0 * 3.0 * (c.rx1 - c.rx0 + 1) * (c.ry1 - c.ry0 + 1);
         timing_note_bytes(u0_bytes);
         const int ablu = env_int("HLMI_LL_ABLU", 0);
-        if (ablu && vec && lut_lds) {
+        const bool fast = vec && same && nc == 3 && (ow & 1) == 0 && (p.ox0 & 1) == 0 &&
+                          (double)(levels + 1) * (4.0 * (double)c.ps) < 4.0e9 && !ablu && !env_int("HLMI_LL_UP0_OLD", 0);
+        if (fast) {
+            const bool b1 = (beta == 1.0f);
+            if (lut_lds && b1) HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0f<true, true>), grid, block, lut_sh, p, gm);
+            else if (lut_lds) HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0f<true, false>), grid, block, lut_sh, p, gm);
+            else if (b1) HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0f<false, true>), grid, block, lut_sh, p, gm);
+            else HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0f<false, false>), grid, block, lut_sh, p, gm);
+        } else if (ablu && vec && lut_lds) {
 #define LL_U0A(A)                                                                                      \
     case A:                                                                                            \
         HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0<true, true, A>), grid, block, lut_sh, p, gm);            \
@@ -861,6 +999,26 @@ extern "C" int hlmi_debug_dpp_probe(void) {
     hipLaunchKernelGGL(ll_dpp_probe, dim3(1), dim3(64), 0, 0, flag);
     if (hipMemcpy(&h, flag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     (void)hipFree(flag);
+    return h;
+}
+
+// Test hook: div3_by against the correctly-rounded `/` on `count` operand pairs (host pointers); returns the
+// number of quotients that differ bitwise (0 expected), < 0 = HIP error.
+extern "C" int hlmi_debug_div3_check(const float *n, const float *d, int count) {
+    float *dn = nullptr, *dd = nullptr;
+    int *bad = nullptr, h = -1;
+    if (hipMalloc(&dn, sizeof(float) * count) != hipSuccess || hipMalloc(&dd, sizeof(float) * count) != hipSuccess ||
+        hipMalloc(&bad, sizeof(int)) != hipSuccess) {
+        return -1;
+    }
+    if (hipMemcpy(dn, n, sizeof(float) * count, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dd, d, sizeof(float) * count, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(bad, 0, sizeof(int)) != hipSuccess) {
+        return -1;
+    }
+    hipLaunchKernelGGL(ll_div3_check, dim3((count + 255) / 256), dim3(256), 0, 0, dn, dd, count, bad);
+    if (hipMemcpy(&h, bad, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) h = -1;
+    (void)hipFree(dn), (void)hipFree(dd), (void)hipFree(bad);
     return h;
 }
 

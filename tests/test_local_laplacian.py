@@ -156,6 +156,34 @@ def test_dpp_wave_shift_probe(hl):
     assert fn() == 1
 
 
+@pytest.mark.gpu
+def test_shared_reciprocal_division_is_correctly_rounded(hl):
+    """ll_up0f divides the three colour numerators by one denominator through a shared reciprocal
+    (div3_by); the quotients must equal IEEE `/` bit for bit over the operand range of the pipeline:
+    d = gray + 0.01 in [0.01, 1.01], n = u16 * (outG + 0.01)."""
+    import ctypes
+    fn = hl.lib.hlmi_debug_div3_check
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    rng = np.random.default_rng(5)
+    count = 1 << 24
+    for trial in range(4):
+        d = (rng.random(count, dtype=np.float32) * np.float32(1.0) + np.float32(0.01)).astype(np.float32)
+        if trial == 0:
+            n = (rng.integers(0, 65536, count).astype(np.float32) * (rng.random(count, dtype=np.float32) * 1.3 - 0.1)
+                 ).astype(np.float32)
+        elif trial == 1:   # quotients next to integers (the u16 truncation boundary)
+            n = (rng.integers(0, 65536, count).astype(np.float32) * d).astype(np.float32)
+        elif trial == 2:   # tiny and zero numerators
+            n = (rng.random(count, dtype=np.float32) * np.float32(1e-6)).astype(np.float32)
+            n[::7] = 0.0
+        else:              # wide dynamic range
+            n = np.exp(rng.uniform(-40, 40, count)).astype(np.float32)
+            d = np.exp(rng.uniform(np.log(0.005), np.log(4.0), count)).astype(np.float32)
+        bad = fn(n.ctypes.data, d.ctypes.data, count)
+        assert bad == 0, f"trial {trial}: {bad} quotients differ from IEEE division"
+
+
 def _run_hip(hl, inp, levels, alpha, beta, out_arr=None):
     a = hl.Buffer(inp)
     o = hl.Buffer(np.zeros_like(inp) if out_arr is None else out_arr)
