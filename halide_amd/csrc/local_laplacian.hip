@@ -441,16 +441,32 @@ __device__ __forceinline__ float up_at(const float *__restrict__ f, int lox, int
     return dev::lerpf(ua, ub, wy);
 }
 
-// outGPyramid[J-1] = outLPyramid[J-1] (:76, :63-72 with lPyramid[J-1] = gPyramid[J-1], :51)
+// outGPyramid[J-1] = outLPyramid[J-1] (:76, :63-72 with lPyramid[J-1] = gPyramid[J-1], :51); o = element offset
+__device__ __forceinline__ float top_value(const float *__restrict__ g, size_t ps, size_t o, int K, float Km1) {
+    float level = g[(size_t)K * ps + o] * Km1;
+    int li = dev::clampi((int)level, 0, K - 2);
+    float lf = level - (float)li;
+    return (1.0f - lf) * g[(size_t)li * ps + o] + lf * g[(size_t)(li + 1) * ps + o];
+}
+// outLPyramid[j](X,Y), 0 < j < J-1 (:50-54, :63-72): g = level j (origin lox/loy), gc = level j+1
+__device__ __forceinline__ float outl_value(const float *__restrict__ g, int ws, size_t ps, int lox, int loy,
+                                            const float *__restrict__ gc, int cws, size_t cps, int clox, int cloy,
+                                            int X, int Y, int K, float Km1) {
+    size_t o = (size_t)(Y - loy) * ws + (X - lox);
+    float level = g[(size_t)K * ps + o] * Km1;
+    int li = dev::clampi((int)level, 0, K - 2);
+    float lf = level - (float)li;
+    float l0 = g[(size_t)li * ps + o] - up_at(gc + (size_t)li * cps, clox, cloy, cws, X, Y);
+    float l1 = g[(size_t)(li + 1) * ps + o] - up_at(gc + (size_t)(li + 1) * cps, clox, cloy, cws, X, Y);
+    return (1.0f - lf) * l0 + lf * l1;
+}
+
 __global__ void ll_top(const float *__restrict__ g, int ws, size_t ps, int lox, int loy, int rx0, int ry0, int rw,
                        int rh, int K, float Km1, float *__restrict__ out) {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= rw || y >= rh) return;
     size_t o = (size_t)(ry0 + y - loy) * ws + (rx0 + x - lox);
-    float level = g[(size_t)K * ps + o] * Km1;
-    int li = dev::clampi((int)level, 0, K - 2);
-    float lf = level - (float)li;
-    out[o] = (1.0f - lf) * g[(size_t)li * ps + o] + lf * g[(size_t)(li + 1) * ps + o];
+    out[o] = top_value(g, ps, o, K, Km1);
 }
 
 // outGPyramid[j] = upsample(outGPyramid[j+1]) + outLPyramid[j], 1 <= j <= J-2 (:50-54, :63-79)
@@ -462,13 +478,174 @@ __global__ __launch_bounds__(256) void ll_up(const float *__restrict__ g, int ws
     if (x >= rw || y >= rh) return;
     int X = rx0 + x, Y = ry0 + y;
     size_t o = (size_t)(Y - loy) * ws + (X - lox);
-    float level = g[(size_t)K * ps + o] * Km1;
-    int li = dev::clampi((int)level, 0, K - 2);
-    float lf = level - (float)li;
-    float l0 = g[(size_t)li * ps + o] - up_at(gc + (size_t)li * cps, clox, cloy, cws, X, Y);
-    float l1 = g[(size_t)(li + 1) * ps + o] - up_at(gc + (size_t)(li + 1) * cps, clox, cloy, cws, X, Y);
-    float outL = (1.0f - lf) * l0 + lf * l1;
+    float outL = outl_value(g, ws, ps, lox, loy, gc, cws, cps, clox, cloy, X, Y, K, Km1);
     out[o] = up_at(outc, clox, cloy, cws, X, Y) + outL;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The coarse end of the pyramid (levels >= 5: at most a few thousand pixels per plane) is latency, not
+// bandwidth: every launch of the chain costs ~4 us of dispatch + dependent-load latency however little it
+// computes.  The two kernels below replace 2 (J-1-S) launches by 2: values of intermediate levels that a thread
+// needs are RECOMPUTED in registers with exactly the operation order of the single-level kernels (so the
+// results are bit-identical) instead of being exchanged through memory between launches.
+struct DevLevel {
+    float *g, *out;
+    int lox, loy, w, h, ws;  // storage box (see Level)
+    unsigned ps;
+    int rx0, ry0, rw, rh;    // R_j
+};
+struct CoarseArgs {
+    DevLevel lv[4];          // lv[0] = level S (stored), lv[d] = level S+d
+    int K;
+    float Km1;
+};
+
+// ---- ll_down_multi<DEPTH>: levels S+1 .. S+DEPTH of one plane from level S.
+// A workgroup owns a TxT tile of the DEEPEST level and everything of the levels in between whose repeated
+// floor(x/2) lands in that tile.  Window of level d (all coordinates absolute, clamped to the level's storage box,
+// exactly as a read of that level is): [clamp(2 lo_{d+1} - 1), clamp(2 hi_{d+1} + 2)].  Level S+1's window is
+// computed from global memory (16 clamped loads per value), the deeper ones from the previous window in LDS;
+// window values a workgroup does not own are recomputed by the neighbours (identical operations, identical bits).
+constexpr int DM_T = 4;                                      // tile edge at the deepest level
+__host__ __device__ constexpr int dm_win(int depth_below) {  // window edge `depth_below` levels above the deepest
+    int w = DM_T;
+    for (int i = 0; i < depth_below; i++) w = 2 * w + 2;
+    return w;
+}
+struct Range2 { int x0, x1, y0, y1; };  // inclusive, absolute
+__device__ __forceinline__ Range2 clamp_to_box(const DevLevel &L, int x0, int x1, int y0, int y1) {
+    Range2 r;
+    r.x0 = dev::clampi(x0, L.lox, L.lox + L.w - 1), r.x1 = dev::clampi(x1, L.lox, L.lox + L.w - 1);
+    r.y0 = dev::clampi(y0, L.loy, L.loy + L.h - 1), r.y1 = dev::clampi(y1, L.loy, L.loy + L.h - 1);
+    return r;
+}
+template<int DEPTH>
+__global__ __launch_bounds__(256) void ll_down_multi(CoarseArgs a, int ntx, int nty) {
+    constexpr int W1 = dm_win(DEPTH - 1), W2 = DEPTH >= 2 ? dm_win(DEPTH - 2) : 1, W3 = DEPTH >= 3 ? dm_win(DEPTH - 3) : 1;
+    __shared__ float tile1[W1 * W1], tile2[W2 * W2], tile3[W3 * W3];  // windows of levels S+1, S+2, S+3
+    float *const tiles[4] = {nullptr, tile1, tile2, tile3};
+    const int ws_[4] = {0, W1, W2, W3};
+    const int tx = blockIdx.x % ntx, ty = (blockIdx.x / ntx) % nty, plane = blockIdx.x / (ntx * nty);
+    // windows (win[d]) and owned ranges (own[d]) of levels S+d, deepest first
+    Range2 win[4], own[4];
+    {
+        const DevLevel &T = a.lv[DEPTH];
+        win[DEPTH] = own[DEPTH] = clamp_to_box(T, T.lox + tx * DM_T, T.lox + tx * DM_T + DM_T - 1, T.loy + ty * DM_T,
+                                               T.loy + ty * DM_T + DM_T - 1);
+#pragma unroll
+        for (int d = DEPTH - 1; d >= 1; d--) {
+            const DevLevel &L = a.lv[d];
+            win[d] = clamp_to_box(L, 2 * win[d + 1].x0 - 1, 2 * win[d + 1].x1 + 2, 2 * win[d + 1].y0 - 1, 2 * win[d + 1].y1 + 2);
+            own[d] = clamp_to_box(L, 2 * own[d + 1].x0, 2 * own[d + 1].x1 + 1, 2 * own[d + 1].y0, 2 * own[d + 1].y1 + 1);
+        }
+    }
+#pragma unroll
+    for (int d = 1; d <= DEPTH; d++) {
+        const DevLevel &L = a.lv[d], &Sx = a.lv[d - 1];
+        const Range2 w = win[d], o = own[d];
+        const int nx = w.x1 - w.x0 + 1, n = nx * (w.y1 - w.y0 + 1);
+        float *const dst = tiles[d];
+        const float *const src_g = Sx.g + (size_t)plane * Sx.ps;
+        const float *const src_t = tiles[d - 1];
+        const Range2 pw = win[d == 1 ? 1 : d - 1];
+        const int pnx = ws_[d == 1 ? 1 : d - 1];
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int yy = e / nx, X = w.x0 + (e - yy * nx), Y = w.y0 + yy;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {  // vertical pass first (downy, :270), then horizontal (downx, :271)
+                float r[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int qx = dev::clampi(2 * X - 1 + i, Sx.lox, Sx.lox + Sx.w - 1);
+                    const int qy = dev::clampi(2 * Y - 1 + k, Sx.loy, Sx.loy + Sx.h - 1);
+                    r[k] = (d == 1) ? src_g[(size_t)(qy - Sx.loy) * Sx.ws + (qx - Sx.lox)]
+                                    : src_t[(qy - pw.y0) * pnx + (qx - pw.x0)];
+                }
+                v[i] = down4_raw(r[0], r[1], r[2], r[3]);
+            }
+            const float val = down4_tail(v[0], v[1], v[2], v[3]);
+            dst[yy * ws_[d] + (X - w.x0)] = val;
+            if (X >= o.x0 && X <= o.x1 && Y >= o.y0 && Y <= o.y1) {
+                L.g[(size_t)plane * L.ps + (size_t)(Y - L.loy) * L.ws + (X - L.lox)] = val;
+            }
+        }
+        if (d < DEPTH) __syncthreads();
+    }
+}
+
+// ---- ll_up_multi<TOP>: outGPyramid[S] on R_S from gPyramid / inGPyramid of levels S .. S+TOP (= J-1).
+// A workgroup owns a 16x16 tile of R_S.  Everything that needs memory — outLPyramid of every level over the
+// region the tile depends on (the top level's outGPyramid is its outLPyramid, :76) — is independent of the
+// coarse-to-fine recursion, so it is computed first, by all threads at once, into LDS; the recursion
+// outG_j = upsample(outG_{j+1}) + outL_j (:77-79) then runs through LDS, one barrier per level.
+constexpr int UM_T = 16;
+__host__ __device__ constexpr int um_win(int d) {  // edge of the region of level S+d a tile depends on
+    int w = UM_T;
+    for (int i = 0; i < d; i++) w = w / 2 + 2;
+    return w;
+}
+template<int TOP>
+__global__ __launch_bounds__(256) void ll_up_multi(CoarseArgs a, int ntx) {
+    constexpr int W1 = um_win(1), W2 = TOP >= 2 ? um_win(2) : 1, W3 = TOP >= 3 ? um_win(3) : 1;
+    __shared__ float t0[UM_T * UM_T], t1[W1 * W1], t2[W2 * W2], t3[W3 * W3];
+    float *const tiles[4] = {t0, t1, t2, t3};
+    const int ws_[4] = {UM_T, W1, W2, W3};
+    const int tx = blockIdx.x % ntx, ty = blockIdx.x / ntx;
+    Range2 reg[4];
+    {
+        const DevLevel &L = a.lv[0];
+        reg[0].x0 = L.rx0 + tx * UM_T, reg[0].x1 = min(reg[0].x0 + UM_T - 1, L.rx0 + L.rw - 1);
+        reg[0].y0 = L.ry0 + ty * UM_T, reg[0].y1 = min(reg[0].y0 + UM_T - 1, L.ry0 + L.rh - 1);
+#pragma unroll
+        for (int d = 1; d <= TOP; d++) {
+            reg[d].x0 = dev::fdiv2(reg[d - 1].x0 - 1), reg[d].x1 = dev::fdiv2(reg[d - 1].x1 + 1);
+            reg[d].y0 = dev::fdiv2(reg[d - 1].y0 - 1), reg[d].y1 = dev::fdiv2(reg[d - 1].y1 + 1);
+        }
+    }
+    // 1. outLPyramid of every level (memory-bound part, all of it independent)
+#pragma unroll
+    for (int d = TOP; d >= 0; d--) {
+        const DevLevel &L = a.lv[d];
+        const Range2 r = reg[d];
+        const int nx = r.x1 - r.x0 + 1, n = nx * (r.y1 - r.y0 + 1);
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int yy = e / nx, X = r.x0 + (e - yy * nx), Y = r.y0 + yy;
+            float v;
+            if (d == TOP) {
+                v = top_value(L.g, L.ps, (size_t)(Y - L.loy) * L.ws + (X - L.lox), a.K, a.Km1);
+            } else {
+                const DevLevel &C = a.lv[d + 1];
+                v = outl_value(L.g, L.ws, L.ps, L.lox, L.loy, C.g, C.ws, C.ps, C.lox, C.loy, X, Y, a.K, a.Km1);
+            }
+            tiles[d][yy * ws_[d] + (X - r.x0)] = v;
+        }
+    }
+    __syncthreads();
+    // 2. collapse: level S+d from level S+d+1 (both in LDS), operation order of up_at
+#pragma unroll
+    for (int d = TOP - 1; d >= 0; d--) {
+        const Range2 r = reg[d], c = reg[d + 1];
+        const float *const ct = tiles[d + 1];
+        const int cw = ws_[d + 1];
+        const int nx = r.x1 - r.x0 + 1, n = nx * (r.y1 - r.y0 + 1);
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int yy = e / nx, X = r.x0 + (e - yy * nx), Y = r.y0 + yy;
+            const int xa = dev::fdiv2(X + 1) - c.x0, xb = dev::fdiv2(X - 1) - c.x0;
+            const int ya = dev::fdiv2(Y + 1) - c.y0, yb = dev::fdiv2(Y - 1) - c.y0;
+            const float wx = (float)(dev::fmod2(X) * 2 + 1) * 0.25f, wy = (float)(dev::fmod2(Y) * 2 + 1) * 0.25f;
+            const float ua = dev::lerpf(ct[ya * cw + xa], ct[ya * cw + xb], wx);
+            const float ub = dev::lerpf(ct[yb * cw + xa], ct[yb * cw + xb], wx);
+            const float v = dev::lerpf(ua, ub, wy) + tiles[d][yy * ws_[d] + (X - r.x0)];
+            if (d == 0) {
+                const DevLevel &L = a.lv[0];
+                L.out[(size_t)(Y - L.loy) * L.ws + (X - L.lox)] = v;
+            } else {
+                tiles[d][yy * ws_[d] + (X - r.x0)] = v;
+            }
+        }
+        if (d > 0) __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -894,7 +1071,35 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
 #undef LL_D0A
         if (r) return r;
     }
+    // levels >= S are produced / collapsed by the two multi-level kernels (S = 4: 2 launches instead of 7)
+    const int S = [&] {
+        int v = env_int("HLMI_LL_FUSE_FROM", 4);
+        return (v >= J - 4 && v <= J - 2) ? v : J;
+    }();
+    CoarseArgs ca;
+    if (S < J) {
+        for (int dl = 0; S + dl < J; dl++) {
+            const Level &L = lv[S + dl];
+            DevLevel &D = ca.lv[dl];
+            D.g = L.g, D.out = L.out, D.lox = L.lox, D.loy = L.loy, D.w = L.w, D.h = L.h, D.ws = L.ws, D.ps = (unsigned)L.ps;
+            D.rx0 = L.rx0, D.ry0 = L.ry0, D.rw = L.rx1 - L.rx0 + 1, D.rh = L.ry1 - L.ry0 + 1;
+        }
+        ca.K = levels, ca.Km1 = gm.Km1;
+    }
     for (int j = 1; j + 1 < J; j++) {
+        if (j == S) {
+            long total = 0;
+            for (int dl = 1; S + dl < J; dl++) total += (long)(levels + 1) * lv[S + dl].w * lv[S + dl].h;
+            const int ntx = (lv[J - 1].w + DM_T - 1) / DM_T, nty = (lv[J - 1].h + DM_T - 1) / DM_T;
+            dim3 grid((unsigned)(ntx * nty * (levels + 1))), block(256);
+            char nm[32];
+            snprintf(nm, sizeof nm, "ll_down_multi:%d", S);
+            timing_note_bytes(4.0 * ((double)(levels + 1) * lv[S].w * lv[S].h + (double)total));
+            if (J - 1 - S == 3) HLMI_LAUNCH(uc, nm, st, (ll_down_multi<3>), grid, block, 0, ca, ntx, nty);
+            else if (J - 1 - S == 2) HLMI_LAUNCH(uc, nm, st, (ll_down_multi<2>), grid, block, 0, ca, ntx, nty);
+            else HLMI_LAUNCH(uc, nm, st, (ll_down_multi<1>), grid, block, 0, ca, ntx, nty);
+            break;
+        }
         const Level &s = lv[j], &d = lv[j + 1];
         // enough waves to fill the chip on the big levels, short strips on the small ones
         const int cols = d.nsx * (levels + 1);
@@ -911,13 +1116,21 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         if (d.odd) LL_DS(true); else LL_DS(false);
 #undef LL_DS
     }
-    {
+    if (S < J) {
+        const int ntx = (ca.lv[0].rw + UM_T - 1) / UM_T, nty = (ca.lv[0].rh + UM_T - 1) / UM_T;
+        dim3 grid((unsigned)(ntx * nty)), block(256);
+        char nm[32];
+        snprintf(nm, sizeof nm, "ll_up_multi:%d", S);
+        if (J - 1 - S == 3) HLMI_LAUNCH(uc, nm, st, (ll_up_multi<3>), grid, block, 0, ca, ntx);
+        else if (J - 1 - S == 2) HLMI_LAUNCH(uc, nm, st, (ll_up_multi<2>), grid, block, 0, ca, ntx);
+        else HLMI_LAUNCH(uc, nm, st, (ll_up_multi<1>), grid, block, 0, ca, ntx);
+    } else {
         const Level &t = lv[J - 1];
         int rw = t.rx1 - t.rx0 + 1, rh = t.ry1 - t.ry0 + 1;
         HLMI_LAUNCH(uc, "ll_top", st, ll_top, dim3((rw + 63) / 64, rh), dim3(64), 0, t.g, t.ws, t.ps, t.lox, t.loy, t.rx0,
                     t.ry0, rw, rh, levels, gm.Km1, t.out);
     }
-    for (int j = J - 2; j >= 1; j--) {
+    for (int j = min(S, J - 1) - 1; j >= 1; j--) {
         const Level &a = lv[j], &c = lv[j + 1];
         int rw = a.rx1 - a.rx0 + 1, rh = a.ry1 - a.ry0 + 1;
         char nm[32];

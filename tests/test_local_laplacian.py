@@ -210,16 +210,20 @@ def test_hip_matches_oracle(hl, oracle, w, h, levels, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fuse_from", [8, 6, 5, 4])
 @pytest.mark.parametrize("w,h,origin", [(640, 480, (0, 0)), (1000, 300, (0, 0)), (301, 203, (17, 33)), (150, 90, (-6, 2))])
-def test_hip_pyramid_levels_match_oracle(hl, oracle, w, h, origin):
+def test_hip_pyramid_levels_match_oracle(hl, oracle, monkeypatch, w, h, origin, fuse_from):
     """Every outGPyramid level (coarse to fine) must be bit-identical to the oracle's: localises a mismatch
-    to the down chain (level 7 wrong), one up step, or the final recolouring."""
+    to the down chain (level 7 wrong), one up step, or the final recolouring.  fuse_from = S: levels >= S are
+    handled by the two multi-level kernels (ll_down_multi / ll_up_multi), which materialise outGPyramid[S] but
+    not the coarser ones; 8 = one launch per level."""
+    monkeypatch.setenv("HLMI_LL_FUSE_FROM", str(fuse_from))
     inp = _rand_image(w, h, seed=w + h, kind="smooth")
     a = hl.Buffer(inp).set_min(origin[0], origin[1], 0)
     o = hl.Buffer(np.zeros_like(inp)).set_min(origin[0], origin[1], 0)
     hl.local_laplacian(a, 8, 1.0 / 7, 1.0, o)
     bad = []
-    for level in range(7, 0, -1):
+    for level in range(min(7, fuse_from), 0, -1):
         got = hl.debug_local_laplacian_outg(level)
         want = oracle.local_laplacian_outg(inp, 8, 1.0 / 7, 1.0, level, origin=origin)
         assert got.shape == want.shape
