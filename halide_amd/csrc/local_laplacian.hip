@@ -32,6 +32,7 @@
 
 #include <atomic>
 #include <stdlib.h>
+#include <type_traits>
 
 using namespace hlmi;
 
@@ -199,8 +200,7 @@ __device__ __forceinline__ void load_raw(Raw &r, const uint16_t *__restrict__ rp
 // and the next row pair) + 12 (raw input in flight) + 18 (results awaiting their stores) + temporaries: two waves per
 // SIMD (launch bound); the LUT reads of plane k+1 are issued before the arithmetic of plane k so that the LDS latency
 // hides inside the wave itself.
-// FULL: levels == KCH, one chunk with every plane slot live (no per-plane run-time guards)
-template<bool ODD, bool VEC, bool LUT_LDS, bool B1, int ABL = 0, bool FULL = false>
+template<bool ODD, bool VEC, bool LUT_LDS, bool B1, int ABL = 0>
 __global__ __launch_bounds__(D0_THREADS, 2) void ll_down0(const uint16_t *__restrict__ in, long in_sy, long co0, long co1,
                                                    long co2, Geometry gm, Levels lev, float beta,
                                                    const float *__restrict__ lut_g, float *__restrict__ g1, int Xs,
@@ -233,9 +233,9 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down0(const uint16_t *__rest
         return in + (long)(dev::clampi(y_abs - gm.iy0, 0, ih)) * in_sy;
     };
 
-    for (int kb = 0; kb < (FULL ? KCH : gm.K); kb += KCH) {
-        const int nk = FULL ? KCH : min(KCH, gm.K - kb);
-        const bool with_in = FULL || (kb == 0);  // plane K (inGPyramid[1], :58-61) rides along with the first chunk
+    for (int kb = 0; kb < gm.K; kb += KCH) {
+        const int nk = min(KCH, gm.K - kb);
+        const bool with_in = (kb == 0);  // plane K (inGPyramid[1], :58-61) rides along with the first chunk
         const int lbase = gm.half - 256 * (kb + KCH - 1);  // lut index of plane kb+7 is idx + lbase (< 0 only if unused)
         float level[KCH];                // level_k of this chunk's planes, pinned in scalar registers
 #pragma unroll
@@ -384,6 +384,170 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down0(const uint16_t *__rest
             ++t;
         }
     }
+}
+
+// ---- ll_down0f: ll_down0 for the common case (levels == KCH, vectorisable input, LUT in LDS), written for
+// instruction count — the kernel is bound by instruction issue, not by HBM or the LDS:
+//   * the results of a step wait for their store batch in registers (levels == KCH: no per-plane guards, so there is room)
+//   * gray AND the LUT positions of the next row pair are carried in registers instead of being recomputed
+//   * gray >= 0, so the lower bound of clamp(cast<int>(idx), 0, (levels-1)*256) (:43) can never bind: one v_min
+//   * the horizontal pass of plane k-1 is issued after the vertical pass of plane k, so that the DPP lane
+//     exchanges never read a register written by the previous instruction (no s_nop hazard padding)
+//   * only waves that touch the left / right image edge run the per-column clamp selects (a second instance of
+//     the strip walk behind ONE wave-uniform branch); their extra work must stay small, because every wave is
+//     resident at once and the launch lasts as long as its slowest wave
+template<bool ODD, bool B1>
+__global__ __launch_bounds__(D0_THREADS, 2) void ll_down0f(const uint16_t *__restrict__ in, long in_sy, long co0, long co1,
+                                                    long co2, Geometry gm, Levels lev, float beta,
+                                                    const float *__restrict__ lut_g, float *__restrict__ g1, int Xs,
+                                                    int loy1, int w1, int h1, int ws1, size_t ps1, int nsx, int nsy,
+                                                    int nunits) {
+    extern __shared__ float slut[];
+    for (int i = threadIdx.x; i <= 2 * gm.half; i += D0_THREADS) slut[i] = lut_g[i];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int unit = xcd_block() * (D0_THREADS / 64) + wave;
+    if (unit >= nunits) return;
+    const int lane = threadIdx.x & 63;
+    const int sy = unit % nsy, sx = unit / nsy;
+    const int off = STRIP * sx + 2 * lane;
+    const int P = Xs + off;
+    const int q0 = ODD ? 2 * P - 1 : 2 * P - 2;
+    const int iw = gm.ix1 - gm.ix0 + 1, ih = gm.iy1 - gm.iy0;
+    const QuadSel qs = quad_sel(q0 - gm.ix0, iw);
+    int xo[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) xo[i] = qs.oq + qs.sel[i];
+    const bool edge_wave = __any(!qs.plain);
+    const bool store_ok = (lane < 63) && (off < w1);
+    const int t0 = (int)((long)sy * h1 / nsy), t1 = (int)((long)(sy + 1) * h1 / nsy) - 1;
+    const int lbase = gm.half - 256 * (KCH - 1);
+    float level[KCH];
+#pragma unroll
+    for (int kk = 0; kk < KCH; kk++) {
+        level[kk] = lev.v[kk];
+        asm volatile("" : "+s"(level[kk]));
+    }
+    // the whole strip walk is instantiated twice and selected by ONE wave-uniform branch: a branch around the
+    // loads inside the row loop would make the compiler wait for all outstanding VMEM traffic at every join
+    auto walk = [&](auto edge_tag) {
+    constexpr bool EDGE = decltype(edge_tag)::value;
+    auto load_row = [&](Raw &r, int y_abs) {
+        const uint16_t *rp = in + (long)(dev::clampi(y_abs - gm.iy0, 0, ih)) * in_sy;
+        load_raw<true>(r, rp, co0, co1, co2, qs.oq, xo);
+    };
+    auto u16s = [&](const ushort4 &c, uint16_t (&o)[4]) {
+        // two dwords, explicit halves: the conversions become SDWA word selects
+        const uint2 w = __builtin_bit_cast(uint2, c);
+        o[0] = (uint16_t)(w.x & 0xffffu), o[1] = (uint16_t)(w.x >> 16);
+        o[2] = (uint16_t)(w.y & 0xffffu), o[3] = (uint16_t)(w.y >> 16);
+    };
+    struct Row {
+        float g[4];  // gray
+        int l[4];    // LUT position of plane KCH-1 (plane k reads l + 256 (KCH-1-k))
+    };
+    auto prep_row = [&](const Raw &r, Row &o) {
+        uint16_t rr[4], gg[4], bb[4];
+        u16s(r.c0, rr), u16s(r.c1, gg), u16s(r.c2, bb);
+#pragma unroll
+        for (int i = 0; i < 4; i++) o.g[i] = gray_from(rr[i], gg[i], bb[i]);
+        if (EDGE) {  // the aligned quad was loaded; column i takes its (clamped) element sel[i]
+            const float g0 = o.g[0], g1v = o.g[1], g2 = o.g[2], g3 = o.g[3];
+#pragma unroll
+            for (int i = 0; i < 4; i++) o.g[i] = pick4(g0, g1v, g2, g3, qs.sel[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) o.l[i] = min((int)((o.g[i] * gm.Km1) * 256.0f), gm.half) + lbase;
+    };
+    auto lut_issue = [&](int kk, const Row &r0, const Row &r1, float (&dst)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            dst[i] = slut[r0.l[i] + 256 * (KCH - 1 - kk)];
+            dst[4 + i] = slut[r1.l[i] + 256 * (KCH - 1 - kk)];
+        }
+    };
+    // gPyramid[0] (slot kk < KCH) or gray (slot KCH) of the lane's 4 columns in the two rows r0, r1
+    auto plane_vals = [&](int kk, const Row &r0, const Row &r1, const float (&lv)[8], float (&v0)[4], float (&v1)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            v0[i] = kk < KCH ? g0_val<B1>(r0.g[i], level[kk < KCH ? kk : 0], beta, lv[i]) : r0.g[i];
+            v1[i] = kk < KCH ? g0_val<B1>(r1.g[i], level[kk < KCH ? kk : 0], beta, lv[4 + i]) : r1.g[i];
+        }
+    };
+
+    float a[KCH + 1][4], b[KCH + 1][4], a2[KCH + 1][4], b2[KCH + 1][4];
+    const int T0 = loy1 + t0;
+    {   // the two rows above the first output row: window state only
+        Raw ra, rb;
+        load_row(ra, 2 * T0 - 1);
+        load_row(rb, 2 * T0);
+        Row r0, r1;
+        prep_row(ra, r0);
+        prep_row(rb, r1);
+        float lv[2][8];
+        lut_issue(0, r0, r1, lv[0]);
+#pragma unroll
+        for (int kk = 0; kk <= KCH; kk++) {
+            if (kk + 1 < KCH) lut_issue(kk + 1, r0, r1, lv[(kk + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            plane_vals(kk, r0, r1, lv[kk & 1], a[kk], b[kk]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    Raw rc, rd;
+    // One output row; order of VMEM traffic as in ll_down0 (arithmetic, next rows' gray, store batch, loads).
+    auto step = [&](int t, const Row &c0, const Row &c1, Row &n0, Row &n1, float (&ia)[KCH + 1][4],
+                    float (&ib)[KCH + 1][4], float (&oa)[KCH + 1][4], float (&ob)[KCH + 1][4]) {
+        const int T = loy1 + t;
+        float lv[2][8], dy[2][4];
+        float2 res[KCH + 1];
+        lut_issue(0, c0, c1, lv[0]);
+#pragma unroll
+        for (int kk = 0; kk <= KCH; kk++) {
+            if (kk + 1 < KCH) lut_issue(kk + 1, c0, c1, lv[(kk + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            plane_vals(kk, c0, c1, lv[kk & 1], oa[kk], ob[kk]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) dy[kk & 1][i] = down4_raw(ia[kk][i], ib[kk][i], oa[kk][i], ob[kk][i]);
+            if (kk > 0) res[kk - 1] = hpair<ODD>(dy[(kk - 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        res[KCH] = hpair<ODD>(dy[KCH & 1]);
+        if (t < t1) {
+            prep_row(rc, n0);
+            prep_row(rd, n1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float *drow = g1 + (size_t)t * ws1 + off;
+        if (store_ok) {
+#pragma unroll
+            for (int kk = 0; kk <= KCH; kk++) *reinterpret_cast<float2 *>(drow + (size_t)kk * ps1) = res[kk];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < t1) {
+            load_row(rc, 2 * T + 5);
+            load_row(rd, 2 * T + 6);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    Row p0, p1, p2, p3;
+    load_row(rc, 2 * T0 + 1);
+    load_row(rd, 2 * T0 + 2);
+    prep_row(rc, p0);
+    prep_row(rd, p1);
+    if (t0 < t1) {
+        load_row(rc, 2 * T0 + 3);
+        load_row(rd, 2 * T0 + 4);
+    }
+    for (int t = t0; t <= t1;) {
+        step(t, p0, p1, p2, p3, a, b, a2, b2);
+        if (++t > t1) break;
+        step(t, p2, p3, p0, p1, a2, b2, a, b);
+        ++t;
+    }
+    };  // walk
+    if (edge_wave) walk(std::true_type{});
+    else walk(std::false_type{});
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -825,8 +989,10 @@ __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
     const uint32_t colb = (uint32_t)((X >> 1) - 1 - p.lox1) * 4u;         // coarse column c-1, bytes
     const uint32_t inb = (uint32_t)(X - gm.ix0) * 2u, outb = (uint32_t)x * 2u;
     const uint32_t psb = (uint32_t)p.ps1 * 4u;
-    auto hl0 = [](float rm, float r0) { return r0 * 0.75f + rm * 0.25f; };  // lerp(f[c], f[c-1], 1/4): X even
-    auto hl1 = [](float r0, float rp) { return rp * 0.25f + r0 * 0.75f; };  // lerp(f[c+1], f[c], 3/4): X odd
+    // lerp(zero, one, w) = zero*(1-w) + one*w with w in {1/4, 3/4}: the product by 1/4 is exact, so adding it with
+    // an fma rounds exactly like the separate multiply and add of the definition (one instruction less per lerp)
+    auto hl0 = [](float rm, float r0) { return __builtin_fmaf(rm, 0.25f, r0 * 0.75f); };  // lerp(f[c], f[c-1], 1/4): X even
+    auto hl1 = [](float r0, float rp) { return __builtin_fmaf(rp, 0.25f, r0 * 0.75f); };  // lerp(f[c+1], f[c], 3/4): X odd
     for (int y = y0; y < y1; y++) {
         const int Y = p.oy0 + y;
         const uint16_t *irow = p.in + (long)(Y - gm.iy0) * p.in_sy;
@@ -834,10 +1000,13 @@ __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
         const ushort2 c0 = ld_su<ushort2>(irow + p.gco[0], inb), c1 = ld_su<ushort2>(irow + p.gco[1], inb),
                       c2 = ld_su<ushort2>(irow + p.gco[2], inb);
         const int ya = dev::fdiv2(Y + 1) - p.loy1, yb = dev::fdiv2(Y - 1) - p.loy1;
-        const float wy = dev::fmod2(Y) ? 0.75f : 0.25f, wy1 = 1.0f - wy;
-        const float *ga = p.g1 + (size_t)ya * p.ws1, *gb = p.g1 + (size_t)yb * p.ws1;
-        const float *oa = p.out1 + (size_t)ya * p.ws1, *ob = p.out1 + (size_t)yb * p.ws1;
-        auto vl = [&](float ua, float ub) { return ua * wy1 + ub * wy; };
+        const bool yodd = dev::fmod2(Y) != 0;  // wave-uniform
+        // lerp(ua, ub, wy) (:280), ua from coarse row ya, ub from yb: wy = 3/4 for odd Y, 1/4 for even Y.  The row
+        // whose weight is 1/4 (an exact product) is called q, the other t — a scalar choice of row pointers.
+        const int yq = yodd ? ya : yb, yt = yodd ? yb : ya;
+        const float *ga = p.g1 + (size_t)yq * p.ws1, *gb = p.g1 + (size_t)yt * p.ws1;
+        const float *oa = p.out1 + (size_t)yq * p.ws1, *ob = p.out1 + (size_t)yt * p.ws1;
+        auto vl = [&](float uq, float ut) { return __builtin_fmaf(uq, 0.25f, ut * 0.75f); };
         const F3U OA = ld_su<F3U>(oa, colb), OB = ld_su<F3U>(ob, colb);
         const float uo[2] = {vl(hl0(OA.x, OA.y), hl0(OB.x, OB.y)), vl(hl1(OA.y, OA.z), hl1(OB.y, OB.z))};
         const uint16_t ch[3][2] = {{c0.x, c0.y}, {c1.x, c1.y}, {c2.x, c2.y}};
@@ -846,9 +1015,10 @@ __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
         for (int i = 0; i < 2; i++) {
             const float gray = gray_from(ch[0][i], ch[1][i], ch[2][i]);
             const float level = gray * gm.Km1;
-            const int li = dev::clampi((int)level, 0, gm.K - 2);
+            // gray >= 0: the lower bounds of clamp(.., 0, ..) (:43, :66) can never bind
+            const int li = min((int)level, gm.K - 2);
             const float lif = (float)li, lf = level - lif;
-            const int idx = dev::clampi((int)(level * 256.0f), 0, gm.half);
+            const int idx = min((int)(level * 256.0f), gm.half);
             const float *lp = lut + (idx - 256 * li + gm.half);
             const float lev0 = lif * gm.inv_Km1, lev1 = (lif + 1.0f) * gm.inv_Km1;
             const uint32_t pb = (uint32_t)li * psb + colb + 4u * i;
@@ -869,7 +1039,7 @@ __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
             float q[3];
             div3_by(n, gr, q);
 #pragma unroll
-            for (int c = 0; c < 3; c++) res[c][i] = (uint16_t)dev::clampf(q[c], 0.0f, 65535.0f);
+            for (int c = 0; c < 3; c++) res[c][i] = (uint16_t)__builtin_amdgcn_fmed3f(q[c], 0.0f, 65535.0f);  // q is never NaN
         }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -1052,9 +1222,9 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         r = launch_d0(&ll_down0<false, true, true, true, A>);         \
         break;
         const int abl0 = env_int("HLMI_LL_ABL0", 0);
-        if (!abl0 && levels == KCH && (variant & 7) == 7 && !env_int("HLMI_LL_NO_FULL", 0)) {
-            r = d.odd ? launch_d0(&ll_down0<true, true, true, true, 0, true>)
-                      : launch_d0(&ll_down0<false, true, true, true, 0, true>);
+        if (!abl0 && levels == KCH && vec && lut_lds && env_int("HLMI_LL_D0F", 1)) {
+            if (d.odd) r = b1 ? launch_d0(&ll_down0f<true, true>) : launch_d0(&ll_down0f<true, false>);
+            else r = b1 ? launch_d0(&ll_down0f<false, true>) : launch_d0(&ll_down0f<false, false>);
         } else if (abl0 && variant == 7) {  // timing experiments on the main variant only
             switch (abl0) { LL_D0A(1) LL_D0A(2) LL_D0A(3) LL_D0A(4) LL_D0A(6) LL_D0A(7) }
         } else {
