@@ -659,7 +659,7 @@ struct DevLevel {
     int rx0, ry0, rw, rh;    // R_j
 };
 struct CoarseArgs {
-    DevLevel lv[4];          // lv[0] = level S (stored), lv[d] = level S+d
+    DevLevel lv[J];          // lv[0] = level S (stored), lv[d] = level S+d
     int K;
     float Km1;
 };
@@ -749,14 +749,16 @@ __host__ __device__ constexpr int um_win(int d) {  // edge of the region of leve
     for (int i = 0; i < d; i++) w = w / 2 + 2;
     return w;
 }
+__host__ __device__ constexpr int um_off(int d) {  // offset of level S+d's region in the workgroup's LDS array
+    int o = 0;
+    for (int i = 0; i < d; i++) o += um_win(i) * um_win(i);
+    return o;
+}
 template<int TOP>
 __global__ __launch_bounds__(256) void ll_up_multi(CoarseArgs a, int ntx) {
-    constexpr int W1 = um_win(1), W2 = TOP >= 2 ? um_win(2) : 1, W3 = TOP >= 3 ? um_win(3) : 1;
-    __shared__ float t0[UM_T * UM_T], t1[W1 * W1], t2[W2 * W2], t3[W3 * W3];
-    float *const tiles[4] = {t0, t1, t2, t3};
-    const int ws_[4] = {UM_T, W1, W2, W3};
+    __shared__ float tl[um_off(TOP + 1)];
     const int tx = blockIdx.x % ntx, ty = blockIdx.x / ntx;
-    Range2 reg[4];
+    Range2 reg[TOP + 1];
     {
         const DevLevel &L = a.lv[0];
         reg[0].x0 = L.rx0 + tx * UM_T, reg[0].x1 = min(reg[0].x0 + UM_T - 1, L.rx0 + L.rw - 1);
@@ -767,11 +769,14 @@ __global__ __launch_bounds__(256) void ll_up_multi(CoarseArgs a, int ntx) {
             reg[d].y0 = dev::fdiv2(reg[d - 1].y0 - 1), reg[d].y1 = dev::fdiv2(reg[d - 1].y1 + 1);
         }
     }
-    // 1. outLPyramid of every level (memory-bound part, all of it independent)
+    // 1. outLPyramid of every level (memory-bound part, all of it independent), finest level first so that its
+    //    loads (the bulk of the traffic) are in flight while the coarse ones are computed
 #pragma unroll
-    for (int d = TOP; d >= 0; d--) {
+    for (int d = 0; d <= TOP; d++) {
         const DevLevel &L = a.lv[d];
         const Range2 r = reg[d];
+        float *const tile = tl + um_off(d);
+        const int tw = um_win(d);
         const int nx = r.x1 - r.x0 + 1, n = nx * (r.y1 - r.y0 + 1);
         for (int e = threadIdx.x; e < n; e += 256) {
             const int yy = e / nx, X = r.x0 + (e - yy * nx), Y = r.y0 + yy;
@@ -782,7 +787,7 @@ __global__ __launch_bounds__(256) void ll_up_multi(CoarseArgs a, int ntx) {
                 const DevLevel &C = a.lv[d + 1];
                 v = outl_value(L.g, L.ws, L.ps, L.lox, L.loy, C.g, C.ws, C.ps, C.lox, C.loy, X, Y, a.K, a.Km1);
             }
-            tiles[d][yy * ws_[d] + (X - r.x0)] = v;
+            tile[yy * tw + (X - r.x0)] = v;
         }
     }
     __syncthreads();
@@ -790,8 +795,9 @@ __global__ __launch_bounds__(256) void ll_up_multi(CoarseArgs a, int ntx) {
 #pragma unroll
     for (int d = TOP - 1; d >= 0; d--) {
         const Range2 r = reg[d], c = reg[d + 1];
-        const float *const ct = tiles[d + 1];
-        const int cw = ws_[d + 1];
+        const float *const ct = tl + um_off(d + 1);
+        float *const tile = tl + um_off(d);
+        const int cw = um_win(d + 1), tw = um_win(d);
         const int nx = r.x1 - r.x0 + 1, n = nx * (r.y1 - r.y0 + 1);
         for (int e = threadIdx.x; e < n; e += 256) {
             const int yy = e / nx, X = r.x0 + (e - yy * nx), Y = r.y0 + yy;
@@ -800,12 +806,12 @@ __global__ __launch_bounds__(256) void ll_up_multi(CoarseArgs a, int ntx) {
             const float wx = (float)(dev::fmod2(X) * 2 + 1) * 0.25f, wy = (float)(dev::fmod2(Y) * 2 + 1) * 0.25f;
             const float ua = dev::lerpf(ct[ya * cw + xa], ct[ya * cw + xb], wx);
             const float ub = dev::lerpf(ct[yb * cw + xa], ct[yb * cw + xb], wx);
-            const float v = dev::lerpf(ua, ub, wy) + tiles[d][yy * ws_[d] + (X - r.x0)];
+            const float v = dev::lerpf(ua, ub, wy) + tile[yy * tw + (X - r.x0)];
             if (d == 0) {
                 const DevLevel &L = a.lv[0];
                 L.out[(size_t)(Y - L.loy) * L.ws + (X - L.lox)] = v;
             } else {
-                tiles[d][yy * ws_[d] + (X - r.x0)] = v;
+                tile[yy * tw + (X - r.x0)] = v;
             }
         }
         if (d > 0) __syncthreads();
@@ -1286,21 +1292,40 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         if (d.odd) LL_DS(true); else LL_DS(false);
 #undef LL_DS
     }
-    if (S < J) {
-        const int ntx = (ca.lv[0].rw + UM_T - 1) / UM_T, nty = (ca.lv[0].rh + UM_T - 1) / UM_T;
+    // the collapse (outGPyramid[J-1] .. outGPyramid[SU]) is ONE launch (ll_up_multi); opt-in: on the large levels its per-pixel overhead exceeds the saved launches
+    const int SU = [&] {
+        int v = env_int("HLMI_LL_UPCHAIN_FROM", 0);
+        return (v >= 1 && v <= J - 2) ? v : S;
+    }();
+    if (SU < J) {
+        CoarseArgs cu;
+        for (int dl = 0; SU + dl < J; dl++) {
+            const Level &L = lv[SU + dl];
+            DevLevel &D = cu.lv[dl];
+            D.g = L.g, D.out = L.out, D.lox = L.lox, D.loy = L.loy, D.w = L.w, D.h = L.h, D.ws = L.ws, D.ps = (unsigned)L.ps;
+            D.rx0 = L.rx0, D.ry0 = L.ry0, D.rw = L.rx1 - L.rx0 + 1, D.rh = L.ry1 - L.ry0 + 1;
+        }
+        cu.K = levels, cu.Km1 = gm.Km1;
+        const int ntx = (cu.lv[0].rw + UM_T - 1) / UM_T, nty = (cu.lv[0].rh + UM_T - 1) / UM_T;
         dim3 grid((unsigned)(ntx * nty)), block(256);
         char nm[32];
-        snprintf(nm, sizeof nm, "ll_up_multi:%d", S);
-        if (J - 1 - S == 3) HLMI_LAUNCH(uc, nm, st, (ll_up_multi<3>), grid, block, 0, ca, ntx);
-        else if (J - 1 - S == 2) HLMI_LAUNCH(uc, nm, st, (ll_up_multi<2>), grid, block, 0, ca, ntx);
-        else HLMI_LAUNCH(uc, nm, st, (ll_up_multi<1>), grid, block, 0, ca, ntx);
+        snprintf(nm, sizeof nm, "ll_up_multi:%d", SU);
+        {   // per output pixel of level SU: 2 planes of g + inG read, outG written; coarser levels add 1/3
+            const double px = (double)cu.lv[0].rw * cu.lv[0].rh;
+            timing_note_bytes(4.0 * 4.0 * px * (SU + 1 < J ? 4.0 / 3.0 : 1.0));
+        }
+        switch (J - 1 - SU) {
+#define LL_UM(T) case T: HLMI_LAUNCH(uc, nm, st, (ll_up_multi<T>), grid, block, 0, cu, ntx); break;
+            LL_UM(1) LL_UM(2) LL_UM(3) LL_UM(4) LL_UM(5) LL_UM(6)
+#undef LL_UM
+        }
     } else {
         const Level &t = lv[J - 1];
         int rw = t.rx1 - t.rx0 + 1, rh = t.ry1 - t.ry0 + 1;
         HLMI_LAUNCH(uc, "ll_top", st, ll_top, dim3((rw + 63) / 64, rh), dim3(64), 0, t.g, t.ws, t.ps, t.lox, t.loy, t.rx0,
                     t.ry0, rw, rh, levels, gm.Km1, t.out);
     }
-    for (int j = min(S, J - 1) - 1; j >= 1; j--) {
+    for (int j = min(SU, J - 1) - 1; j >= 1; j--) {
         const Level &a = lv[j], &c = lv[j + 1];
         int rw = a.rx1 - a.rx0 + 1, rh = a.ry1 - a.ry0 + 1;
         char nm[32];

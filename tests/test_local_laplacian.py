@@ -210,14 +210,18 @@ def test_hip_matches_oracle(hl, oracle, w, h, levels, kind):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fuse_from", [8, 6, 5, 4])
+@pytest.mark.parametrize("fuse_from,upchain_from", [(8, 0), (6, 0), (5, 0), (4, 0), (4, 3), (4, 2), (4, 1)])
 @pytest.mark.parametrize("w,h,origin", [(640, 480, (0, 0)), (1000, 300, (0, 0)), (301, 203, (17, 33)), (150, 90, (-6, 2))])
-def test_hip_pyramid_levels_match_oracle(hl, oracle, monkeypatch, w, h, origin, fuse_from):
+def test_hip_pyramid_levels_match_oracle(hl, oracle, monkeypatch, w, h, origin, fuse_from, upchain_from):
     """Every outGPyramid level (coarse to fine) must be bit-identical to the oracle's: localises a mismatch
     to the down chain (level 7 wrong), one up step, or the final recolouring.  fuse_from = S: levels >= S are
     handled by the two multi-level kernels (ll_down_multi / ll_up_multi), which materialise outGPyramid[S] but
     not the coarser ones; 8 = one launch per level."""
     monkeypatch.setenv("HLMI_LL_FUSE_FROM", str(fuse_from))
+    # upchain_from = SU: outGPyramid[J-1] .. outGPyramid[SU] are collapsed by ONE ll_up_multi launch (0: SU = S)
+    monkeypatch.setenv("HLMI_LL_UPCHAIN_FROM", str(upchain_from))
+    if upchain_from:
+        fuse_from = upchain_from
     inp = _rand_image(w, h, seed=w + h, kind="smooth")
     a = hl.Buffer(inp).set_min(origin[0], origin[1], 0)
     o = hl.Buffer(np.zeros_like(inp)).set_min(origin[0], origin[1], 0)
