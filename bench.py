@@ -66,8 +66,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("HLMI_BENCH_STREAMS", "1")),
-                    help="HIP streams the frames of a step are spread over (independent frames may overlap)")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("HLMI_BENCH_STREAMS", "2")),
+                    help="HIP streams the frames of a step are spread over: frames are independent units, so the "
+                         "launch-latency-bound coarse pyramid levels of one frame overlap the large kernels of another")
     args = ap.parse_args()
 
     import numpy as np
@@ -100,12 +101,12 @@ def main():
 
     streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else []
 
-    def step():
+    def step(use_streams=True):
         for i, (a, o) in enumerate(zip(ins, outs)):
-            if streams:  # frame i is enqueued on stream i % n: its kernels may overlap the neighbours' launch gaps
+            if streams and use_streams:  # frame i goes to stream i % n: its kernels may overlap the neighbours' launch gaps
                 hl.set_stream(streams[i % len(streams)].cuda_stream)
             hl.local_laplacian(a, LEVELS, ALPHA, BETA, o)
-        if streams:
+        if streams and use_streams:
             hl.set_stream(None)
 
     def barrier():
@@ -124,11 +125,12 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = sharding.max_over_ranks(elapsed, dist, "cuda")
 
-    # --- per-kernel durations, HIP events on the launch stream, separate untimed pass
+    # --- per-kernel durations: HIP events around every launch on the launch stream, in a separate untimed pass on ONE
+    #     stream (kernels of different frames must not overlap while a single kernel is being timed)
     hl.kernel_timing_reset()
     hl.kernel_timing(True)
     for _ in range(3):
-        step()
+        step(use_streams=False)
     torch.cuda.synchronize()
     hl.kernel_timing(False)
     kernels = hl.kernel_timing_report()

@@ -8,9 +8,9 @@ rocminfo 2>/dev/null | grep -m2 -E "Marketing Name" > $OUT/rocminfo.txt; nproc >
 echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q --maxfail=10 --tb=short --durations=8 2>&1 | tail -30 | tee $OUT/pytest_gpu.log
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke.log
 echo "== bench"; timeout 900 python bench.py 2>&1 | tail -1 | tee $OUT/bench.json
-echo "== bench 2 streams"; timeout 900 python bench.py --streams 2 --no-cpu-baseline 2>&1 | tail -1 | tee $OUT/bench_2streams.json
+echo "== bench 1 stream"; timeout 900 python bench.py --streams 1 --no-cpu-baseline 2>&1 | tail -1 | tee $OUT/bench_1stream.json
 cd /tmp
-CMD="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+CMD="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --streams 1"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $CMD > $OUT/kt.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- $CMD > $OUT/pmc_$c.log 2>&1

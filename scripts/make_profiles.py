@@ -35,7 +35,7 @@ if ks:
             if i:
                 row[0] = short(row[0])
             w.writerow(row)
-for name in ("bench.json", "bench_2streams.json", "pytest_gpu.log", "rocminfo.txt"):
+for name in ("bench.json", "bench_1stream.json", "bench_2streams.json", "pytest_gpu.log", "rocminfo.txt", "smoke.log"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f"{rnd}_{name}"))
@@ -69,6 +69,10 @@ if rows:
         for base in ("ll_down0", "ll_up0", "ll_top", "ll_remap_lut"):
             if r[0].startswith(base):
                 per[base] = r[5]
+        # the multi-level kernels are reported as ll_down_multi:<S> / ll_up_multi:<S>; one instantiation each per run
+        for base, depth_to_s in (("ll_down_multi", lambda d: 7 - d), ("ll_up_multi", lambda d: 7 - d)):
+            if r[0].startswith(base + "<"):
+                per[f"{base}:{depth_to_s(int(r[0].split('<')[1].split('>')[0]))}"] = r[5]
     json.dump({"source": f"profiles/{rnd}_pmc_traffic.csv", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per dispatch",
                "bytes_per_launch": per}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print("wrote", sorted(os.listdir(dst)))
