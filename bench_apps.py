@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""bench_apps.py — the other rows of SURVEY.md §8(a) at their BASELINE.json configs, one JSON line per pipeline.
+
+bench.py measures the headline metric (local_laplacian 4K); this script times the remaining entry points of
+libhlmi.so the same way — inputs resident in HBM, calls through the C ABI, `benchmark()`-style best-of-samples of
+`iters` back-to-back calls + device sync (tools/halide_benchmark.h:165-241 of the reference) — and prices each
+against the roofline that bounds it: HBM bytes for the stencil pipelines, fp32 VALU for
+nl_means, bf16 / f32 matrix-core flops for conv_layer.
+
+    python bench_apps.py [--only name,name] [--samples 5]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md
+VALU_F32_PEAK_TF = 157.3       # packed-FMA vector peak
+MFMA_BF16_PEAK_TF = 2500.0     # dense
+MFMA_F32_PEAK_TF = 157.3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--samples", type=int, default=5)
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    import halide_amd as hl
+    if not torch.cuda.is_available():
+        raise SystemExit("bench_apps.py needs a HIP device (no CPU fallback)")
+    rng = np.random.default_rng(0)
+    only = set(filter(None, args.only.split(",")))
+
+    def timed(call, sync_buf, iters):
+        call()
+        sync_buf.device_sync()
+        best = 1e30
+        for _ in range(args.samples):
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                call()
+            sync_buf.device_sync()
+            best = min(best, (time.perf_counter() - t0) / iters)
+        return best
+
+    def kernels(call, sync_buf):
+        hl.kernel_timing_reset()
+        hl.kernel_timing(True)
+        for _ in range(3):
+            call()
+        sync_buf.device_sync()
+        hl.kernel_timing(False)
+        rep = hl.kernel_timing_report()
+        hl.kernel_timing_reset()
+        return {k["name"]: round(k["total_ms"] / 3, 5) for k in rep}
+
+    def emit(name, workload, t, mpx, bound, achieved, peak, unit, extra):
+        print(json.dumps({"pipeline": name, "workload": workload, "ms_per_call": round(t * 1e3, 4),
+                          "value": round(mpx / t / 1e6, 1), "unit": "Mpx/s",
+                          "roofline": {"bound": bound, "achieved": round(achieved, 1), "peak": peak, "unit": unit,
+                                       "frac": round(achieved / peak, 4)}, **extra}), flush=True)
+
+    # ---- configs[0]: blur 3x3, u16 1536x2560 (input 1538x2562)
+    if not only or "blur" in only:
+        W, H = 1536, 2560
+        a = hl.Buffer(rng.integers(0, 65536, (H + 2, W + 2), dtype=np.uint16))
+        o = hl.Buffer(np.zeros((H, W), np.uint16))
+        call = lambda: hl.halide_blur(a, o)
+        t = timed(call, o, 50)
+        emit("halide_blur", "apps/blur 3x3 box, u16 1536x2560", t, W * H, "hbm", 4.0 * W * H / t / 1e9, HBM_PEAK_GBS, "GB/s",
+             {"alg_bytes": 4 * W * H, "kernels_ms": kernels(call, o)})
+
+    # ---- configs[1]: bilateral_grid f32 1920x1080, r_sigma 0.1
+    if not only or "bilateral_grid" in only:
+        W, H = 1920, 1080
+        yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+        img = (0.5 + 0.25 * np.sin(xx / 97.0) * np.cos(yy / 61.0) + 0.2 * (xx > W / 2) + rng.normal(0, 0.03, (H, W))).clip(0, 1)
+        a, o = hl.Buffer(img.astype(np.float32)), hl.Buffer(np.zeros((H, W), np.float32))
+        call = lambda: hl.bilateral_grid(a, 0.1, o)
+        t = timed(call, o, 50)
+        emit("bilateral_grid", "apps/bilateral_grid f32 1920x1080 s_sigma=8 r_sigma=0.1", t, W * H, "hbm",
+             8.0 * W * H / t / 1e9, HBM_PEAK_GBS, "GB/s", {"alg_bytes": 8 * W * H, "kernels_ms": kernels(call, o)})
+
+    # ---- stencil_chain u16 1536x2560, 32 stages
+    if not only or "stencil_chain" in only:
+        W, H = 1536, 2560
+        a = hl.Buffer(rng.integers(0, 65536, (H, W), dtype=np.uint16))
+        o = hl.Buffer(np.zeros((H, W), np.uint16))
+        call = lambda: hl.stencil_chain(a, o)
+        t = timed(call, o, 20)
+        emit("stencil_chain", "apps/stencil_chain 32 stages 5x5, u16 1536x2560", t, W * H, "hbm", 4.0 * W * H / t / 1e9,
+             HBM_PEAK_GBS, "GB/s", {"alg_bytes": 4 * W * H, "kernels_ms": kernels(call, o),
+                                    "note": "4 B/px compulsory; 32 stages x 25 taps = 1600 u16 mul-adds per pixel"})
+
+    # ---- camera_pipe 2592x1968 raw -> 2560x1920x3 u8
+    if not only or "camera_pipe" in only:
+        IW, IH, OW, OH = 2592, 1968, 2560, 1920
+        raw = hl.Buffer(rng.integers(0, 1024, (IH, IW), dtype=np.uint16))
+        m3 = hl.Buffer(np.array([[1.6697, -0.2693, -0.4004, -42.4346], [-0.3576, 1.0615, 1.5949, -37.1158],
+                                 [-0.2175, -1.8751, 6.9640, -26.6970]], np.float32))
+        m7 = hl.Buffer(np.array([[2.2997, -0.4478, 0.1706, -39.0923], [-0.3826, 1.5906, -0.2080, -25.4311],
+                                 [-0.0888, -0.7344, 2.2832, -20.0826]], np.float32))
+        o = hl.Buffer(np.zeros((3, OH, OW), np.uint8))
+        call = lambda: hl.camera_pipe(raw, m3, m7, 3700.0, 2.0, 50.0, 1.0, 25, 1023, o)
+        t = timed(call, o, 50)
+        emit("camera_pipe", "apps/camera_pipe u16 2592x1968 -> u8 2560x1920x3", t, OW * OH, "hbm", 5.0 * OW * OH / t / 1e9,
+             HBM_PEAK_GBS, "GB/s", {"alg_bytes": 5 * OW * OH, "kernels_ms": kernels(call, o)})
+
+    # ---- configs[3]: nl_means 7x7 / 7x7, f32 1920x1080x3 (one frame per call; frames of a batch are independent)
+    if not only or "nl_means" in only:
+        W, H = 1920, 1080
+        a = hl.Buffer(rng.random((3, H, W), dtype=np.float32))
+        o = hl.Buffer(np.zeros((3, H, W), np.float32))
+        call = lambda: hl.nl_means(a, 7, 7, 0.12, o)
+        t = timed(call, o, 10)
+        flops = 2200.0 * W * H       # ~49 offsets x ~45 flops per pixel
+        emit("nl_means", "apps/nl_means patch 7 search 7 sigma 0.12, f32 1920x1080x3", t, W * H, "valu",
+             flops / t / 1e12, VALU_F32_PEAK_TF, "TFLOP/s", {"alg_flops": flops, "alg_bytes": 24 * W * H,
+                                                            "kernels_ms": kernels(call, o)})
+
+    # ---- configs[4]: conv_layer N=16 CI=CO=128 56x56 k=3 — bf16 matrix cores and the exact f32 path
+    for name, fn, peak in (("conv_layer_bf16", "conv_layer_bf16", MFMA_BF16_PEAK_TF), ("conv_layer", "conv_layer", MFMA_F32_PEAK_TF)):
+        if only and name not in only:
+            continue
+        N, Hh, Ww, CI, CO = 16, 56, 56, 128, 128
+        inp = hl.Buffer(rng.uniform(-1, 1, (N, Hh + 2, Ww + 2, CI)).astype(np.float32))
+        filt = hl.Buffer(rng.uniform(-1, 1, (CI, 3, 3, CO)).astype(np.float32))
+        bias = hl.Buffer(rng.uniform(-1, 1, CO).astype(np.float32))
+        o = hl.Buffer(np.zeros((N, Hh, Ww, CO), np.float32))
+        f = getattr(hl, fn)
+        call = lambda: f(inp, filt, bias, o)
+        t = timed(call, o, 50)
+        flops = 2.0 * N * Hh * Ww * CI * CO * 9
+        emit(name, f"apps/conv_layer N=16 CI=CO=128 56x56 k=3 ({'bf16 operands, f32 accumulate' if 'bf16' in name else 'exact f32'})",
+             t, N * Hh * Ww, "mfma", flops / t / 1e12, peak, "TFLOP/s",
+             {"alg_flops": flops, "alg_bytes": 4 * (N * (Hh + 2) * (Ww + 2) * CI + N * Hh * Ww * CO), "kernels_ms": kernels(call, o)})
+
+
+if __name__ == "__main__":
+    main()

@@ -69,6 +69,14 @@ int conv_layer(struct halide_buffer_t *input, struct halide_buffer_t *filter, st
                struct halide_buffer_t *relu);
 HLMI_DECLARE_AUX(conv_layer)
 
+/* Same algorithm, buffers and layouts as conv_layer (apps/conv_layer/conv_layer_generator.cpp:9-12, :21-27, :35-50),
+ * evaluated on the bf16 matrix cores (BASELINE.json configs[4]): input and filter are rounded to bfloat16
+ * (nearest even), products accumulate in f32 from the f32 bias.  CI must be a multiple of 64, CO of 128.
+ * Not bit-exact against the f32 reference by construction: tolerance parity (tests/test_conv_layer.py). */
+int conv_layer_bf16(struct halide_buffer_t *input, struct halide_buffer_t *filter, struct halide_buffer_t *bias,
+                    struct halide_buffer_t *relu);
+HLMI_DECLARE_AUX(conv_layer_bf16)
+
 /* apps/camera_pipe/camera_pipe_generator.cpp:219-228,622 — raw u16 Bayer -> u8 [W,H,3]. */
 int camera_pipe(struct halide_buffer_t *input, struct halide_buffer_t *matrix_3200,
                 struct halide_buffer_t *matrix_7000, float color_temp, float gamma, float contrast,

@@ -163,6 +163,22 @@ def conv_layer(inp: np.ndarray, filt: np.ndarray, bias: np.ndarray) -> np.ndarra
     assert _lib.oracle_conv_layer(inp, filt, bias, out, ci, co, wp - 2, hp - 2, n) == 0
     return out
 
+_lib.oracle_conv_layer_bf16.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+_lib.oracle_conv_layer_bf16.restype = C.c_int
+
+
+def conv_layer_bf16(inp: np.ndarray, filt: np.ndarray, bias: np.ndarray):
+    """Operands rounded to bfloat16 (nearest even), double accumulation.  Returns (relu, mag) where
+    mag = |bias| + sum |products| per output, the scale of the accumulation error of an f32 MFMA chain."""
+    inp, filt, bias = (np.ascontiguousarray(a, np.float32) for a in (inp, filt, bias))
+    n, hp, wp, ci = inp.shape
+    co = bias.shape[0]
+    assert filt.shape == (ci, 3, 3, co)
+    out = np.zeros((n, hp - 2, wp - 2, co), np.float32)
+    mag = np.zeros_like(out)
+    assert _lib.oracle_conv_layer_bf16(inp, filt, bias, out, mag, ci, co, wp - 2, hp - 2, n) == 0
+    return out, mag
+
 _i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
 _lib.oracle_camera_pipe.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.c_int]

@@ -59,6 +59,58 @@ def test_hip_f32_exact_matches_oracle(hl, oracle, n, h, w, ci, co):
         f"{np.count_nonzero(got != want)} of {got.size} differ, max abs {np.max(np.abs(got - want))}"
 
 
+def test_bf16_oracle_rounds_operands_to_nearest_even(oracle):
+    """1 + 2^-8 is the midpoint between the bf16 neighbours 1 and 1 + 2^-7: ties go to the even mantissa (1);
+    1 + 3*2^-8 is the midpoint between 1 + 2^-7 (odd) and 1 + 2^-6 (even)."""
+    ci, co = 64, 128
+    inp = np.zeros((1, 3, 3, ci), np.float32)
+    filt = np.zeros((ci, 3, 3, co), np.float32)
+    bias = np.zeros(co, np.float32)
+    inp[0, 1, 1, 0] = 1.0 + 2.0 ** -8
+    inp[0, 1, 1, 1] = 1.0 + 3 * 2.0 ** -8
+    filt[0, 1, 1, 0] = 1.0
+    filt[1, 1, 1, 1] = 1.0
+    out, mag = oracle.conv_layer_bf16(inp, filt, bias)
+    assert out[0, 0, 0, 0] == 1.0 and out[0, 0, 0, 1] == 1.0 + 2.0 ** -6
+    assert mag[0, 0, 0, 0] == 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,h,w,ci,co", [(16, 56, 56, 128, 128), (5, 80, 100, 128, 128), (1, 1, 1, 64, 128),
+                                         (2, 7, 9, 64, 256), (3, 5, 13, 192, 128)])
+def test_hip_bf16_matches_oracle_within_accumulation_tolerance(hl, oracle, n, h, w, ci, co):
+    """bf16 operands (same rounding as the oracle), f32 accumulation on the matrix cores in hardware order:
+    |gpu - oracle| <= 2e-6 * (|bias| + sum |products|) + 1e-6 — about 16 ulp of the accumulation scale for
+    K = 9 CI <= 1728 terms."""
+    inp, filt, bias = _data(n, h, w, ci, co, seed=3 * n + h + w)
+    got = _run(hl, hl.conv_layer_bf16, inp, filt, bias)
+    want, mag = oracle.conv_layer_bf16(inp, filt, bias)
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    tol = 2e-6 * mag.astype(np.float64) + 1e-6
+    assert (err <= tol).all(), f"{np.count_nonzero(err > tol)} of {got.size} beyond tolerance, worst ratio {np.max(err / tol):.2f}"
+    # and it must really be a bf16 computation: far from the exact f32 result, close to the bf16 oracle
+    exact = oracle.conv_layer(inp, filt, bias)
+    assert np.max(np.abs(got - exact)) > 10 * np.max(err)
+
+
+@pytest.mark.gpu
+def test_hip_bf16_lane_mapping_with_asymmetric_operands(hl, oracle):
+    """A = one-hot pixels, B asymmetric in (ci, co): catches a swapped row/column or k-half mapping exactly
+    (all values are small integers: bf16 and f32 accumulation are exact)."""
+    n, h, w, ci, co = 1, 4, 8, 64, 128
+    inp = np.zeros((n, h + 2, w + 2, ci), np.float32)
+    rng = np.random.default_rng(0)
+    for y in range(h + 2):
+        for x in range(w + 2):
+            inp[0, y, x, rng.integers(0, ci)] = float(rng.integers(1, 4))
+    filt = ((np.arange(ci)[:, None, None, None] * 3 + np.arange(3)[None, :, None, None] * 5 +
+             np.arange(3)[None, None, :, None] * 7 + np.arange(co)[None, None, None, :]) % 17 - 8).astype(np.float32)
+    bias = (np.arange(co) % 5).astype(np.float32)
+    got = _run(hl, hl.conv_layer_bf16, inp, filt, bias)
+    want = oracle.conv_layer(inp, filt, bias)
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.gpu
 def test_hip_rejects_non_dense_layout(hl):
     inp, filt, bias = _data(1, 4, 4, 32, 128, 0)
