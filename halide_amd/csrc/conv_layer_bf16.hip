@@ -15,12 +15,14 @@
 //   conv3x3_bf16_mfma  workgroup = 4 waves = 128 pixels x 128 output channels, wave = 64 x 64 (2x2 accumulators of
 //                      32x32).  Per (ky, kx) and 64-ci chunk: A (128 px x 64 ci, 256 B contiguous per pixel, f32 ->
 //                      bf16 on the way) and B (128 co x 64 ci bf16) are staged in LDS with rows padded to 144 B;
-//                      operands are read with ds_read_b128 (lane l: row l&31, k = 8 (l>>5) .. +7).  The next
-//                      chunk's global loads are issued before the current chunk's 16 MFMAs (register double
-//                      buffer + two LDS buffers, one barrier per chunk).
+//                      operands are read with ds_read_b128 (lane l: row l&31, k = 8 (l>>5) .. +7).  A chunk is only
+//                      16 MFMAs (~0.2 us) against ~1.5 us of memory latency, so three chunks are in flight behind
+//                      the one being multiplied: two in registers (two sets), one in the second LDS buffer.
 //   Algorithmic bytes: input + output once (f32) + the bf16 filter: 27.6 + 25.7 + 0.3 MB at configs[4];
 //   flops 2 N H W CI CO 9 = 14.8 G.
 #include "hlmi_internal.h"
+
+#include <stdlib.h>
 
 using namespace hlmi;
 
@@ -28,6 +30,7 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in registers (HIP's uint4 class does not always)
 
 constexpr int TP = 128;       // pixels per workgroup
 constexpr int TC = 128;       // output channels per workgroup
@@ -39,23 +42,49 @@ struct CGeom {
     long npix;
 };
 
+// n / d for 0 <= n < 2^31 by a multiply and a shift (d is uniform and known on the host): with s = ceil(log2 d) and
+// m = ceil(2^(31+s) / d) the error term m d - 2^(31+s) is < d <= 2^s, so floor(n m / 2^(31+s)) == floor(n / d).
+struct FastDiv {
+    uint32_t m, sh, d;
+};
+FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    uint32_t s = 0;
+    while ((1ull << s) < d) s++;
+    f.m = (uint32_t)((((unsigned long long)1 << (31 + s)) + d - 1) / d);
+    f.sh = 31 + s, f.d = d;
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f) { return (uint32_t)(((unsigned long long)n * f.m) >> f.sh); }
+
 __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {  // {bf16(lo), bf16(hi)}, round to nearest even
     uint32_t r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
 
-// filter f32 [ci][ky][kx][co] (co fastest) -> bf16 wB[kk][co][ci]
+// filter f32 [ci][ky][kx][co] (co fastest) -> bf16
+//   FRAG = false: wB[kk][co][ci]                                  (rows of k, staged through LDS by conv3x3_bf16_mfma)
+//   FRAG = true : wB[kk][ci / 64][(ci % 64) / 16][co / 32][lane][8], lane = co % 32 + 32 ((ci % 16) / 8): every
+//                 32x16 MFMA B fragment is 1 KB contiguous in lane order (one coalesced 16-byte load per lane)
+template<bool FRAG>
 __global__ void conv_filter_bf16(const float *__restrict__ filt, uint16_t *__restrict__ wb, int CI, int CO) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (kk, co, ci pair)
     const int half = CI / 2, total = 9 * CO * half;
     if (e >= total) return;
     const int cp = e % half, co = (e / half) % CO, kk = e / (half * CO);
     const float a = filt[((size_t)(2 * cp) * 9 + kk) * CO + co], b = filt[((size_t)(2 * cp + 1) * 9 + kk) * CO + co];
-    reinterpret_cast<uint32_t *>(wb)[((size_t)kk * CO + co) * half + cp] = pk_bf16(a, b);
+    size_t o;                                             // in bf16 pairs
+    if (FRAG) {
+        const int ci = 2 * cp, cc = ci / KC, ks = (ci % KC) / 16, kh = (ci % 16) / 8, j = ci % 8;
+        o = ((((((size_t)kk * (CI / KC) + cc) * 4 + ks) * (CO / 32) + co / 32) * 64 + (co % 32) + 32 * kh) * 8 + j) / 2;
+    } else {
+        o = ((size_t)kk * CO + co) * half + cp;
+    }
+    reinterpret_cast<uint32_t *>(wb)[o] = pk_bf16(a, b);
 }
 
-__global__ __launch_bounds__(256, 2) void conv3x3_bf16_mfma(const float *__restrict__ in, const uint16_t *__restrict__ wb,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_bf16_mfma(const float *__restrict__ in, const uint16_t *__restrict__ wb,
                                                            const float *__restrict__ bias, float *__restrict__ out, CGeom g) {
     extern __shared__ uint16_t smem[];                       // [2][A: TP x PA | B: TC x PA] bf16
     constexpr int BUF = (TP + TC) * PA;
@@ -67,41 +96,51 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_mfma(const float *__restr
     // loader roles.  A: float4 index aq of the 64-ci chunk, pixels ap + 16 i.  B: 16-byte piece bq, rows bp + 32 i.
     const int aq = tid & 15, ap = tid >> 4;
     const int bq = tid & 7, bp = tid >> 3;
-    long a_base[8];
+    uint32_t a_base[8];                                      // element offsets (buffers hold < 2^31 elements)
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        long p = p0 + ap + 16 * i;
-        if (p >= g.npix) p = g.npix - 1;                     // padded rows are computed but never stored
-        const int x = (int)(p % g.W);
-        const long t = p / g.W;
-        const int y = (int)(t % g.H), n = (int)(t / g.H);
-        a_base[i] = (((long)n * (g.H + 2) + y) * (g.W + 2) + x) * g.CI + 4 * aq;
+        long pl = p0 + ap + 16 * i;
+        if (pl >= g.npix) pl = g.npix - 1;                   // padded rows are computed but never stored
+        const int p = (int)pl;                               // npix < 2^31 (check_shape)
+        const int x = p % g.W, t = p / g.W;
+        const int y = t % g.H, n = t / g.H;
+        a_base[i] = (uint32_t)((((long)n * (g.H + 2) + y) * (g.W + 2) + x) * g.CI + 4 * aq);
     }
-    const long in_row = (long)(g.W + 2) * g.CI;
+    const uint32_t in_row = (uint32_t)(g.W + 2) * g.CI;
     const int cpk = g.CI / KC, nchunk = 9 * cpk;             // chunks per (ky, kx); total
 
-    float4 ra[8];
-    uint4 rb[4];
-    auto gload = [&](int c) {
+    // A (HBM / MALL latency) travels two chunks ahead through two register sets (chunk j in set j & 1) and one
+    // chunk ahead through the second LDS buffer; B (the 295 KB bf16 filter, L2-resident) one chunk ahead.
+    float4 ra[2][8];
+    u32x4 rb[4];
+    auto chunk_off = [&](int c, uint32_t &a_off, uint32_t &b_off) {
         const int kk = c / cpk, ci0 = (c - kk * cpk) * KC;
         const int ky = kk / 3, kx = kk - 3 * ky;
-        const long a_off = (long)ky * in_row + (long)kx * g.CI + ci0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) ra[i] = *reinterpret_cast<const float4 *>(in + a_base[i] + a_off);
-        const uint16_t *bsrc = wb + ((size_t)kk * g.CO + co0) * g.CI + ci0 + 8 * bq;
-#pragma unroll
-        for (int i = 0; i < 4; i++) rb[i] = *reinterpret_cast<const uint4 *>(bsrc + (size_t)(bp + 32 * i) * g.CI);
+        a_off = (uint32_t)ky * in_row + (uint32_t)kx * g.CI + ci0;
+        b_off = ((uint32_t)kk * g.CO + co0 + bp) * g.CI + ci0 + 8 * bq;
     };
-    auto lstore = [&](int buf) {
+    auto gload_a = [&](int c, float4 (&xa)[8]) {
+        uint32_t a_off, b_off;
+        chunk_off(c, a_off, b_off);
+#pragma unroll
+        for (int i = 0; i < 8; i++) xa[i] = *reinterpret_cast<const float4 *>(in + (a_base[i] + a_off));
+    };
+    auto gload_b = [&](int c) {
+        uint32_t a_off, b_off;
+        chunk_off(c, a_off, b_off);
+#pragma unroll
+        for (int i = 0; i < 4; i++) rb[i] = *reinterpret_cast<const u32x4 *>(wb + (b_off + (uint32_t)(32 * i) * g.CI));
+    };
+    auto lstore = [&](int buf, const float4 (&xa)[8]) {
         uint16_t *sA = smem + buf * BUF, *sB = sA + TP * PA;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             uint2 v;
-            v.x = pk_bf16(ra[i].x, ra[i].y), v.y = pk_bf16(ra[i].z, ra[i].w);
+            v.x = pk_bf16(xa[i].x, xa[i].y), v.y = pk_bf16(xa[i].z, xa[i].w);
             *reinterpret_cast<uint2 *>(sA + (ap + 16 * i) * PA + 4 * aq) = v;
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) *reinterpret_cast<uint4 *>(sB + (bp + 32 * i) * PA + 8 * bq) = rb[i];
+        for (int i = 0; i < 4; i++) *reinterpret_cast<u32x4 *>(sB + (bp + 32 * i) * PA + 8 * bq) = rb[i];
     };
 
     floatx16 acc[2][2];
@@ -113,14 +152,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_mfma(const float *__restr
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = bv;
         }
-
-    gload(0);
-    lstore(0);
-    __syncthreads();
-#pragma unroll 1
-    for (int c = 0; c < nchunk; c++) {
-        if (c + 1 < nchunk) gload(c + 1);
-        const uint16_t *sA = smem + (c & 1) * BUF, *sB = sA + TP * PA;
+    auto compute = [&](int buf) {
+        const uint16_t *sA = smem + buf * BUF, *sB = sA + TP * PA;
         const uint16_t *pa = sA + (64 * wm + (lane & 31)) * PA + 8 * (lane >> 5);
         const uint16_t *pb = sB + (64 * wn + (lane & 31)) * PA + 8 * (lane >> 5);
 #pragma unroll
@@ -134,8 +167,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_mfma(const float *__restr
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (c + 1 < nchunk) lstore((c + 1) & 1);             // the other buffer: last read before the previous barrier
+    };
+    // one chunk: B(c+1) loads, MFMAs on LDS buffer c & 1, chunk c+1 registers -> the other LDS buffer, A(c+3) loads
+    // into the register set just freed; one barrier
+    auto chunk = [&](int c, float4 (&xa)[8]) {
+        if (c + 1 < nchunk) gload_b(c + 1);
+        compute(c & 1);
+        if (c + 1 < nchunk) lstore((c + 1) & 1, xa);
+        if (c + 3 < nchunk) gload_a(c + 3, xa);
         __syncthreads();
+    };
+
+    gload_a(0, ra[0]);
+    gload_b(0);
+    lstore(0, ra[0]);
+    if (1 < nchunk) gload_a(1, ra[1]);
+    if (2 < nchunk) gload_a(2, ra[0]);
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < nchunk; c += 2) {
+        chunk(c, ra[1]);                              // chunk c+1 lives in set 1 (c even)
+        if (c + 1 < nchunk) chunk(c + 1, ra[0]);
     }
     // ---- epilogue: relu = max(0, conv), store (co fastest); C/D map: row = (r&3) + 8 (r>>2) + 4 (lane>>5), col = lane&31
 #pragma unroll
@@ -149,6 +201,117 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_mfma(const float *__restr
                 for (int b = 0; b < 2; b++) {
                     const float v = acc[a][b][r];
                     out[p * g.CO + co0 + 64 * wn + 32 * b + (lane & 31)] = v > 0.0f ? v : 0.0f;
+                }
+            }
+        }
+}
+
+// ---- conv3x3_bf16_lin: the same GEMM tiled in INPUT-LINEAR pixel space.
+// With q = (n (H+2) + y) (W+2) + x the tap (ky, kx) of output pixel q reads input pixel q + ky (W+2) + kx: for a tile
+// of 128 consecutive q all nine taps read rows of ONE window of 128 + 2 (W+2) + 2 input pixels.  The window of a
+// 64-ci chunk is staged in LDS once (f32 -> bf16) and the nine taps are nine row offsets into it — 9x less A traffic
+// through L1 / LDS than re-staging an im2col slice per tap; B streams from L2 into registers.
+// Positions q with x >= W or y >= H are not outputs (7 % of a 56x56 image): computed, never stored.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv3x3_bf16_lin(const float *__restrict__ in, const uint16_t *__restrict__ wb, const float *__restrict__ bias,
+                      float *__restrict__ out, CGeom g, int AR, FastDiv d_img, FastDiv d_row) {
+    extern __shared__ uint16_t smem[];                       // A window: AR x PA bf16
+    uint16_t *const sA = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int Wp = g.W + 2, Hp = g.H + 2;
+    const long NQ = (long)g.N * Hp * Wp;
+    const long Q0 = (long)blockIdx.x * TP;
+    const int co0 = blockIdx.y * TC;
+    const int aq = tid & 15, ap = tid >> 4;                  // A loader: float4 aq of the chunk, window rows ap + 16 i
+    const int cpk = g.CI / KC, ntap = 9 * cpk;
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const float bv = bias[co0 + 64 * wn + 32 * b + (lane & 31)];
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = bv;
+        }
+    // B operands come straight from the bf16 filter in L2 (lane l: column co = .. + (l & 31), k = 8 (l >> 5) .. + 7 of
+    // each 16-k step: one 16-byte load), three taps ahead through three register stages; tap t uses stage t % 3 (9 taps
+    // per ci chunk, so the stage is kk % 3).  No LDS and no barrier on the B side: within a ci chunk the waves run free.
+    bf16x8 bfr[3][2][4];
+    const uint32_t cot0 = (uint32_t)(co0 + 64 * wn) / 32, ncot = (uint32_t)g.CO / 32;
+    auto load_b = [&](int t, bf16x8 (&dst)[2][4]) {          // tap t = cc * 9 + kk; fragment layout of conv_filter_bf16<true>
+        const int cc = t / 9, kk = t - 9 * cc;
+        const uint32_t f0 = ((uint32_t)kk * cpk + cc) * 4;
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++)
+                dst[b][ks] = *reinterpret_cast<const bf16x8 *>(wb + ((((f0 + ks) * ncot + cot0 + b) * 64 + lane) * 8));
+    };
+    auto tap = [&](int t, int kk, bf16x8 (&bs)[2][4]) {
+        const int ky = kk / 3, kx = kk - 3 * ky;
+        const uint16_t *pa = sA + (64 * wm + (lane & 31) + ky * Wp + kx) * PA + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ks++) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(pa + 16 * ks);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(pa + 32 * PA + 16 * ks);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bs[0][ks], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bs[1][ks], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bs[0][ks], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bs[1][ks], acc[1][1], 0, 0, 0);
+        }
+        if (t + 3 < ntap) load_b(t + 3, bs);                 // refill the stage just consumed
+    };
+    load_b(0, bfr[0]);
+    load_b(1, bfr[1]);
+    load_b(2, bfr[2]);
+#pragma unroll 1
+    for (int cc = 0; cc < cpk; cc++) {
+        if (cc > 0) __syncthreads();                         // every wave is done with the previous window
+        // ---- stage the window of this ci chunk: rows ap + 16 i, 8 rows in flight per thread
+#pragma unroll 1
+        for (int r0 = ap; r0 < AR; r0 += 128) {
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t q = min((uint32_t)Q0 + r0 + 16 * i, (uint32_t)NQ - 1);   // NQ CI < 2^31 elements
+                v[i] = *reinterpret_cast<const float4 *>(in + (q * g.CI + cc * KC + 4 * aq));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (r0 + 16 * i < AR) {
+                    uint2 w;
+                    w.x = pk_bf16(v[i].x, v[i].y), w.y = pk_bf16(v[i].z, v[i].w);
+                    *reinterpret_cast<uint2 *>(sA + (r0 + 16 * i) * PA + 4 * aq) = w;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int k3 = 0; k3 < 9; k3 += 3) {
+            tap(cc * 9 + k3, k3, bfr[0]);
+            tap(cc * 9 + k3 + 1, k3 + 1, bfr[1]);
+            tap(cc * 9 + k3 + 2, k3 + 2, bfr[2]);
+        }
+    }
+    // ---- epilogue
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const long q = Q0 + 64 * wm + 32 * a + row;
+            if (q < NQ) {
+                const uint32_t qi = (uint32_t)q;
+                const uint32_t n = fdiv(qi, d_img), rem = qi - n * d_img.d, y = fdiv(rem, d_row), x = rem - y * d_row.d;
+                if ((int)y < g.H && (int)x < g.W) {
+                    const long p = ((long)n * g.H + y) * g.W + x;
+#pragma unroll
+                    for (int b = 0; b < 2; b++) {
+                        const float v = acc[a][b][r];
+                        out[p * g.CO + co0 + 64 * wn + 32 * b + (lane & 31)] = v > 0.0f ? v : 0.0f;
+                    }
                 }
             }
         }
@@ -195,9 +358,29 @@ extern "C" int conv_layer_bf16(halide_buffer_t *input, halide_buffer_t *filter, 
         if ((r = get_workspace(uc, ctx, wb_bytes, &ws))) return r;
         uint16_t *wb = (uint16_t *)ws;
         const int pairs = 9 * g.CO * (g.CI / 2);
+        const int AR = TP + 2 * (g.W + 2) + 2;               // input-linear window of a 128-pixel tile
+        const size_t sh_lin = (size_t)AR * PA * sizeof(uint16_t);
+        const long NQ = (long)g.N * (g.H + 2) * (g.W + 2);
+        const bool lin = sh_lin <= 80 * 1024 && NQ < (1L << 31) && !getenv("HLMI_CONV_IM2COL");
         timing_note_bytes(6.0 * 9 * g.CO * g.CI);
-        HLMI_LAUNCH(uc, "conv_filter_bf16", ctx.stream, conv_filter_bf16, dim3((pairs + 255) / 256), dim3(256), 0,
-                    dev_ptr<float>(filter), wb, g.CI, g.CO);
+        if (lin) {
+            HLMI_LAUNCH(uc, "conv_filter_bf16", ctx.stream, conv_filter_bf16<true>, dim3((pairs + 255) / 256), dim3(256), 0,
+                        dev_ptr<float>(filter), wb, g.CI, g.CO);
+        } else {
+            HLMI_LAUNCH(uc, "conv_filter_bf16", ctx.stream, conv_filter_bf16<false>, dim3((pairs + 255) / 256), dim3(256), 0,
+                        dev_ptr<float>(filter), wb, g.CI, g.CO);
+        }
+        if (lin) {
+            HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_lin),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_lin));
+            dim3 grid((unsigned)((NQ + TP - 1) / TP), g.CO / TC);
+            timing_note_bytes(4.0 * ((double)NQ * g.CI + (double)g.npix * g.CO) + (double)wb_bytes);
+            HLMI_LAUNCH(uc, "conv3x3_bf16_mfma", ctx.stream, conv3x3_bf16_lin, grid, dim3(256), sh_lin, dev_ptr<float>(input),
+                        wb, dev_ptr<float>(bias), dev_ptr<float>(relu), g, AR,
+                        make_fastdiv((uint32_t)((g.H + 2) * (g.W + 2))), make_fastdiv((uint32_t)(g.W + 2)));
+            mark_output_written(relu);
+            return 0;
+        }
         const size_t sh = (size_t)2 * (TP + TC) * PA * sizeof(uint16_t);  // 73.7 KB: above the 64 KB default window
         HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_mfma),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
