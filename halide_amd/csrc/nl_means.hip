@@ -11,25 +11,30 @@
 // Fast path (patch_size == search_area == 7, the reference's benchmark setting, :79-81): one workgroup owns a
 // 58 x 64 output tile, stages the (58+12) x (64+12) x 3 clamped input window in LDS once, then for each of the
 // 49 offsets (dy outer, dx inner):
-//   phase 1  thread <-> (column of the 64-wide blur_d_y tile, 16-row segment): walks down the column with the
+//   phase 1  thread <-> (column of the 64-wide blur_d_y tile, 8-row segment): walks down the column with the
 //            last 7 values of d in registers, writes blur_d_y to LDS
-//   phase 2  thread <-> (row, 15-px segment): walks along the row with the last 7 blur_d_y values in registers,
-//            w = fast_exp(blur_d * inv_sigma_sq), accumulates 4 sums per pixel in registers (60 VGPRs)
+//   phase 2  thread <-> (row, 8-px segment): walks along the row with the last 7 blur_d_y values in registers,
+//            w = fast_exp(blur_d * inv_sigma_sq), accumulates 4 sums per pixel in registers
+// 512 threads per workgroup (the 81 KB window allows one workgroup per CU: 2 waves per SIMD).
 // Odd LDS pitches (71, 65) keep the row-per-lane accesses of phase 2 conflict-free.
 // Any other (patch_size, search_area): a straightforward one-thread-per-pixel kernel from global memory.
 #include "hlmi_device_math.h"
 #include "hlmi_internal.h"
+
+#include <stdlib.h>
 
 using namespace hlmi;
 
 namespace {
 
 constexpr int P = 7, SA = 7, HALF = 3;
-constexpr int TW = 58, TH = 64;                  // output tile
-constexpr int IW = TW + 4 * HALF, IH = TH + 4 * HALF, IWP = 71;  // input window (halo 3 patch + 3 search), padded pitch
+constexpr int TW = 58;                           // output tile width; the height TH is a template parameter (64 or 80)
+constexpr int IW = TW + 4 * HALF, IWP = 71;      // input window (halo 3 patch + 3 search), padded pitch
 constexpr int BWP = 65;                          // blur_d_y tile: TW + 6 = 64 columns, padded pitch
-constexpr int SEG = 15;                          // phase-2 x segments: 15,15,15,13
-constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)3 * IH * IWP + (size_t)TH * BWP);
+constexpr int NT = 1024;                         // threads per workgroup (the window allows one workgroup per CU: 4 waves
+                                                 // per SIMD hide the LDS latency of the walks)
+constexpr int GROUPS = NT / 64;                  // phase-1 row groups
+constexpr size_t lds_bytes(int th) { return sizeof(float) * ((size_t)3 * (th + 4 * HALF) * IWP + (size_t)th * BWP); }
 
 struct NGeom {
     int ix0, ix1, iy0, iy1, ic0, ic1;  // clamp box of the input (absolute)
@@ -37,8 +42,15 @@ struct NGeom {
     float inv;                         // -1 / (sigma*sigma*patch*patch)
 };
 
-__global__ __launch_bounds__(256) void nlm_7x7(const float *__restrict__ in, long in_sy, long in_sc, NGeom g,
+// TH: tile height (a multiple of GROUPS).  Phase 2 is thread <-> (row r2 = tid % TH, x segment s2 = tid / TH).
+template<int TH>
+__global__ __launch_bounds__(NT) void nlm_7x7(const float *__restrict__ in, long in_sy, long in_sc, NGeom g,
                                               float *__restrict__ out, long out_sy, long out_sc) {
+    constexpr int IH = TH + 4 * HALF;
+    constexpr int ROWS1 = TH / GROUPS;               // rows of blur_d_y a phase-1 thread produces
+    constexpr int NSEG = NT / TH;                    // phase-2 x segments
+    constexpr int SEG = (TW + NSEG - 1) / NSEG;      // pixels per segment (the last one shorter)
+    static_assert(TH % GROUPS == 0 && NSEG * SEG >= TW, "tile shape");
     extern __shared__ float lds[];
     float *sin = lds;                       // [3][IH][IWP]
     float *sbdy = lds + 3 * IH * IWP;       // [TH][BWP]
@@ -46,7 +58,7 @@ __global__ __launch_bounds__(256) void nlm_7x7(const float *__restrict__ in, lon
     const int tx0 = g.ox0 + blockIdx.x * TW, ty0 = g.oy0 + blockIdx.y * TH;  // absolute coords of the tile
 
     // stage the clamped input window (repeat_edge on x, y and c, generator :27)
-    for (int i = tid; i < 3 * IH * IW; i += 256) {
+    for (int i = tid; i < 3 * IH * IW; i += NT) {
         int c = i / (IH * IW), rem = i - c * (IH * IW), r = rem / IW, col = rem - r * IW;
         int x = dev::clampi(tx0 - 2 * HALF + col, g.ix0, g.ix1) - g.ix0;
         int y = dev::clampi(ty0 - 2 * HALF + r, g.iy0, g.iy1) - g.iy0;
@@ -55,11 +67,11 @@ __global__ __launch_bounds__(256) void nlm_7x7(const float *__restrict__ in, lon
     }
     __syncthreads();
 
-    // phase-1 role: column cx of the blur_d_y tile (abs x = tx0 - 3 + cx), rows [16*g1, 16*g1 + 16)
+    // phase-1 role: column cx of the blur_d_y tile (abs x = tx0 - 3 + cx), rows [ROWS1*g1, ROWS1*g1 + ROWS1)
     const int cx = tid & 63, g1 = tid >> 6;
     // phase-2 role: row r2, pixels [SEG*s2, SEG*s2 + npx)
-    const int r2 = tid & 63, s2 = tid >> 6;
-    const int xb = s2 * SEG, npx = min(SEG, TW - xb);
+    const int r2 = tid % TH, s2 = tid / TH;
+    const int xb = s2 * SEG, npx = (s2 < NSEG) ? max(0, min(SEG, TW - xb)) : 0;
 
     float acc[SEG][4];
 #pragma unroll
@@ -72,10 +84,10 @@ __global__ __launch_bounds__(256) void nlm_7x7(const float *__restrict__ in, lon
             // ---- phase 1: d -> blur_d_y
             {
                 const int col = cx + HALF;            // window column of abs x
-                const int row0 = 16 * g1 + HALF;      // window row of abs y = ty0 + 16*g1 - 3
+                const int row0 = ROWS1 * g1 + HALF;   // window row of abs y = ty0 + ROWS1*g1 - 3
                 float dwin[7];
 #pragma unroll
-                for (int i = 0; i < 16 + 6; i++) {
+                for (int i = 0; i < ROWS1 + 6; i++) {
                     const int r = row0 + i;
                     float d = 0.0f;
 #pragma unroll
@@ -94,13 +106,13 @@ __global__ __launch_bounds__(256) void nlm_7x7(const float *__restrict__ in, lon
                         float s = 0.0f;
 #pragma unroll
                         for (int q = 0; q < 7; q++) s = s + dwin[q];
-                        sbdy[(16 * g1 + i - 6) * BWP + cx] = s;
+                        sbdy[(ROWS1 * g1 + i - 6) * BWP + cx] = s;
                     }
                 }
             }
             __syncthreads();
             // ---- phase 2: blur_d, weight, accumulate
-            {
+            if (npx > 0) {
                 const float *brow = sbdy + r2 * BWP + xb;
                 float bwin[7];
 #pragma unroll
@@ -240,13 +252,18 @@ extern "C" int nl_means(halide_buffer_t *input, int32_t patch_size, int32_t sear
     const long in_sy = input->dim[1].stride, in_sc = input->dim[2].stride;
     const long out_sy = output->dim[1].stride, out_sc = output->dim[2].stride;
     if (patch_size == P && search_area == SA) {
-        static bool attr_set[64] = {false};
-        if (!attr_set[ctx.device]) {
-            HLMI_HIP(uc, hipFuncSetAttribute((const void *)nlm_7x7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-            attr_set[ctx.device] = true;
+        // tile height 64; HLMI_NLM_TH=80 selects the taller tile (fewer, larger workgroups: measured 3 % slower at 1080p)
+        const char *e = getenv("HLMI_NLM_TH");
+        const int th = e ? atoi(e) : 64;
+        if (th == 80) {
+            HLMI_HIP(uc, hipFuncSetAttribute((const void *)nlm_7x7<80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(80)));
+            dim3 grid((ow + TW - 1) / TW, (oh + 79) / 80);
+            HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, nlm_7x7<80>, grid, dim3(NT), lds_bytes(80), din, in_sy, in_sc, g, dout, out_sy, out_sc);
+        } else {
+            HLMI_HIP(uc, hipFuncSetAttribute((const void *)nlm_7x7<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(64)));
+            dim3 grid((ow + TW - 1) / TW, (oh + 63) / 64);
+            HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, nlm_7x7<64>, grid, dim3(NT), lds_bytes(64), din, in_sy, in_sc, g, dout, out_sy, out_sc);
         }
-        dim3 grid((ow + TW - 1) / TW, (oh + TH - 1) / TH);
-        HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, nlm_7x7, grid, dim3(256), LDS_BYTES, din, in_sy, in_sc, g, dout, out_sy, out_sc);
     } else {
         HLMI_LAUNCH(uc, "nlm_generic", ctx.stream, nlm_generic, dim3((ow + 255) / 256, oh), dim3(256), 0, din, in_sy, in_sc, g,
                     patch_size, search_area, dout, out_sy, out_sc);
