@@ -21,13 +21,15 @@ namespace {
 constexpr int STENCILS = 32;  // GeneratorParam stencils (:7)
 constexpr int FUSE = 8, TW = 64, TH = 64, RW = TW + 4 * FUSE, RH = TH + 4 * FUSE;
 constexpr int LDW = RW + 2;   // +2 u16 = one bank: rows start on different banks
+constexpr int LDD = LDW / 2;  // row pitch in dwords (49: odd)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 // src: u16 image with origin (sx0, sy0) in absolute coords and extent sw x sh; CLAMP => repeat_edge (stage 0)
 template<bool CLAMP>
 __global__ __launch_bounds__(256) void stencil_fused8(const uint16_t *__restrict__ src, long src_sy, int sx0, int sy0, int sw,
                                                       int sh, uint16_t *__restrict__ dst, long dst_sy, int dx0, int dy0,
                                                       int dw, int dh) {
-    __shared__ uint16_t buf[2][RH * LDW];
+    __shared__ __attribute__((aligned(4))) uint16_t buf[2][RH * LDW];
     const int tid = threadIdx.x;
     const int ox = dx0 + blockIdx.x * TW, oy = dy0 + blockIdx.y * TH;  // absolute coords of the output tile
     const int gx = ox - 2 * FUSE, gy = oy - 2 * FUSE;                  // absolute coords of the window origin
@@ -51,19 +53,29 @@ __global__ __launch_bounds__(256) void stencil_fused8(const uint16_t *__restrict
     for (int m = 0; m < FUSE; m++) {
         const int lo = 2 * (m + 1);           // output box [lo, RW-1-lo] x [lo, RH-1-lo] in window coords
         const int ow = RW - 2 * lo, oh = RH - 2 * lo;
-        const int nseg = 256 / ow;            // 2..4
+        // A lane owns the column PAIR (x, x+1), x even, as one packed u16x2 register: the box edges lo and RW-1-lo
+        // are even / odd, rows are read as aligned dwords, and all arithmetic is packed 16-bit (v_pk_mad_u16 wraps
+        // each half mod 2^16, which is exactly the reference's uint16 arithmetic).
+        const int pw = ow / 2;                // pairs per row: 46 .. 32
+        const int nseg = 256 / pw;            // 5 .. 8 row segments
         const int seglen = (oh + nseg - 1) / nseg;
-        const uint16_t *s = buf[cur];
-        uint16_t *d = buf[cur ^ 1];
-        if (tid < ow * nseg) {
-            const int seg = tid / ow, x = lo + (tid - seg * ow);
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(buf[cur]);
+        uint32_t *d = reinterpret_cast<uint32_t *>(buf[cur ^ 1]);
+        if (tid < pw * nseg) {
+            const int seg = tid / pw, xp = lo / 2 + (tid - seg * pw);   // dword column of the pair
             const int ys = lo + seg * seglen, ye = min(ys + seglen, lo + oh);
-            unsigned h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0;
+            const u16x2 k2 = {2, 2}, k3 = {3, 3}, k4 = {4, 4}, k5 = {5, 5};
+            u16x2 h0 = {0, 0}, h1 = h0, h2 = h0, h3 = h0, h4 = h0;
+#pragma unroll 5  // five rows per trip: the rotation of the five-row window becomes register renaming
             for (int y = ys - 2; y < ye + 2; y++) {
-                const uint16_t *p = s + y * LDW + x;
-                unsigned h = (unsigned)p[-2] + 2u * p[-1] + 3u * p[0] + 4u * p[1] + 5u * p[2];
+                const uint32_t *p = s + y * LDD + xp;
+                const uint32_t a = p[-1], b = p[0], c = p[1];          // (x-2,x-1) (x,x+1) (x+2,x+3)
+                const u16x2 A = __builtin_bit_cast(u16x2, a), B = __builtin_bit_cast(u16x2, b), C = __builtin_bit_cast(u16x2, c);
+                const u16x2 S1 = __builtin_bit_cast(u16x2, __builtin_amdgcn_alignbit(b, a, 16));  // (x-1, x)
+                const u16x2 S2 = __builtin_bit_cast(u16x2, __builtin_amdgcn_alignbit(c, b, 16));  // (x+1, x+2)
+                const u16x2 h = A + k2 * S1 + k3 * B + k4 * S2 + k5 * C;
                 h0 = h1, h1 = h2, h2 = h3, h3 = h4, h4 = h;
-                if (y >= ys + 2) d[(y - 2) * LDW + x] = (uint16_t)(h0 + 2u * h1 + 3u * h2 + 4u * h3 + 5u * h4);
+                if (y >= ys + 2) d[(y - 2) * LDD + xp] = __builtin_bit_cast(uint32_t, (u16x2)(h0 + k2 * h1 + k3 * h2 + k4 * h3 + k5 * h4));
             }
         }
         __syncthreads();
