@@ -1,0 +1,568 @@
+// hlmi_rungen — command-line runner for the pipelines of libhlmi.so, with the command line and the output format of
+// the reference's RunGen (/root/reference/tools/RunGenMain.cpp:41-190 usage text, tools/RunGen.h:1212-1300), so that
+// the commands its build files issue for `benchmark_apps` keep working:
+//
+//     hlmi_rungen --name=local_laplacian --estimate_all --benchmarks=all --parsable_output
+//     local_laplacian.rungen input=random:0:[3840,2160,3] levels=8 alpha=0.142857 beta=1 output=out.ppm
+//
+// (the reference links one RunGen binary per generator; here the pipeline is `--name=` or the basename of argv[0]
+// up to the first '.').  It drives a pipeline ONLY through what the reference's RunGen uses: `<name>_argv`
+// (src/CodeGen_C.cpp:688-694), `<name>_metadata` (HalideRuntime.h:1937-1975), the bounds-query protocol
+// (HalideRuntime.h:1851-1853: buffers with host == device == 0) and `buf->device_interface` for sync / copy_to_host.
+//
+// Differences, all printed by --help: image files are PGM / PPM (8- or 16-bit) and NumPy .npy; PNG and JPG need
+// libpng / libjpeg, which this build does not link.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+#include <unistd.h>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <map>
+#include <random>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "hlmi_abi.h"
+#include "hlmi_runtime.h"
+
+namespace {
+
+using Shape = std::vector<halide_dimension_t>;
+
+[[noreturn]] void fail(const std::string &msg) {
+    std::cerr << "hlmi_rungen: " << msg << "\n";
+    exit(1);
+}
+
+std::vector<std::string> split(const std::string &s, char sep) {
+    std::vector<std::string> out;
+    std::stringstream ss(s);
+    std::string item;
+    while (std::getline(ss, item, sep)) out.push_back(item);
+    return out;
+}
+
+bool parse_extents(const std::string &s, std::vector<int> *out) {  // "[a,b,c]"
+    if (s.size() < 2 || s.front() != '[' || s.back() != ']') return false;
+    out->clear();
+    for (const auto &t : split(s.substr(1, s.size() - 2), ',')) {
+        char *end = nullptr;
+        long v = strtol(t.c_str(), &end, 10);
+        if (end == t.c_str() || *end) return false;
+        out->push_back((int)v);
+    }
+    return true;
+}
+
+size_t elem_bytes(halide_type_t t) { return (t.bits + 7) / 8; }
+
+std::string type_name(halide_type_t t) {
+    const char *base = t.code == halide_type_int ? "int" : t.code == halide_type_uint ? "uint" : t.code == halide_type_float ? "float" : "handle";
+    return std::string(base) + std::to_string((int)t.bits);
+}
+
+// one argument of the pipeline
+struct Arg {
+    const halide_filter_argument_t *md = nullptr;
+    std::string spec;                 // raw command-line value ("" if none)
+    halide_scalar_value_t scalar{};   // scalars
+    halide_buffer_t buf{};            // buffers
+    Shape dims;
+    std::vector<uint8_t> storage;
+    std::string out_path;
+};
+
+Shape dense_shape(const std::vector<int> &mins, const std::vector<int> &extents) {
+    Shape s(extents.size());
+    int stride = 1;
+    for (size_t i = 0; i < extents.size(); i++) {
+        s[i].min = mins.empty() ? 0 : mins[i];
+        s[i].extent = extents[i];
+        s[i].stride = stride;
+        s[i].flags = 0;
+        stride *= extents[i];
+    }
+    return s;
+}
+
+void allocate(Arg &a) {
+    size_t n = 1;
+    for (auto &d : a.dims) n *= (size_t)std::max(0, d.extent);
+    a.storage.assign(n * elem_bytes(a.md->type) + 64, 0);
+    a.buf = halide_buffer_t{};
+    a.buf.host = a.storage.data();
+    a.buf.type = a.md->type;
+    a.buf.dimensions = (int)a.dims.size();
+    a.buf.dim = a.dims.data();
+}
+
+size_t count(const Arg &a) {
+    size_t n = 1;
+    for (auto &d : a.dims) n *= (size_t)std::max(0, d.extent);
+    return n;
+}
+
+template<typename F>
+void for_each_element(Arg &a, F f) {  // f(index, coords)
+    const size_t n = count(a);
+    std::vector<int> c(a.dims.size(), 0);
+    for (size_t i = 0; i < n; i++) {
+        f(i, c);
+        for (size_t d = 0; d < c.size(); d++) {
+            if (++c[d] < a.dims[d].extent) break;
+            c[d] = 0;
+        }
+    }
+}
+
+void store_value(Arg &a, size_t i, double v) {
+    uint8_t *p = a.storage.data() + i * elem_bytes(a.md->type);
+    const halide_type_t t = a.md->type;
+    if (t.code == halide_type_float && t.bits == 32) { float x = (float)v; memcpy(p, &x, 4); }
+    else if (t.code == halide_type_float && t.bits == 64) { memcpy(p, &v, 8); }
+    else if (t.bits == 8) { uint8_t x = (uint8_t)(int64_t)v; memcpy(p, &x, 1); }
+    else if (t.bits == 16) { uint16_t x = (uint16_t)(int64_t)v; memcpy(p, &x, 2); }
+    else if (t.bits == 32) { uint32_t x = (uint32_t)(int64_t)v; memcpy(p, &x, 4); }
+    else if (t.bits == 64) { uint64_t x = (uint64_t)(int64_t)v; memcpy(p, &x, 8); }
+    else fail("unsupported element type " + type_name(t));
+}
+
+double load_value(const Arg &a, size_t i) {
+    const uint8_t *p = a.storage.data() + i * elem_bytes(a.md->type);
+    const halide_type_t t = a.md->type;
+    if (t.code == halide_type_float && t.bits == 32) { float x; memcpy(&x, p, 4); return x; }
+    if (t.code == halide_type_float && t.bits == 64) { double x; memcpy(&x, p, 8); return x; }
+    if (t.bits == 8) return t.code == halide_type_int ? (double)*(const int8_t *)p : (double)*p;
+    if (t.bits == 16) { uint16_t x; memcpy(&x, p, 2); return t.code == halide_type_int ? (double)(int16_t)x : (double)x; }
+    if (t.bits == 32) { uint32_t x; memcpy(&x, p, 4); return t.code == halide_type_int ? (double)(int32_t)x : (double)x; }
+    fail("unsupported element type " + type_name(t));
+}
+
+// random fill: mt19937_64 seeded as given; floats uniform in [0, 1), integers uniform over the whole range of the type
+// (the convention the reference's RunGen documents, tools/RunGenMain.cpp:98-104)
+void fill_random(Arg &a, uint64_t seed) {
+    std::mt19937_64 rng(seed);
+    const halide_type_t t = a.md->type;
+    const size_t n = count(a);
+    for (size_t i = 0; i < n; i++) {
+        if (t.code == halide_type_float) store_value(a, i, std::uniform_real_distribution<double>(0.0, 1.0)(rng));
+        else store_value(a, i, (double)(rng() & ((t.bits >= 64) ? ~0ull : ((1ull << t.bits) - 1))) - (t.code == halide_type_int ? std::ldexp(1.0, t.bits - 1) : 0.0));
+    }
+}
+
+// ---- image files: binary PGM / PPM (maxval 255 or 65535, big-endian samples) and .npy (C order, little endian)
+bool ends_with(const std::string &s, const std::string &e) { return s.size() >= e.size() && s.compare(s.size() - e.size(), e.size(), e) == 0; }
+
+// conversion rule of the reference's image I/O when the file's sample type differs from the buffer's
+// (tools/halide_image_io.h:79-240): integers rescale by the ratio of the maxima (u8 -> u16 is x257), integer <-> float
+// maps the full range to [0, 1]
+double convert_sample(double v, double file_max, halide_type_t t) {
+    if (t.code == halide_type_float) return v / file_max;
+    const double tmax = std::ldexp(1.0, t.bits) - 1;
+    if (tmax == file_max) return v;
+    return std::floor(v * (tmax / file_max) + 0.5);
+}
+
+void load_pnm(const std::string &path, Arg &a) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) fail("cannot open " + path);
+    std::string magic;
+    int w, h, maxv;
+    f >> magic >> w >> h >> maxv;
+    f.get();
+    const int ch = magic == "P6" ? 3 : magic == "P5" ? 1 : 0;
+    if (!ch) fail(path + ": only binary PGM (P5) / PPM (P6) are supported");
+    const int bps = maxv > 255 ? 2 : 1;
+    std::vector<uint8_t> raw((size_t)w * h * ch * bps);
+    f.read((char *)raw.data(), raw.size());
+    std::vector<int> ext = {w, h};
+    if ((int)a.md->dimensions >= 3) ext.push_back(ch);
+    while ((int)ext.size() < a.md->dimensions) ext.push_back(1);
+    a.dims = dense_shape({}, ext);
+    allocate(a);
+    for_each_element(a, [&](size_t i, const std::vector<int> &c) {
+        const int cc = c.size() >= 3 ? std::min(c[2], ch - 1) : 0;
+        const size_t o = (((size_t)c[1] * w + c[0]) * ch + cc) * bps;
+        const double v = bps == 2 ? (double)((raw[o] << 8) | raw[o + 1]) : (double)raw[o];
+        store_value(a, i, convert_sample(v, maxv, a.md->type));
+    });
+}
+
+void save_pnm(const std::string &path, const Arg &a) {
+    const int w = a.dims.size() > 0 ? a.dims[0].extent : 1, h = a.dims.size() > 1 ? a.dims[1].extent : 1;
+    const int ch = a.dims.size() > 2 ? a.dims[2].extent : 1;
+    if (ch != 1 && ch != 3) fail(path + ": PGM/PPM need 1 or 3 channels, the buffer has " + std::to_string(ch));
+    const halide_type_t t = a.md->type;
+    const bool wide = t.code == halide_type_float || t.bits > 8;
+    const int maxv = wide ? 65535 : 255;
+    std::ofstream f(path, std::ios::binary);
+    f << (ch == 3 ? "P6" : "P5") << "\n" << w << " " << h << "\n" << maxv << "\n";
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            for (int c = 0; c < ch; c++) {
+                const size_t i = (size_t)x * a.dims[0].stride + (a.dims.size() > 1 ? (size_t)y * a.dims[1].stride : 0) +
+                                 (a.dims.size() > 2 ? (size_t)c * a.dims[2].stride : 0);
+                double v = load_value(a, i);
+                if (t.code == halide_type_float) v = std::floor(std::min(1.0, std::max(0.0, v)) * maxv + 0.5);
+                else if (t.bits > 16) v = std::min(65535.0, std::max(0.0, v));
+                const unsigned u = (unsigned)v;
+                if (wide) f.put((char)(u >> 8));
+                f.put((char)(u & 255));
+            }
+}
+
+std::string npy_descr(halide_type_t t) {
+    const char k = t.code == halide_type_float ? 'f' : t.code == halide_type_int ? 'i' : 'u';
+    return std::string(t.bits == 8 ? "|" : "<") + k + std::to_string(t.bits / 8);
+}
+
+void save_npy(const std::string &path, const Arg &a) {  // numpy axes = halide dimensions reversed (C order)
+    std::string shape = "(";
+    for (int d = (int)a.dims.size() - 1; d >= 0; d--) shape += std::to_string(a.dims[d].extent) + ",";
+    shape += ")";
+    std::string hdr = "{'descr': '" + npy_descr(a.md->type) + "', 'fortran_order': False, 'shape': " + shape + ", }";
+    while ((10 + hdr.size() + 1) % 64) hdr += ' ';
+    hdr += '\n';
+    std::ofstream f(path, std::ios::binary);
+    f.write("\x93NUMPY\x01\x00", 8);
+    const uint16_t hl = (uint16_t)hdr.size();
+    f.write((const char *)&hl, 2);
+    f << hdr;
+    f.write((const char *)a.storage.data(), count(a) * elem_bytes(a.md->type));
+}
+
+void load_npy(const std::string &path, Arg &a) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) fail("cannot open " + path);
+    char magic[8];
+    f.read(magic, 8);
+    uint16_t hl;
+    f.read((char *)&hl, 2);
+    std::string hdr(hl, ' ');
+    f.read(&hdr[0], hl);
+    if (hdr.find(npy_descr(a.md->type)) == std::string::npos) fail(path + ": dtype must be " + npy_descr(a.md->type) + " for this argument");
+    if (hdr.find("'fortran_order': False") == std::string::npos) fail(path + ": fortran_order arrays are not supported");
+    const size_t p0 = hdr.find('(', hdr.find("shape")), p1 = hdr.find(')', p0);
+    std::vector<int> np;
+    for (const auto &t : split(hdr.substr(p0 + 1, p1 - p0 - 1), ','))
+        if (t.find_first_of("0123456789") != std::string::npos) np.push_back(atoi(t.c_str()));
+    if ((int)np.size() != a.md->dimensions) fail(path + ": expected " + std::to_string(a.md->dimensions) + " dimensions");
+    std::reverse(np.begin(), np.end());
+    a.dims = dense_shape({}, np);
+    allocate(a);
+    f.read((char *)a.storage.data(), count(a) * elem_bytes(a.md->type));
+}
+
+// ---- benchmark: protocol of tools/halide_benchmark.h:165-241 (>= 3 samples, iterations per sample grown until a
+// sample set lasts min_time, more samples until best and third best agree within 3 % or max_time is spent)
+struct BenchResult { double wall_time; uint64_t samples, iterations; double accuracy; };
+
+double time_iters(uint64_t iters, const std::function<void()> &op) {
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    for (uint64_t i = 0; i < iters; i++) op();
+    const auto t1 = std::chrono::high_resolution_clock::now();
+    return std::chrono::duration<double>(t1 - t0).count() / (double)iters;
+}
+
+BenchResult run_benchmark(const std::function<void()> &op, double min_time_cfg) {
+    const double min_time = std::max(10e-6, min_time_cfg), max_time = std::max(min_time, 4 * min_time_cfg), accuracy = 1.03;
+    BenchResult r{0, 0, 0, 0};
+    double times[4] = {0, 0, 0, 0}, total = 0;
+    uint64_t iters = 1;
+    for (;;) {
+        r.samples = r.iterations = 0, total = 0;
+        for (int i = 0; i < 3; i++) {
+            times[i] = time_iters(iters, op);
+            r.samples++, r.iterations += iters, total += times[i] * iters;
+        }
+        std::sort(times, times + 3);
+        if (times[0] < 1e-9) { iters *= 2; }
+        else {
+            const double f = times[0] * 3;
+            if (f * iters >= min_time) break;
+            iters = (uint64_t)std::llround(std::max(min_time / f, iters * 2.0));
+        }
+        if (iters >= 1000000) { iters = 1000000; break; }
+    }
+    while ((times[0] * accuracy < times[2] || total < min_time) && total < max_time) {
+        times[3] = time_iters(iters, op);
+        r.samples++, r.iterations += iters, total += times[3] * iters;
+        std::sort(times, times + 4);
+    }
+    r.wall_time = times[0], r.accuracy = times[2] / times[0] - 1.0;
+    return r;
+}
+
+void usage() {
+    std::cout <<
+        "Usage: hlmi_rungen --name=PIPELINE argument=value [argument=value ...] [flags]\n"
+        "   or: PIPELINE.rungen argument=value ... (pipeline = basename of argv[0] up to the first '.')\n\n"
+        "Arguments follow the reference's RunGen (tools/RunGenMain.cpp): scalars as literals or `default` / `estimate`;\n"
+        "buffers as a file (.pgm .ppm .npy) or a pseudo-file: zero:[e0,e1,..]  constant:V:[..]  identity:[..]\n"
+        "random:SEED:[..]; `auto` or `estimate` may stand for the extents.\n\n"
+        "Flags: --help --describe --output_extents=[..]|estimate --benchmarks=all --benchmark_min_time=SEC\n"
+        "       --parsable_output --estimate_all --default_input_buffers[=V] --default_input_scalars[=V]\n"
+        "       --success --verbose --quiet\n\n"
+        "PNG / JPG files are not supported by this build (no libpng / libjpeg): use PGM, PPM or .npy.\n";
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    std::string name, default_bufs, default_scalars, output_extents;
+    std::map<std::string, std::string> given;
+    bool describe = false, benchmarks = false, parsable = false, success = false, verbose = false;
+    double min_time = 0.1;
+    {
+        std::string base = argv[0];
+        base = base.substr(base.find_last_of('/') + 1);
+        if (base.find('.') != std::string::npos && base.rfind("hlmi_rungen", 0) != 0) name = base.substr(0, base.find('.'));
+    }
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto val = [&](const std::string &flag) { return a.size() > flag.size() + 1 ? a.substr(flag.size() + 1) : std::string(); };
+        if (a == "--help") { usage(); return 0; }
+        else if (a.rfind("--name=", 0) == 0) name = val("--name");
+        else if (a == "--describe") describe = true;
+        else if (a.rfind("--output_extents", 0) == 0) output_extents = val("--output_extents");
+        else if (a.rfind("--benchmarks", 0) == 0) { if (val("--benchmarks") != "all") fail("--benchmarks only supports 'all'"); benchmarks = true; }
+        else if (a.rfind("--benchmark_min_time", 0) == 0) min_time = atof(val("--benchmark_min_time").c_str());
+        else if (a == "--parsable_output") parsable = true;
+        else if (a == "--estimate_all") { default_bufs = "estimate_then_auto", default_scalars = "estimate", output_extents = "estimate"; }
+        else if (a.rfind("--default_input_buffers", 0) == 0) { default_bufs = val("--default_input_buffers"); if (default_bufs.empty()) default_bufs = "zero:auto"; }
+        else if (a.rfind("--default_input_scalars", 0) == 0) { default_scalars = val("--default_input_scalars"); if (default_scalars.empty()) default_scalars = "estimate,default"; }
+        else if (a == "--success") success = true;
+        else if (a == "--verbose") verbose = true;
+        else if (a == "--quiet" || a == "--track_memory" || a == "--skip_bad_environement") {}
+        else if (a.rfind("--", 0) == 0) fail("unknown flag " + a);
+        else {
+            const size_t eq = a.find('=');
+            if (eq == std::string::npos) fail("expected argument=value, got " + a);
+            given[a.substr(0, eq)] = a.substr(eq + 1);
+        }
+    }
+    if (name.empty()) { usage(); fail("no pipeline: use --name=PIPELINE"); }
+    using argv_fn = int (*)(void **);
+    using md_fn = const halide_filter_metadata_t *(*)();
+    // the library: $HLMI_LIB, else ../lib/libhlmi.so next to this binary, else the loader's search path
+    void *lib = nullptr;
+    if (const char *e = getenv("HLMI_LIB")) lib = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) {
+        char self[4096];
+        const ssize_t n = readlink("/proc/self/exe", self, sizeof self - 1);
+        if (n > 0) {
+            self[n] = 0;
+            std::string dir = self;
+            dir = dir.substr(0, dir.find_last_of('/'));
+            lib = dlopen((dir + "/../lib/libhlmi.so").c_str(), RTLD_NOW | RTLD_GLOBAL);
+        }
+    }
+    if (!lib) lib = dlopen("libhlmi.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) fail(std::string("cannot load libhlmi.so: ") + dlerror());
+    auto f_argv = (argv_fn)dlsym(lib, (name + "_argv").c_str());
+    auto f_md = (md_fn)dlsym(lib, (name + "_metadata").c_str());
+    if (!f_argv || !f_md) fail("libhlmi.so exports no pipeline named '" + name + "'");
+    const halide_filter_metadata_t *md = f_md();
+
+    std::vector<Arg> args(md->num_arguments);
+    for (int i = 0; i < md->num_arguments; i++) {
+        args[i].md = &md->arguments[i];
+        auto it = given.find(md->arguments[i].name);
+        if (it != given.end()) { args[i].spec = it->second; given.erase(it); }
+    }
+    if (!given.empty()) fail("unknown argument '" + given.begin()->first + "' (see --describe)");
+    if (describe) {
+        std::cout << "Filter name: \"" << md->name << "\"\n";
+        for (auto &a : args) {
+            const char *kind = a.md->kind == halide_argument_kind_input_scalar ? "Input" : a.md->kind == halide_argument_kind_input_buffer ? "Input" : "Output";
+            std::cout << "  " << kind << " \"" << a.md->name << "\" is of type ";
+            if (a.md->kind == halide_argument_kind_input_scalar) std::cout << type_name(a.md->type) << "\n";
+            else std::cout << "Buffer<" << type_name(a.md->type) << "> with " << a.md->dimensions << " dimensions\n";
+        }
+        return 0;
+    }
+
+    auto estimate_extents = [&](const Arg &a, std::vector<int> *mins, std::vector<int> *ext) {
+        if (!a.md->buffer_estimates) return false;
+        mins->clear(), ext->clear();
+        for (int d = 0; d < a.md->dimensions; d++) {
+            const int64_t *m = a.md->buffer_estimates[2 * d], *e = a.md->buffer_estimates[2 * d + 1];
+            if (!m || !e) return false;
+            mins->push_back((int)*m), ext->push_back((int)*e);
+        }
+        return true;
+    };
+
+    // ---- scalars
+    for (auto &a : args) {
+        if (a.md->kind != halide_argument_kind_input_scalar) continue;
+        std::string spec = a.spec.empty() ? default_scalars : a.spec;
+        if (spec.empty()) fail(std::string("no value for scalar '") + a.md->name + "' (or use --default_input_scalars / --estimate_all)");
+        bool done = false;
+        for (const auto &tok : split(spec, ',')) {
+            const halide_scalar_value_t *src = tok == "default" ? a.md->scalar_def : tok == "estimate" ? a.md->scalar_estimate : nullptr;
+            if (tok == "default" || tok == "estimate") {
+                if (src) { a.scalar = *src; done = true; break; }
+                continue;
+            }
+            const halide_type_t t = a.md->type;
+            if (t.code == halide_type_float && t.bits == 32) a.scalar.u.f32 = (float)atof(tok.c_str());
+            else if (t.code == halide_type_float) a.scalar.u.f64 = atof(tok.c_str());
+            else if (t.bits == 1 || tok == "true" || tok == "false") a.scalar.u.b = (tok == "true" || tok == "1");
+            else a.scalar.u.i64 = atoll(tok.c_str());
+            done = true;
+            break;
+        }
+        if (!done) fail(std::string("scalar '") + a.md->name + "' has no " + spec + " value in the metadata");
+    }
+
+    // ---- output shapes requested on the command line
+    std::vector<int> out_ext;
+    const bool out_estimate = output_extents == "estimate";
+    if (!output_extents.empty() && !out_estimate && !parse_extents(output_extents, &out_ext)) fail("bad --output_extents " + output_extents);
+
+    // ---- input buffers (pass 1: everything that does not need a bounds query)
+    std::vector<Arg *> auto_inputs;
+    for (auto &a : args) {
+        if (a.md->kind != halide_argument_kind_input_buffer) continue;
+        std::string spec = a.spec.empty() ? default_bufs : a.spec;
+        if (spec.empty()) fail(std::string("no value for buffer '") + a.md->name + "' (or use --default_input_buffers / --estimate_all)");
+        if (spec == "estimate_then_auto") spec = a.md->buffer_estimates ? "random:0:estimate" : "random:0:auto";
+        auto parts = split(spec, ':');
+        const std::string kind = parts[0];
+        if (kind == "zero" || kind == "constant" || kind == "identity" || kind == "random") {
+            const std::string ext_s = parts.back();
+            std::vector<int> mins, ext;
+            if (ext_s == "auto") {
+                a.spec = spec;
+                auto_inputs.push_back(&a);
+                continue;
+            } else if (ext_s == "estimate") {
+                if (!estimate_extents(a, &mins, &ext)) fail(std::string("no estimate for '") + a.md->name + "'");
+            } else if (!parse_extents(ext_s, &ext)) {
+                fail("bad extents in " + spec);
+            }
+            if ((int)ext.size() != a.md->dimensions) fail(std::string("'") + a.md->name + "' has " + std::to_string(a.md->dimensions) + " dimensions");
+            a.dims = dense_shape(mins, ext);
+            allocate(a);
+            a.spec = spec;
+        } else if (ends_with(spec, ".pgm") || ends_with(spec, ".ppm")) {
+            load_pnm(spec, a);
+            a.spec.clear();
+        } else if (ends_with(spec, ".npy")) {
+            load_npy(spec, a);
+            a.spec.clear();
+        } else {
+            fail("cannot read '" + spec + "': supported are .pgm .ppm .npy and the pseudo-files of --help");
+        }
+    }
+    // ---- outputs: shape from --output_extents, the estimates, or a bounds query constrained by the inputs
+    for (auto &a : args) {
+        if (a.md->kind != halide_argument_kind_output_buffer) continue;
+        a.out_path = a.spec;
+        std::vector<int> mins, ext;
+        if (out_estimate) {
+            if (!estimate_extents(a, &mins, &ext)) fail(std::string("no estimate for output '") + a.md->name + "'");
+        } else if (!out_ext.empty()) {
+            ext = out_ext;
+            if ((int)ext.size() != a.md->dimensions) fail("--output_extents has the wrong number of dimensions");
+        }
+        if (!ext.empty()) {
+            a.dims = dense_shape(mins, ext);
+            allocate(a);
+        }
+    }
+    auto call = [&](std::vector<Arg> &as) {
+        std::vector<void *> av;
+        for (auto &a : as) av.push_back(a.md->kind == halide_argument_kind_input_scalar ? (void *)&a.scalar : (void *)&a.buf);
+        return f_argv(av.data());
+    };
+    // bounds query (tools/RunGen.h:1212-1250): every buffer whose shape is still unknown goes in with host == device == 0
+    // and comes back with the shape the pipeline proposes given the others
+    {
+        bool need = false;
+        for (auto &a : args) need |= (a.md->kind != halide_argument_kind_input_scalar && a.storage.empty());
+        if (need) {
+            for (auto &a : args) {
+                if (a.md->kind == halide_argument_kind_input_scalar || !a.storage.empty()) continue;
+                if (a.dims.empty()) a.dims = dense_shape({}, std::vector<int>(a.md->dimensions, 0));
+                a.buf = halide_buffer_t{};
+                a.buf.type = a.md->type, a.buf.dimensions = a.md->dimensions, a.buf.dim = a.dims.data();
+            }
+            if (int r = call(args)) fail("bounds query failed with error " + std::to_string(r));
+            for (auto &a : args) {
+                if (a.md->kind == halide_argument_kind_input_scalar || !a.storage.empty()) continue;
+                allocate(a);
+            }
+        }
+    }
+    // ---- fill the pseudo-file inputs
+    for (auto &a : args) {
+        if (a.md->kind != halide_argument_kind_input_buffer || a.spec.empty()) continue;
+        auto parts = split(a.spec, ':');
+        if (parts[0] == "constant") { const double v = atof(parts[1].c_str()); for (size_t i = 0, n = count(a); i < n; i++) store_value(a, i, v); }
+        else if (parts[0] == "identity") for_each_element(a, [&](size_t i, const std::vector<int> &c) { store_value(a, i, (c.size() >= 2 && c[0] == c[1]) ? 1.0 : 0.0); });
+        else if (parts[0] == "random") fill_random(a, strtoull(parts[1].c_str(), nullptr, 10));
+        a.buf.flags |= 1;  // host_dirty: the pipeline uploads it
+    }
+    if (verbose) {
+        for (auto &a : args) {
+            if (a.md->kind == halide_argument_kind_input_scalar) continue;
+            std::cout << "Argument " << a.md->name << ": [";
+            for (auto &d : a.dims) std::cout << " (" << d.min << "," << d.extent << "," << d.stride << ")";
+            std::cout << " ]\n";
+        }
+    }
+
+    // ---- run
+    auto sync_outputs = [&]() {
+        for (auto &a : args)
+            if (a.md->kind == halide_argument_kind_output_buffer && a.buf.device_interface) a.buf.device_interface->device_sync(nullptr, &a.buf);
+    };
+    if (int r = call(args)) fail(std::string(md->name) + " returned error " + std::to_string(r));
+    sync_outputs();
+    double pixels = 0;
+    for (auto &a : args) {
+        if (a.md->kind != halide_argument_kind_output_buffer) continue;
+        pixels += a.dims.size() >= 2 ? (double)a.dims[0].extent * a.dims[1].extent : a.dims.size() == 1 ? a.dims[0].extent : 1;
+    }
+    if (benchmarks) {
+        const BenchResult r = run_benchmark([&]() { (void)call(args); sync_outputs(); }, min_time);
+        const double mpix = pixels / (1024.0 * 1024.0);
+        if (!parsable) {
+            std::cout << "Benchmark for " << md->name << " produces best case of " << r.wall_time << " sec/iter (over " << r.samples
+                      << " samples, " << r.iterations << " iterations, accuracy " << (r.accuracy * 100.0) << "%).\n"
+                      << "Best output throughput is " << (mpix / r.wall_time) << " mpix/sec.\n";
+        } else {
+            std::cout << md->name << "  BEST_TIME_MSEC_PER_ITER  " << r.wall_time * 1000.0 << "\n"
+                      << md->name << "  SAMPLES                  " << r.samples << "\n"
+                      << md->name << "  ITERATIONS               " << r.iterations << "\n"
+                      << md->name << "  TIMING_ACCURACY          " << r.accuracy << "\n"
+                      << md->name << "  THROUGHPUT_MPIX_PER_SEC  " << (mpix / r.wall_time) << "\n"
+                      << md->name << "  HALIDE_TARGET            " << md->target << "\n";
+        }
+    }
+    // ---- save outputs
+    for (auto &a : args) {
+        if (a.md->kind != halide_argument_kind_output_buffer) continue;
+        if (a.buf.device_interface && (a.buf.flags & 2)) {
+            if (int r = a.buf.device_interface->copy_to_host(nullptr, &a.buf)) fail("copy_to_host failed with " + std::to_string(r));
+        }
+        if (a.out_path.empty()) continue;
+        if (ends_with(a.out_path, ".npy")) save_npy(a.out_path, a);
+        else if (ends_with(a.out_path, ".pgm") || ends_with(a.out_path, ".ppm")) save_pnm(a.out_path, a);
+        else fail("cannot write '" + a.out_path + "': supported are .pgm .ppm .npy");
+    }
+    for (auto &a : args)
+        if (a.md->kind != halide_argument_kind_input_scalar && a.buf.device_interface) a.buf.device_interface->device_free(nullptr, &a.buf);
+    if (success) std::cout << "Success!\n";
+    return 0;
+}

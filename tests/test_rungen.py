@@ -1,0 +1,69 @@
+"""hlmi_rungen: the RunGen-compatible runner (reference: tools/RunGenMain.cpp usage :41-190, output format
+tools/RunGen.h:1285-1298).  It reaches the pipelines only through `<name>_argv` / `<name>_metadata` and the
+bounds-query protocol, like the reference's RunGen."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RUNGEN = os.path.join(ROOT, "halide_amd", "bin", "hlmi_rungen")
+
+
+def _run(*args, check=True):
+    p = subprocess.run([RUNGEN, *args], capture_output=True, text=True, timeout=300)
+    if check:
+        assert p.returncode == 0, p.stdout + p.stderr
+    return p
+
+
+def test_describe_lists_the_generator_arguments():
+    out = _run("--name=local_laplacian", "--describe").stdout
+    assert 'Input "input" is of type Buffer<uint16> with 3 dimensions' in out
+    assert 'Input "levels" is of type int32' in out and 'Input "alpha" is of type float32' in out
+    assert 'Output "output" is of type Buffer<uint16> with 3 dimensions' in out
+    out = _run("--name=nl_means", "--describe").stdout
+    assert 'Input "sigma" is of type float32' in out and 'Output "non_local_means"' in out
+
+
+def test_unknown_pipeline_and_argument_are_errors():
+    assert _run("--name=no_such_filter", "--describe", check=False).returncode != 0
+    p = _run("--name=halide_blur", "bogus=1", "--describe", check=False)
+    assert p.returncode != 0 and "unknown argument" in p.stderr
+
+
+def test_argv0_basename_selects_the_pipeline(tmp_path):
+    link = tmp_path / "stencil_chain.rungen"
+    os.symlink(RUNGEN, link)
+    p = subprocess.run([str(link), "--describe"], capture_output=True, text=True, env={**os.environ, "HLMI_LIB": os.path.join(ROOT, "halide_amd", "lib", "libhlmi.so")})
+    assert p.returncode == 0 and 'Filter name: "stencil_chain"' in p.stdout
+
+
+@pytest.mark.gpu
+def test_estimate_all_benchmark_parsable_output():
+    out = _run("--name=local_laplacian", "--estimate_all", "--benchmarks=all", "--parsable_output", "--success").stdout
+    keys = {l.split()[1] for l in out.splitlines() if l.startswith("local_laplacian ")}
+    assert {"BEST_TIME_MSEC_PER_ITER", "SAMPLES", "ITERATIONS", "TIMING_ACCURACY", "THROUGHPUT_MPIX_PER_SEC", "HALIDE_TARGET"} <= keys
+    assert "Success!" in out
+
+
+@pytest.mark.gpu
+def test_npy_round_trip_matches_the_direct_call(hl, oracle, tmp_path):
+    rng = np.random.default_rng(3)
+    inp = rng.integers(0, 65536, (3, 120, 200), dtype=np.uint16)
+    np.save(tmp_path / "in.npy", inp)
+    _run("--name=local_laplacian", f"input={tmp_path / 'in.npy'}", "levels=8", "alpha=0.14285714285714285", "beta=1",
+         f"output={tmp_path / 'out.npy'}", "--output_extents=[200,120,3]")
+    got = np.load(tmp_path / "out.npy")
+    want = oracle.local_laplacian(inp, 8, np.float32(0.14285714285714285), 1.0)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_bounds_query_sizes_auto_inputs_and_ppm_output(tmp_path):
+    # blur reads (W+2) x (H+2): `auto` must come back from the bounds query as 66 x 50 for a 64 x 48 output
+    p = _run("--name=halide_blur", "input=random:1:auto", f"blur_y={tmp_path / 'o.pgm'}", "--output_extents=[64,48]", "--verbose")
+    assert "Argument input: [ (0,66,1) (0,50,66) ]" in p.stdout
+    with open(tmp_path / "o.pgm", "rb") as f:
+        assert f.read(2) == b"P5"
