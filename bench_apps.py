@@ -124,6 +124,18 @@ def main():
              flops / t / 1e12, VALU_F32_PEAK_TF, "TFLOP/s", {"alg_flops": flops, "alg_bytes": 24 * W * H,
                                                             "kernels_ms": kernels(call, o)})
 
+    # ---- depthwise_separable_conv at the driver's shape (MobileNet-v2 layer 2, process.cpp:13)
+    if not only or "depthwise_separable_conv" in only:
+        N, Hh, Ww, CI, CO = 4, 112, 112, 32, 16
+        bufs = [hl.Buffer(rng.uniform(-1, 1, sh).astype(np.float32)) for sh in ((N, Hh, Ww, CI), (3, 3, CI, 1), (CI, CO), (CO,))]
+        o = hl.Buffer(np.zeros((N, Hh, Ww, CO), np.float32))
+        call = lambda: hl.depthwise_separable_conv(*bufs, o)
+        t = timed(call, o, 50)
+        nbytes = 4.0 * N * Hh * Ww * (CI + CO)
+        emit("depthwise_separable_conv", "apps/depthwise_separable_conv N=4 CI=32 CO=16 CM=1 112x112 3x3", t, N * Hh * Ww, "hbm",
+             nbytes / t / 1e9, HBM_PEAK_GBS, "GB/s", {"alg_bytes": nbytes, "alg_flops": 2.0 * N * Hh * Ww * (CI * 9 + CI * CO),
+                                                      "kernels_ms": kernels(call, o)})
+
     # ---- configs[4]: conv_layer N=16 CI=CO=128 56x56 k=3 — bf16 matrix cores and the exact f32 path
     for name, fn, peak in (("conv_layer_bf16", "conv_layer_bf16", MFMA_BF16_PEAK_TF), ("conv_layer", "conv_layer", MFMA_F32_PEAK_TF)):
         if only and name not in only:

@@ -1,0 +1,197 @@
+// depthwise_separable_conv.hip — gfx950 implementation of the reference's depthwise_separable_conv AOT pipeline
+// (depthwise FWxFH convolution with zero padding, pointwise 1x1 convolution, bias, ReLU).
+//
+// Algorithm: /root/reference/apps/depthwise_separable_conv/depthwise_separable_conv_generator.cpp:24-75; boundary:
+// `int depthwise_separable_conv(halide_buffer_t *input, halide_buffer_t *depthwise_filter, halide_buffer_t
+// *pointwise_filter, halide_buffer_t *bias, halide_buffer_t *output)` (:11-23).  Layouts (dimension 0 innermost):
+// input [CI, W, H, N], depthwise_filter [CM, IC', FW, FH] with stride(1) == CM (:283), pointwise_filter [CO, IC],
+// bias [CO], output [CO, W, H, N].  The reference's driver runs MobileNet-v2's second layer: N=4, CI=32, CO=16, CM=1,
+// 112x112, 3x3 (process.cpp:13).
+//
+// Arithmetic: every update of the two reductions is one fma in RDom order (rd fastest, then rx, ry; rc ascending
+// from the bias) — the same canonical order as oracle/depthwise_separable_conv_oracle.c, so the result is bit-exact.
+//
+// The layer is HBM/launch bound (80 MFLOP against 6.4 MB in + 3.2 MB out at the driver's shape), so no matrix
+// cores: a workgroup owns TP consecutive pixels of one image row; phase 1 computes the IC depthwise channels of each
+// pixel into LDS (thread <-> (pixel, channel): channel-contiguous = coalesced input rows), phase 2 the CO outputs of
+// each pixel from LDS (thread <-> (pixel, output channel)), with both filters staged in LDS once per workgroup.
+#include "hlmi_internal.h"
+
+using namespace hlmi;
+
+namespace {
+
+constexpr int TP = 32;  // pixels of one output row per workgroup
+
+struct DGeom {
+    int CI, W, H, N, CM, FW, FH, IC, CO;
+    int ix0, iy0;            // input mins in x, y (<= 0)
+    int ox0, oy0, ow, oh;    // output region
+    long in_sx, in_sy, in_sn, out_sx, out_sy, out_sn;
+    long d_s1, d_sx, d_sy, p_s1;
+};
+
+__global__ __launch_bounds__(256) void dsc_fused(const float *__restrict__ in, const float *__restrict__ dw,
+                                                const float *__restrict__ pw, const float *__restrict__ bias,
+                                                float *__restrict__ out, DGeom g) {
+    extern __shared__ float lds[];
+    float *s_mid = lds;                              // [TP][IC]
+    float *s_dw = s_mid + TP * g.IC;                 // [FH][FW][IC][CM]
+    float *s_pw = s_dw + g.FH * g.FW * g.IC * g.CM;  // [IC][CO]
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TP, y = blockIdx.y, n = blockIdx.z;
+    for (int i = tid; i < g.FH * g.FW * g.IC * g.CM; i += 256) {
+        const int rd = i % g.CM, d = (i / g.CM) % g.IC, rx = (i / (g.CM * g.IC)) % g.FW, ry = i / (g.CM * g.IC * g.FW);
+        s_dw[i] = dw[rd + d * g.d_s1 + rx * g.d_sx + ry * g.d_sy];
+    }
+    for (int i = tid; i < g.IC * g.CO; i += 256) s_pw[i] = pw[(i % g.CO) + (long)(i / g.CO) * g.p_s1];
+    __syncthreads();
+    const int padw = g.FW / 2, padh = g.FH / 2;
+    const int Y = g.oy0 + y;
+    // ---- phase 1: depthwise_convolved(d, X, Y, n) for the tile's pixels
+    for (int e = tid; e < TP * g.IC; e += 256) {
+        const int px = e / g.IC, d = e - px * g.IC;
+        const int X = g.ox0 + x0 + px;
+        float acc = 0.0f;
+        if (x0 + px < g.ow) {
+            for (int ry = 0; ry < g.FH; ry++) {
+                for (int rx = 0; rx < g.FW; rx++) {
+                    const int xx = X + rx - padw, yy = Y + ry - padh;
+                    // (:36-43): in_bounds tests against the EXTENTS, the read is clamped to [0, max]
+                    const bool inb = xx >= 0 && xx < g.W && yy >= 0 && yy < g.H;
+                    const int cx = min(max(xx, 0), g.ix0 + g.W - 1), cy = min(max(yy, 0), g.iy0 + g.H - 1);
+                    const float v = inb ? in[(long)n * g.in_sn + (long)(cy - g.iy0) * g.in_sy + (long)(cx - g.ix0) * g.in_sx + d / g.CM] : 0.0f;
+                    const float *f = s_dw + ((ry * g.FW + rx) * g.IC + d) * g.CM;
+                    for (int rd = 0; rd < g.CM; rd++) acc = __builtin_fmaf(f[rd], v, acc);
+                }
+            }
+        }
+        s_mid[e] = acc;
+    }
+    __syncthreads();
+    // ---- phase 2: pointwise + bias + ReLU
+    for (int e = tid; e < TP * g.CO; e += 256) {
+        const int px = e / g.CO, c = e - px * g.CO;
+        if (x0 + px >= g.ow) continue;
+        float acc = bias[c];
+        const float *m = s_mid + px * g.IC;
+        for (int rc = 0; rc < g.IC; rc++) acc = __builtin_fmaf(s_pw[rc * g.CO + c], m[rc], acc);
+        out[(long)n * g.out_sn + (long)y * g.out_sy + (long)(x0 + px) * g.out_sx + c] = acc > 0.0f ? acc : 0.0f;
+    }
+}
+
+const halide_type_t ty_f32 = {(decltype(halide_type_t::code))2, 32, 0};
+// estimates: generator :78-99 (N=4, CI=32, CO=16, CM=1, 112x112; depthwise_filter.dim(0) estimate is CI/CO as written)
+const int64_t e0 = 0, e32 = 32, e112 = 112, e4 = 4, e2 = 2, e3 = 3, e16 = 16;
+const int64_t *const est_in[8] = {&e0, &e32, &e0, &e112, &e0, &e112, &e0, &e4};
+const int64_t *const est_dw[8] = {&e0, &e2, &e0, &e32, &e0, &e3, &e0, &e3};
+const int64_t *const est_pw[4] = {&e0, &e16, &e0, &e32};
+const int64_t *const est_b[2] = {&e0, &e16};
+const int64_t *const est_o[8] = {&e0, &e16, &e0, &e112, &e0, &e112, &e0, &e4};
+const halide_filter_argument_t dsc_args[5] = {
+    {"input", halide_argument_kind_input_buffer, 4, ty_f32, nullptr, nullptr, nullptr, nullptr, est_in},
+    {"depthwise_filter", halide_argument_kind_input_buffer, 4, ty_f32, nullptr, nullptr, nullptr, nullptr, est_dw},
+    {"pointwise_filter", halide_argument_kind_input_buffer, 2, ty_f32, nullptr, nullptr, nullptr, nullptr, est_pw},
+    {"bias", halide_argument_kind_input_buffer, 1, ty_f32, nullptr, nullptr, nullptr, nullptr, est_b},
+    {"output", halide_argument_kind_output_buffer, 4, ty_f32, nullptr, nullptr, nullptr, nullptr, est_o},
+};
+const halide_filter_metadata_t dsc_md = {1, 5, dsc_args, kTargetString, "depthwise_separable_conv"};
+
+}  // namespace
+
+extern "C" int depthwise_separable_conv(halide_buffer_t *input, halide_buffer_t *depthwise_filter,
+                                        halide_buffer_t *pointwise_filter, halide_buffer_t *bias, halide_buffer_t *output) {
+    void *uc = nullptr;
+    BufArg args[5] = {{"input", input, T_F32, 4, false}, {"depthwise_filter", depthwise_filter, T_F32, 4, false},
+                      {"pointwise_filter", pointwise_filter, T_F32, 2, false}, {"bias", bias, T_F32, 1, false},
+                      {"output", output, T_F32, 4, true}};
+    int r = check_not_null(uc, args, 5);
+    if (r) return r;
+    if ((r = check_type_and_dims(uc, args, 5))) return r;
+    auto real = [](halide_buffer_t *b) { return !(b->host == nullptr && b->device == 0); };
+    if (any_bounds_query(args, 5)) {
+        // shapes follow from whichever buffers are real; the generator's estimates (:78-99, with CM = 1) fill the rest
+        int ci = 32, w = 112, h = 112, n = 4, cm = 1, fw = 3, fh = 3, co = 16;
+        if (real(input)) ci = input->dim[0].extent, w = input->dim[1].extent, h = input->dim[2].extent, n = input->dim[3].extent;
+        else if (real(output)) w = output->dim[1].extent, h = output->dim[2].extent, n = output->dim[3].extent;
+        if (real(depthwise_filter)) cm = depthwise_filter->dim[0].extent, fw = depthwise_filter->dim[2].extent, fh = depthwise_filter->dim[3].extent;
+        if (real(output)) co = output->dim[0].extent;
+        else if (real(pointwise_filter)) co = pointwise_filter->dim[0].extent;
+        else if (real(bias)) co = bias->dim[0].extent;
+        const int ic = real(pointwise_filter) ? pointwise_filter->dim[1].extent : ci * cm;
+        int z4[4] = {0, 0, 0, 0}, z2[2] = {0, 0}, z1[1] = {0};
+        int ei[4] = {ci, w, h, n}, ed[4] = {cm, ic, fw, fh}, ep[2] = {co, ic}, eb[1] = {co}, eo[4] = {co, w, h, n};
+        answer_query(input, z4, ei);
+        answer_query(depthwise_filter, z4, ed);
+        answer_query(pointwise_filter, z2, ep);
+        answer_query(bias, z1, eb);
+        answer_query(output, z4, eo);
+        return 0;
+    }
+    for (int i = 0; i < 5; i++)
+        if ((r = check_shape(uc, args[i]))) return r;
+    DGeom g;
+    g.CI = input->dim[0].extent, g.W = input->dim[1].extent, g.H = input->dim[2].extent, g.N = output->dim[3].extent;
+    g.CM = depthwise_filter->dim[0].extent, g.FW = depthwise_filter->dim[2].extent, g.FH = depthwise_filter->dim[3].extent;
+    g.IC = pointwise_filter->dim[1].extent, g.CO = output->dim[0].extent;
+    // depthwise_filter.dim(1).stride == channel_multiplier (:283)
+    if ((r = check_equal(uc, "depthwise_filter.stride.1", depthwise_filter->dim[1].stride, "depthwise_filter.extent.0", g.CM))) return r;
+    // required regions (what the reference's bounds inference demands of each input; access_out_of_bounds otherwise)
+    if ((r = check_covers(uc, args[1], 0, 0, g.CM)) || (r = check_covers(uc, args[1], 1, 0, g.IC)) ||
+        (r = check_covers(uc, args[1], 2, 0, g.FW)) || (r = check_covers(uc, args[1], 3, 0, g.FH))) return r;
+    if ((r = check_covers(uc, args[2], 0, output->dim[0].min, g.CO)) || (r = check_covers(uc, args[2], 1, 0, g.IC))) return r;
+    if ((r = check_covers(uc, args[3], 0, output->dim[0].min, g.CO))) return r;
+    if (g.CM > 0 && (r = check_covers(uc, args[0], 0, 0, (g.IC + g.CM - 1) / g.CM))) return r;
+    if ((r = check_covers(uc, args[0], 3, output->dim[3].min, g.N))) return r;
+    // clamp(x, 0, input.dim(1).max()) (:38-41) reads coordinate 0 whenever the image is not empty: the input must
+    // start at or before 0 in x and y
+    if (g.W > 0 && g.H > 0 && ((r = check_covers(uc, args[0], 1, 0, 1)) || (r = check_covers(uc, args[0], 2, 0, 1)))) return r;
+    if (g.CM < 1 || g.FW < 1 || g.FH < 1) {
+        return report(uc, halide_error_code_constraint_violated, "depthwise_filter extents must be >= 1");
+    }
+    DeviceCtx ctx;
+    if ((r = acquire_device(uc, &ctx))) return r;
+    for (int i = 0; i < 4; i++)
+        if ((r = input_to_device(uc, ctx, args[i]))) return r;
+    if ((r = output_on_device(uc, ctx, args[4]))) return r;
+    g.ow = output->dim[1].extent, g.oh = output->dim[2].extent;
+    if (g.ow > 0 && g.oh > 0 && g.N > 0 && g.CO > 0) {
+        // in-bounds test of the generator (:36-37): 0 <= x < input.dim(1).extent(), i.e. W counts from the input's min
+        g.ix0 = input->dim[1].min, g.iy0 = input->dim[2].min;
+        g.ox0 = output->dim[1].min, g.oy0 = output->dim[2].min;
+        g.in_sx = input->dim[1].stride, g.in_sy = input->dim[2].stride, g.in_sn = input->dim[3].stride;
+        g.out_sx = output->dim[1].stride, g.out_sy = output->dim[2].stride, g.out_sn = output->dim[3].stride;
+        g.d_s1 = depthwise_filter->dim[1].stride, g.d_sx = depthwise_filter->dim[2].stride, g.d_sy = depthwise_filter->dim[3].stride;
+        g.p_s1 = pointwise_filter->dim[1].stride;
+        const size_t sh = sizeof(float) * ((size_t)TP * g.IC + (size_t)g.FH * g.FW * g.IC * g.CM + (size_t)g.IC * g.CO);
+        if (sh > 150 * 1024) {
+            return report(uc, halide_error_code_constraint_violated,
+                          "depthwise_separable_conv: filters of %zu bytes do not fit the 160 KB LDS of a CU", sh);
+        }
+        HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(dsc_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        // pointers offset to the first element each kernel index addresses
+        const float *d_in = dev_ptr<float>(input) + (long)(0 - input->dim[0].min) + (long)(output->dim[3].min - input->dim[3].min) * g.in_sn;
+        const float *d_dw = dev_ptr<float>(depthwise_filter) + (long)(0 - depthwise_filter->dim[0].min) +
+                            (long)(0 - depthwise_filter->dim[1].min) * g.d_s1 + (long)(0 - depthwise_filter->dim[2].min) * g.d_sx +
+                            (long)(0 - depthwise_filter->dim[3].min) * g.d_sy;
+        const float *d_pw = dev_ptr<float>(pointwise_filter) + (long)(output->dim[0].min - pointwise_filter->dim[0].min) +
+                            (long)(0 - pointwise_filter->dim[1].min) * g.p_s1;
+        const float *d_b = dev_ptr<float>(bias) + (long)(output->dim[0].min - bias->dim[0].min);
+        dim3 grid((g.ow + TP - 1) / TP, g.oh, g.N);
+        timing_note_bytes(4.0 * ((double)g.CI * g.W * g.H * g.N + (double)g.CO * g.ow * g.oh * g.N));
+        HLMI_LAUNCH(uc, "dsc_fused", ctx.stream, dsc_fused, grid, dim3(256), sh, d_in, d_dw, d_pw, d_b, dev_ptr<float>(output), g);
+    }
+    mark_output_written(output);
+    return 0;
+}
+
+extern "C" int depthwise_separable_conv_argv(void **a) {
+    return depthwise_separable_conv((halide_buffer_t *)a[0], (halide_buffer_t *)a[1], (halide_buffer_t *)a[2],
+                                    (halide_buffer_t *)a[3], (halide_buffer_t *)a[4]);
+}
+extern "C" const halide_filter_metadata_t *depthwise_separable_conv_metadata(void) { return &dsc_md; }
+extern "C" int depthwise_separable_conv_auto_schedule(halide_buffer_t *input, halide_buffer_t *depthwise_filter,
+                                                      halide_buffer_t *pointwise_filter, halide_buffer_t *bias,
+                                                      halide_buffer_t *output) {
+    return depthwise_separable_conv(input, depthwise_filter, pointwise_filter, bias, output);
+}

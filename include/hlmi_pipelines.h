@@ -77,6 +77,14 @@ int conv_layer_bf16(struct halide_buffer_t *input, struct halide_buffer_t *filte
                     struct halide_buffer_t *relu);
 HLMI_DECLARE_AUX(conv_layer_bf16)
 
+/* apps/depthwise_separable_conv/depthwise_separable_conv_generator.cpp:11-23 — f32 input [CI,W,H,N], depthwise_filter
+ * [CM,IC,FW,FH] (stride(1) == CM, :283), pointwise_filter [CO,IC], bias [CO], output [CO,W,H,N]; zero padding,
+ * depthwise FWxFH convolution, pointwise 1x1 convolution, bias, ReLU.  Bit-exact fma chains in RDom order. */
+int depthwise_separable_conv(struct halide_buffer_t *input, struct halide_buffer_t *depthwise_filter,
+                             struct halide_buffer_t *pointwise_filter, struct halide_buffer_t *bias,
+                             struct halide_buffer_t *output);
+HLMI_DECLARE_AUX(depthwise_separable_conv)
+
 /* apps/camera_pipe/camera_pipe_generator.cpp:219-228,622 — raw u16 Bayer -> u8 [W,H,3]. */
 int camera_pipe(struct halide_buffer_t *input, struct halide_buffer_t *matrix_3200,
                 struct halide_buffer_t *matrix_7000, float color_temp, float gamma, float contrast,
@@ -95,6 +103,9 @@ int nl_means_auto_schedule(struct halide_buffer_t *input, int32_t patch_size, in
 int stencil_chain_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);
 int conv_layer_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *filter,
                              struct halide_buffer_t *bias, struct halide_buffer_t *relu);
+int depthwise_separable_conv_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *depthwise_filter,
+                                           struct halide_buffer_t *pointwise_filter, struct halide_buffer_t *bias,
+                                           struct halide_buffer_t *output);
 int camera_pipe_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *matrix_3200,
                               struct halide_buffer_t *matrix_7000, float color_temp, float gamma, float contrast,
                               float sharpen_strength, int32_t blackLevel, int32_t whiteLevel,

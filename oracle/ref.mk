@@ -11,7 +11,8 @@ CXXFLAGS := -std=c++17 -O2 -fopenmp -DHALIDE_NO_PNG -DHALIDE_NO_JPEG -I$(RT) -I$
 LDFLAGS  := -L$(LIBDIR) -lhlmi -Wl,-rpath,'$$ORIGIN/../../halide_amd/lib' -lpthread -ldl
 
 TARGETS := $(OUTDIR)/blur_test $(OUTDIR)/local_laplacian_process $(OUTDIR)/bilateral_grid_filter \
-           $(OUTDIR)/nl_means_process $(OUTDIR)/stencil_chain_process $(OUTDIR)/conv_layer_process $(OUTDIR)/camera_pipe_process
+           $(OUTDIR)/nl_means_process $(OUTDIR)/stencil_chain_process $(OUTDIR)/conv_layer_process $(OUTDIR)/camera_pipe_process \
+           $(OUTDIR)/depthwise_separable_conv_process
 
 all: $(TARGETS)
 
@@ -33,4 +34,6 @@ $(OUTDIR)/stencil_chain_process: $(REF)/apps/stencil_chain/process.cpp $(LIBDIR)
 $(OUTDIR)/conv_layer_process: $(REF)/apps/conv_layer/process.cpp $(LIBDIR)/libhlmi.so
 	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)
 $(OUTDIR)/camera_pipe_process: $(REF)/apps/camera_pipe/process.cpp $(LIBDIR)/libhlmi.so
+	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)
+$(OUTDIR)/depthwise_separable_conv_process: $(REF)/apps/depthwise_separable_conv/process.cpp $(LIBDIR)/libhlmi.so
 	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)

@@ -179,6 +179,21 @@ def conv_layer_bf16(inp: np.ndarray, filt: np.ndarray, bias: np.ndarray):
     assert _lib.oracle_conv_layer_bf16(inp, filt, bias, out, mag, ci, co, wp - 2, hp - 2, n) == 0
     return out, mag
 
+_lib.oracle_depthwise_separable_conv.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p] + [C.c_int] * 9
+_lib.oracle_depthwise_separable_conv.restype = C.c_int
+
+
+def depthwise_separable_conv(inp: np.ndarray, dw: np.ndarray, pw: np.ndarray, bias: np.ndarray) -> np.ndarray:
+    """inp (N, H, W, CI); dw (FH, FW, IC, CM); pw (IC, CO); bias (CO,) [numpy axes = halide dims reversed] -> (N, H, W, CO)."""
+    inp, dw, pw, bias = (np.ascontiguousarray(a, np.float32) for a in (inp, dw, pw, bias))
+    n, h, w, ci = inp.shape
+    fh, fw, ic, cm = dw.shape
+    ic2, co = pw.shape
+    assert ic == ic2 and bias.shape == (co,)
+    out = np.zeros((n, h, w, co), np.float32)
+    assert _lib.oracle_depthwise_separable_conv(inp, dw, pw, bias, out, ci, w, h, n, cm, fw, fh, ic, co) == 0
+    return out
+
 _i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
 _lib.oracle_camera_pipe.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.c_int]

@@ -139,6 +139,13 @@ def test_conv_layer_process_cpp():
 
 
 @pytest.mark.gpu
+def test_depthwise_separable_conv_process_cpp():
+    exe = _exe("depthwise_separable_conv_process")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Success!" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
 def test_camera_pipe_process_cpp(tmp_path, oracle):
     exe = _exe("camera_pipe_process")
     from test_camera_pipe import M3200, M7000, _raw
