@@ -1,0 +1,161 @@
+"""PyTorch-ROCm operators over libhlmi.so — SURVEY.md §8(f4).
+
+The reference puts AOT pipelines behind torch through generated wrappers that build a ``halide_buffer_t`` around a
+tensor's storage with the dimensions reversed (``src/runtime/HalidePyTorchHelpers.h:28-120``, ``apps/HelloPyTorch``).
+This module does the same against the C ABI, without a copy: a CUDA(HIP) tensor's ``data_ptr()`` is attached with
+``halide_hip_wrap_device_ptr`` (counterpart of ``halide_cuda_wrap_device_ptr``, ``src/runtime/HalideRuntimeCuda.h:44-58``),
+the library enqueues on torch's current stream (``halide_hip_set_stream``), the result lands in a tensor allocated by
+torch, and the wrapper detaches before returning so the library never owns torch memory.
+
+    import torch, halide_amd.torch_ops          # registers torch.ops.hlmi.*
+    out = torch.ops.hlmi.local_laplacian(img_u16_cuda, 8, 1 / 7, 1.0)       # (3, H, W) uint16 -> same
+
+Tensor axes are the Halide dimensions REVERSED (innermost last), as in the reference's Python bindings: an image
+``Buffer<uint16_t, 3>(W, H, 3)`` is a tensor of shape ``(3, H, W)``.  There is no CPU fallback: CPU tensors are an error.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+import halide_amd as hl
+
+_NP = {torch.uint8: np.uint8, torch.uint16: np.uint16, torch.int16: np.int16, torch.int32: np.int32, torch.float32: np.float32}
+
+
+class _Wrapped:
+    """`with _Wrapped(t0, t1, ...) as (b0, b1, ...)`: zero-copy halide buffers on torch's current stream."""
+
+    def __init__(self, *tensors):
+        self.tensors, self.bufs = tensors, []
+
+    def __enter__(self):
+        for t in self.tensors:
+            if not t.is_cuda:
+                raise RuntimeError("hlmi ops need tensors on the GPU (there is no CPU implementation)")
+            if t.dtype not in _NP:
+                raise TypeError(f"unsupported dtype {t.dtype}")
+            if t.dim() and t.stride(-1) != 1:
+                raise RuntimeError("the innermost dimension must be dense (halide dim[0].stride == 1)")
+            self.bufs.append(hl.Buffer.wrap_device(t.data_ptr(), _NP[t.dtype], list(reversed(t.shape)),
+                                                   list(reversed(t.stride()))))
+        # torch's default stream is the NULL stream (handle 0), which halide_hip_set_stream reads as "the library's own
+        # stream": name it by HIP's explicit handle hipStreamLegacy (= 1) instead
+        s = torch.cuda.current_stream(self.tensors[0].device).cuda_stream
+        hl.set_stream(s if s else 1)
+        hl.set_gpu_device(self.tensors[0].device.index or 0)
+        return self.bufs
+
+    def __exit__(self, *exc):
+        hl.set_stream(None)
+        for b in self.bufs:
+            b.device_detach()   # the storage belongs to torch
+        return False
+
+
+@torch.library.custom_op("hlmi::local_laplacian", mutates_args=())
+def local_laplacian(input: torch.Tensor, levels: int, alpha: float, beta: float) -> torch.Tensor:
+    """apps/local_laplacian: (3, H, W) uint16 -> (3, H, W) uint16; `alpha` as the drivers pass it (alpha / (levels - 1))."""
+    out = torch.empty_like(input)
+    with _Wrapped(input, out) as (a, o):
+        hl.local_laplacian(a, levels, alpha, beta, o)
+    return out
+
+
+@torch.library.custom_op("hlmi::bilateral_grid", mutates_args=())
+def bilateral_grid(input: torch.Tensor, r_sigma: float) -> torch.Tensor:
+    """apps/bilateral_grid: (H, W) float32 -> (H, W) float32, s_sigma = 8."""
+    out = torch.empty_like(input)
+    with _Wrapped(input, out) as (a, o):
+        hl.bilateral_grid(a, r_sigma, o)
+    return out
+
+
+@torch.library.custom_op("hlmi::nl_means", mutates_args=())
+def nl_means(input: torch.Tensor, patch_size: int, search_area: int, sigma: float) -> torch.Tensor:
+    """apps/nl_means: (3, H, W) float32 -> (3, H, W) float32."""
+    out = torch.empty_like(input)
+    with _Wrapped(input, out) as (a, o):
+        hl.nl_means(a, patch_size, search_area, sigma, o)
+    return out
+
+
+@torch.library.custom_op("hlmi::stencil_chain", mutates_args=())
+def stencil_chain(input: torch.Tensor) -> torch.Tensor:
+    """apps/stencil_chain: (H, W) uint16 -> (H, W) uint16, 32 stages."""
+    out = torch.empty_like(input)
+    with _Wrapped(input, out) as (a, o):
+        hl.stencil_chain(a, o)
+    return out
+
+
+@torch.library.custom_op("hlmi::blur", mutates_args=())
+def blur(input: torch.Tensor) -> torch.Tensor:
+    """apps/blur: (H + 2, W + 2) uint16 -> (H, W) uint16."""
+    out = torch.empty((input.shape[0] - 2, input.shape[1] - 2), dtype=input.dtype, device=input.device)
+    with _Wrapped(input, out) as (a, o):
+        hl.halide_blur(a, o)
+    return out
+
+
+def _conv(fn, input, filter, bias):
+    n, hp, wp, _ = input.shape
+    out = torch.empty((n, hp - 2, wp - 2, bias.shape[0]), dtype=torch.float32, device=input.device)
+    with _Wrapped(input, filter, bias, out) as (a, f, b, o):
+        fn(a, f, b, o)
+    return out
+
+
+@torch.library.custom_op("hlmi::conv_layer", mutates_args=())
+def conv_layer(input: torch.Tensor, filter: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """apps/conv_layer, exact f32: input (N, H+2, W+2, CI), filter (CI, 3, 3, CO), bias (CO,) -> relu (N, H, W, CO)."""
+    return _conv(hl.conv_layer, input, filter, bias)
+
+
+@torch.library.custom_op("hlmi::conv_layer_bf16", mutates_args=())
+def conv_layer_bf16(input: torch.Tensor, filter: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """Same buffers as conv_layer; operands rounded to bf16, f32 accumulation on the matrix cores."""
+    return _conv(hl.conv_layer_bf16, input, filter, bias)
+
+
+@torch.library.custom_op("hlmi::depthwise_separable_conv", mutates_args=())
+def depthwise_separable_conv(input: torch.Tensor, depthwise_filter: torch.Tensor, pointwise_filter: torch.Tensor,
+                             bias: torch.Tensor) -> torch.Tensor:
+    """apps/depthwise_separable_conv: input (N, H, W, CI), depthwise (FH, FW, IC, CM), pointwise (IC, CO), bias (CO,)."""
+    n, h, w, _ = input.shape
+    out = torch.empty((n, h, w, bias.shape[0]), dtype=torch.float32, device=input.device)
+    with _Wrapped(input, depthwise_filter, pointwise_filter, bias, out) as (a, d, p, b, o):
+        hl.depthwise_separable_conv(a, d, p, b, o)
+    return out
+
+
+@torch.library.custom_op("hlmi::camera_pipe", mutates_args=())
+def camera_pipe(input: torch.Tensor, matrix_3200: torch.Tensor, matrix_7000: torch.Tensor, color_temp: float, gamma: float,
+                contrast: float, sharpen_strength: float, black_level: int, white_level: int, out_width: int,
+                out_height: int) -> torch.Tensor:
+    """apps/camera_pipe: raw (IH, IW) uint16 Bayer -> (3, out_height, out_width) uint8."""
+    out = torch.empty((3, out_height, out_width), dtype=torch.uint8, device=input.device)
+    with _Wrapped(input, matrix_3200, matrix_7000, out) as (a, m3, m7, o):
+        hl.camera_pipe(a, m3, m7, color_temp, gamma, contrast, sharpen_strength, black_level, white_level, o)
+    return out
+
+
+# shape functions for torch.compile / meta tensors
+@local_laplacian.register_fake
+def _(input, levels, alpha, beta):
+    return torch.empty_like(input)
+
+
+@bilateral_grid.register_fake
+def _(input, r_sigma):
+    return torch.empty_like(input)
+
+
+@nl_means.register_fake
+def _(input, patch_size, search_area, sigma):
+    return torch.empty_like(input)
+
+
+@stencil_chain.register_fake
+def _(input):
+    return torch.empty_like(input)

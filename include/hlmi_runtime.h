@@ -86,7 +86,8 @@ int halide_get_gpu_device(void *user_context);
 #endif
 /* Stream override (mirrors halide_set_cuda_get_stream, HalideRuntimeCuda.h:76-82, simplified to a
  * per-thread value): all work of subsequent calls on this thread is enqueued on `stream`
- * (a hipStream_t); NULL restores the library's own per-device stream. */
+ * (a hipStream_t); NULL restores the library's own per-device stream.  To enqueue on HIP's null stream (the
+ * default stream of torch-ROCm) pass its explicit handle hipStreamLegacy, not 0. */
 void halide_hip_set_stream(void *stream);
 void *halide_hip_get_stream(void *user_context);
 
