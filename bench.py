@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 W, H, C = 3840, 2160, 3
 LEVELS, ALPHA, BETA = 8, 1.0 / 7.0, 1.0
-FRAMES_PER_STEP = 4           # distinct frames per GPU per step (4 x 99.5 MB of u16 I/O > 256 MB MALL)
+FRAMES_PER_STEP = int(os.environ.get("HLMI_BENCH_FRAMES", "4"))  # distinct frames per GPU per step (4 x 99.5 MB of u16 I/O > 256 MB MALL)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 ALG_BYTES_PER_PX = 12         # SURVEY.md §8(d) primary figure: 6 B read + 6 B written per pixel
 
