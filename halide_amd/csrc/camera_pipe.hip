@@ -14,6 +14,8 @@
 #include "hlmi_device_math.h"
 #include "hlmi_internal.h"
 
+#include <stdlib.h>
+
 using namespace hlmi;
 
 namespace {
@@ -59,7 +61,7 @@ __device__ __forceinline__ uint16_t u16(uint32_t v) { return (uint16_t)v; }
 // raw: pointer to shifted(0,0) = input(16,12) relative to the buffer's own min; cv: u8 planes [3][CH][CW] of curved on
 // [-1, W] x [-1, H]
 __global__ __launch_bounds__(256) void cp_demosaic(const uint16_t *__restrict__ raw, long in_sy, const CPSetup *__restrict__ s,
-                                                  uint8_t *__restrict__ cv, int CW, int CH, int nqx, int nqy) {
+                                                  uint8_t *__restrict__ cv, int CW, int CH, int CWL, int nqx, int nqy) {
     const int qi = blockIdx.x * blockDim.x + threadIdx.x, qj = blockIdx.y;
     if (qi >= nqx) return;
     const int qx = qi - 1, qy = qj - 1;  // quads start at fdiv(-1, 2) = -1
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void cp_demosaic(const uint16_t *__restrict__ 
     for (int site = 0; site < 4; site++) {
         const int X = 2 * qx + (site & 1), Y = 2 * qy + (site >> 1);
         const int cxx = X + 1, cyy = Y + 1;
-        if (cxx < 0 || cxx >= CW || cyy < 0 || cyy >= CH) continue;
+        if (cxx < 0 || cxx >= CWL || cyy < 0 || cyy >= CH) continue;   // CWL = logical width W+2, CW = row pitch
         const int32_t ir = (int16_t)px[site][0], ig = (int16_t)px[site][1], ib = (int16_t)px[site][2];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -172,6 +174,45 @@ __global__ __launch_bounds__(256) void cp_sharpen(const uint8_t *__restrict__ cv
         int16_t q = (int16_t)(prod >> 5);               // floor division by 32
         int16_t v = (int16_t)((int16_t)p[0] + q);
         out[(long)y * out_sy + x + (long)c * out_sc] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}
+
+// cp_sharpen for aligned geometry (row pitch and output strides multiples of 4): a lane owns 4 adjacent pixels.
+// Rows arrive as aligned dwords; the rounding byte averages avg8(a, b) = (a + b + 1) >> 1 of :398-404 are v_lerp_u8 with
+// the rounding bit set in every byte; the horizontal neighbours are v_alignbyte shifts of the two dwords of a row; the
+// int16 part (mask, product, floor /32, saturating cast) runs on packed i16 pairs (even bytes / odd bytes).
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void cp_sharpen4(const uint8_t *__restrict__ cv, int CW, int CH, const CPSetup *__restrict__ s,
+                                                  uint8_t *__restrict__ out, long out_sy, long out_sc, int W, int H) {
+    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x), y = blockIdx.y;
+    if (x >= W) return;
+    const short st = (short)s->strength_x32;
+    const i16x2 strength = {st, st}, zero = {0, 0}, top = {255, 255};
+    const uint32_t one = 0x01010101u;
+    const size_t plane = (size_t)CW * CH;
+    auto avg4 = [&](uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, one); };
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        // cv columns x .. x+7 of rows y, y+1, y+2 (output pixel j sits at cv column x+1+j, row y+1)
+        const uint32_t *r0 = reinterpret_cast<const uint32_t *>(cv + (size_t)c * plane + (size_t)y * CW + x);
+        const uint32_t *r1 = reinterpret_cast<const uint32_t *>(cv + (size_t)c * plane + (size_t)(y + 1) * CW + x);
+        const uint32_t *r2 = reinterpret_cast<const uint32_t *>(cv + (size_t)c * plane + (size_t)(y + 2) * CW + x);
+        const uint32_t a0 = r0[0], b0 = r0[1], a1 = r1[0], b1 = r1[1], a2 = r2[0], b2 = r2[1];
+        const uint32_t uya = avg4(avg4(a0, a2), a1), uyb = avg4(avg4(b0, b2), b1);            // unsharp_y, columns x..x+7
+        const uint32_t L = uya, C = __builtin_amdgcn_alignbyte(uyb, uya, 1), R = __builtin_amdgcn_alignbyte(uyb, uya, 2);
+        const uint32_t un = avg4(avg4(L, R), C);                                              // unsharp, 4 pixels
+        const uint32_t P = __builtin_amdgcn_alignbyte(b1, a1, 1);                             // curved, 4 pixels
+        auto sharpen2 = [&](uint32_t p2, uint32_t u2) -> uint32_t {                           // two pixels as i16 pairs
+            const i16x2 p = __builtin_bit_cast(i16x2, p2), u = __builtin_bit_cast(i16x2, u2);
+            const i16x2 mask = p - u;
+            const i16x2 q = (i16x2)(mask * strength) >> 5;   // int16 product wraps (src/IROperator.cpp:769-816); floor /32
+            i16x2 v = p + q;
+            v = v < zero ? zero : v;
+            v = v > top ? top : v;
+            return __builtin_bit_cast(uint32_t, v);
+        };
+        const uint32_t even = sharpen2(P & 0x00ff00ffu, un & 0x00ff00ffu), odd = sharpen2((P >> 8) & 0x00ff00ffu, (un >> 8) & 0x00ff00ffu);
+        *reinterpret_cast<uint32_t *>(out + (long)y * out_sy + x + (long)c * out_sc) = even | (odd << 8);
     }
 }
 
@@ -250,7 +291,8 @@ extern "C" int camera_pipe(halide_buffer_t *input, halide_buffer_t *matrix_3200,
         mark_output_written(processed);
         return 0;
     }
-    const int CW = W + 2, CH = H + 2;
+    const int CWL = W + 2, CW = (CWL + 3 + 4) & ~3, CH = H + 2;   // logical width; row pitch: a multiple of 4 with >= 4 spare
+                                                                 // columns (cp_sharpen4 reads two dwords per row)
     const size_t setup_bytes = (sizeof(CPSetup) + 255) & ~(size_t)255;
     void *ws = nullptr;
     if ((r = get_workspace(uc, ctx, setup_bytes + (size_t)3 * CW * CH + 256, &ws))) return r;
@@ -265,9 +307,14 @@ extern "C" int camera_pipe(halide_buffer_t *input, halide_buffer_t *matrix_3200,
     const long in_sy = input->dim[1].stride;
     const uint16_t *raw = dev_ptr<uint16_t>(input) + (long)(oy + 12 - input->dim[1].min) * in_sy + (ox + 16 - input->dim[0].min);
     const int nqx = floor_div(W, 2) + 2, nqy = floor_div(H, 2) + 2;
-    HLMI_LAUNCH(uc, "cp_demosaic", st, cp_demosaic, dim3((nqx + 255) / 256, nqy), dim3(256), 0, raw, in_sy, setup, cv, CW, CH, nqx, nqy);
-    HLMI_LAUNCH(uc, "cp_sharpen", st, cp_sharpen, dim3((W + 255) / 256, H), dim3(256), 0, cv, CW, CH, setup, dev_ptr<uint8_t>(processed),
-                (long)processed->dim[1].stride, (long)processed->dim[2].stride, W, H);
+    HLMI_LAUNCH(uc, "cp_demosaic", st, cp_demosaic, dim3((nqx + 255) / 256, nqy), dim3(256), 0, raw, in_sy, setup, cv, CW, CH, CWL, nqx, nqy);
+    const long o_sy = processed->dim[1].stride, o_sc = processed->dim[2].stride;
+    uint8_t *dout = dev_ptr<uint8_t>(processed);
+    if (W % 4 == 0 && o_sy % 4 == 0 && o_sc % 4 == 0 && (uintptr_t)dout % 4 == 0 && !getenv("HLMI_CP_SCALAR")) {
+        HLMI_LAUNCH(uc, "cp_sharpen", st, cp_sharpen4, dim3((W / 4 + 255) / 256, H), dim3(256), 0, cv, CW, CH, setup, dout, o_sy, o_sc, W, H);
+    } else {
+        HLMI_LAUNCH(uc, "cp_sharpen", st, cp_sharpen, dim3((W + 255) / 256, H), dim3(256), 0, cv, CW, CH, setup, dout, o_sy, o_sc, W, H);
+    }
     mark_output_written(processed);
     return 0;
 }
