@@ -60,6 +60,7 @@ __device__ __forceinline__ uint16_t u16(uint32_t v) { return (uint16_t)v; }
 
 // raw: pointer to shifted(0,0) = input(16,12) relative to the buffer's own min; cv: u8 planes [3][CH][CW] of curved on
 // [-1, W] x [-1, H]
+template<bool PAIRS>
 __global__ __launch_bounds__(256) void cp_demosaic(const uint16_t *__restrict__ raw, long in_sy, const CPSetup *__restrict__ s,
                                                   uint8_t *__restrict__ cv, int CW, int CH, int CWL, int nqx, int nqy) {
     const int qi = blockIdx.x * blockDim.x + threadIdx.x, qj = blockIdx.y;
@@ -68,14 +69,27 @@ __global__ __launch_bounds__(256) void cp_demosaic(const uint16_t *__restrict__ 
     // 10x10 raw window, origin (2qx-4, 2qy-4)
     uint16_t R[10][10];
     const uint16_t *base = raw + (long)(2 * qy - 4) * in_sy + (2 * qx - 4);
+    if (PAIRS) {
+        // the window starts at an even column: with an even row stride and a 4-byte aligned image every (2k, 2k+1)
+        // column pair is one aligned dword — 44 loads instead of 84
 #pragma unroll
-    for (int j = 0; j < 10; j++)
+        for (int j = 0; j < 10; j++)
 #pragma unroll
-        for (int i = 0; i < 10; i++) {
-            // only the plus-shaped footprint of the 6x6 centre is ever used; skip the 2x2 corners
-            bool used = !((i < 2 || i > 7) && (j < 2 || j > 7));
-            R[j][i] = used ? base[(long)j * in_sy + i] : (uint16_t)0;
-        }
+            for (int i = 0; i < 10; i += 2) {
+                const bool used = !((i < 2 || i > 7) && (j < 2 || j > 7));
+                const uint32_t w = used ? *reinterpret_cast<const uint32_t *>(base + (long)j * in_sy + i) : 0u;
+                R[j][i] = (uint16_t)(w & 0xffffu), R[j][i + 1] = (uint16_t)(w >> 16);
+            }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 10; j++)
+#pragma unroll
+            for (int i = 0; i < 10; i++) {
+                // only the plus-shaped footprint of the 6x6 centre is ever used; skip the 2x2 corners
+                bool used = !((i < 2 || i > 7) && (j < 2 || j > 7));
+                R[j][i] = used ? base[(long)j * in_sy + i] : (uint16_t)0;
+            }
+    }
     // hot-pixel suppression (:240-250) + deinterleave (:252-263): D[c][dy+1][dx+1]
     uint16_t D[4][3][3];
 #pragma unroll
@@ -307,7 +321,11 @@ extern "C" int camera_pipe(halide_buffer_t *input, halide_buffer_t *matrix_3200,
     const long in_sy = input->dim[1].stride;
     const uint16_t *raw = dev_ptr<uint16_t>(input) + (long)(oy + 12 - input->dim[1].min) * in_sy + (ox + 16 - input->dim[0].min);
     const int nqx = floor_div(W, 2) + 2, nqy = floor_div(H, 2) + 2;
-    HLMI_LAUNCH(uc, "cp_demosaic", st, cp_demosaic, dim3((nqx + 255) / 256, nqy), dim3(256), 0, raw, in_sy, setup, cv, CW, CH, CWL, nqx, nqy);
+    if (in_sy % 2 == 0 && (uintptr_t)raw % 4 == 0 && !getenv("HLMI_CP_SCALAR")) {
+        HLMI_LAUNCH(uc, "cp_demosaic", st, cp_demosaic<true>, dim3((nqx + 255) / 256, nqy), dim3(256), 0, raw, in_sy, setup, cv, CW, CH, CWL, nqx, nqy);
+    } else {
+        HLMI_LAUNCH(uc, "cp_demosaic", st, cp_demosaic<false>, dim3((nqx + 255) / 256, nqy), dim3(256), 0, raw, in_sy, setup, cv, CW, CH, CWL, nqx, nqy);
+    }
     const long o_sy = processed->dim[1].stride, o_sc = processed->dim[2].stride;
     uint8_t *dout = dev_ptr<uint8_t>(processed);
     if (W % 4 == 0 && o_sy % 4 == 0 && o_sc % 4 == 0 && (uintptr_t)dout % 4 == 0 && !getenv("HLMI_CP_SCALAR")) {
