@@ -8,6 +8,7 @@ rocminfo 2>/dev/null | grep -m2 -E "Marketing Name" > $OUT/rocminfo.txt; nproc >
 echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q --maxfail=10 --tb=short --durations=8 2>&1 | tail -30 | tee $OUT/pytest_gpu.log
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke.log
 echo "== bench"; timeout 900 python bench.py 2>&1 | tail -1 | tee $OUT/bench.json
+echo "== bench_apps"; timeout 900 python bench_apps.py 2>/dev/null | grep pipeline | tee $OUT/bench_apps.jsonl
 echo "== bench 1 stream"; timeout 900 python bench.py --streams 1 --no-cpu-baseline 2>&1 | tail -1 | tee $OUT/bench_1stream.json
 cd /tmp
 CMD="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --streams 1"
