@@ -4,6 +4,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -69,6 +70,12 @@ void answer_query(halide_buffer_t *buf, const int *mins, const int *extents);
 struct DeviceCtx {
     int device = -1;
     hipStream_t stream = nullptr;
+    // Held from acquire_device() until the context goes out of scope at the end of the entry point: calls that share
+    // a (device, stream) — and therefore its scratch arena — enqueue their launches one call at a time, so that stream
+    // order alone makes the shared arena safe when several host threads call pipelines concurrently (the reference's
+    // generated code is re-entrant, test/generator/gpu_multi_context_threaded_aottest.cpp).  Threads that want their
+    // calls to overlap on the GPU use distinct streams (halide_hip_set_stream).
+    std::unique_lock<std::recursive_mutex> call_lock;
 };
 // choose device (halide_set_gpu_device / HL_GPU_DEVICE / 0), hipSetDevice, choose stream.
 // Fails with -29 when no gfx950 device is usable: there is NO CPU fallback.

@@ -188,6 +188,7 @@ static thread_local hipStream_t t_stream_override = nullptr;
 struct Arena {
     void *ptr = nullptr;
     size_t bytes = 0;
+    std::recursive_mutex call_mu;  // serialises the ENQUEUE of whole pipeline calls on this (device, stream)
 };
 
 struct DeviceState {
@@ -250,6 +251,14 @@ int acquire_device(void *uc, DeviceCtx *ctx) {
         }
         ctx->device = dev;
         ctx->stream = t_stream_override ? t_stream_override : st.stream;
+    }
+    {
+        std::recursive_mutex *mu;
+        {
+            std::lock_guard<std::mutex> lock(g_mu);
+            mu = &g_dev[dev].arenas[ctx->stream].call_mu;  // std::map: the node (and the mutex in it) never moves
+        }
+        ctx->call_lock = std::unique_lock<std::recursive_mutex>(*mu);  // taken with g_mu released (lock order: call -> g_mu)
     }
     HLMI_HIP(uc, hipSetDevice(dev));
     return 0;
