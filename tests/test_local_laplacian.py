@@ -312,3 +312,18 @@ def test_hip_full_4k_matches_oracle_and_is_deterministic(hl, oracle):
     # size-independent property: alpha=0, beta=1 reproduces the input within 1 LSB
     hl.local_laplacian(a, 8, 0.0, 1.0, o)
     assert np.max(np.abs(o.numpy().astype(np.int64) - inp.astype(np.int64))) <= 1
+
+
+@pytest.mark.gpu
+def test_hip_8k_smooth_frame_matches_oracle(hl, oracle):
+    """SURVEY.md §8(d) also names 7680x4320: 33 Mpx, 400 MB of pyramid — the level table, the 32-bit lane offsets of
+    ll_up0f and the multi-level kernels at twice every extent.  A smooth frame (the data-dependent plane choice is
+    locally constant, unlike uniform noise)."""
+    inp = _rand_image(7680, 4320, seed=2, kind="smooth")
+    a, o = hl.Buffer(inp), hl.Buffer(np.zeros_like(inp))
+    hl.local_laplacian(a, 8, 1.0 / 7, 1.0, o)
+    got = o.numpy()
+    want = oracle.local_laplacian(inp, 8, 1.0 / 7, 1.0)
+    assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} differ"
+    a.device_free()
+    o.device_free()
