@@ -124,6 +124,16 @@ def main():
              flops / t / 1e12, VALU_F32_PEAK_TF, "TFLOP/s", {"alg_flops": flops, "alg_bytes": 24 * W * H,
                                                             "kernels_ms": kernels(call, o)})
 
+    # ---- unsharp f32 1536x2560x3 (generator estimates)
+    if not only or "unsharp" in only:
+        W, H = 1536, 2560
+        a = hl.Buffer((rng.random((3, H, W), dtype=np.float32) * 0.9 + 0.05).astype(np.float32))
+        o = hl.Buffer(np.zeros((3, H, W), np.float32))
+        call = lambda: hl.unsharp(a, o)
+        t = timed(call, o, 50)
+        emit("unsharp", "apps/unsharp sigma=1.5, f32 1536x2560x3", t, W * H, "hbm", 24.0 * W * H / t / 1e9, HBM_PEAK_GBS, "GB/s",
+             {"alg_bytes": 24 * W * H, "kernels_ms": kernels(call, o)})
+
     # ---- depthwise_separable_conv at the driver's shape (MobileNet-v2 layer 2, process.cpp:13)
     if not only or "depthwise_separable_conv" in only:
         N, Hh, Ww, CI, CO = 4, 112, 112, 32, 16

@@ -1,0 +1,127 @@
+// unsharp.hip — gfx950 implementation of the reference's unsharp AOT pipeline (an adjacent app with the
+// same boundary).  Algorithm: /root/reference/apps/unsharp/unsharp_generator.cpp:13-52 (sigma = 1.5, :7); boundary:
+// `int unsharp(halide_buffer_t *input, halide_buffer_t *output)`, f32 [W,H,3] planar in and out (:9-10).
+//
+// gray -> 7-tap Gaussian down the columns -> 7-tap along the rows -> sharpen = 2 gray - blur -> ratio = sharpen / gray ->
+// output = ratio * input.  Every operator rounds once in source order (the library is built with -ffp-contract=off), as
+// oracle/unsharp_oracle.c fixes it; the four kernel taps are constants the reference's simplifier folds at compile time
+// with the host's double exp (src/Simplify_Call.cpp:767-780) — computed the same way on the host here.
+//
+// HBM bound: 12 B/px read + 12 B/px written.  One workgroup = a 64 x 16 output tile: gray of the (64+6) x (16+6) window
+// goes to LDS once (edge-clamped), blur_y of 70 x 16 to LDS, then each thread finishes 4 pixels.
+#include "hlmi_internal.h"
+
+#include <math.h>
+
+using namespace hlmi;
+
+namespace {
+
+constexpr int TW = 64, TH = 16, R = 3;
+constexpr int GW = TW + 2 * R, GH = TH + 2 * R, GP = GW + 1;   // gray window and its LDS pitch
+
+struct UGeom {
+    int ix0, iy0, W, H;        // input origin and extents (clamp box)
+    int ox0, oy0, ow, oh;      // output region
+    long in_sy, in_sc, out_sy, out_sc;
+    float k[4];
+};
+
+__global__ __launch_bounds__(256) void unsharp_tile(const float *__restrict__ in, float *__restrict__ out, UGeom g) {
+    __shared__ float s_gray[GH * GP];
+    __shared__ float s_by[TH * GP];
+    const int tid = threadIdx.x;
+    const int X0 = g.ox0 + blockIdx.x * TW, Y0 = g.oy0 + blockIdx.y * TH;   // absolute origin of the tile
+    for (int i = tid; i < GW * GH; i += 256) {
+        const int r = i / GW, c = i - r * GW;
+        const int x = min(max(X0 - R + c, g.ix0), g.ix0 + g.W - 1) - g.ix0, y = min(max(Y0 - R + r, g.iy0), g.iy0 + g.H - 1) - g.iy0;
+        const float *p = in + (long)y * g.in_sy + x;
+        s_gray[r * GP + c] = (0.299f * p[0] + 0.587f * p[g.in_sc]) + 0.114f * p[2 * g.in_sc];
+    }
+    __syncthreads();
+    for (int i = tid; i < GW * TH; i += 256) {
+        const int r = i / GW, c = i - r * GW;
+        const float *q = s_gray + (r + R) * GP + c;
+        s_by[r * GP + c] = ((g.k[0] * q[0] + g.k[1] * (q[-GP] + q[GP])) + g.k[2] * (q[-2 * GP] + q[2 * GP])) + g.k[3] * (q[-3 * GP] + q[3 * GP]);
+    }
+    __syncthreads();
+    for (int i = tid; i < TW * TH; i += 256) {
+        const int r = i / TW, c = i - r * TW;
+        const int x = blockIdx.x * TW + c, y = blockIdx.y * TH + r;
+        if (x >= g.ow || y >= g.oh) continue;
+        const float *q = s_by + r * GP + c + R;
+        const float bx = ((g.k[0] * q[0] + g.k[1] * (q[-1] + q[1])) + g.k[2] * (q[-2] + q[2])) + g.k[3] * (q[-3] + q[3]);
+        const float gr = s_gray[(r + R) * GP + c + R];
+        const float ratio = (2.0f * gr - bx) / gr;
+        const float *p = in + (long)(g.oy0 + y - g.iy0) * g.in_sy + (g.ox0 + x - g.ix0);
+        float *o = out + (long)y * g.out_sy + x;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) o[ch * g.out_sc] = ratio * p[ch * g.in_sc];
+    }
+}
+
+const int64_t e0 = 0, ew = 1536, eh = 2560, ec = 3;
+const int64_t *const est[6] = {&e0, &ew, &e0, &eh, &e0, &ec};
+const halide_type_t ty_f32 = {(decltype(halide_type_t::code))2, 32, 0};
+// estimates: generator :54-61
+const halide_filter_argument_t us_args[2] = {
+    {"input", halide_argument_kind_input_buffer, 3, ty_f32, nullptr, nullptr, nullptr, nullptr, est},
+    {"output", halide_argument_kind_output_buffer, 3, ty_f32, nullptr, nullptr, nullptr, nullptr, est},
+};
+const halide_filter_metadata_t us_md = {1, 2, us_args, kTargetString, "unsharp"};
+
+}  // namespace
+
+extern "C" int unsharp(halide_buffer_t *input, halide_buffer_t *output) {
+    void *uc = nullptr;
+    BufArg args[2] = {{"input", input, T_F32, 3, false}, {"output", output, T_F32, 3, true}};
+    int r = check_not_null(uc, args, 2);
+    if (r) return r;
+    if ((r = check_type_and_dims(uc, args, 2))) return r;
+    if (any_bounds_query(args, 2)) {
+        // the final tap input(x, y, c) is unclamped (:52): the input must cover the output's x, y region and channels 0..2
+        int mins[3] = {output->dim[0].min, output->dim[1].min, 0}, ext[3] = {output->dim[0].extent, output->dim[1].extent, 3};
+        answer_query(input, mins, ext);
+        answer_query(output, mins, ext);
+        return 0;
+    }
+    if ((r = check_shape(uc, args[0])) || (r = check_shape(uc, args[1]))) return r;
+    const int ow = output->dim[0].extent, oh = output->dim[1].extent, oc = output->dim[2].extent;
+    if ((r = check_covers(uc, args[0], 0, output->dim[0].min, ow)) || (r = check_covers(uc, args[0], 1, output->dim[1].min, oh))) return r;
+    // gray reads channels 0, 1, 2 (through repeat_edge: any non-empty channel range is legal); the output's channels are
+    // read unclamped
+    if ((r = check_covers(uc, args[0], 2, output->dim[2].min, oc))) return r;
+    if (output->dim[2].min < 0 || output->dim[2].min + oc > 3) {
+        return report(uc, halide_error_code_constraint_violated, "Output buffer output: channels must lie in [0, 3)");
+    }
+    if (input->dim[2].min > 0 || input->dim[2].min + input->dim[2].extent < 3) {
+        return report(uc, halide_error_code_constraint_violated, "Input buffer input must hold channels 0..2 (clamped channel reads are not supported)");
+    }
+    DeviceCtx ctx;
+    if ((r = acquire_device(uc, &ctx))) return r;
+    if ((r = input_to_device(uc, ctx, args[0]))) return r;
+    if ((r = output_on_device(uc, ctx, args[1]))) return r;
+    if (ow > 0 && oh > 0 && oc > 0) {
+        UGeom g;
+        g.ix0 = input->dim[0].min, g.iy0 = input->dim[1].min, g.W = input->dim[0].extent, g.H = input->dim[1].extent;
+        g.ox0 = output->dim[0].min, g.oy0 = output->dim[1].min, g.ow = ow, g.oh = oh;
+        g.in_sy = input->dim[1].stride, g.in_sc = input->dim[2].stride;
+        g.out_sy = output->dim[1].stride, g.out_sc = output->dim[2].stride;
+        const float kPi = 3.14159265358979310000f, sigma = 1.5f;
+        const float den = sqrtf(2 * kPi) * sigma;
+        for (int i = 0; i < 4; i++) g.k[i] = (float)exp((double)((float)(-i * i) / (2 * sigma * sigma))) / den;
+        if (oc != 3 || output->dim[2].min != 0) {
+            return report(uc, halide_error_code_constraint_violated, "Output buffer output: all three channels are produced together");
+        }
+        const float *din = dev_ptr<float>(input) + (long)(0 - input->dim[2].min) * g.in_sc;
+        timing_note_bytes(24.0 * ow * oh);
+        HLMI_LAUNCH(uc, "unsharp_tile", ctx.stream, unsharp_tile, dim3((ow + TW - 1) / TW, (oh + TH - 1) / TH), dim3(256), 0, din,
+                    dev_ptr<float>(output), g);
+    }
+    mark_output_written(output);
+    return 0;
+}
+
+extern "C" int unsharp_argv(void **a) { return unsharp((halide_buffer_t *)a[0], (halide_buffer_t *)a[1]); }
+extern "C" const halide_filter_metadata_t *unsharp_metadata(void) { return &us_md; }
+extern "C" int unsharp_auto_schedule(halide_buffer_t *input, halide_buffer_t *output) { return unsharp(input, output); }

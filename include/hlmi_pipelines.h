@@ -85,6 +85,11 @@ int depthwise_separable_conv(struct halide_buffer_t *input, struct halide_buffer
                              struct halide_buffer_t *output);
 HLMI_DECLARE_AUX(depthwise_separable_conv)
 
+/* apps/unsharp/unsharp_generator.cpp:9-10,113 — f32 [W,H,3] planar in and out, sigma = 1.5 (GeneratorParam :7): gray,
+ * separable 7-tap Gaussian, sharpen, ratio, recolour.  An adjacent app with the same boundary. */
+int unsharp(struct halide_buffer_t *input, struct halide_buffer_t *output);
+HLMI_DECLARE_AUX(unsharp)
+
 /* apps/camera_pipe/camera_pipe_generator.cpp:219-228,622 — raw u16 Bayer -> u8 [W,H,3]. */
 int camera_pipe(struct halide_buffer_t *input, struct halide_buffer_t *matrix_3200,
                 struct halide_buffer_t *matrix_7000, float color_temp, float gamma, float contrast,
@@ -106,6 +111,7 @@ int conv_layer_auto_schedule(struct halide_buffer_t *input, struct halide_buffer
 int depthwise_separable_conv_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *depthwise_filter,
                                            struct halide_buffer_t *pointwise_filter, struct halide_buffer_t *bias,
                                            struct halide_buffer_t *output);
+int unsharp_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);
 int camera_pipe_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *matrix_3200,
                               struct halide_buffer_t *matrix_7000, float color_temp, float gamma, float contrast,
                               float sharpen_strength, int32_t blackLevel, int32_t whiteLevel,

@@ -194,6 +194,30 @@ def depthwise_separable_conv(inp: np.ndarray, dw: np.ndarray, pw: np.ndarray, bi
     assert _lib.oracle_depthwise_separable_conv(inp, dw, pw, bias, out, ci, w, h, n, cm, fw, fh, ic, co) == 0
     return out
 
+_lib.oracle_unsharp.argtypes = [_f32p, C.c_int, C.c_int, C.c_long, C.c_long, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int,
+                                C.c_int, C.c_long, C.c_long]
+_lib.oracle_unsharp.restype = C.c_int
+_lib.oracle_unsharp_kernel.argtypes = [_f32p]
+_lib.oracle_unsharp_kernel.restype = None
+
+
+def unsharp_kernel() -> np.ndarray:
+    k = np.zeros(4, np.float32)
+    _lib.oracle_unsharp_kernel(k)
+    return k
+
+
+def unsharp(inp: np.ndarray, out_origin=(0, 0), out_size=None, in_origin=(0, 0)) -> np.ndarray:
+    """inp: f32 (3, H, W) planar whose first element sits at absolute in_origin; output region out_origin + out_size."""
+    inp = np.ascontiguousarray(inp, np.float32)
+    c, h, w = inp.shape
+    assert c == 3
+    ow, oh = out_size if out_size else (w, h)
+    out = np.zeros((3, oh, ow), np.float32)
+    assert _lib.oracle_unsharp(inp, w, h, w, w * h, in_origin[0], in_origin[1], out, out_origin[0], out_origin[1], ow, oh,
+                               ow, ow * oh) == 0
+    return out
+
 _i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
 _lib.oracle_camera_pipe.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.c_int]
