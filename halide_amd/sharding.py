@@ -62,3 +62,50 @@ def run_batch(frames: Iterable, process: Callable, rank: int, world: int) -> Dic
     """Apply `process(frame)` to the frames this rank owns; returns {batch index: result}."""
     frames = list(frames)
     return {i: process(frames[i]) for i in shard(len(frames), rank, world)}
+
+
+def scatter_process_gather(frames, process: Callable, dist=None, root: int = 0, like=None, n_items: int | None = None):
+    """The one workload of BASELINE.json with a real exchange step (configs[3]: a batch of nl_means frames that
+    originates and terminates on ONE GPU): rank `root` holds `frames` (a list of equally shaped tensors), every rank
+    processes its round-robin share, the results return to `root`.
+
+    Point-to-point transfers (`isend` / `irecv`: RCCL over xGMI with the "nccl" backend, one link per peer) instead
+    of a scatter/gather collective, because they pipeline: all receives are posted up front, rank r computes frame k
+    while frames k+1.. are still arriving and returns each result as soon as it exists; `root` works on its own share
+    meanwhile.  xGMI is point-to-point, so the seven peers of a node load seven different links of `root`.
+
+    `process(tensor) -> tensor` must return a tensor shaped like its input.  Non-root ranks pass `frames=None`,
+    `like` = a tensor with the frames' shape/dtype/device and `n_items`.  Returns the list of results on `root`
+    (batch order), None elsewhere.  world == 1: plain local loop."""
+    world = 1 if dist is None or not dist.is_initialized() else dist.get_world_size()
+    if world == 1:
+        return [process(f) for f in frames]
+    import torch
+    rank = dist.get_rank()
+    if rank == root:
+        n = len(frames)
+        sends = [dist.isend(frames[i], dst=(i % world), tag=i) for i in range(n) if i % world != root]
+        results = [None] * n
+        recvs = []
+        for i in range(n):
+            if i % world != root:
+                results[i] = torch.empty_like(frames[i])
+                recvs.append(dist.irecv(results[i], src=(i % world), tag=n + i))
+        for i in shard(n, root, world):  # own share, overlapped with the transfers
+            results[i] = process(frames[i])
+        for w in sends + recvs:
+            w.wait()
+        return results
+    n = int(n_items)
+    mine = shard(n, rank, world)
+    bufs = {i: torch.empty_like(like) for i in mine}
+    recvs = {i: dist.irecv(bufs[i], src=root, tag=i) for i in mine}
+    sends, keep = [], []
+    for i in mine:
+        recvs[i].wait()
+        out = process(bufs[i])
+        keep.append(out)
+        sends.append(dist.isend(out, dst=root, tag=n + i))
+    for w in sends:
+        w.wait()
+    return None

@@ -73,3 +73,52 @@ def test_two_ranks_over_gloo_match_single_process():
     for rank, digests, slowest in results:
         assert digests == want          # every rank sees the digests of the whole batch
         assert slowest == 0.5           # max over ranks of 0.25*(rank+1)
+
+
+def _sg_worker(rank, world, port, n_frames, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from halide_amd import sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+
+    def process(t):
+        calls.append(int(t[0, 0].item()))
+        return t * 2 + 1
+
+    like = torch.zeros((6, 5), dtype=torch.float32)
+    frames = [torch.full((6, 5), float(i)) for i in range(n_frames)] if rank == 0 else None
+    res = sharding.scatter_process_gather(frames, process, dist, root=0, like=like, n_items=n_frames)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, sorted(calls), None if res is None else [float(r[0, 0].item()) for r in res]))
+
+
+def test_scatter_process_gather_over_gloo():
+    """configs[3]'s exchange pattern: the batch starts and ends on rank 0, every rank computes its round-robin share."""
+    import torch.multiprocessing as mp
+    n_frames, world = 7, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sg_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {r: (calls, res) for r, calls, res in (q.get(timeout=180) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[0][0] == [0, 2, 4, 6] and results[1][0] == [1, 3, 5]      # who computed what
+    assert results[0][1] == [2.0 * i + 1 for i in range(n_frames)] and results[1][1] is None
+
+
+def test_scatter_process_gather_single_process():
+    import torch
+    from halide_amd import sharding
+    out = sharding.scatter_process_gather([torch.full((2, 2), float(i)) for i in range(3)], lambda t: t + 1)
+    assert [float(o[0, 0]) for o in out] == [1.0, 2.0, 3.0]
