@@ -194,13 +194,11 @@ __device__ __forceinline__ void load_raw(Raw &r, const uint16_t *__restrict__ rp
 }
 
 // 165 VGPRs: 3 waves/SIMD; the scalar-load variant (odd strides / widths) needs more and is not the fast path
-// ABL != 0: ablation variants for timing experiments (HLMI_LL_ABL0), results are NOT valid:
-//   1 = no LUT reads, 2 = no stores, 4 = no input loads after the first row pair
 // Register budget: 72 (vertical window state) + 16 (double-buffered LUT values) + 32 (gray / LUT positions of this
 // and the next row pair) + 12 (raw input in flight) + 18 (results awaiting their stores) + temporaries: two waves per
 // SIMD (launch bound); the LUT reads of plane k+1 are issued before the arithmetic of plane k so that the LDS latency
 // hides inside the wave itself.
-template<bool ODD, bool VEC, bool LUT_LDS, bool B1, int ABL = 0>
+template<bool ODD, bool VEC, bool LUT_LDS, bool B1>
 __global__ __launch_bounds__(D0_THREADS, 2) void ll_down0(const uint16_t *__restrict__ in, long in_sy, long co0, long co1,
                                                    long co2, Geometry gm, Levels lev, float beta,
                                                    const float *__restrict__ lut_g, float *__restrict__ g1, int Xs,
@@ -270,8 +268,8 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down0(const uint16_t *__rest
         auto lut_issue = [&](int kk, const int (&l0)[4], const int (&l1)[4], float (&dst)[8]) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                dst[i] = (ABL & 1) ? __int_as_float(l0[i]) : lut[l0[i] + 256 * (KCH - 1 - kk)];
-                dst[4 + i] = (ABL & 1) ? __int_as_float(l1[i]) : lut[l1[i] + 256 * (KCH - 1 - kk)];
+                dst[i] = lut[l0[i] + 256 * (KCH - 1 - kk)];
+                dst[4 + i] = lut[l1[i] + 256 * (KCH - 1 - kk)];
             }
         };
         // Walk the planes of one row pair (r0 = gray/positions of the first row, r1 of the second).  F(kk, i, v0, v1)
@@ -353,13 +351,13 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down0(const uint16_t *__rest
                 if (kk < KCH ? (kk < nk) : with_in) {
                     const int plane = (kk < KCH) ? kb + kk : gm.K;
                     const float2 o = stage[kk * D0_THREADS];
-                    if ((ABL & 2) ? (store_ok && o.x == 12345.678f) : store_ok) {
+                    if (store_ok) {
                         *reinterpret_cast<float2 *>(drow + (size_t)plane * ps1) = o;
                     }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < t1 && !(ABL & 4)) {
+            if (t + 1 < t1) {
                 load_raw<VEC>(rc, row_ptr(2 * T + 5), co0, co1, co2, qs.oq, xo);
                 load_raw<VEC>(rd, row_ptr(2 * T + 6), co0, co1, co2, qs.oq, xo);
             }
@@ -836,9 +834,7 @@ struct Up0Args {
     float beta;
 };
 
-// ABL != 0: ablation variants for timing experiments (HLMI_LL_ABLU), results NOT valid:
-//   1 = no level-1 gathers, 2 = no LUT reads, 4 = no division, 8 = no stores
-template<bool VEC, bool LUT_LDS, int ABL = 0>
+template<bool VEC, bool LUT_LDS>
 __global__ __launch_bounds__(256) void ll_up0(Up0Args p, Geometry gm) {
     extern __shared__ float slut[];
     if (LUT_LDS) {
@@ -898,23 +894,22 @@ __global__ __launch_bounds__(256) void ll_up0(Up0Args p, Geometry gm) {
             const float *lp = lut + (idx - 256 * li + gm.half);
             float lev0 = (float)li * gm.inv_Km1, lev1 = (float)(li + 1) * gm.inv_Km1;
             const float *gp = p.g1 + (size_t)li * p.ps1;
-            float l0 = g0_val(gray, lev0, p.beta, (ABL & 2) ? lf : lp[0]) - ((ABL & 1) ? lev0 : up_at(gp, p.lox1, p.loy1, p.ws1, Xi, Y));
-            float l1 = g0_val(gray, lev1, p.beta, (ABL & 2) ? lf : lp[-256]) -
-                       ((ABL & 1) ? lev1 : up_at(gp + p.ps1, p.lox1, p.loy1, p.ws1, Xi, Y));
+            float l0 = g0_val(gray, lev0, p.beta, lp[0]) - up_at(gp, p.lox1, p.loy1, p.ws1, Xi, Y);
+            float l1 = g0_val(gray, lev1, p.beta, lp[-256]) - up_at(gp + p.ps1, p.lox1, p.loy1, p.ws1, Xi, Y);
             float outL = (1.0f - lf) * l0 + lf * l1;
-            float og = (((ABL & 1) ? lf : up_at(p.out1, p.lox1, p.loy1, p.ws1, Xi, Y)) + outL) + 0.01f;
+            float og = (up_at(p.out1, p.lox1, p.loy1, p.ws1, Xi, Y) + outL) + 0.01f;
             float gr = gray + 0.01f;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 // color = input * (outG0 + eps) / (gray + eps); input is the UNclamped input here (:84)
-                float v = (ABL & 4) ? ((float)cch[c][i] * og) * gr : ((float)cch[c][i] * og) / gr;
+                float v = ((float)cch[c][i] * og) / gr;
                 res[c][i] = (uint16_t)dev::clampf(v, 0.0f, 65535.0f);
             }
         }
         if (vec) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                if ((ABL & 8) ? (c < p.nc && res[c][0] == 12345) : (c < p.nc)) {
+                if (c < p.nc) {
                     *reinterpret_cast<ushort2 *>(op + (long)c * p.out_sc) = make_ushort2(res[c][0], res[c][1]);
                 }
             }
@@ -1223,16 +1218,9 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     case ((O ? 8 : 0) | (V ? 4 : 0) | (L ? 2 : 0) | (B ? 1 : 0)):      \
         r = launch_d0(&ll_down0<O, V, L, B>);                         \
         break;
-#define LL_D0A(A)                                                     \
-    case A:                                                           \
-        r = launch_d0(&ll_down0<false, true, true, true, A>);         \
-        break;
-        const int abl0 = env_int("HLMI_LL_ABL0", 0);
-        if (!abl0 && levels == KCH && vec && lut_lds && env_int("HLMI_LL_D0F", 1)) {
+        if (levels == KCH && vec && lut_lds && env_int("HLMI_LL_D0F", 1)) {
             if (d.odd) r = b1 ? launch_d0(&ll_down0f<true, true>) : launch_d0(&ll_down0f<true, false>);
             else r = b1 ? launch_d0(&ll_down0f<false, true>) : launch_d0(&ll_down0f<false, false>);
-        } else if (abl0 && variant == 7) {  // timing experiments on the main variant only
-            switch (abl0) { LL_D0A(1) LL_D0A(2) LL_D0A(3) LL_D0A(4) LL_D0A(6) LL_D0A(7) }
         } else {
             switch (variant) {
                 LL_D0(false, false, false, false) LL_D0(false, false, false, true) LL_D0(false, false, true, false)
@@ -1244,7 +1232,6 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             }
         }
 #undef LL_D0
-#undef LL_D0A
         if (r) return r;
     }
     // levels >= S are produced / collapsed by the two multi-level kernels (S = 4: 2 launches instead of 7)
@@ -1360,22 +1347,14 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         // input read + output written (u16 x nc channels), 2 selected planes of g_1 + outG_1 read
         const double u0_bytes = 2.0 * (3 + nc) * ow * oh + 4.0 * 3.0 * (c.rx1 - c.rx0 + 1) * (c.ry1 - c.ry0 + 1);
         timing_note_bytes(u0_bytes);
-        const int ablu = env_int("HLMI_LL_ABLU", 0);
         const bool fast = vec && same && nc == 3 && (ow & 1) == 0 && (p.ox0 & 1) == 0 &&
-                          (double)(levels + 1) * (4.0 * (double)c.ps) < 4.0e9 && !ablu && !env_int("HLMI_LL_UP0_OLD", 0);
+                          (double)(levels + 1) * (4.0 * (double)c.ps) < 4.0e9 && !env_int("HLMI_LL_UP0_OLD", 0);
         if (fast) {
             const bool b1 = (beta == 1.0f);
             if (lut_lds && b1) HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0f<true, true>), grid, block, lut_sh, p, gm);
             else if (lut_lds) HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0f<true, false>), grid, block, lut_sh, p, gm);
             else if (b1) HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0f<false, true>), grid, block, lut_sh, p, gm);
             else HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0f<false, false>), grid, block, lut_sh, p, gm);
-        } else if (ablu && vec && lut_lds) {
-#define LL_U0A(A)                                                                                      \
-    case A:                                                                                            \
-        HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0<true, true, A>), grid, block, lut_sh, p, gm);            \
-        break;
-            switch (ablu) { LL_U0A(1) LL_U0A(2) LL_U0A(3) LL_U0A(4) LL_U0A(7) LL_U0A(8) LL_U0A(15) }
-#undef LL_U0A
         } else if (vec) {
             if (lut_lds) HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0<true, true>), grid, block, lut_sh, p, gm);
             else HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0<true, false>), grid, block, lut_sh, p, gm);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# ablation timings (results invalid, timing only).  Usage: bash scripts/gpu_abl.sh tag "VAR=val ..." ...
+# A/B timings of run-time switches (env vars).  Usage: bash scripts/gpu_abl.sh tag "VAR=val ..." ...
 TAG=$1; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 for v in "$@"; do
