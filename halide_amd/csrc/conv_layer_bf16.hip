@@ -65,7 +65,7 @@ __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {  // {bf16(lo),
 
 // filter f32 [ci][ky][kx][co] (co fastest) -> bf16
 //   FRAG = false: wB[kk][co][ci]                                  (rows of k, staged through LDS by conv3x3_bf16_mfma)
-//   FRAG = true : wB[kk][ci / 64][(ci % 64) / 16][co / 32][lane][8], lane = co % 32 + 32 ((ci % 16) / 8): every
+//   FRAG = true : wB[kk][ci / 32][(ci % 32) / 16][co / 32][lane][8], lane = co % 32 + 32 ((ci % 16) / 8): every
 //                 32x16 MFMA B fragment is 1 KB contiguous in lane order (one coalesced 16-byte load per lane)
 template<bool FRAG>
 __global__ void conv_filter_bf16(const float *__restrict__ filt, uint16_t *__restrict__ wb, int CI, int CO) {
@@ -76,8 +76,8 @@ __global__ void conv_filter_bf16(const float *__restrict__ filt, uint16_t *__res
     const float a = filt[((size_t)(2 * cp) * 9 + kk) * CO + co], b = filt[((size_t)(2 * cp + 1) * 9 + kk) * CO + co];
     size_t o;                                             // in bf16 pairs
     if (FRAG) {
-        const int ci = 2 * cp, cc = ci / KC, ks = (ci % KC) / 16, kh = (ci % 16) / 8, j = ci % 8;
-        o = ((((((size_t)kk * (CI / KC) + cc) * 4 + ks) * (CO / 32) + co / 32) * 64 + (co % 32) + 32 * kh) * 8 + j) / 2;
+        const int ci = 2 * cp, cc = ci / 32, ks = (ci % 32) / 16, kh = (ci % 16) / 8, j = ci % 8;   // 32-ci chunks (KL)
+        o = ((((((size_t)kk * (CI / 32) + cc) * 2 + ks) * (CO / 32) + co / 32) * 64 + (co % 32) + 32 * kh) * 8 + j) / 2;
     } else {
         o = ((size_t)kk * CO + co) * half + cp;
     }
@@ -212,19 +212,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // 64-ci chunk is staged in LDS once (f32 -> bf16) and the nine taps are nine row offsets into it — 9x less A traffic
 // through L1 / LDS than re-staging an im2col slice per tap; B streams from L2 into registers.
 // Positions q with x >= W or y >= H are not outputs (7 % of a 56x56 image): computed, never stored.
+constexpr int KL = 32;        // ci per window chunk of conv3x3_bf16_lin
+constexpr int PL = KL + 8;    // its LDS row pitch in bf16 elements (80 B)
+// NP: staging passes of 32 window rows per thread (window rows AR <= 32 NP)
+template<int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv3x3_bf16_lin(const float *__restrict__ in, const uint16_t *__restrict__ wb, const float *__restrict__ bias,
                       float *__restrict__ out, CGeom g, int AR, FastDiv d_img, FastDiv d_row) {
-    extern __shared__ uint16_t smem[];                       // A window: AR x PA bf16
-    uint16_t *const sA = smem;
+    extern __shared__ uint16_t smem[];                       // two A windows: 2 x AR x PL bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int Wp = g.W + 2, Hp = g.H + 2;
     const long NQ = (long)g.N * Hp * Wp;
     const long Q0 = (long)blockIdx.x * TP;
     const int co0 = blockIdx.y * TC;
-    const int aq = tid & 15, ap = tid >> 4;                  // A loader: float4 aq of the chunk, window rows ap + 16 i
-    const int cpk = g.CI / KC, ntap = 9 * cpk;
+    const int aq = tid & 7, ap = tid >> 3;                   // A loader: float4 aq of the 32-ci chunk, window rows ap + 32 i
+    const int cpk = g.CI / KL, ntap = 9 * cpk;
 
     floatx16 acc[2][2];
 #pragma unroll
@@ -235,27 +238,49 @@ void conv3x3_bf16_lin(const float *__restrict__ in, const uint16_t *__restrict__
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = bv;
         }
-    // B operands come straight from the bf16 filter in L2 (lane l: column co = .. + (l & 31), k = 8 (l >> 5) .. + 7 of
-    // each 16-k step: one 16-byte load), three taps ahead through three register stages; tap t uses stage t % 3 (9 taps
-    // per ci chunk, so the stage is kk % 3).  No LDS and no barrier on the B side: within a ci chunk the waves run free.
-    bf16x8 bfr[3][2][4];
+    // B operands come straight from the fragment-ordered bf16 filter in L2 (one coalesced 16-byte load per lane and
+    // 32x16 fragment), three taps ahead through three register stages; tap t uses stage t % 3 (9 taps per chunk, so the
+    // stage is kk % 3).  No LDS and no barrier on the B side.
+    bf16x8 bfr[3][2][2];
     const uint32_t cot0 = (uint32_t)(co0 + 64 * wn) / 32, ncot = (uint32_t)g.CO / 32;
-    auto load_b = [&](int t, bf16x8 (&dst)[2][4]) {          // tap t = cc * 9 + kk; fragment layout of conv_filter_bf16<true>
+    auto load_b = [&](int t, bf16x8 (&dst)[2][2]) {          // tap t = cc * 9 + kk; layout of conv_filter_bf16<true>
         const int cc = t / 9, kk = t - 9 * cc;
-        const uint32_t f0 = ((uint32_t)kk * cpk + cc) * 4;
+        const uint32_t f0 = ((uint32_t)kk * cpk + cc) * 2;
 #pragma unroll
         for (int b = 0; b < 2; b++)
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++)
+            for (int ks = 0; ks < 2; ks++)
                 dst[b][ks] = *reinterpret_cast<const bf16x8 *>(wb + ((((f0 + ks) * ncot + cot0 + b) * 64 + lane) * 8));
     };
-    auto tap = [&](int t, int kk, bf16x8 (&bs)[2][4]) {
-        const int ky = kk / 3, kx = kk - 3 * ky;
-        const uint16_t *pa = sA + (64 * wm + (lane & 31) + ky * Wp + kx) * PA + 8 * (lane >> 5);
+    // A: the input-linear window of a 32-ci chunk, f32 -> bf16 on the way into LDS.  The window of chunk cc+1 is
+    // requested when chunk cc starts, converted and written to the OTHER LDS window when chunk cc's taps are done:
+    // only the first window's memory latency is exposed.
+    float4 va[NP];
+    auto load_a = [&](int cc) {
 #pragma unroll
-        for (int ks = 0; ks < KC / 16; ks++) {
+        for (int i = 0; i < NP; i++) {
+            const uint32_t q = min((uint32_t)Q0 + ap + 32 * i, (uint32_t)NQ - 1);   // NQ CI < 2^31 elements
+            va[i] = *reinterpret_cast<const float4 *>(in + (q * g.CI + cc * KL + 4 * aq));
+        }
+    };
+    auto store_a = [&](int buf) {
+        uint16_t *sA = smem + (size_t)buf * AR * PL;
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            if (ap + 32 * i < AR) {
+                uint2 w;
+                w.x = pk_bf16(va[i].x, va[i].y), w.y = pk_bf16(va[i].z, va[i].w);
+                *reinterpret_cast<uint2 *>(sA + (ap + 32 * i) * PL + 4 * aq) = w;
+            }
+        }
+    };
+    auto tap = [&](int t, int kk, const uint16_t *sA, bf16x8 (&bs)[2][2]) {
+        const int ky = kk / 3, kx = kk - 3 * ky;
+        const uint16_t *pa = sA + (64 * wm + (lane & 31) + ky * Wp + kx) * PL + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < KL / 16; ks++) {
             const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(pa + 16 * ks);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(pa + 32 * PA + 16 * ks);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(pa + 32 * PL + 16 * ks);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bs[0][ks], acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bs[1][ks], acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bs[0][ks], acc[1][0], 0, 0, 0);
@@ -263,37 +288,24 @@ void conv3x3_bf16_lin(const float *__restrict__ in, const uint16_t *__restrict__
         }
         if (t + 3 < ntap) load_b(t + 3, bs);                 // refill the stage just consumed
     };
+    load_a(0);
     load_b(0, bfr[0]);
     load_b(1, bfr[1]);
     load_b(2, bfr[2]);
+    store_a(0);
+    __syncthreads();
 #pragma unroll 1
     for (int cc = 0; cc < cpk; cc++) {
-        if (cc > 0) __syncthreads();                         // every wave is done with the previous window
-        // ---- stage the window of this ci chunk: rows ap + 16 i, 8 rows in flight per thread
-#pragma unroll 1
-        for (int r0 = ap; r0 < AR; r0 += 128) {
-            float4 v[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const uint32_t q = min((uint32_t)Q0 + r0 + 16 * i, (uint32_t)NQ - 1);   // NQ CI < 2^31 elements
-                v[i] = *reinterpret_cast<const float4 *>(in + (q * g.CI + cc * KC + 4 * aq));
-            }
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                if (r0 + 16 * i < AR) {
-                    uint2 w;
-                    w.x = pk_bf16(v[i].x, v[i].y), w.y = pk_bf16(v[i].z, v[i].w);
-                    *reinterpret_cast<uint2 *>(sA + (r0 + 16 * i) * PA + 4 * aq) = w;
-                }
-            }
-        }
-        __syncthreads();
+        if (cc + 1 < cpk) load_a(cc + 1);
+        const uint16_t *sA = smem + (size_t)(cc & 1) * AR * PL;
 #pragma unroll 1
         for (int k3 = 0; k3 < 9; k3 += 3) {
-            tap(cc * 9 + k3, k3, bfr[0]);
-            tap(cc * 9 + k3 + 1, k3 + 1, bfr[1]);
-            tap(cc * 9 + k3 + 2, k3 + 2, bfr[2]);
+            tap(cc * 9 + k3, k3, sA, bfr[0]);
+            tap(cc * 9 + k3 + 1, k3 + 1, sA, bfr[1]);
+            tap(cc * 9 + k3 + 2, k3 + 2, sA, bfr[2]);
         }
+        if (cc + 1 < cpk) store_a((cc + 1) & 1);             // that window was last read before the previous barrier
+        __syncthreads();
     }
     // ---- epilogue
 #pragma unroll
@@ -359,9 +371,9 @@ extern "C" int conv_layer_bf16(halide_buffer_t *input, halide_buffer_t *filter, 
         uint16_t *wb = (uint16_t *)ws;
         const int pairs = 9 * g.CO * (g.CI / 2);
         const int AR = TP + 2 * (g.W + 2) + 2;               // input-linear window of a 128-pixel tile
-        const size_t sh_lin = (size_t)AR * PA * sizeof(uint16_t);
+        const size_t sh_lin = (size_t)2 * AR * (32 + 8) * sizeof(uint16_t);   // two windows of 32-ci chunks, 80-byte rows
         const long NQ = (long)g.N * (g.H + 2) * (g.W + 2);
-        const bool lin = sh_lin <= 80 * 1024 && NQ < (1L << 31) && !getenv("HLMI_CONV_IM2COL");
+        const bool lin = AR <= 32 * 12 && NQ < (1L << 31) && !getenv("HLMI_CONV_IM2COL");   // W <= 125
         timing_note_bytes(6.0 * 9 * g.CO * g.CI);
         if (lin) {
             HLMI_LAUNCH(uc, "conv_filter_bf16", ctx.stream, conv_filter_bf16<true>, dim3((pairs + 255) / 256), dim3(256), 0,
@@ -371,13 +383,20 @@ extern "C" int conv_layer_bf16(halide_buffer_t *input, halide_buffer_t *filter, 
                         dev_ptr<float>(filter), wb, g.CI, g.CO);
         }
         if (lin) {
-            HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_lin),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_lin));
             dim3 grid((unsigned)((NQ + TP - 1) / TP), g.CO / TC);
             timing_note_bytes(4.0 * ((double)NQ * g.CI + (double)g.npix * g.CO) + (double)wb_bytes);
-            HLMI_LAUNCH(uc, "conv3x3_bf16_mfma", ctx.stream, conv3x3_bf16_lin, grid, dim3(256), sh_lin, dev_ptr<float>(input),
-                        wb, dev_ptr<float>(bias), dev_ptr<float>(relu), g, AR,
-                        make_fastdiv((uint32_t)((g.H + 2) * (g.W + 2))), make_fastdiv((uint32_t)(g.W + 2)));
+            const FastDiv d_img = make_fastdiv((uint32_t)((g.H + 2) * (g.W + 2))), d_row = make_fastdiv((uint32_t)(g.W + 2));
+            if (AR <= 32 * 8) {
+                HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_lin<8>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_lin));
+                HLMI_LAUNCH(uc, "conv3x3_bf16_mfma", ctx.stream, conv3x3_bf16_lin<8>, grid, dim3(256), sh_lin, dev_ptr<float>(input),
+                            wb, dev_ptr<float>(bias), dev_ptr<float>(relu), g, AR, d_img, d_row);
+            } else {
+                HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_lin<12>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_lin));
+                HLMI_LAUNCH(uc, "conv3x3_bf16_mfma", ctx.stream, conv3x3_bf16_lin<12>, grid, dim3(256), sh_lin, dev_ptr<float>(input),
+                            wb, dev_ptr<float>(bias), dev_ptr<float>(relu), g, AR, d_img, d_row);
+            }
             mark_output_written(relu);
             return 0;
         }
