@@ -10,14 +10,13 @@
 // entry point is `conv_layer`.
 //
 // Implicit GEMM  D[pixel][co] = bias[co] + sum_k A[pixel][k] B[k][co],  k = (ky, kx, ci):
-//   conv_filter_bf16   filter f32 [ci][ky][kx][co] -> bf16 wB[ky*3+kx][co][ci] (k contiguous per output channel,
-//                      the order an MFMA B operand wants: lane j = column, 8 consecutive k)
-//   conv3x3_bf16_mfma  workgroup = 4 waves = 128 pixels x 128 output channels, wave = 64 x 64 (2x2 accumulators of
-//                      32x32).  Per (ky, kx) and 64-ci chunk: A (128 px x 64 ci, 256 B contiguous per pixel, f32 ->
-//                      bf16 on the way) and B (128 co x 64 ci bf16) are staged in LDS with rows padded to 144 B;
-//                      operands are read with ds_read_b128 (lane l: row l&31, k = 8 (l>>5) .. +7).  A chunk is only
-//                      16 MFMAs (~0.2 us) against ~1.5 us of memory latency, so three chunks are in flight behind
-//                      the one being multiplied: two in registers (two sets), one in the second LDS buffer.
+//   conv_filter_bf16   filter f32 [ci][ky][kx][co] -> bf16, either rows of k (im2col kernel) or pre-ordered into 1 KB
+//                      MFMA B fragments (input-linear kernel)
+//   conv3x3_bf16_lin   the kernel that runs for W <= 125: tiles of 128 consecutive INPUT-LINEAR pixels, the window of
+//                      a 32-ci chunk staged once in LDS (double-buffered), nine taps = nine row offsets, B fragments
+//                      streamed L2 -> registers three taps ahead (see the comment at the kernel)
+//   conv3x3_bf16_mfma  fallback for wider images: workgroup = 4 waves = 128 pixels x 128 output channels; per (ky, kx)
+//                      and 64-ci chunk A and B are staged in LDS (rows padded to 144 B), three chunks in flight
 //   Algorithmic bytes: input + output once (f32) + the bf16 filter: 27.6 + 25.7 + 0.3 MB at configs[4];
 //   flops 2 N H W CI CO 9 = 14.8 G.
 #include "hlmi_internal.h"
