@@ -134,6 +134,16 @@ def main():
         emit("unsharp", "apps/unsharp sigma=1.5, f32 1536x2560x3", t, W * H, "hbm", 24.0 * W * H / t / 1e9, HBM_PEAK_GBS, "GB/s",
              {"alg_bytes": 24 * W * H, "kernels_ms": kernels(call, o)})
 
+    # ---- hist u8 1536x2560x3 (generator estimates)
+    if not only or "hist" in only:
+        W, H = 1536, 2560
+        a = hl.Buffer(rng.integers(0, 256, (3, H, W), dtype=np.uint8))
+        o = hl.Buffer(np.zeros((3, H, W), np.uint8))
+        call = lambda: hl.hist(a, o)
+        t = timed(call, o, 50)
+        emit("hist", "apps/hist histogram equalisation, u8 1536x2560x3", t, W * H, "hbm", 9.0 * W * H / t / 1e9, HBM_PEAK_GBS, "GB/s",
+             {"alg_bytes": 9 * W * H, "kernels_ms": kernels(call, o)})
+
     # ---- depthwise_separable_conv at the driver's shape (MobileNet-v2 layer 2, process.cpp:13)
     if not only or "depthwise_separable_conv" in only:
         N, Hh, Ww, CI, CO = 4, 112, 112, 32, 16

@@ -129,6 +129,24 @@ def depthwise_separable_conv(input: torch.Tensor, depthwise_filter: torch.Tensor
     return out
 
 
+@torch.library.custom_op("hlmi::unsharp", mutates_args=())
+def unsharp(input: torch.Tensor) -> torch.Tensor:
+    """apps/unsharp: (3, H, W) float32 -> (3, H, W) float32, sigma = 1.5."""
+    out = torch.empty_like(input)
+    with _Wrapped(input, out) as (a, o):
+        hl.unsharp(a, o)
+    return out
+
+
+@torch.library.custom_op("hlmi::hist", mutates_args=())
+def hist(input: torch.Tensor) -> torch.Tensor:
+    """apps/hist: (3, H, W) uint8 -> (3, H, W) uint8, histogram equalisation of the luma."""
+    out = torch.empty_like(input)
+    with _Wrapped(input, out) as (a, o):
+        hl.hist(a, o)
+    return out
+
+
 @torch.library.custom_op("hlmi::camera_pipe", mutates_args=())
 def camera_pipe(input: torch.Tensor, matrix_3200: torch.Tensor, matrix_7000: torch.Tensor, color_temp: float, gamma: float,
                 contrast: float, sharpen_strength: float, black_level: int, white_level: int, out_width: int,

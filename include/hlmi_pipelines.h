@@ -90,6 +90,11 @@ HLMI_DECLARE_AUX(depthwise_separable_conv)
 int unsharp(struct halide_buffer_t *input, struct halide_buffer_t *output);
 HLMI_DECLARE_AUX(unsharp)
 
+/* apps/hist/hist_generator.cpp:9-10,215 — u8 [W,H,3] planar in and out: histogram equalisation of the luma (integer
+ * histogram over the whole input, cdf, pointwise recolouring).  An adjacent app with the same boundary. */
+int hist(struct halide_buffer_t *input, struct halide_buffer_t *output);
+HLMI_DECLARE_AUX(hist)
+
 /* apps/camera_pipe/camera_pipe_generator.cpp:219-228,622 — raw u16 Bayer -> u8 [W,H,3]. */
 int camera_pipe(struct halide_buffer_t *input, struct halide_buffer_t *matrix_3200,
                 struct halide_buffer_t *matrix_7000, float color_temp, float gamma, float contrast,
@@ -112,6 +117,7 @@ int depthwise_separable_conv_auto_schedule(struct halide_buffer_t *input, struct
                                            struct halide_buffer_t *pointwise_filter, struct halide_buffer_t *bias,
                                            struct halide_buffer_t *output);
 int unsharp_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);
+int hist_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);
 int camera_pipe_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *matrix_3200,
                               struct halide_buffer_t *matrix_7000, float color_temp, float gamma, float contrast,
                               float sharpen_strength, int32_t blackLevel, int32_t whiteLevel,

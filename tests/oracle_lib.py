@@ -218,6 +218,23 @@ def unsharp(inp: np.ndarray, out_origin=(0, 0), out_size=None, in_origin=(0, 0))
                                ow, ow * oh) == 0
     return out
 
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_lib.oracle_hist.argtypes = [_u8p, C.c_int, C.c_int, C.c_long, C.c_long, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long,
+                             _i32p]
+_lib.oracle_hist.restype = C.c_int
+
+
+def hist(inp: np.ndarray, out_origin=(0, 0), out_size=None, return_cdf=False):
+    """inp: u8 (3, H, W) planar with origin (0, 0); output region out_origin + out_size (default: the whole image)."""
+    inp = np.ascontiguousarray(inp, np.uint8)
+    c, h, w = inp.shape
+    assert c == 3
+    ow, oh = out_size if out_size else (w, h)
+    out = np.zeros((3, oh, ow), np.uint8)
+    cdf = np.zeros(256, np.int32)
+    assert _lib.oracle_hist(inp, w, h, w, w * h, out, out_origin[0], out_origin[1], ow, oh, ow, ow * oh, cdf) == 0
+    return (out, cdf) if return_cdf else out
+
 _i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
 _lib.oracle_camera_pipe.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.c_int]
