@@ -144,6 +144,16 @@ def main():
         emit("hist", "apps/hist histogram equalisation, u8 1536x2560x3", t, W * H, "hbm", 9.0 * W * H / t / 1e9, HBM_PEAK_GBS, "GB/s",
              {"alg_bytes": 9 * W * H, "kernels_ms": kernels(call, o)})
 
+    # ---- harris f32 1536x2560x3 -> 1530x2554 (generator estimates)
+    if not only or "harris" in only:
+        W, H = 1536, 2560
+        a = hl.Buffer(rng.random((3, H, W), dtype=np.float32))
+        o = hl.Buffer(np.zeros((H - 6, W - 6), np.float32)).set_min(3, 3)
+        call = lambda: hl.harris(a, o)
+        t = timed(call, o, 50)
+        emit("harris", "apps/harris corner response, f32 1536x2560x3 -> 1530x2554", t, (W - 6) * (H - 6), "hbm", 16.0 * W * H / t / 1e9,
+             HBM_PEAK_GBS, "GB/s", {"alg_bytes": 16 * W * H, "kernels_ms": kernels(call, o)})
+
     # ---- depthwise_separable_conv at the driver's shape (MobileNet-v2 layer 2, process.cpp:13)
     if not only or "depthwise_separable_conv" in only:
         N, Hh, Ww, CI, CO = 4, 112, 112, 32, 16

@@ -325,6 +325,7 @@ _conv_bf16 = _bind("conv_layer_bf16", [_BP, _BP, _BP, _BP])
 _dsc = _bind("depthwise_separable_conv", [_BP, _BP, _BP, _BP, _BP])
 _unsharp = _bind("unsharp", [_BP, _BP])
 _hist = _bind("hist", [_BP, _BP])
+_harris = _bind("harris", [_BP, _BP])
 _cam = _bind("camera_pipe", [_BP, _BP, _BP, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _BP])
 
 
@@ -382,6 +383,10 @@ def unsharp(input, output) -> int:
 
 def hist(input, output) -> int:
     return _check(_hist(_as_ptr(input), _as_ptr(output)))
+
+
+def harris(input, output) -> int:
+    return _check(_harris(_as_ptr(input), _as_ptr(output)))
 
 
 def camera_pipe(input, matrix_3200, matrix_7000, color_temp, gamma, contrast, sharpen_strength, black_level,

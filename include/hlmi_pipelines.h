@@ -95,6 +95,11 @@ HLMI_DECLARE_AUX(unsharp)
 int hist(struct halide_buffer_t *input, struct halide_buffer_t *output);
 HLMI_DECLARE_AUX(hist)
 
+/* apps/harris/harris_generator.cpp:13-15,130 — f32 [W,H,3] planar in, f32 [.,.] out: Harris corner response; no
+ * boundary condition (the input must cover the output grown by 2).  Adjacent app, same boundary. */
+int harris(struct halide_buffer_t *input, struct halide_buffer_t *output);
+HLMI_DECLARE_AUX(harris)
+
 /* apps/camera_pipe/camera_pipe_generator.cpp:219-228,622 — raw u16 Bayer -> u8 [W,H,3]. */
 int camera_pipe(struct halide_buffer_t *input, struct halide_buffer_t *matrix_3200,
                 struct halide_buffer_t *matrix_7000, float color_temp, float gamma, float contrast,
@@ -118,6 +123,7 @@ int depthwise_separable_conv_auto_schedule(struct halide_buffer_t *input, struct
                                            struct halide_buffer_t *output);
 int unsharp_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);
 int hist_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);
+int harris_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);
 int camera_pipe_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *matrix_3200,
                               struct halide_buffer_t *matrix_7000, float color_temp, float gamma, float contrast,
                               float sharpen_strength, int32_t blackLevel, int32_t whiteLevel,

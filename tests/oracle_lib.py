@@ -235,6 +235,20 @@ def hist(inp: np.ndarray, out_origin=(0, 0), out_size=None, return_cdf=False):
     assert _lib.oracle_hist(inp, w, h, w, w * h, out, out_origin[0], out_origin[1], ow, oh, ow, ow * oh, cdf) == 0
     return (out, cdf) if return_cdf else out
 
+_lib.oracle_harris.argtypes = [_f32p, C.c_long, C.c_long, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long]
+_lib.oracle_harris.restype = C.c_int
+
+
+def harris(inp: np.ndarray, out_origin=(3, 3), out_size=None, in_origin=(0, 0)) -> np.ndarray:
+    """inp: f32 (3, H, W) planar at absolute in_origin; output region out_origin + out_size (default: the driver's W-6 x H-6 at (3, 3))."""
+    inp = np.ascontiguousarray(inp, np.float32)
+    c, h, w = inp.shape
+    assert c == 3
+    ow, oh = out_size if out_size else (w - 6, h - 6)
+    out = np.zeros((oh, ow), np.float32)
+    assert _lib.oracle_harris(inp, w, w * h, in_origin[0], in_origin[1], out, out_origin[0], out_origin[1], ow, oh, ow) == 0
+    return out
+
 _i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
 _lib.oracle_camera_pipe.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.c_int]
