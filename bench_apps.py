@@ -154,6 +154,18 @@ def main():
         emit("harris", "apps/harris corner response, f32 1536x2560x3 -> 1530x2554", t, (W - 6) * (H - 6), "hbm", 16.0 * W * H / t / 1e9,
              HBM_PEAK_GBS, "GB/s", {"alg_bytes": 16 * W * H, "kernels_ms": kernels(call, o)})
 
+    # ---- interpolate f32 1536x2560x4 -> x3 (generator estimates)
+    if not only or "interpolate" in only:
+        W, H = 1536, 2560
+        img = rng.random((4, H, W), dtype=np.float32)
+        img[3][rng.random((H, W)) < 0.4] = 0.0
+        a = hl.Buffer(img)
+        o = hl.Buffer(np.zeros((3, H, W), np.float32))
+        call = lambda: hl.interpolate(a, o)
+        t = timed(call, o, 20)
+        emit("interpolate", "apps/interpolate 10-level pull-push, f32 1536x2560x4 -> x3", t, W * H, "hbm", 28.0 * W * H / t / 1e9,
+             HBM_PEAK_GBS, "GB/s", {"alg_bytes": 28 * W * H, "kernels_ms": kernels(call, o)})
+
     # ---- depthwise_separable_conv at the driver's shape (MobileNet-v2 layer 2, process.cpp:13)
     if not only or "depthwise_separable_conv" in only:
         N, Hh, Ww, CI, CO = 4, 112, 112, 32, 16

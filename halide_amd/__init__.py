@@ -326,6 +326,7 @@ _dsc = _bind("depthwise_separable_conv", [_BP, _BP, _BP, _BP, _BP])
 _unsharp = _bind("unsharp", [_BP, _BP])
 _hist = _bind("hist", [_BP, _BP])
 _harris = _bind("harris", [_BP, _BP])
+_interp = _bind("interpolate", [_BP, _BP])
 _cam = _bind("camera_pipe", [_BP, _BP, _BP, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _BP])
 
 
@@ -387,6 +388,10 @@ def hist(input, output) -> int:
 
 def harris(input, output) -> int:
     return _check(_harris(_as_ptr(input), _as_ptr(output)))
+
+
+def interpolate(input, output) -> int:
+    return _check(_interp(_as_ptr(input), _as_ptr(output)))
 
 
 def camera_pipe(input, matrix_3200, matrix_7000, color_temp, gamma, contrast, sharpen_strength, black_level,

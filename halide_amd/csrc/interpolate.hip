@@ -1,0 +1,193 @@
+// interpolate.hip — gfx950 implementation of the reference's interpolate AOT pipeline (alpha-weighted pull-push
+// pyramid, 10 levels; SURVEY.md §8 f3 — the adjacent app closest to local_laplacian).
+// Algorithm: /root/reference/apps/interpolate/interpolate_generator.cpp:20-77; boundary: `int interpolate(
+// halide_buffer_t *input, halide_buffer_t *output)`, f32 [W,H,4] planar in (:23 pins 4 channels), f32 [W,H,3] out over
+// exactly the input's [0,W) x [0,H) (:83-87).
+//
+// Every Func is a total function on Z^2 (only the input is edge-clamped, plus the coordinate clamp the generator adds
+// in front of level 4, :40-49), so level l is materialised on the box its readers touch:
+//   I_0 = [0, W-1],  I_{l+1} = [floor(lo/2), floor((hi+1)/2)]                 interpolated[l]  (read by the level below)
+//   D_9 = I_9,  D_l = I_l  U  [2 lo(D_{l+1}) - 1, 2 hi(D_{l+1}) + 1]           downsampled[l]   (clamped to [0, W/8] for l = 3)
+// as float4 {r a, g a, b a, a} per pixel (one 16-byte load serves all four channels).  downsampled[0] and
+// interpolated[0] are never stored.  Sums left to right as written, one rounding per operator (oracle/
+// interpolate_oracle.c).  18 launches, one thread per pixel: levels >= 3 are launch-latency bound, exactly the regime
+// local_laplacian's multi-level kernels address — the same treatment is the obvious next step here.
+#include "hlmi_device_math.h"
+#include "hlmi_internal.h"
+
+using namespace hlmi;
+
+namespace {
+
+constexpr int IL = 10;   // GeneratorParam levels (:15)
+
+struct Lvl {
+    float4 *v;           // v[(y - y0) * w + (x - x0)]
+    int x0, y0, w, h;
+};
+struct InGeom {
+    const float *in;     // element (0, 0, 0)
+    long sy, sc;
+    int W, H;
+};
+
+__device__ __forceinline__ float4 ds0(const InGeom &g, int X, int Y) {   // downsampled[0] (:31), input edge-clamped
+    const long off = (long)dev::clampi(Y, 0, g.H - 1) * g.sy + dev::clampi(X, 0, g.W - 1);
+    const float a = g.in[3 * g.sc + off];
+    return make_float4(g.in[off] * a, g.in[g.sc + off] * a, g.in[2 * g.sc + off] * a, a);
+}
+__device__ __forceinline__ float4 at(const Lvl &L, int X, int Y) { return L.v[(size_t)(Y - L.y0) * L.w + (X - L.x0)]; }
+__device__ __forceinline__ float4 tap3(float4 a, float4 b, float4 c) {   // (a + 2 b + c) * 0.25 per channel (:51-58)
+    return make_float4(((a.x + 2.0f * b.x) + c.x) * 0.25f, ((a.y + 2.0f * b.y) + c.y) * 0.25f, ((a.z + 2.0f * b.z) + c.z) * 0.25f,
+                       ((a.w + 2.0f * b.w) + c.w) * 0.25f);
+}
+
+// downsampled[l] on dst's box from downsampled[l-1] (src; FROM_INPUT: level 0 computed from the input);
+// CLAMP4: the coordinate clamp in front of level 4
+template<bool FROM_INPUT, bool CLAMP4>
+__global__ __launch_bounds__(256) void ip_down(InGeom g, Lvl src, Lvl dst, int cw, int ch) {
+    const int xs = blockIdx.x * 256 + threadIdx.x, ys = blockIdx.y;
+    if (xs >= dst.w) return;
+    const int x = dst.x0 + xs, y = dst.y0 + ys;
+    float4 dx[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        float4 p[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            int X = 2 * x - 1 + i, Y = 2 * y - 1 + j;
+            if (CLAMP4) X = dev::clampi(X, 0, cw), Y = dev::clampi(Y, 0, ch);
+            p[i] = FROM_INPUT ? ds0(g, X, Y) : at(src, X, Y);
+        }
+        dx[j] = tap3(p[0], p[1], p[2]);
+    }
+    dst.v[(size_t)ys * dst.w + xs] = tap3(dx[0], dx[1], dx[2]);
+}
+
+__device__ __forceinline__ float4 interp_value(const float4 d, const Lvl &up, int x, int y) {   // (:61-72)
+    const int xa = dev::fdiv2(x), xb = dev::fdiv2(x + 1), ya = dev::fdiv2(y), yb = dev::fdiv2(y + 1);
+    const float4 aa = at(up, xa, ya), ba = at(up, xb, ya), ab = at(up, xa, yb), bb = at(up, xb, yb);
+    const float alpha = 1.0f - d.w;
+    auto one = [&](float d_c, float paa, float pba, float pab, float pbb) {
+        const float ua = (paa + pba) * 0.5f, ub = (pab + pbb) * 0.5f;
+        return d_c + alpha * ((ua + ub) * 0.5f);
+    };
+    return make_float4(one(d.x, aa.x, ba.x, ab.x, bb.x), one(d.y, aa.y, ba.y, ab.y, bb.y), one(d.z, aa.z, ba.z, ab.z, bb.z),
+                       one(d.w, aa.w, ba.w, ab.w, bb.w));
+}
+
+// interpolated[l] on dst's box from downsampled[l] (ds) and interpolated[l+1] (up)
+__global__ __launch_bounds__(256) void ip_up(Lvl ds, Lvl up, Lvl dst) {
+    const int xs = blockIdx.x * 256 + threadIdx.x, ys = blockIdx.y;
+    if (xs >= dst.w) return;
+    const int x = dst.x0 + xs, y = dst.y0 + ys;
+    dst.v[(size_t)ys * dst.w + xs] = interp_value(at(ds, x, y), up, x, y);
+}
+
+// level 0: interpolated[0] (never stored) and the normalisation (:74-75), planar output
+__global__ __launch_bounds__(256) void ip_final(InGeom g, Lvl up, float *__restrict__ out, long out_sy, long out_sc) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= g.W) return;
+    const float4 v = interp_value(ds0(g, x, y), up, x, y);
+    float *o = out + (long)y * out_sy + x;
+    o[0] = v.x / v.w, o[out_sc] = v.y / v.w, o[2 * out_sc] = v.z / v.w;
+}
+
+const int64_t e0 = 0, ew = 1536, eh = 2560, e4 = 4, e3 = 3;
+const int64_t *const est_in[6] = {&e0, &ew, &e0, &eh, &e0, &e4};
+const int64_t *const est_out[6] = {&e0, &ew, &e0, &eh, &e0, &e3};
+const halide_type_t ty_f32 = {(decltype(halide_type_t::code))2, 32, 0};
+// estimates: generator :204-211
+const halide_filter_argument_t ip_args[2] = {
+    {"input", halide_argument_kind_input_buffer, 3, ty_f32, nullptr, nullptr, nullptr, nullptr, est_in},
+    {"output", halide_argument_kind_output_buffer, 3, ty_f32, nullptr, nullptr, nullptr, nullptr, est_out},
+};
+const halide_filter_metadata_t ip_md = {1, 2, ip_args, kTargetString, "interpolate"};
+
+struct Box {
+    int x0, x1, y0, y1;
+};
+
+}  // namespace
+
+extern "C" int interpolate(halide_buffer_t *input, halide_buffer_t *output) {
+    void *uc = nullptr;
+    BufArg args[2] = {{"input", input, T_F32, 3, false}, {"output", output, T_F32, 3, true}};
+    int r = check_not_null(uc, args, 2);
+    if (r) return r;
+    if ((r = check_type_and_dims(uc, args, 2))) return r;
+    auto real = [](halide_buffer_t *b) { return !(b->host == nullptr && b->device == 0); };
+    if (any_bounds_query(args, 2)) {
+        // output = input's [0,W) x [0,H) with 3 channels (:83-87); input has channels [0,4) (:23)
+        halide_buffer_t *k = real(input) ? input : output;
+        const int w = real(input) || real(output) ? k->dim[0].extent : 1536, h = real(input) || real(output) ? k->dim[1].extent : 2560;
+        int z[3] = {0, 0, 0}, ei[3] = {w, h, 4}, eo[3] = {w, h, 3};
+        answer_query(input, z, ei);
+        answer_query(output, z, eo);
+        return 0;
+    }
+    if ((r = check_shape(uc, args[0])) || (r = check_shape(uc, args[1]))) return r;
+    const int W = input->dim[0].extent, H = input->dim[1].extent;
+    // input.dim(2).set_bounds(0, 4) (:23); normalize.bound(x, 0, input.width()) etc. (:83-87)
+    if ((r = check_equal(uc, "input.min.2", input->dim[2].min, "0", 0)) || (r = check_equal(uc, "input.extent.2", input->dim[2].extent, "4", 4)) ||
+        (r = check_equal(uc, "input.min.0", input->dim[0].min, "0", 0)) || (r = check_equal(uc, "input.min.1", input->dim[1].min, "0", 0)) ||
+        (r = check_equal(uc, "output.min.0", output->dim[0].min, "0", 0)) || (r = check_equal(uc, "output.extent.0", output->dim[0].extent, "input.extent.0", W)) ||
+        (r = check_equal(uc, "output.min.1", output->dim[1].min, "0", 0)) || (r = check_equal(uc, "output.extent.1", output->dim[1].extent, "input.extent.1", H)) ||
+        (r = check_equal(uc, "output.min.2", output->dim[2].min, "0", 0)) || (r = check_equal(uc, "output.extent.2", output->dim[2].extent, "3", 3))) {
+        return r;
+    }
+    DeviceCtx ctx;
+    if ((r = acquire_device(uc, &ctx))) return r;
+    if ((r = input_to_device(uc, ctx, args[0]))) return r;
+    if ((r = output_on_device(uc, ctx, args[1]))) return r;
+    if (W > 0 && H > 0) {
+        Box I[IL], D[IL];
+        I[0] = {0, W - 1, 0, H - 1};
+        for (int l = 1; l < IL; l++) I[l] = {0, floor_div(I[l - 1].x1 + 1, 2), 0, floor_div(I[l - 1].y1 + 1, 2)};
+        D[IL - 1] = I[IL - 1];
+        const int cw = W / 8, ch = H / 8;
+        auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+        for (int l = IL - 2; l >= 0; l--) {
+            Box n = {2 * D[l + 1].x0 - 1, 2 * D[l + 1].x1 + 1, 2 * D[l + 1].y0 - 1, 2 * D[l + 1].y1 + 1};
+            if (l + 1 == 4) n = {clampi(n.x0, 0, cw), clampi(n.x1, 0, cw), clampi(n.y0, 0, ch), clampi(n.y1, 0, ch)};
+            D[l] = {n.x0 < I[l].x0 ? n.x0 : I[l].x0, n.x1 > I[l].x1 ? n.x1 : I[l].x1, n.y0 < I[l].y0 ? n.y0 : I[l].y0,
+                    n.y1 > I[l].y1 ? n.y1 : I[l].y1};
+        }
+        size_t off_d[IL], off_i[IL], total = 0;
+        auto area = [](const Box &b) { return ((size_t)(b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1) + 15) & ~(size_t)15; };
+        for (int l = 1; l < IL; l++) off_d[l] = total, total += area(D[l]);
+        for (int l = 1; l < IL - 1; l++) off_i[l] = total, total += area(I[l]);
+        void *ws = nullptr;
+        if ((r = get_workspace(uc, ctx, total * sizeof(float4), &ws))) return r;
+        float4 *base = (float4 *)ws;
+        auto lvl = [&](float4 *p, const Box &b) { return Lvl{p, b.x0, b.y0, b.x1 - b.x0 + 1, b.y1 - b.y0 + 1}; };
+        Lvl ds[IL], ip[IL];
+        for (int l = 1; l < IL; l++) ds[l] = lvl(base + off_d[l], D[l]);
+        for (int l = 1; l < IL - 1; l++) ip[l] = lvl(base + off_i[l], I[l]);
+        ip[IL - 1] = ds[IL - 1];   // interpolated[9] = downsampled[9], and D_9 == I_9
+        InGeom g{dev_ptr<float>(input), input->dim[1].stride, input->dim[2].stride, W, H};
+        hipStream_t st = ctx.stream;
+        char nm[32];
+        for (int l = 1; l < IL; l++) {
+            dim3 grid((ds[l].w + 255) / 256, ds[l].h), block(256);
+            snprintf(nm, sizeof nm, "ip_down:%d", l);
+            if (l == 1) HLMI_LAUNCH(uc, nm, st, (ip_down<true, false>), grid, block, 0, g, ds[1], ds[1], cw, ch);
+            else if (l == 4) HLMI_LAUNCH(uc, nm, st, (ip_down<false, true>), grid, block, 0, g, ds[l - 1], ds[l], cw, ch);
+            else HLMI_LAUNCH(uc, nm, st, (ip_down<false, false>), grid, block, 0, g, ds[l - 1], ds[l], cw, ch);
+        }
+        for (int l = IL - 2; l >= 1; l--) {
+            dim3 grid((ip[l].w + 255) / 256, ip[l].h), block(256);
+            snprintf(nm, sizeof nm, "ip_up:%d", l);
+            HLMI_LAUNCH(uc, nm, st, ip_up, grid, block, 0, ds[l], ip[l + 1], ip[l]);
+        }
+        timing_note_bytes(28.0 * W * H);
+        HLMI_LAUNCH(uc, "ip_final", st, ip_final, dim3((W + 255) / 256, H), dim3(256), 0, g, ip[1], dev_ptr<float>(output),
+                    (long)output->dim[1].stride, (long)output->dim[2].stride);
+    }
+    mark_output_written(output);
+    return 0;
+}
+
+extern "C" int interpolate_argv(void **a) { return interpolate((halide_buffer_t *)a[0], (halide_buffer_t *)a[1]); }
+extern "C" const halide_filter_metadata_t *interpolate_metadata(void) { return &ip_md; }
+extern "C" int interpolate_auto_schedule(halide_buffer_t *input, halide_buffer_t *output) { return interpolate(input, output); }

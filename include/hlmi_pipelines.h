@@ -100,6 +100,11 @@ HLMI_DECLARE_AUX(hist)
 int harris(struct halide_buffer_t *input, struct halide_buffer_t *output);
 HLMI_DECLARE_AUX(harris)
 
+/* apps/interpolate/interpolate_generator.cpp:17-18,215 — f32 [W,H,4] planar in (r, g, b, alpha), f32 [W,H,3] out over
+ * the input's extent: alpha-weighted pull-push pyramid, 10 levels.  Adjacent app, same boundary. */
+int interpolate(struct halide_buffer_t *input, struct halide_buffer_t *output);
+HLMI_DECLARE_AUX(interpolate)
+
 /* apps/camera_pipe/camera_pipe_generator.cpp:219-228,622 — raw u16 Bayer -> u8 [W,H,3]. */
 int camera_pipe(struct halide_buffer_t *input, struct halide_buffer_t *matrix_3200,
                 struct halide_buffer_t *matrix_7000, float color_temp, float gamma, float contrast,
@@ -124,6 +129,7 @@ int depthwise_separable_conv_auto_schedule(struct halide_buffer_t *input, struct
 int unsharp_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);
 int hist_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);
 int harris_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);
+int interpolate_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);
 int camera_pipe_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *matrix_3200,
                               struct halide_buffer_t *matrix_7000, float color_temp, float gamma, float contrast,
                               float sharpen_strength, int32_t blackLevel, int32_t whiteLevel,

@@ -249,6 +249,27 @@ def harris(inp: np.ndarray, out_origin=(3, 3), out_size=None, in_origin=(0, 0)) 
     assert _lib.oracle_harris(inp, w, w * h, in_origin[0], in_origin[1], out, out_origin[0], out_origin[1], ow, oh, ow) == 0
     return out
 
+_lib.oracle_interpolate.argtypes = [_f32p, C.c_int, C.c_int, C.c_long, C.c_long, _f32p, C.c_long, C.c_long]
+_lib.oracle_interpolate.restype = C.c_int
+_lib.oracle_interpolate_boxes.argtypes = [C.c_int, C.c_int, _i32p, _i32p]
+_lib.oracle_interpolate_boxes.restype = None
+
+
+def interpolate(inp: np.ndarray) -> np.ndarray:
+    """inp: f32 (4, H, W) planar r, g, b, alpha -> (3, H, W)."""
+    inp = np.ascontiguousarray(inp, np.float32)
+    c, h, w = inp.shape
+    assert c == 4
+    out = np.zeros((3, h, w), np.float32)
+    assert _lib.oracle_interpolate(inp, w, h, w, w * h, out, w, w * h) == 0
+    return out
+
+
+def interpolate_boxes(w: int, h: int):
+    bi, bd = np.zeros(40, np.int32), np.zeros(40, np.int32)
+    _lib.oracle_interpolate_boxes(w, h, bi, bd)
+    return bi.reshape(10, 4), bd.reshape(10, 4)
+
 _i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
 _lib.oracle_camera_pipe.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.c_int]
