@@ -166,6 +166,17 @@ def main():
         emit("interpolate", "apps/interpolate 10-level pull-push, f32 1536x2560x4 -> x3", t, W * H, "hbm", 28.0 * W * H / t / 1e9,
              HBM_PEAK_GBS, "GB/s", {"alg_bytes": 28 * W * H, "kernels_ms": kernels(call, o)})
 
+    # ---- iir_blur f32 1536x2560x3, alpha 0.1 (the shape the generator pins)
+    if not only or "iir_blur" in only:
+        W, H = 1536, 2560
+        a = hl.Buffer(rng.random((3, H, W), dtype=np.float32))
+        o = hl.Buffer(np.zeros((3, H, W), np.float32))
+        call = lambda: hl.iir_blur(a, 0.1, o)
+        t = timed(call, o, 10)
+        emit("iir_blur", "apps/iir_blur alpha=0.1, f32 1536x2560x3", t, W * H, "hbm", 24.0 * W * H / t / 1e9, HBM_PEAK_GBS, "GB/s",
+             {"alg_bytes": 24 * W * H, "kernels_ms": kernels(call, o),
+              "note": "bound by the sequential recurrence: 2 (W + H) dependent multiply-add steps per scan line"})
+
     # ---- depthwise_separable_conv at the driver's shape (MobileNet-v2 layer 2, process.cpp:13)
     if not only or "depthwise_separable_conv" in only:
         N, Hh, Ww, CI, CO = 4, 112, 112, 32, 16

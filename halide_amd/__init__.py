@@ -327,6 +327,7 @@ _unsharp = _bind("unsharp", [_BP, _BP])
 _hist = _bind("hist", [_BP, _BP])
 _harris = _bind("harris", [_BP, _BP])
 _interp = _bind("interpolate", [_BP, _BP])
+_iir = _bind("iir_blur", [_BP, C.c_float, _BP])
 _cam = _bind("camera_pipe", [_BP, _BP, _BP, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _BP])
 
 
@@ -392,6 +393,10 @@ def harris(input, output) -> int:
 
 def interpolate(input, output) -> int:
     return _check(_interp(_as_ptr(input), _as_ptr(output)))
+
+
+def iir_blur(input, alpha, output) -> int:
+    return _check(_iir(_as_ptr(input), float(alpha), _as_ptr(output)))
 
 
 def camera_pipe(input, matrix_3200, matrix_7000, color_temp, gamma, contrast, sharpen_strength, black_level,

@@ -105,6 +105,12 @@ HLMI_DECLARE_AUX(harris)
 int interpolate(struct halide_buffer_t *input, struct halide_buffer_t *output);
 HLMI_DECLARE_AUX(interpolate)
 
+/* apps/iir_blur/iir_blur_generator.cpp:136-144,181 — f32 [W,H,C] planar in and out, `alpha` = weight of the input:
+ * first-order IIR low pass down and up the columns, then along the rows.  Adjacent app; the reference
+ * pins 1536 x 2560 x 3 (:158-163), this entry point accepts any extents. */
+int iir_blur(struct halide_buffer_t *input, float alpha, struct halide_buffer_t *output);
+HLMI_DECLARE_AUX(iir_blur)
+
 /* apps/camera_pipe/camera_pipe_generator.cpp:219-228,622 — raw u16 Bayer -> u8 [W,H,3]. */
 int camera_pipe(struct halide_buffer_t *input, struct halide_buffer_t *matrix_3200,
                 struct halide_buffer_t *matrix_7000, float color_temp, float gamma, float contrast,
@@ -130,6 +136,7 @@ int unsharp_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t 
 int hist_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);
 int harris_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);
 int interpolate_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);
+int iir_blur_auto_schedule(struct halide_buffer_t *input, float alpha, struct halide_buffer_t *output);
 int camera_pipe_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *matrix_3200,
                               struct halide_buffer_t *matrix_7000, float color_temp, float gamma, float contrast,
                               float sharpen_strength, int32_t blackLevel, int32_t whiteLevel,

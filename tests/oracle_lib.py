@@ -270,6 +270,18 @@ def interpolate_boxes(w: int, h: int):
     _lib.oracle_interpolate_boxes(w, h, bi, bd)
     return bi.reshape(10, 4), bd.reshape(10, 4)
 
+_lib.oracle_iir_blur.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_float, _f32p, C.c_long, C.c_long]
+_lib.oracle_iir_blur.restype = C.c_int
+
+
+def iir_blur(inp: np.ndarray, alpha: float) -> np.ndarray:
+    """inp: f32 (C, H, W) planar."""
+    inp = np.ascontiguousarray(inp, np.float32)
+    c, h, w = inp.shape
+    out = np.zeros_like(inp)
+    assert _lib.oracle_iir_blur(inp, w, h, c, w, w * h, alpha, out, w, w * h) == 0
+    return out
+
 _i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
 _lib.oracle_camera_pipe.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.c_int]

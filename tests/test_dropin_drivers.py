@@ -178,6 +178,16 @@ def test_harris_filter_cpp(tmp_path):
 
 
 @pytest.mark.gpu
+def test_iir_blur_filter_cpp(tmp_path):
+    exe = _exe("iir_blur_filter")
+    img8 = _scene8(192, 130, 9, 3)
+    src, dst = str(tmp_path / "in.ppm"), str(tmp_path / "out.ppm")
+    write_ppm8(src, img8)
+    r = subprocess.run([exe, src, dst], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Success!" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
 def test_camera_pipe_process_cpp(tmp_path, oracle):
     exe = _exe("camera_pipe_process")
     from test_camera_pipe import M3200, M7000, _raw

@@ -1,0 +1,56 @@
+"""iir_blur: first-order IIR low pass down/up the columns, then along the rows, f32 planar
+(reference: /root/reference/apps/iir_blur/iir_blur_generator.cpp:13-31, 146-156).  The recurrences are sequential by
+definition; GPU == oracle bit for bit."""
+import numpy as np
+import pytest
+
+
+def test_oracle_against_float64_recurrence(oracle):
+    rng = np.random.default_rng(0)
+    inp = rng.random((2, 9, 13), dtype=np.float32)
+    got = oracle.iir_blur(inp, 0.3)
+
+    def cols(a, alpha):                       # a: (H, W) -> blurred columns
+        b = a.astype(np.float64).copy()
+        for y in range(1, b.shape[0]):
+            b[y] = (1 - alpha) * b[y - 1] + alpha * a[y]
+        for y in range(b.shape[0] - 2, -1, -1):
+            b[y] = (1 - alpha) * b[y + 1] + alpha * b[y]
+        return b
+    alpha = float(np.float32(0.3))
+    ref = np.stack([cols(cols(ch, alpha).T, alpha).T for ch in inp])
+    assert np.max(np.abs(got - ref)) < 1e-5
+
+
+def test_oracle_constant_image_is_a_fixed_point(oracle):
+    inp = np.full((3, 20, 30), 0.625, np.float32)
+    assert np.array_equal(oracle.iir_blur(inp, 0.5), inp)     # (1-a) v + a v with a = 1/2 and v = 5/8 is exact
+
+
+def _run(hl, inp, alpha):
+    a, o = hl.Buffer(inp), hl.Buffer(np.zeros_like(inp))
+    hl.iir_blur(a, alpha, o)
+    return o.numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,c,alpha", [(1536, 2560, 3, 0.1), (1, 1, 3, 0.5), (64, 64, 1, 0.5), (65, 130, 3, 0.25), (200, 77, 2, 0.9)])
+def test_hip_matches_oracle_bit_for_bit(hl, oracle, w, h, c, alpha):
+    rng = np.random.default_rng(w + h)
+    inp = rng.random((c, h, w), dtype=np.float32)
+    got, want = _run(hl, inp, alpha), oracle.iir_blur(inp, alpha)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"{np.count_nonzero(got != want)} of {got.size} differ"
+
+
+@pytest.mark.gpu
+def test_hip_output_shape_is_pinned_to_the_input(hl):
+    inp = np.zeros((3, 16, 16), np.float32)
+    with pytest.raises(hl.HalideError) as e:
+        hl.iir_blur(hl.Buffer(inp), 0.5, hl.Buffer(np.zeros((3, 16, 15), np.float32)))
+    assert e.value.code == -8
+
+
+def test_bounds_query(hl):
+    q = hl.Buffer.bounds_query(np.float32, 3)
+    hl.iir_blur(q, 0.5, hl.Buffer(np.zeros((3, 20, 30), np.float32)))
+    assert q.extents == [30, 20, 3]
