@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/oracle_digests.json: sha256 of the CPU oracle's output on fixed seeded inputs, one entry per
+pipeline.  These are REGRESSION pins of the restatement (the reference ships no golden outputs for its apps and cannot be
+built here), so that an accidental change of an oracle — the thing every GPU parity test is measured against — fails a
+CPU test.  tests/test_oracle_digests.py recomputes and compares them."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def cases():
+    import oracle_lib as o
+    r = lambda seed: np.random.default_rng(seed)
+    f32 = lambda seed, shape: r(seed).random(shape, dtype=np.float32)
+    u16 = lambda seed, shape: r(seed).integers(0, 65536, shape, dtype=np.uint16)
+    m3 = np.array([[1.6697, -0.2693, -0.4004, -42.4346], [-0.3576, 1.0615, 1.5949, -37.1158], [-0.2175, -1.8751, 6.9640, -26.6970]], np.float32)
+    m7 = np.array([[2.2997, -0.4478, 0.1706, -39.0923], [-0.3826, 1.5906, -0.2080, -25.4311], [-0.0888, -0.7344, 2.2832, -20.0826]], np.float32)
+    rgba = f32(9, (4, 21, 34))
+    rgba[3][r(10).random((21, 34)) < 0.4] = 0
+    return {
+        "local_laplacian_64x48_seed11_K8": lambda: o.local_laplacian(u16(11, (3, 48, 64)), 8, 1.0 / 7.0, 1.0),
+        "blur_70x50_seed1": lambda: o.blur(u16(1, (52, 72))),
+        "stencil_chain_80x60_seed2": lambda: o.stencil_chain(u16(2, (60, 80))),
+        "bilateral_grid_96x72_seed3_r0.1": lambda: o.bilateral_grid(f32(3, (72, 96)), 0.1),
+        "nl_means_40x30_seed4": lambda: o.nl_means(f32(4, (3, 30, 40)), 7, 7, 0.12),
+        "conv_layer_2x7x9_32to128_seed5": lambda: o.conv_layer(r(5).uniform(-1, 1, (2, 9, 11, 32)).astype(np.float32),
+                                                               r(6).uniform(-1, 1, (32, 3, 3, 128)).astype(np.float32),
+                                                               r(7).uniform(-1, 1, 128).astype(np.float32)),
+        "conv_layer_bf16_1x5x6_64to128_seed5": lambda: o.conv_layer_bf16(r(5).uniform(-1, 1, (1, 7, 8, 64)).astype(np.float32),
+                                                                        r(6).uniform(-1, 1, (64, 3, 3, 128)).astype(np.float32),
+                                                                        r(7).uniform(-1, 1, 128).astype(np.float32))[0],
+        "camera_pipe_160x120_seed8": lambda: o.camera_pipe(r(8).integers(0, 1024, (152, 200), dtype=np.uint16), m3, m7, 3700.0, 2.0,
+                                                           50.0, 1.0, 25, 1023, 160, 120),
+        "depthwise_separable_conv_2x6x7_8to5_seed9": lambda: o.depthwise_separable_conv(
+            r(9).uniform(-1, 1, (2, 6, 7, 8)).astype(np.float32), r(10).uniform(-1, 1, (3, 3, 8, 1)).astype(np.float32),
+            r(11).uniform(-1, 1, (8, 5)).astype(np.float32), r(12).uniform(-1, 1, 5).astype(np.float32)),
+        "unsharp_50x40_seed13": lambda: o.unsharp(f32(13, (3, 40, 50)) * 0.9 + 0.05),
+        "hist_90x60_seed14": lambda: o.hist(r(14).integers(0, 256, (3, 60, 90), dtype=np.uint8)),
+        "harris_50x40_seed15": lambda: o.harris(f32(15, (3, 40, 50))),
+        "interpolate_34x21_seed9": lambda: o.interpolate(rgba),
+        "iir_blur_30x20_seed16_a0.3": lambda: o.iir_blur(f32(16, (3, 20, 30)), 0.3),
+    }
+
+
+def digests():
+    return {k: hashlib.sha256(np.ascontiguousarray(f()).tobytes()).hexdigest() for k, f in cases().items()}
+
+
+if __name__ == "__main__":
+    d = {"_comment": "Regression digests of the canonical CPU oracle (sha256 of the output bytes on fixed seeded inputs, "
+                     "scripts/make_golden.py). NOT reference-derived: the reference ships no golden outputs for these pipelines."}
+    d.update(digests())
+    with open(os.path.join(ROOT, "tests", "golden", "oracle_digests.json"), "w") as f:
+        json.dump(d, f, indent=1)
+    print(json.dumps(d, indent=1))
