@@ -151,10 +151,14 @@ def main():
         # measured HBM traffic of that kernel (rocprofv3 PMC passes, FETCH_SIZE corrected x2 as
         # MI355X_MICROARCH.md prescribes for wide coalesced reads + WRITE_SIZE), committed under profiles/
         traffic = None
+        frame_traffic = None   # all launches of one frame: what the whole pipeline moves through HBM / MALL
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get("bytes_per_launch", {}).get(dom)
+                per_launch = json.load(f).get("bytes_per_launch", {})
+            traffic = per_launch.get(dom)
+            if all(k in per_launch for k in per_frame):
+                frame_traffic = int(sum(per_launch[k] for k in per_frame))
         result = {
             "metric": "megapixels/sec local_laplacian 8-level fp32 4K",
             "value": round(value, 2), "unit": "Mpx/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -171,6 +175,10 @@ def main():
                          "kernel_avg_ms": round(dom_rec["avg_ms"], 5),
                          "pipeline_alg_bytes_per_frame": ALG_BYTES_PER_PX * W * H,
                          "pipeline_frac": round(ALG_BYTES_PER_PX * W * H / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         # measured (PMC) bytes of all launches of a frame over the frame time: the pipeline's real HBM load
+                         "pipeline_traffic_per_frame": frame_traffic,
+                         "pipeline_traffic_frac": None if frame_traffic is None else
+                         round(frame_traffic / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "kernel_ms_per_frame": {k: round(v, 5) for k, v in per_frame.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:
