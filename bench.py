@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 W, H, C = 3840, 2160, 3
 LEVELS, ALPHA, BETA = 8, 1.0 / 7.0, 1.0
-FRAMES_PER_STEP = int(os.environ.get("HLMI_BENCH_FRAMES", "4"))  # distinct frames per GPU per step (4 x 99.5 MB of u16 I/O > 256 MB MALL)
+FRAMES_PER_STEP = int(os.environ.get("HLMI_BENCH_FRAMES", "8"))  # distinct frames per GPU per step (8 x 99.5 MB of u16 I/O > 256 MB MALL)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 ALG_BYTES_PER_PX = 12         # SURVEY.md §8(d) primary figure: 6 B read + 6 B written per pixel
 
@@ -66,9 +66,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--partitions", type=int, default=int(os.environ.get("HLMI_BENCH_PARTITIONS", "4")),
+                    help="frames of a step are spread over this many CU-partitioned streams (halide_hip_partition_stream: "
+                         "disjoint quarters of the chip by default), one frame per partition at a time: frames are "
+                         "independent units, so the latency-bound coarse pyramid levels of one frame run beside the large "
+                         "kernels of the others instead of competing with them; 0 = plain streams (--streams)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("HLMI_BENCH_STREAMS", "2")),
-                    help="HIP streams the frames of a step are spread over: frames are independent units, so the "
-                         "launch-latency-bound coarse pyramid levels of one frame overlap the large kernels of another")
+                    help="with --partitions 0: plain HIP streams the frames of a step are spread over")
     args = ap.parse_args()
 
     import numpy as np
@@ -99,12 +103,20 @@ def main():
         hl.local_laplacian(a, LEVELS, ALPHA, BETA, o)
     outs[-1].device_sync()
 
-    streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else []
+    streams, keep, mode = [], [], "1 stream"
+    if args.partitions > 1:
+        streams = [hl.partition_stream(p, args.partitions) for p in range(args.partitions)]
+        mode = f"{args.partitions} CU-partitioned streams"
+        if not all(streams):
+            streams = []            # the device refused a CU mask: plain streams instead
+    if not streams and args.streams > 1:
+        keep = [torch.cuda.Stream() for _ in range(args.streams)]
+        streams, mode = [s.cuda_stream for s in keep], f"{args.streams} streams"
 
     def step(use_streams=True):
         for i, (a, o) in enumerate(zip(ins, outs)):
-            if streams and use_streams:  # frame i goes to stream i % n: its kernels may overlap the neighbours' launch gaps
-                hl.set_stream(streams[i % len(streams)].cuda_stream)
+            if streams and use_streams:  # frame i goes to stream i % n
+                hl.set_stream(streams[i % len(streams)])
             hl.local_laplacian(a, LEVELS, ALPHA, BETA, o)
         if streams and use_streams:
             hl.set_stream(None)
@@ -166,7 +178,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "apps/local_laplacian J=8 levels=8 alpha=1/7 beta=1, u16 RGB planar 3840x2160",
                        "frames_per_step_per_gpu": FRAMES_PER_STEP, "frame_ms": round(frame_ms, 4),
-                       "streams_per_gpu": max(1, args.streams),
+                       "streams_per_gpu": max(1, len(streams)), "frame_scheduling": mode,
                        "boundary": "C ABI local_laplacian(halide_buffer_t*,int32,float,float,halide_buffer_t*)",
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

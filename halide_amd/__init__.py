@@ -157,6 +157,13 @@ def set_stream(stream_ptr: int | None) -> None:
     lib.halide_hip_set_stream(C.c_void_p(stream_ptr or 0))
 
 
+def partition_stream(part: int, nparts: int) -> int | None:
+    """hipStream_t of partition `part` of `nparts` disjoint CU partitions (include/hlmi_runtime.h), or None."""
+    lib.halide_hip_partition_stream.restype = C.c_void_p
+    lib.halide_hip_partition_stream.argtypes = [C.c_int, C.c_int]
+    return lib.halide_hip_partition_stream(int(part), int(nparts))
+
+
 def kernel_timing(enable: bool) -> None:
     lib.hlmi_kernel_timing_enable(1 if enable else 0)
 

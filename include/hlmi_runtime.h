@@ -90,6 +90,10 @@ int halide_get_gpu_device(void *user_context);
  * default stream of torch-ROCm) pass its explicit handle hipStreamLegacy, not 0. */
 void halide_hip_set_stream(void *stream);
 void *halide_hip_get_stream(void *user_context);
+/* A library-owned stream confined to partition `part` of `nparts` disjoint partitions of the device's compute units
+ * (every nparts-th bit of the CU mask; hipExtStreamCreateWithCUMask).  For batches of independent frames: one frame per
+ * partition at a time keeps the frames from slowing each other down.  NULL if the device refuses.  No reference counterpart. */
+void *halide_hip_partition_stream(int part, int nparts);
 
 /* ---- measurement hooks (no reference counterpart; used by bench.py) ---------------------------
  * When enabled, every kernel launch is bracketed by hipEvents on its stream; the report is a

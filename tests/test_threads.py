@@ -44,3 +44,24 @@ def test_concurrent_calls_from_host_threads(hl, oracle, own_streams):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.gpu
+def test_partition_streams_are_distinct_and_compute_correctly(hl, oracle):
+    """halide_hip_partition_stream: library-owned streams confined to disjoint CU partitions (bench.py spreads the
+    frames of a step over four of them).  Results on a partition must be the oracle's; handles are cached."""
+    streams = [hl.partition_stream(p, 4) for p in range(4)]
+    assert all(streams) and len(set(streams)) == 4
+    assert hl.partition_stream(2, 4) == streams[2]
+    assert hl.partition_stream(4, 4) is None and hl.partition_stream(0, 0) is None
+    rng = np.random.default_rng(1)
+    frames = [rng.integers(0, 65536, (3, 180, 256), dtype=np.uint16) for _ in range(4)]
+    outs = []
+    for f, s in zip(frames, streams):
+        hl.set_stream(s)
+        a, o = hl.Buffer(f), hl.Buffer(np.zeros_like(f))
+        hl.local_laplacian(a, 8, 1.0 / 7.0, 1.0, o)
+        outs.append((a, o))
+    hl.set_stream(None)
+    for f, (a, o) in zip(frames, outs):
+        assert np.array_equal(o.numpy(), oracle.local_laplacian(f, 8, 1.0 / 7.0, 1.0))
