@@ -331,6 +331,7 @@ _conv = _bind("conv_layer", [_BP, _BP, _BP, _BP])
 _conv_bf16 = _bind("conv_layer_bf16", [_BP, _BP, _BP, _BP])
 _dsc = _bind("depthwise_separable_conv", [_BP, _BP, _BP, _BP, _BP])
 _unsharp = _bind("unsharp", [_BP, _BP])
+_maxf = _bind("max_filter", [_BP, _BP])
 _hist = _bind("hist", [_BP, _BP])
 _harris = _bind("harris", [_BP, _BP])
 _interp = _bind("interpolate", [_BP, _BP])
@@ -388,6 +389,10 @@ def depthwise_separable_conv(input, depthwise_filter, pointwise_filter, bias, ou
 
 def unsharp(input, output) -> int:
     return _check(_unsharp(_as_ptr(input), _as_ptr(output)))
+
+
+def max_filter(input, output) -> int:
+    return _check(_maxf(_as_ptr(input), _as_ptr(output)))
 
 
 def hist(input, output) -> int:

@@ -1,0 +1,266 @@
+// max_filter.hip — gfx950 implementation of the reference's max_filter AOT pipeline (an adjacent app with
+// the same boundary).  Algorithm: /root/reference/apps/max_filter/max_filter_generator.cpp:14-53 (radius = 26, :10);
+// boundary: `int max_filter(halide_buffer_t *input, halide_buffer_t *output)`, f32 [W,H,3] planar in and out (:11-12).
+//
+// Closed form of the reference's log-slice construction (oracle/max_filter_oracle.c evaluates it literally; the parity
+// tests are the proof): with h(dx) = clamp(filter_height(dx), 0, 27) and the input edge-clamped in x and y,
+//     output(x, y, c) = max { input(x + dx, y + dy, c) : |dx| <= 26, |dy| <= h(dx) }.
+// vert(., y, ., t) is the max over rows [y - t, y + t] — the two 2^s-tall samples overlap or abut for s =
+// floor(log2(2t + 1)), and the rows the vert_log update never touches (below -26, above height - 1) hold the clamped edge
+// row, which the other sample covers.  That argument needs the input's rows to start at 0 (the update's row range is
+// absolute, :28); other mins are refused.  It also fails for output rows ABOVE the image (-26 <= y <= -12): there the second
+// sample can start below row -26, where vert_log was never updated and holds row 0 alone, so the reference's result misses
+// rows the footprint has.  Output rows y < 0 therefore go through max_filter_literal, which evaluates vert as written.
+// Only comparisons: the result is exact whatever the evaluation order.
+//
+// The footprint is transposed here — rows of a 55-row window, each a horizontal max of half-width w(|dy|) = max{dx :
+// h(dx) >= |dy|} — so that lanes read consecutive LDS words: a workgroup owns a 64 x 64 output tile, walks the 118 input
+// rows it depends on in chunks of 8, builds the horizontal doubling slices R_s[i] = max of 2^s consecutive pixels in LDS
+// (5 steps), and every thread folds max(R_s[x - w], R_s[x + w + 1 - 2^s]) into its 8 outputs.  110 LDS reads per output;
+// HBM: 4 B/px/channel read (+ the tile halo from L2) and 4 written.
+#include "hlmi_internal.h"
+
+#include <math.h>
+
+using namespace hlmi;
+
+namespace {
+
+constexpr int RAD = 26, VR = RAD + 1;          // horizontal radius; largest vertical half-height (filter_height(0) = 27)
+constexpr int TW = 64, TY = 64, NT = 512;      // output tile, threads (one wave per 8 output rows)
+constexpr int CH = 8;                          // input rows per chunk = output rows per wave
+constexpr int SW = TW + 2 * RAD;               // 116 staged pixels per row
+constexpr int SP = 128;                        // LDS row pitch
+static_assert(SW <= SP, "a staged row fits its pitch");
+constexpr int NSLOT = 5;                       // LDS slices: R_0, R_2, R_3, R_4, R_5 (R_s = max of 2^s consecutive pixels)
+constexpr int NCHUNK = (TY + 2 * VR + CH - 1) / CH;
+constexpr int NFOLD = (CH - 1 + 2 * VR) / CH + 1;   // chunks that hold rows of one wave's 8 + 54 row window
+
+// filter_height(dx) clamped to [0, 27] (generator :47-53)
+constexpr int mf_height(int dx) {
+    int n = 0;
+    for (int dy = 0; dy <= RAD; dy++) n += ((float)(dx * dx + dy * dy) < (RAD + 0.25f) * (RAD + 0.25f)) ? 1 : 0;
+    return n < VR ? n : VR;
+}
+// half-width of the footprint's row |dy|: the largest dx whose column reaches it (the heights fall with |dx|)
+constexpr int mf_halfwidth(int ady) {
+    int w = 0;
+    for (int dx = 0; dx <= RAD; dx++) {
+        if (mf_height(dx) >= ady) w = dx;
+    }
+    return w;
+}
+constexpr int mf_log2(int v) {   // floor(log2(v)), v >= 1: slice_for_radius(t) = mf_log2(2t + 1) (:37)
+    int s = 0;
+    while ((2 << s) <= v) s++;
+    return s;
+}
+static_assert(mf_halfwidth(0) == RAD && mf_halfwidth(VR) == 3 && mf_log2(2 * 3 + 1) == 2 && mf_log2(2 * RAD + 1) == 5,
+              "every row of the footprint is two samples of a slice R_2 .. R_5");
+// LDS word offsets (relative to row start + own column) of the two samples covering [x - w, x + w]
+constexpr int mf_slot(int ady) { return mf_log2(2 * mf_halfwidth(ady) + 1) - 1; }
+constexpr int mf_offA(int ady) { return mf_slot(ady) * CH * SP + RAD - mf_halfwidth(ady); }
+constexpr int mf_offB(int ady) { return mf_slot(ady) * CH * SP + RAD + mf_halfwidth(ady) + 1 - (1 << (mf_slot(ady) + 1)); }
+
+struct MFGeom {
+    int ix0, iy0, W, H;
+    int ox0, oy0, ow, oh;
+    long in_sy, in_sc, out_sy, out_sc;
+    int t_of[RAD + 1], s_of[RAD + 1]; // per |dx|: clamp(filter_height, 0, 27) and its slice (max_filter_literal)
+    int lit_rows;                     // output rows y < 0, handled by max_filter_literal
+};
+
+// vert_log(x, row, c, s) as the reference leaves it (:26-30): rows -26 .. H-1 were updated and hold the max of 2^s rows
+// starting at `row` (edge-clamped); every other row still holds the clamped input row.
+__device__ __forceinline__ float mf_vert_log(const float *col, long sy, int H, int row, int s) {
+    const int n = (row >= -RAD && row <= H - 1) ? (1 << s) : 1;
+    float m = -INFINITY;
+    for (int i = 0; i < n; i++) m = fmaxf(m, col[(long)min(max(row + i, 0), H - 1) * sy]);
+    return m;
+}
+
+// Output rows above the image (y < 0; a few rows of a region nobody normally asks for): the definition as written, one
+// thread per output pixel.
+__global__ __launch_bounds__(256) void max_filter_literal(const float *__restrict__ in, float *__restrict__ out, MFGeom g) {
+    const int x = blockIdx.x * 256 + threadIdx.x, yr = blockIdx.y;
+    if (x >= g.ow) return;
+    const int X = g.ox0 + x, Y = g.oy0 + yr;
+    const float *inc = in + (long)blockIdx.z * g.in_sc;
+    float m = -INFINITY;
+    for (int dx = -RAD; dx <= RAD; dx++) {
+        const int t = g.t_of[dx < 0 ? -dx : dx], s = g.s_of[dx < 0 ? -dx : dx];
+        const float *col = inc + (min(max(X + dx, g.ix0), g.ix0 + g.W - 1) - g.ix0);
+        m = fmaxf(m, fmaxf(mf_vert_log(col, g.in_sy, g.H, Y - t, s), mf_vert_log(col, g.in_sy, g.H, Y + t + 1 - (1 << s), s)));
+    }
+    out[(long)blockIdx.z * g.out_sc + (long)yr * g.out_sy + x] = m;
+}
+
+// acc = max(acc, a, b) as one instruction; the compiler's fmaxf would first canonicalise both loaded values
+__device__ __forceinline__ void mf_max3(float &acc, float a, float b) { asm("v_max3_f32 %0, %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b)); }
+
+// Fold the chunk that sits M chunks below the wave's first output row into its 8 accumulators: input row r of the chunk
+// meets output row k at dy = 8M + r - k - 27.  Everything but the lane's column is a compile-time constant, so each pair
+// is two ds_read_b32 with immediate offsets and one v_max3; pairs outside the footprint do not exist.
+template <int M, int I = 0>
+__device__ __forceinline__ void mf_fold(float (&acc)[CH], const float *base) {
+    if constexpr (I < CH * CH) {
+        constexpr int r = I / CH, k = I % CH, dy = M * CH + r - k - VR, ady = dy < 0 ? -dy : dy;
+        if constexpr (ady <= VR) mf_max3(acc[k], base[r * SP + mf_offA(ady)], base[r * SP + mf_offB(ady)]);
+        mf_fold<M, I + 1>(acc, base);
+    }
+}
+
+__global__ __launch_bounds__(NT) void max_filter_tile(const float *__restrict__ in, float *__restrict__ out, MFGeom g) {
+    __shared__ float s_r[NSLOT * CH * SP + SP];      // + one row: the slice builds read up to 16 words past a row's end
+    const int tid = threadIdx.x, cx = tid & 63;
+    const float *base = s_r + cx;
+    const int rg = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int X0 = g.ox0 + blockIdx.x * TW, Y0 = g.oy0 + g.lit_rows + blockIdx.y * TY;
+    const float *inc = in + (long)blockIdx.z * g.in_sc;
+    float acc[CH];
+#pragma unroll
+    for (int k = 0; k < CH; k++) acc[k] = -INFINITY;
+
+    // slice 0 of a chunk: CH clamped input rows, columns X0 - 26 .. X0 + 101 (116 used); fetched one chunk ahead into
+    // registers so the HBM/L2 latency hides behind the previous chunk's LDS work
+    constexpr int PER = CH * SP / NT;
+    float nxt[PER];
+    auto fetch = [&](int chunk) {
+#pragma unroll
+        for (int e = 0; e < PER; e++) {
+            const int i = tid + e * NT, r = i >> 7, c = i & (SP - 1);
+            const int y = min(max(Y0 - VR + chunk * CH + r, g.iy0), g.iy0 + g.H - 1) - g.iy0;
+            const int x = min(max(X0 - RAD + c, g.ix0), g.ix0 + g.W - 1) - g.ix0;
+            nxt[e] = inc[(long)y * g.in_sy + x];
+        }
+    };
+    fetch(0);
+    for (int chunk = 0; chunk < NCHUNK; chunk++) {
+#pragma unroll
+        for (int e = 0; e < PER; e++) s_r[tid + e * NT] = nxt[e];
+        __syncthreads();
+        if (chunk + 1 < NCHUNK) fetch(chunk + 1);
+        // R_2 from R_0 (four neighbours), then R_3, R_4, R_5 by doubling.  Entries whose window runs past column 115 pick
+        // up words of the next row; no fold sample ever reads them (the samples end at x + w <= column 115).
+#pragma unroll
+        for (int e = 0; e < PER; e++) {
+            const float *p = s_r + tid + e * NT;
+            s_r[CH * SP + tid + e * NT] = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3]));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int slot = 2; slot < NSLOT; slot++) {
+#pragma unroll
+            for (int e = 0; e < PER; e++) {
+                const float *p = s_r + (slot - 1) * CH * SP + tid + e * NT;
+                s_r[slot * CH * SP + tid + e * NT] = fmaxf(p[0], p[2 << (slot - 1)]);
+            }
+            __syncthreads();
+        }
+        switch (chunk - rg) {   // wave-uniform
+        case 0: mf_fold<0>(acc, base); break;
+        case 1: mf_fold<1>(acc, base); break;
+        case 2: mf_fold<2>(acc, base); break;
+        case 3: mf_fold<3>(acc, base); break;
+        case 4: mf_fold<4>(acc, base); break;
+        case 5: mf_fold<5>(acc, base); break;
+        case 6: mf_fold<6>(acc, base); break;
+        case 7: mf_fold<7>(acc, base); break;
+        default: break;
+        }
+        static_assert(NFOLD == 8, "one case per chunk of a wave's window");
+        // no barrier here: the next chunk's first write goes to slice 0, which the folds do not read
+    }
+    const int x = blockIdx.x * TW + cx;
+    if (x < g.ow) {
+        float *o = out + (long)blockIdx.z * g.out_sc + x;
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int y = g.lit_rows + blockIdx.y * TY + rg * CH + k;
+            if (y < g.oh) o[(long)y * g.out_sy] = acc[k];
+        }
+    }
+}
+
+const int64_t e0 = 0, ew = 1536, eh = 2560, ec = 3;
+const int64_t *const est[6] = {&e0, &ew, &e0, &eh, &e0, &ec};
+const halide_type_t ty_f32 = {(decltype(halide_type_t::code))2, 32, 0};
+// estimates: generator :55-62
+const halide_filter_argument_t mf_args[2] = {
+    {"input", halide_argument_kind_input_buffer, 3, ty_f32, nullptr, nullptr, nullptr, nullptr, est},
+    {"output", halide_argument_kind_output_buffer, 3, ty_f32, nullptr, nullptr, nullptr, nullptr, est},
+};
+const halide_filter_metadata_t mf_md = {1, 2, mf_args, kTargetString, "max_filter"};
+
+}  // namespace
+
+extern "C" int max_filter(halide_buffer_t *input, halide_buffer_t *output) {
+    void *uc = nullptr;
+    BufArg args[2] = {{"input", input, T_F32, 3, false}, {"output", output, T_F32, 3, true}};
+    int r = check_not_null(uc, args, 2);
+    if (r) return r;
+    if ((r = check_type_and_dims(uc, args, 2))) return r;
+    if (any_bounds_query(args, 2)) {
+        // every x, y tap goes through repeat_edge (:17-19); the channel is read as asked
+        int mins[3], ext[3];
+        for (int d = 0; d < 3; d++) mins[d] = output->dim[d].min, ext[d] = output->dim[d].extent;
+        answer_query(input, mins, ext);
+        answer_query(output, mins, ext);
+        return 0;
+    }
+    if ((r = check_shape(uc, args[0])) || (r = check_shape(uc, args[1]))) return r;
+    const int ow = output->dim[0].extent, oh = output->dim[1].extent, oc = output->dim[2].extent;
+    if ((r = check_covers(uc, args[0], 2, output->dim[2].min, oc))) return r;
+    if (ow > 0 && oh > 0 && oc > 0) {
+        if (input->dim[0].extent < 1 || input->dim[1].extent < 1) {
+            return report(uc, halide_error_code_access_out_of_bounds, "Input buffer input is empty in x or y: nothing to clamp to");
+        }
+        if (input->dim[1].min != 0) {
+            // the vert_log update runs over absolute rows -26 .. height-1 (:28); only with min 0 is the pipeline the
+            // footprint max this kernel computes
+            return report(uc, halide_error_code_constraint_violated, "Input buffer input: dimension 1 must start at 0");
+        }
+    }
+    DeviceCtx ctx;
+    if ((r = acquire_device(uc, &ctx))) return r;
+    if ((r = input_to_device(uc, ctx, args[0]))) return r;
+    if ((r = output_on_device(uc, ctx, args[1]))) return r;
+    if (ow > 0 && oh > 0 && oc > 0) {
+        MFGeom g;
+        g.ix0 = input->dim[0].min, g.iy0 = input->dim[1].min, g.W = input->dim[0].extent, g.H = input->dim[1].extent;
+        g.ox0 = output->dim[0].min, g.oy0 = output->dim[1].min, g.ow = ow, g.oh = oh;
+        g.in_sy = input->dim[1].stride, g.in_sc = input->dim[2].stride;
+        g.out_sy = output->dim[1].stride, g.out_sc = output->dim[2].stride;
+        // filter_height (:47-49) and, from it, the half-width of every row of the footprint
+        int h[RAD + 1];
+        const float lim = (RAD + 0.25f) * (RAD + 0.25f);
+        for (int dx = 0; dx <= RAD; dx++) {
+            int n = 0;
+            for (int dy = 0; dy <= RAD; dy++) n += ((float)(dx * dx + dy * dy) < lim) ? 1 : 0;
+            h[dx] = n < VR ? n : VR;
+        }
+        for (int dx = 0; dx <= RAD; dx++) {
+            g.t_of[dx] = h[dx];
+            int sl = 0;
+            while ((2 << sl) <= 2 * h[dx] + 1) sl++;     // slice_for_radius (:37), never above slices - 1 = 5
+            g.s_of[dx] = sl;
+        }
+        g.lit_rows = output->dim[1].min < 0 ? (-output->dim[1].min < oh ? -output->dim[1].min : oh) : 0;
+        const float *din = dev_ptr<float>(input) + (long)(output->dim[2].min - input->dim[2].min) * g.in_sc;
+        timing_note_bytes(8.0 * ow * oh * oc);
+        if (g.lit_rows > 0) {
+            HLMI_LAUNCH(uc, "max_filter_literal", ctx.stream, max_filter_literal, dim3((ow + 255) / 256, g.lit_rows, oc), dim3(256), 0, din,
+                        dev_ptr<float>(output), g);
+        }
+        if (oh > g.lit_rows) {
+            HLMI_LAUNCH(uc, "max_filter_tile", ctx.stream, max_filter_tile, dim3((ow + TW - 1) / TW, (oh - g.lit_rows + TY - 1) / TY, oc),
+                        dim3(NT), 0, din, dev_ptr<float>(output), g);
+        }
+    }
+    mark_output_written(output);
+    return 0;
+}
+
+extern "C" int max_filter_argv(void **a) { return max_filter((halide_buffer_t *)a[0], (halide_buffer_t *)a[1]); }
+extern "C" const halide_filter_metadata_t *max_filter_metadata(void) { return &mf_md; }
+extern "C" int max_filter_auto_schedule(halide_buffer_t *input, halide_buffer_t *output) { return max_filter(input, output); }

@@ -138,6 +138,15 @@ def unsharp(input: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@torch.library.custom_op("hlmi::max_filter", mutates_args=())
+def max_filter(input: torch.Tensor) -> torch.Tensor:
+    """apps/max_filter: (3, H, W) float32 -> (3, H, W) float32, max over the radius-26 footprint of the edge-clamped input."""
+    out = torch.empty_like(input)
+    with _Wrapped(input, out) as (a, o):
+        hl.max_filter(a, o)
+    return out
+
+
 @torch.library.custom_op("hlmi::hist", mutates_args=())
 def hist(input: torch.Tensor) -> torch.Tensor:
     """apps/hist: (3, H, W) uint8 -> (3, H, W) uint8, histogram equalisation of the luma."""

@@ -90,6 +90,11 @@ HLMI_DECLARE_AUX(depthwise_separable_conv)
 int unsharp(struct halide_buffer_t *input, struct halide_buffer_t *output);
 HLMI_DECLARE_AUX(unsharp)
 
+/* apps/max_filter/max_filter_generator.cpp:11-12,121 — f32 [W,H,3] planar in and out, radius = 26 (GeneratorParam :10):
+ * max over a disc-like footprint of the edge-clamped input.  An adjacent app with the same boundary. */
+int max_filter(struct halide_buffer_t *input, struct halide_buffer_t *output);
+HLMI_DECLARE_AUX(max_filter)
+
 /* apps/hist/hist_generator.cpp:9-10,215 — u8 [W,H,3] planar in and out: histogram equalisation of the luma (integer
  * histogram over the whole input, cdf, pointwise recolouring).  An adjacent app with the same boundary. */
 int hist(struct halide_buffer_t *input, struct halide_buffer_t *output);
@@ -133,6 +138,7 @@ int depthwise_separable_conv_auto_schedule(struct halide_buffer_t *input, struct
                                            struct halide_buffer_t *pointwise_filter, struct halide_buffer_t *bias,
                                            struct halide_buffer_t *output);
 int unsharp_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);
+int max_filter_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);
 int hist_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);
 int harris_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);
 int interpolate_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);

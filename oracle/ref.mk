@@ -12,7 +12,7 @@ LDFLAGS  := -L$(LIBDIR) -lhlmi -Wl,-rpath,'$$ORIGIN/../../halide_amd/lib' -lpthr
 
 TARGETS := $(OUTDIR)/blur_test $(OUTDIR)/local_laplacian_process $(OUTDIR)/bilateral_grid_filter \
            $(OUTDIR)/nl_means_process $(OUTDIR)/stencil_chain_process $(OUTDIR)/conv_layer_process $(OUTDIR)/camera_pipe_process \
-           $(OUTDIR)/depthwise_separable_conv_process $(OUTDIR)/unsharp_filter $(OUTDIR)/hist_filter $(OUTDIR)/harris_filter $(OUTDIR)/iir_blur_filter
+           $(OUTDIR)/depthwise_separable_conv_process $(OUTDIR)/unsharp_filter $(OUTDIR)/max_filter_filter $(OUTDIR)/hist_filter $(OUTDIR)/harris_filter $(OUTDIR)/iir_blur_filter
 
 all: $(TARGETS)
 
@@ -38,6 +38,8 @@ $(OUTDIR)/camera_pipe_process: $(REF)/apps/camera_pipe/process.cpp $(LIBDIR)/lib
 $(OUTDIR)/depthwise_separable_conv_process: $(REF)/apps/depthwise_separable_conv/process.cpp $(LIBDIR)/libhlmi.so
 	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)
 $(OUTDIR)/unsharp_filter: $(REF)/apps/unsharp/filter.cpp $(LIBDIR)/libhlmi.so
+	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)
+$(OUTDIR)/max_filter_filter: $(REF)/apps/max_filter/filter.cpp $(LIBDIR)/libhlmi.so
 	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)
 $(OUTDIR)/hist_filter: $(REF)/apps/hist/filter.cpp $(LIBDIR)/libhlmi.so
 	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)

@@ -41,6 +41,7 @@ def cases():
             r(9).uniform(-1, 1, (2, 6, 7, 8)).astype(np.float32), r(10).uniform(-1, 1, (3, 3, 8, 1)).astype(np.float32),
             r(11).uniform(-1, 1, (8, 5)).astype(np.float32), r(12).uniform(-1, 1, 5).astype(np.float32)),
         "unsharp_50x40_seed13": lambda: o.unsharp(f32(13, (3, 40, 50)) * 0.9 + 0.05),
+        "max_filter_70x64_seed17": lambda: o.max_filter(f32(17, (3, 64, 70))),
         "hist_90x60_seed14": lambda: o.hist(r(14).integers(0, 256, (3, 60, 90), dtype=np.uint8)),
         "harris_50x40_seed15": lambda: o.harris(f32(15, (3, 40, 50))),
         "interpolate_34x21_seed9": lambda: o.interpolate(rgba),

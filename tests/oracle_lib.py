@@ -218,6 +218,33 @@ def unsharp(inp: np.ndarray, out_origin=(0, 0), out_size=None, in_origin=(0, 0))
                                ow, ow * oh) == 0
     return out
 
+_lib.oracle_max_filter.argtypes = [_f32p, C.c_int, C.c_int, C.c_long, C.c_long, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_long, C.c_long]
+_lib.oracle_max_filter.restype = C.c_int
+
+
+_lib.oracle_max_filter_tables.argtypes = [np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")] * 2
+_lib.oracle_max_filter_tables.restype = None
+
+
+def max_filter_tables():
+    """(slice_for_radius[0..27], filter_height[dx = -26..26]) as the oracle computes them."""
+    sfr, fh = np.zeros(28, np.int32), np.zeros(53, np.int32)
+    _lib.oracle_max_filter_tables(sfr, fh)
+    return sfr, fh
+
+
+def max_filter(inp: np.ndarray, out_origin=(0, 0), out_size=None, in_origin=(0, 0)) -> np.ndarray:
+    """inp: f32 (C, H, W) planar whose first element sits at absolute in_origin; output region out_origin + out_size (any
+    region: every tap is edge-clamped)."""
+    inp = np.ascontiguousarray(inp, np.float32)
+    c, h, w = inp.shape
+    ow, oh = out_size if out_size else (w, h)
+    out = np.zeros((c, oh, ow), np.float32)
+    assert _lib.oracle_max_filter(inp, w, h, w, w * h, in_origin[0], in_origin[1], out, out_origin[0], out_origin[1], ow, oh, c,
+                                  ow, ow * oh) == 0
+    return out
+
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 _lib.oracle_hist.argtypes = [_u8p, C.c_int, C.c_int, C.c_long, C.c_long, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long,
                              _i32p]

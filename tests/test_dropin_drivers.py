@@ -156,6 +156,20 @@ def test_unsharp_filter_cpp(tmp_path, oracle):
 
 
 @pytest.mark.gpu
+def test_max_filter_filter_cpp(tmp_path, oracle):
+    """apps/max_filter/filter.cpp unmodified: 8-bit in -> float -> max_filter (+ _auto_schedule) -> 16-bit out.  A max of
+    values k/255 is one of them, so the saved image is exactly the footprint max of the 8-bit input (x 257)."""
+    exe = _exe("max_filter_filter")
+    img8 = _scene8(180, 140, 6, 3)
+    src, dst = str(tmp_path / "in.ppm"), str(tmp_path / "out.ppm")
+    write_ppm8(src, img8)
+    r = subprocess.run([exe, src, dst], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Success!" in r.stdout, r.stdout + r.stderr
+    got = read_pnm16(dst)
+    assert np.array_equal(got, oracle.max_filter(img8.astype(np.float32)).astype(np.uint16) * 257)
+
+
+@pytest.mark.gpu
 def test_hist_filter_cpp(tmp_path, oracle):
     exe = _exe("hist_filter")
     img8 = _scene8(256, 160, 7, 3)
