@@ -148,6 +148,10 @@ def main():
     kernels = hl.kernel_timing_report()
     hl.kernel_timing_reset()
 
+    # the practical HBM ceiling of this device, measured live: a float4 copy kernel over 1 GiB buffers (4x the MALL), HIP
+    # events over 10 launches (halide_amd/csrc/membench.hip) — what "HBM-bound" can reach at best for mixed read/write traffic
+    copy_ceiling = hl.membench(1 << 30, 10)["copy_gbs"] if rank == 0 else None
+
     if rank == 0:
         px_per_step = world * FRAMES_PER_STEP * W * H
         value = px_per_step * args.steps / elapsed / 1e6
@@ -191,6 +195,10 @@ def main():
                          "pipeline_traffic_per_frame": frame_traffic,
                          "pipeline_traffic_frac": None if frame_traffic is None else
                          round(frame_traffic / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         # the same against the measured copy ceiling instead of the 8 TB/s spec figure
+                         "hbm_copy_ceiling_gbs": round(copy_ceiling, 1),
+                         "pipeline_traffic_frac_of_copy_ceiling": None if frame_traffic is None else
+                         round(frame_traffic / (frame_ms * 1e-3) / 1e9 / copy_ceiling, 4),
                          "kernel_ms_per_frame": {k: round(v, 5) for k, v in per_frame.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:

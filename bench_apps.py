@@ -66,6 +66,14 @@ def main():
                           "roofline": {"bound": bound, "achieved": round(achieved, 1), "peak": peak, "unit": unit,
                                        "frac": round(achieved / peak, 4)}, **extra}), flush=True)
 
+    # ---- the practical HBM ceiling: copy / read / write kernels over 1 GiB buffers (4x the MALL)
+    if not only or "membench" in only:
+        m = hl.membench(1 << 30, 10)
+        print(json.dumps({"pipeline": "membench", "workload": "grid-stride float4 kernels over 1 GiB buffers, HIP events over 10 launches",
+                          "copy_gbs": round(m["copy_gbs"], 1), "read_gbs": round(m["read_gbs"], 1),
+                          "write_gbs": round(m["write_gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "copy_frac_of_peak": round(m["copy_gbs"] / HBM_PEAK_GBS, 4)}), flush=True)
+
     # ---- configs[0]: blur 3x3, u16 1536x2560 (input 1538x2562)
     if not only or "blur" in only:
         W, H = 1536, 2560

@@ -359,6 +359,17 @@ def debug_local_laplacian_outg(level: int) -> np.ndarray:
     return out
 
 
+def membench(nbytes: int = 1 << 30, iters: int = 10, blocks: int = 0) -> dict:
+    """Measurement hook: achieved GB/s of a device copy / read-only / write-only kernel over buffers of `nbytes` (the
+    practical HBM ceiling the pipelines' roofline fractions can be read against)."""
+    fn = lib.hlmi_membench
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    out = (C.c_double * 3)()
+    _check(fn(int(nbytes), int(iters), int(blocks), out))
+    return {"copy_gbs": out[0], "read_gbs": out[1], "write_gbs": out[2]}
+
+
 def bilateral_grid(input, r_sigma, output) -> int:
     return _check(_bg(_as_ptr(input), float(r_sigma), _as_ptr(output)))
 
