@@ -10,8 +10,10 @@
 //   D_9 = I_9,  D_l = I_l  U  [2 lo(D_{l+1}) - 1, 2 hi(D_{l+1}) + 1]           downsampled[l]   (clamped to [0, W/8] for l = 3)
 // as float4 {r a, g a, b a, a} per pixel (one 16-byte load serves all four channels).  downsampled[0] and
 // interpolated[0] are never stored.  Sums left to right as written, one rounding per operator (oracle/
-// interpolate_oracle.c).  18 launches, one thread per pixel: levels >= 3 are launch-latency bound, exactly the regime
-// local_laplacian's multi-level kernels address — the same treatment is the obvious next step here.
+// interpolate_oracle.c).  One thread per pixel.  Levels >= 6 (at most 25 x 41 pixels) are launch-latency bound, so ONE
+// workgroup walks them all — down 6..9, then up 8..6 — with a barrier between levels (ip_tail): 12 launches instead of 18
+// (0.090 instead of 0.095 ms; starting the tail at level 5 or 4 is slower, 0.103 / 0.152 ms: a level costs a lone
+// workgroup about as much as a launch costs the chip).
 #include "hlmi_device_math.h"
 #include "hlmi_internal.h"
 
@@ -42,13 +44,10 @@ __device__ __forceinline__ float4 tap3(float4 a, float4 b, float4 c) {   // (a +
                        ((a.w + 2.0f * b.w) + c.w) * 0.25f);
 }
 
-// downsampled[l] on dst's box from downsampled[l-1] (src; FROM_INPUT: level 0 computed from the input);
-// CLAMP4: the coordinate clamp in front of level 4
-template<bool FROM_INPUT, bool CLAMP4>
-__global__ __launch_bounds__(256) void ip_down(InGeom g, Lvl src, Lvl dst, int cw, int ch) {
-    const int xs = blockIdx.x * 256 + threadIdx.x, ys = blockIdx.y;
-    if (xs >= dst.w) return;
-    const int x = dst.x0 + xs, y = dst.y0 + ys;
+// downsampled[l](x, y) from downsampled[l-1] (src; FROM_INPUT: level 0 computed from the input);
+// clamp4: the coordinate clamp in front of level 4
+template<bool FROM_INPUT>
+__device__ __forceinline__ float4 down_value(const InGeom &g, const Lvl &src, int x, int y, bool clamp4, int cw, int ch) {
     float4 dx[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
@@ -56,12 +55,18 @@ __global__ __launch_bounds__(256) void ip_down(InGeom g, Lvl src, Lvl dst, int c
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             int X = 2 * x - 1 + i, Y = 2 * y - 1 + j;
-            if (CLAMP4) X = dev::clampi(X, 0, cw), Y = dev::clampi(Y, 0, ch);
+            if (clamp4) X = dev::clampi(X, 0, cw), Y = dev::clampi(Y, 0, ch);
             p[i] = FROM_INPUT ? ds0(g, X, Y) : at(src, X, Y);
         }
         dx[j] = tap3(p[0], p[1], p[2]);
     }
-    dst.v[(size_t)ys * dst.w + xs] = tap3(dx[0], dx[1], dx[2]);
+    return tap3(dx[0], dx[1], dx[2]);
+}
+template<bool FROM_INPUT, bool CLAMP4>
+__global__ __launch_bounds__(256) void ip_down(InGeom g, Lvl src, Lvl dst, int cw, int ch) {
+    const int xs = blockIdx.x * 256 + threadIdx.x, ys = blockIdx.y;
+    if (xs >= dst.w) return;
+    dst.v[(size_t)ys * dst.w + xs] = down_value<FROM_INPUT>(g, src, dst.x0 + xs, dst.y0 + ys, CLAMP4, cw, ch);
 }
 
 __device__ __forceinline__ float4 interp_value(const float4 d, const Lvl &up, int x, int y) {   // (:61-72)
@@ -82,6 +87,32 @@ __global__ __launch_bounds__(256) void ip_up(Lvl ds, Lvl up, Lvl dst) {
     if (xs >= dst.w) return;
     const int x = dst.x0 + xs, y = dst.y0 + ys;
     dst.v[(size_t)ys * dst.w + xs] = interp_value(at(ds, x, y), up, x, y);
+}
+
+// Levels from..IL-1 in one launch of ONE workgroup: downsampled[from..9], then interpolated[8..from]; a level is
+// complete (and visible to the workgroup, which shares its CU's L1) at the barrier that follows it.
+struct TailArgs {
+    Lvl ds[IL], ip[IL];
+    int cw, ch, from;
+};
+__global__ __launch_bounds__(1024) void ip_tail(TailArgs a) {
+    const InGeom none{};
+    for (int l = a.from; l < IL; l++) {
+        const Lvl src = a.ds[l - 1], dst = a.ds[l];
+        for (int i = threadIdx.x; i < dst.w * dst.h; i += 1024) {
+            const int ys = i / dst.w, xs = i - ys * dst.w;
+            dst.v[i] = down_value<false>(none, src, dst.x0 + xs, dst.y0 + ys, l == 4, a.cw, a.ch);
+        }
+        __syncthreads();
+    }
+    for (int l = IL - 2; l >= a.from; l--) {
+        const Lvl d = a.ds[l], up = a.ip[l + 1], dst = a.ip[l];
+        for (int i = threadIdx.x; i < dst.w * dst.h; i += 1024) {
+            const int ys = i / dst.w, xs = i - ys * dst.w;
+            dst.v[i] = interp_value(at(d, dst.x0 + xs, dst.y0 + ys), up, dst.x0 + xs, dst.y0 + ys);
+        }
+        __syncthreads();
+    }
 }
 
 // level 0: interpolated[0] (never stored) and the normalisation (:74-75), planar output
@@ -161,21 +192,32 @@ extern "C" int interpolate(halide_buffer_t *input, halide_buffer_t *output) {
         if ((r = get_workspace(uc, ctx, total * sizeof(float4), &ws))) return r;
         float4 *base = (float4 *)ws;
         auto lvl = [&](float4 *p, const Box &b) { return Lvl{p, b.x0, b.y0, b.x1 - b.x0 + 1, b.y1 - b.y0 + 1}; };
-        Lvl ds[IL], ip[IL];
+        Lvl ds[IL] = {}, ip[IL] = {};
         for (int l = 1; l < IL; l++) ds[l] = lvl(base + off_d[l], D[l]);
         for (int l = 1; l < IL - 1; l++) ip[l] = lvl(base + off_i[l], I[l]);
         ip[IL - 1] = ds[IL - 1];   // interpolated[9] = downsampled[9], and D_9 == I_9
         InGeom g{dev_ptr<float>(input), input->dim[1].stride, input->dim[2].stride, W, H};
         hipStream_t st = ctx.stream;
         char nm[32];
-        for (int l = 1; l < IL; l++) {
+        // levels >= T go through ip_tail (default 6: 25 x 41 pixels and below)
+        const char *te = getenv("HLMI_IP_TAIL_FROM");
+        int T = te ? atoi(te) : 6;
+        if (T < 2 || T > IL - 2) T = IL;
+        for (int l = 1; l < IL && l < T; l++) {
             dim3 grid((ds[l].w + 255) / 256, ds[l].h), block(256);
             snprintf(nm, sizeof nm, "ip_down:%d", l);
             if (l == 1) HLMI_LAUNCH(uc, nm, st, (ip_down<true, false>), grid, block, 0, g, ds[1], ds[1], cw, ch);
             else if (l == 4) HLMI_LAUNCH(uc, nm, st, (ip_down<false, true>), grid, block, 0, g, ds[l - 1], ds[l], cw, ch);
             else HLMI_LAUNCH(uc, nm, st, (ip_down<false, false>), grid, block, 0, g, ds[l - 1], ds[l], cw, ch);
         }
-        for (int l = IL - 2; l >= 1; l--) {
+        if (T < IL) {
+            TailArgs ta;
+            for (int l = 0; l < IL; l++) ta.ds[l] = ds[l], ta.ip[l] = ip[l];
+            ta.cw = cw, ta.ch = ch, ta.from = T;
+            snprintf(nm, sizeof nm, "ip_tail:%d", T);
+            HLMI_LAUNCH(uc, nm, st, ip_tail, dim3(1), dim3(1024), 0, ta);
+        }
+        for (int l = (T < IL ? T - 1 : IL - 2); l >= 1; l--) {
             dim3 grid((ip[l].w + 255) / 256, ip[l].h), block(256);
             snprintf(nm, sizeof nm, "ip_up:%d", l);
             HLMI_LAUNCH(uc, nm, st, ip_up, grid, block, 0, ds[l], ip[l + 1], ip[l]);
