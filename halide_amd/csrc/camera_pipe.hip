@@ -170,6 +170,150 @@ __global__ __launch_bounds__(256) void cp_demosaic(const uint16_t *__restrict__ 
     }
 }
 
+// ---- cp_demosaic_tile: the same stages for a tile of 32 x 8 Bayer quads (64 x 16 pixels) per workgroup, staged through
+// LDS so that every raw pixel is loaded once and every hot-pixel clamp is evaluated once (cp_demosaic loads a 10 x 10
+// window and clamps 36 pixels per quad: 9x redundant):
+//   raw window 72 x 24 (aligned dword pairs) -> LDS;  clamped pairs (sites {Gr,R} and {B,Gb} of a quad are adjacent
+//   pixels: v_pk_max_u16 / v_pk_min_u16) for 34 x 10 quads -> LDS;  one thread per quad: 18 LDS dwords -> demosaic ->
+//   matrix -> curve (LUT in LDS) -> staged u8 rows -> coalesced dword stores of the curved planes.
+// Needs the PAIRS alignment (even row stride, 4-byte aligned origin) and an even W.  Raw pixels outside the footprint the
+// boundary guarantees ([-6, W+5] x [-6, H+5] around the output) are read as 0; they only feed pixels that are not stored.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+constexpr int TQX = 32, TQY = 8;                      // quads per tile
+constexpr int RWD = (2 * TQX + 8) / 2, RH = 2 * TQY + 8, RPD = RWD + 1;   // raw window in dwords (36) x rows (24), pitch 37
+constexpr int DQX = TQX + 2, DQY = TQY + 2, DPD = DQX + 1;              // clamped quads 34 x 10, pitch 35 dwords
+constexpr int OP = 68;                                // staged output row pitch in bytes (column c sits at byte c + 3)
+__global__ __launch_bounds__(256) void cp_demosaic_tile(const uint16_t *__restrict__ raw, long in_sy, const CPSetup *__restrict__ s,
+                                                       uint8_t *__restrict__ cv, int CW, int CH, int CWL, int W, int H) {
+    __shared__ uint32_t s_raw[RH * RPD];
+    __shared__ uint32_t s_d[2 * DQY * DPD];           // [cy][j][i]: sites (2 cy, 2 cy + 1) of clamped quad (i, j)
+    __shared__ uint32_t s_curve[256];
+    __shared__ __attribute__((aligned(4))) uint8_t s_out[3 * 2 * TQY * OP];
+    const int tid = threadIdx.x;
+    const int QX0 = -1 + TQX * (int)blockIdx.x, QY0 = -1 + TQY * (int)blockIdx.y;   // quads start at fdiv(-1, 2) = -1
+    s_curve[tid] = reinterpret_cast<const uint32_t *>(s->curve)[tid];
+    const int rx0 = 2 * QX0 - 4, ry0 = 2 * QY0 - 4;   // raw window origin (even)
+    for (int i = tid; i < RH * RWD; i += 256) {
+        const int r = i / RWD, cdw = i - r * RWD;
+        const int x = rx0 + 2 * cdw, y = ry0 + r;
+        const bool ok = x >= -6 && x + 1 <= W + 5 && y >= -6 && y <= H + 5;
+        s_raw[r * RPD + cdw] = ok ? *reinterpret_cast<const uint32_t *>(raw + (long)y * in_sy + x) : 0u;
+    }
+    __syncthreads();
+    // hot-pixel suppression (:240-250) on pixel pairs: clamped quad (i, j), pair cy -> raw window dword (i + 1, 2 j + cy + 2)
+    for (int it = tid; it < 2 * DQY * DQX; it += 256) {
+        const int cy = it / (DQY * DQX), rem = it - cy * (DQY * DQX), j = rem / DQX, i = rem - j * DQX;
+        const uint32_t *p = s_raw + (2 * j + cy + 2) * RPD + (i + 1);
+        const u16x2 c0 = __builtin_bit_cast(u16x2, p[0]), l = __builtin_bit_cast(u16x2, p[-1]), r = __builtin_bit_cast(u16x2, p[1]),
+                    u = __builtin_bit_cast(u16x2, p[-2 * RPD]), d = __builtin_bit_cast(u16x2, p[2 * RPD]);
+        const u16x2 a = __builtin_elementwise_max(__builtin_elementwise_max(l, r), __builtin_elementwise_max(u, d));
+        s_d[(cy * DQY + j) * DPD + i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(c0, a));
+    }
+    __syncthreads();
+    const int tx = tid & (TQX - 1), ty = tid >> 5;
+    // deinterleave (:252-263): D[c][dy+1][dx+1]
+    uint16_t D[4][3][3];
+#pragma unroll
+    for (int cy = 0; cy < 2; cy++)
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) {
+                const uint32_t w = s_d[(cy * DQY + ty + dy) * DPD + tx + dx];
+                D[2 * cy][dy][dx] = (uint16_t)(w & 0xffffu), D[2 * cy + 1][dy][dx] = (uint16_t)(w >> 16);
+            }
+#define G_GR(dx, dy) D[0][(dy) + 1][(dx) + 1]
+#define R_R(dx, dy) D[1][(dy) + 1][(dx) + 1]
+#define B_B(dx, dy) D[2][(dy) + 1][(dx) + 1]
+#define G_GB(dx, dy) D[3][(dy) + 1][(dx) + 1]
+    auto g_r = [&](int dx, int dy) -> uint16_t {
+        uint16_t gv = avg16(G_GB(dx, dy - 1), G_GB(dx, dy)), gvd = absd16(G_GB(dx, dy - 1), G_GB(dx, dy));
+        uint16_t gh = avg16(G_GR(dx + 1, dy), G_GR(dx, dy)), ghd = absd16(G_GR(dx + 1, dy), G_GR(dx, dy));
+        return ghd < gvd ? gh : gv;
+    };
+    auto g_b = [&](int dx, int dy) -> uint16_t {
+        uint16_t gv = avg16(G_GR(dx, dy + 1), G_GR(dx, dy)), gvd = absd16(G_GR(dx, dy + 1), G_GR(dx, dy));
+        uint16_t gh = avg16(G_GB(dx - 1, dy), G_GB(dx, dy)), ghd = absd16(G_GB(dx - 1, dy), G_GB(dx, dy));
+        return ghd < gvd ? gh : gv;
+    };
+    const uint16_t gr00 = g_r(0, 0), grm0 = g_r(-1, 0), gr01 = g_r(0, 1), grm1 = g_r(-1, 1);
+    const uint16_t gb00 = g_b(0, 0), gb0m = g_b(0, -1), gb10 = g_b(1, 0), gb1m = g_b(1, -1);
+    uint16_t px[4][3];  // [site: gr, r, b, gb][r, g, b]
+    px[0][1] = G_GR(0, 0);
+    px[0][0] = u16(u16(G_GR(0, 0) - avg16(gr00, grm0)) + avg16(R_R(-1, 0), R_R(0, 0)));
+    px[0][2] = u16(u16(G_GR(0, 0) - avg16(gb00, gb0m)) + avg16(B_B(0, 0), B_B(0, -1)));
+    px[1][0] = R_R(0, 0);
+    px[1][1] = gr00;
+    {
+        uint16_t bp = u16(u16(gr00 - avg16(gb00, gb1m)) + avg16(B_B(0, 0), B_B(1, -1)));
+        uint16_t bpd = absd16(B_B(0, 0), B_B(1, -1));
+        uint16_t bn = u16(u16(gr00 - avg16(gb10, gb0m)) + avg16(B_B(1, 0), B_B(0, -1)));
+        uint16_t bnd = absd16(B_B(1, 0), B_B(0, -1));
+        px[1][2] = bpd < bnd ? bp : bn;
+    }
+    px[2][2] = B_B(0, 0);
+    px[2][1] = gb00;
+    {
+        uint16_t rp = u16(u16(gb00 - avg16(gr00, grm1)) + avg16(R_R(0, 0), R_R(-1, 1)));
+        uint16_t rpd = absd16(R_R(0, 0), R_R(-1, 1));
+        uint16_t rn = u16(u16(gb00 - avg16(grm0, gr01)) + avg16(R_R(-1, 0), R_R(0, 1)));
+        uint16_t rnd = absd16(R_R(-1, 0), R_R(0, 1));
+        px[2][0] = rpd < rnd ? rp : rn;
+    }
+    px[3][1] = G_GB(0, 0);
+    px[3][0] = u16(u16(G_GB(0, 0) - avg16(gr00, gr01)) + avg16(R_R(0, 0), R_R(0, 1)));
+    px[3][2] = u16(u16(G_GB(0, 0) - avg16(gb00, gb10)) + avg16(B_B(0, 0), B_B(1, 0)));
+#undef G_GR
+#undef R_R
+#undef B_B
+#undef G_GB
+    // colour matrix (Q8.8, floor /256) + tone curve -> u8, staged: pixel (2 tx + sx, 2 ty + sy) of channel c
+    const uint8_t *curve = reinterpret_cast<const uint8_t *>(s_curve);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int16_t *m = &s->matrix[4 * c];
+#pragma unroll
+        for (int sy = 0; sy < 2; sy++) {
+            uint8_t o[2];
+#pragma unroll
+            for (int sx = 0; sx < 2; sx++) {
+                const int site = 2 * sy + sx;
+                const int32_t ir = (int16_t)px[site][0], ig = (int16_t)px[site][1], ib = (int16_t)px[site][2];
+                const int32_t v = (((int32_t)m[3] + (int32_t)m[0] * ir) + (int32_t)m[1] * ig) + (int32_t)m[2] * ib;
+                o[sx] = curve[dev::clampi((int16_t)(v >> 8), 0, 1023)];
+            }
+            // column 2 tx sits at byte 2 tx + 3: an odd address, two byte stores
+            uint8_t *q = s_out + (c * 2 * TQY + 2 * ty + sy) * OP + 2 * tx + 3;
+            q[0] = o[0], q[1] = o[1];
+        }
+    }
+    __syncthreads();
+    // write-out: staged row (c, r) = curved row cyy = 2 QY0 + r + 1, staged column k = curved column cxx = 2 QX0 + 1 + k
+    // (= 64 bx - 1 + k): columns 1..60 are 15 aligned dwords, columns 0, 61, 62, 63 single bytes
+    const size_t plane = (size_t)CW * CH;
+    const int cx0 = 2 * QX0 + 1, cy0 = 2 * QY0 + 1;
+    for (int it = tid; it < 3 * 2 * TQY * 19; it += 256) {
+        const int rc = it / 19, k = it - rc * 19, c = rc / (2 * TQY), r = rc - c * (2 * TQY);
+        const int cyy = cy0 + r;
+        if (cyy < 0 || cyy >= CH) continue;
+        const uint8_t *srow = s_out + rc * OP + 3;
+        uint8_t *grow = cv + (size_t)c * plane + (size_t)cyy * CW;
+        if (k < 15) {
+            const int col = 1 + 4 * k, cxx = cx0 + col;
+            if (cxx >= 0 && cxx + 3 < CWL) {
+                *reinterpret_cast<uint32_t *>(grow + cxx) = *reinterpret_cast<const uint32_t *>(srow + col);
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                    if (cxx + b >= 0 && cxx + b < CWL) grow[cxx + b] = srow[col + b];
+            }
+        } else {
+            const int col = k == 15 ? 0 : 45 + k, cxx = cx0 + col;   // k = 16, 17, 18 -> columns 61, 62, 63
+            if (cxx >= 0 && cxx < CWL) grow[cxx] = srow[col];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void cp_sharpen(const uint8_t *__restrict__ cv, int CW, int CH, const CPSetup *__restrict__ s,
                                                  uint8_t *__restrict__ out, long out_sy, long out_sc, int W, int H) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -321,7 +465,10 @@ extern "C" int camera_pipe(halide_buffer_t *input, halide_buffer_t *matrix_3200,
     const long in_sy = input->dim[1].stride;
     const uint16_t *raw = dev_ptr<uint16_t>(input) + (long)(oy + 12 - input->dim[1].min) * in_sy + (ox + 16 - input->dim[0].min);
     const int nqx = floor_div(W, 2) + 2, nqy = floor_div(H, 2) + 2;
-    if (in_sy % 2 == 0 && (uintptr_t)raw % 4 == 0 && !getenv("HLMI_CP_SCALAR")) {
+    if (in_sy % 2 == 0 && (uintptr_t)raw % 4 == 0 && W % 2 == 0 && !getenv("HLMI_CP_SCALAR") && !getenv("HLMI_CP_QUAD")) {
+        HLMI_LAUNCH(uc, "cp_demosaic", st, cp_demosaic_tile, dim3((nqx + TQX - 1) / TQX, (nqy + TQY - 1) / TQY), dim3(256), 0, raw, in_sy,
+                    setup, cv, CW, CH, CWL, W, H);
+    } else if (in_sy % 2 == 0 && (uintptr_t)raw % 4 == 0 && !getenv("HLMI_CP_SCALAR")) {
         HLMI_LAUNCH(uc, "cp_demosaic", st, cp_demosaic<true>, dim3((nqx + 255) / 256, nqy), dim3(256), 0, raw, in_sy, setup, cv, CW, CH, CWL, nqx, nqy);
     } else {
         HLMI_LAUNCH(uc, "cp_demosaic", st, cp_demosaic<false>, dim3((nqx + 255) / 256, nqy), dim3(256), 0, raw, in_sy, setup, cv, CW, CH, CWL, nqx, nqy);
