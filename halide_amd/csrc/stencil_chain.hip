@@ -5,13 +5,14 @@
 // s is needed on the output grown by 2*(32-s).  Boundary: `int stencil_chain(halide_buffer_t *input,
 // halide_buffer_t *output)` (:9-10, :150).
 //
-// Design.  mod-2^16 arithmetic is a commutative ring, so (a) the weight matrix (i+3)(j+3) factors into a
-// horizontal [1 2 3 4 5] pass followed by a vertical [1 2 3 4 5] pass with bit-identical results, and
-// (b) sums may be carried in 32-bit registers and truncated on store.  FUSE = 8 stages are computed per
-// launch inside LDS (temporal tiling, like the reference's CPU schedule fuses groups of stages per tile,
-// :115-143): a workgroup loads a (64+32)x(64+32) u16 window, ping-pongs it through 8 stages (the valid
-// box shrinks by 2 per stage) and writes the central 64x64.  Intermediates between launches live on the
-// grown domain in a scratch arena.  HBM traffic: 4 launches x (2 B read + 2 B written)/px (+halo).
+// Design.  mod-2^16 arithmetic is a commutative ring, so (a) the weight matrix (i+3)(j+3) factors into a vertical
+// [1 2 3 4 5] pass and a horizontal [1 2 3 4 5] pass, in either order, with bit-identical results, and (b) v_pk_mad_u16
+// on packed pixel pairs IS the reference's wrapping uint16 arithmetic.  FUSE = 8 stages are computed per launch inside
+// LDS (temporal tiling, like the reference's CPU schedule fuses groups of stages per tile, :115-143): a workgroup loads a
+// 128 x 96 u16 window, ping-pongs it through 8 stages (the valid box shrinks by 2 per stage) and writes the central
+// 96 x 64.  Intermediates between launches live on the grown domain in a scratch arena.  HBM traffic: 4 launches x
+// (2 B read + 2 B written)/px (+halo); the kernel is bound by instruction issue (10 packed multiply-adds per pixel and
+// stage), priced in bench_apps.py against the packed-16-bit VALU rate.
 #include "hlmi_internal.h"
 
 using namespace hlmi;
@@ -19,73 +20,122 @@ using namespace hlmi;
 namespace {
 
 constexpr int STENCILS = 32;  // GeneratorParam stencils (:7)
-constexpr int FUSE = 8, TW = 64, TH = 64, RW = TW + 4 * FUSE, RH = TH + 4 * FUSE;
-constexpr int LDW = RW + 2;   // +2 u16 = one bank: rows start on different banks
-constexpr int LDD = LDW / 2;  // row pitch in dwords (49: odd)
+constexpr int FUSE = 8;
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-// src: u16 image with origin (sx0, sy0) in absolute coords and extent sw x sh; CLAMP => repeat_edge (stage 0)
-template<bool CLAMP>
-__global__ __launch_bounds__(256) void stencil_fused8(const uint16_t *__restrict__ src, long src_sy, int sx0, int sy0, int sw,
-                                                      int sh, uint16_t *__restrict__ dst, long dst_sy, int dx0, int dy0,
-                                                      int dw, int dh) {
-    __shared__ __attribute__((aligned(4))) uint16_t buf[2][RH * LDW];
-    const int tid = threadIdx.x;
-    const int ox = dx0 + blockIdx.x * TW, oy = dy0 + blockIdx.y * TH;  // absolute coords of the output tile
-    const int gx = ox - 2 * FUSE, gy = oy - 2 * FUSE;                  // absolute coords of the window origin
-    for (int i = tid; i < RW * RH; i += 256) {
-        int r = i / RW, c = i - r * RW;
-        int x = gx + c - sx0, y = gy + r - sy0;
-        if (CLAMP) {
-            x = min(max(x, 0), sw - 1);
-            y = min(max(y, 0), sh - 1);
-            buf[0][r * LDW + c] = src[(long)y * src_sy + x];
-        } else {
-            // windows of edge tiles may poke outside the producer's domain; those cells only ever feed outputs
-            // outside the destination domain, which are not stored
-            bool ok = x >= 0 && x < sw && y >= 0 && y < sh;
-            buf[0][r * LDW + c] = ok ? src[(long)y * src_sy + x] : (uint16_t)0;
+// ---- stencil_fused8w: a WAVE owns whole rows of the window: lane l holds the column pair (2l, 2l+1), so the horizontal
+// neighbours are the adjacent lanes and come by DPP wave shifts instead of two more LDS reads.  Per stage a wave walks its
+// share of the rows top to bottom with the five-row vertical window of RAW dwords in registers (vertical pass first),
+// then runs the horizontal pass on the vertical sums.  All 64 lanes are always active: what the edge lanes compute from
+// their missing neighbours is garbage that moves inwards 2 pixels per stage — exactly the shrinking valid box — and is
+// never stored.  Per pair, row and stage: 1 LDS read, 8 v_pk_mad_u16, 2 DPP moves, 2 v_alignbit, 1 LDS write.  (The
+// first version — a 96 x 96 window, lanes = (column pair, row segment), three LDS reads per pair for the horizontal
+// pass, ~10 % idle lanes, element-wise window moves — took 0.200 ms at 1536 x 2560 against 0.117 ms now.)
+constexpr int WTW = 96, WTH = 64, WRW = WTW + 4 * FUSE, WRH = WTH + 4 * FUSE;   // 128 x 96 window
+constexpr int WLD = WRW / 2;                                                      // row pitch in dwords (64)
+__device__ __forceinline__ uint32_t sc_lane_prev(uint32_t v) {   // lane-1's value (0 for lane 0): DPP wave_shr:1
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t sc_lane_next(uint32_t v) {   // lane+1's value (0 for lane 63): DPP wave_shl:1
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
+}
+// PIN / POUT: the window / the tile moves as aligned dwords (even row strides and origins: always true between launches
+// when the width is even)
+template<bool CLAMP, bool PIN, bool POUT>
+__global__ __launch_bounds__(256) void stencil_fused8w(const uint16_t *__restrict__ src, long src_sy, int sx0, int sy0, int sw,
+                                                       int sh, uint16_t *__restrict__ dst, long dst_sy, int dx0, int dy0,
+                                                       int dw, int dh) {
+    __shared__ uint32_t buf[2][WRH * WLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ox = dx0 + blockIdx.x * WTW, oy = dy0 + blockIdx.y * WTH;  // absolute coords of the output tile
+    const int gx = ox - 2 * FUSE, gy = oy - 2 * FUSE;                    // absolute coords of the window origin
+    // CLAMP (stage 0, the caller's input): dwords only for windows that lie inside the input (no clamp binds)
+    const bool inside = gx >= sx0 && gx + WRW <= sx0 + sw && gy >= sy0 && gy + WRH <= sy0 + sh;
+    if (PIN && (!CLAMP || inside)) {
+        for (int i = tid; i < WLD * WRH; i += 256) {
+            const int r = i / WLD, cd = i - r * WLD;
+            const int x = gx + 2 * cd - sx0, y = gy + r - sy0;
+            const bool ok = CLAMP || (x >= 0 && x + 1 < sw && y >= 0 && y < sh);
+            buf[0][i] = ok ? *reinterpret_cast<const uint32_t *>(src + (long)y * src_sy + x) : 0u;
+        }
+    } else {
+        uint16_t *b0 = reinterpret_cast<uint16_t *>(buf[0]);
+        for (int i = tid; i < WRW * WRH; i += 256) {
+            const int r = i / WRW, c = i - r * WRW;
+            int x = gx + c - sx0, y = gy + r - sy0;
+            if (CLAMP) {
+                x = min(max(x, 0), sw - 1);
+                y = min(max(y, 0), sh - 1);
+                b0[r * WRW + c] = src[(long)y * src_sy + x];
+            } else {
+                // windows of edge tiles may poke outside the producer's domain; those cells only ever feed outputs
+                // outside the destination domain, which are not stored
+                const bool ok = x >= 0 && x < sw && y >= 0 && y < sh;
+                b0[r * WRW + c] = ok ? src[(long)y * src_sy + x] : (uint16_t)0;
+            }
         }
     }
     __syncthreads();
     int cur = 0;
+    auto U = [](uint32_t v) { return __builtin_bit_cast(u16x2, v); };
+    // the weights live in scalar registers the compiler cannot see through: with literal 2 and 4 it strength-reduces the
+    // products to v_pk_lshlrev_b16 + v_pk_add_u16 (12 packed ops per row instead of 8 v_pk_mad_u16)
+    uint32_t w2 = 0x00020002u, w3 = 0x00030003u, w4 = 0x00040004u, w5 = 0x00050005u;
+    asm volatile("" : "+s"(w2), "+s"(w3), "+s"(w4), "+s"(w5));
+    const u16x2 k2 = U(w2), k3 = U(w3), k4 = U(w4), k5 = U(w5);
 #pragma unroll 1
     for (int m = 0; m < FUSE; m++) {
-        const int lo = 2 * (m + 1);           // output box [lo, RW-1-lo] x [lo, RH-1-lo] in window coords
-        const int ow = RW - 2 * lo, oh = RH - 2 * lo;
-        // A lane owns the column PAIR (x, x+1), x even, as one packed u16x2 register: the box edges lo and RW-1-lo
-        // are even / odd, rows are read as aligned dwords, and all arithmetic is packed 16-bit (v_pk_mad_u16 wraps
-        // each half mod 2^16, which is exactly the reference's uint16 arithmetic).
-        const int pw = ow / 2;                // pairs per row: 46 .. 32
-        const int nseg = 256 / pw;            // 5 .. 8 row segments
-        const int seglen = (oh + nseg - 1) / nseg;
-        const uint32_t *s = reinterpret_cast<const uint32_t *>(buf[cur]);
-        uint32_t *d = reinterpret_cast<uint32_t *>(buf[cur ^ 1]);
-        if (tid < pw * nseg) {
-            const int seg = tid / pw, xp = lo / 2 + (tid - seg * pw);   // dword column of the pair
-            const int ys = lo + seg * seglen, ye = min(ys + seglen, lo + oh);
-            const u16x2 k2 = {2, 2}, k3 = {3, 3}, k4 = {4, 4}, k5 = {5, 5};
-            u16x2 h0 = {0, 0}, h1 = h0, h2 = h0, h3 = h0, h4 = h0;
-#pragma unroll 5  // five rows per trip: the rotation of the five-row window becomes register renaming
-            for (int y = ys - 2; y < ye + 2; y++) {
-                const uint32_t *p = s + y * LDD + xp;
-                const uint32_t a = p[-1], b = p[0], c = p[1];          // (x-2,x-1) (x,x+1) (x+2,x+3)
-                const u16x2 A = __builtin_bit_cast(u16x2, a), B = __builtin_bit_cast(u16x2, b), C = __builtin_bit_cast(u16x2, c);
-                const u16x2 S1 = __builtin_bit_cast(u16x2, __builtin_amdgcn_alignbit(b, a, 16));  // (x-1, x)
-                const u16x2 S2 = __builtin_bit_cast(u16x2, __builtin_amdgcn_alignbit(c, b, 16));  // (x+1, x+2)
-                const u16x2 h = A + k2 * S1 + k3 * B + k4 * S2 + k5 * C;
-                h0 = h1, h1 = h2, h2 = h3, h3 = h4, h4 = h;
-                if (y >= ys + 2) d[(y - 2) * LDD + xp] = __builtin_bit_cast(uint32_t, (u16x2)(h0 + k2 * h1 + k3 * h2 + k4 * h3 + k5 * h4));
+        const int lo = 2 * (m + 1), oh = WRH - 2 * lo;   // valid output rows [lo, lo + oh)
+        const int seglen = (oh + 3) / 4;
+        const int ys = lo + wave * seglen, ye = min(ys + seglen, lo + oh);
+        const uint32_t *s = buf[cur] + lane;
+        uint32_t *d = buf[cur ^ 1] + lane;
+        if (ys < ye) {
+            u16x2 r0 = U(s[(ys - 2) * WLD]), r1 = U(s[(ys - 1) * WLD]), r2 = U(s[ys * WLD]), r3 = U(s[(ys + 1) * WLD]), r4;
+            // one output row: a..dd = rows y-2..y+1 (oldest first), e receives row y+2
+            auto step = [&](int y, const u16x2 &a, const u16x2 &b, const u16x2 &c, const u16x2 &dd, u16x2 &e) {
+                e = U(s[(y + 2) * WLD]);
+                const u16x2 v = a + k2 * b + k3 * c + k4 * dd + k5 * e;                    // pair (x, x+1), vertical sums
+                const uint32_t vb = __builtin_bit_cast(uint32_t, v);
+                const uint32_t va = sc_lane_prev(vb), vc = sc_lane_next(vb);               // (x-2, x-1), (x+2, x+3)
+                const u16x2 S1 = U(__builtin_amdgcn_alignbit(vb, va, 16)), S2 = U(__builtin_amdgcn_alignbit(vc, vb, 16));
+                d[y * WLD] = __builtin_bit_cast(uint32_t, (u16x2)(U(va) + k2 * S1 + k3 * v + k4 * S2 + k5 * U(vc)));
+            };
+            int y = ys;
+            // five rows per trip: the rotation of the five-row window is a renaming of the arguments (the DPP moves are
+            // convergent operations, which keeps the compiler from unrolling a loop with a remainder by itself)
+            for (; y + 5 <= ye; y += 5) {
+                step(y, r0, r1, r2, r3, r4);
+                step(y + 1, r1, r2, r3, r4, r0);
+                step(y + 2, r2, r3, r4, r0, r1);
+                step(y + 3, r3, r4, r0, r1, r2);
+                step(y + 4, r4, r0, r1, r2, r3);
+            }
+            for (; y < ye; y++) {
+                step(y, r0, r1, r2, r3, r4);
+                r0 = r1, r1 = r2, r2 = r3, r3 = r4;
             }
         }
         __syncthreads();
         cur ^= 1;
     }
-    const uint16_t *res = buf[cur];
-    for (int i = tid; i < TW * TH; i += 256) {
-        int r = i / TW, c = i - r * TW;
-        int X = ox + c - dx0, Y = oy + r - dy0;
-        if (X < dw && Y < dh) dst[(long)Y * dst_sy + X] = res[(r + 2 * FUSE) * LDW + c + 2 * FUSE];
+    if (POUT) {
+        for (int i = tid; i < (WTW / 2) * WTH; i += 256) {
+            const int r = i / (WTW / 2), cd = i - r * (WTW / 2);
+            const int X = ox + 2 * cd - dx0, Y = oy + r - dy0;
+            if (X + 1 < dw && Y < dh) {
+                *reinterpret_cast<uint32_t *>(dst + (long)Y * dst_sy + X) = buf[cur][(r + 2 * FUSE) * WLD + cd + FUSE];
+            } else if (X < dw && Y < dh) {
+                dst[(long)Y * dst_sy + X] = (uint16_t)(buf[cur][(r + 2 * FUSE) * WLD + cd + FUSE] & 0xffffu);
+            }
+        }
+        return;
+    }
+    const uint16_t *res = reinterpret_cast<const uint16_t *>(buf[cur]);
+    for (int i = tid; i < WTW * WTH; i += 256) {
+        const int r = i / WTW, c = i - r * WTW;
+        const int X = ox + c - dx0, Y = oy + r - dy0;
+        if (X < dw && Y < dh) dst[(long)Y * dst_sy + X] = res[(r + 2 * FUSE) * WRW + c + 2 * FUSE];
     }
 }
 
@@ -144,14 +194,22 @@ extern "C" int stencil_chain(halide_buffer_t *input, halide_buffer_t *output) {
         const int dx0 = ox0 - g, dy0 = oy0 - g, dw = W + 2 * g, dh = H + 2 * g;
         uint16_t *dst = (L == NL - 1) ? dev_ptr<uint16_t>(output) : tmp[L & 1];
         long dst_sy = (L == NL - 1) ? (long)output->dim[1].stride : (long)dw;
-        dim3 grid((dw + TW - 1) / TW, (dh + TH - 1) / TH);
+        dim3 gridw((dw + WTW - 1) / WTW, (dh + WTH - 1) / WTH);
+        // dword moves: the intermediates are dense planes on even origins (their offsets from the tile grid are
+        // multiples of 2 FUSE), so an even width makes every pair an aligned dword; the user's output needs checking
+        const bool pin = L > 0 ? (sw % 2 == 0 && src_sy % 2 == 0)
+                               : (src_sy % 2 == 0 && (uintptr_t)src % 4 == 0 && ((dx0 - 2 * FUSE - sx0) & 1) == 0);
+        const bool pout = dst_sy % 2 == 0 && (uintptr_t)dst % 4 == 0;
+#define SC_W(C, I, O)                                                                                                          \
+HLMI_LAUNCH(uc, "stencil_fused8", ctx.stream, (stencil_fused8w<C, I, O>), gridw, dim3(256), 0, src, src_sy, sx0, sy0, sw, sh, dst, \
+            dst_sy, dx0, dy0, dw, dh)
         if (L == 0) {
-            HLMI_LAUNCH(uc, "stencil_fused8", ctx.stream, stencil_fused8<true>, grid, dim3(256), 0, src, src_sy, sx0, sy0, sw, sh,
-                        dst, dst_sy, dx0, dy0, dw, dh);
-        } else {
-            HLMI_LAUNCH(uc, "stencil_fused8", ctx.stream, stencil_fused8<false>, grid, dim3(256), 0, src, src_sy, sx0, sy0, sw, sh,
-                        dst, dst_sy, dx0, dy0, dw, dh);
+            if (pin) { if (pout) SC_W(true, true, true); else SC_W(true, true, false); }
+            else { if (pout) SC_W(true, false, true); else SC_W(true, false, false); }
         }
+        else if (pin) { if (pout) SC_W(false, true, true); else SC_W(false, true, false); }
+        else { if (pout) SC_W(false, false, true); else SC_W(false, false, false); }
+#undef SC_W
         src = dst, src_sy = dst_sy, sx0 = dx0, sy0 = dy0, sw = dw, sh = dh;
     }
     mark_output_written(output);

@@ -71,11 +71,13 @@ def test_hip_full_size_properties(hl, oracle):
 
 
 @pytest.mark.gpu
-def test_hip_output_window_inside_larger_input(hl, oracle):
+@pytest.mark.parametrize("x0,y0,w,h", [(30, 20, 50, 40), (31, 21, 51, 41), (7, 0, 110, 90), (0, 3, 64, 31)])
+def test_hip_output_window_inside_larger_input(hl, oracle, x0, y0, w, h):
+    """Even and odd origins / widths: the dword and the element-wise window moves of the kernel."""
     rng = np.random.default_rng(5)
     inp = rng.integers(0, 65536, (90, 120), dtype=np.uint16)
     full = oracle.stencil_chain(inp)
     a = hl.Buffer(inp)
-    o = hl.Buffer(np.zeros((40, 50), np.uint16)).set_min(30, 20)
+    o = hl.Buffer(np.zeros((h, w), np.uint16)).set_min(x0, y0)
     hl.stencil_chain(a, o)
-    assert np.array_equal(o.numpy(), full[20:60, 30:80])
+    assert np.array_equal(o.numpy(), full[y0:y0 + h, x0:x0 + w])
