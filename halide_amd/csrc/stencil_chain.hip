@@ -32,6 +32,7 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 // first version — a 96 x 96 window, lanes = (column pair, row segment), three LDS reads per pair for the horizontal
 // pass, ~10 % idle lanes, element-wise window moves — took 0.200 ms at 1536 x 2560 against 0.117 ms now.)
 constexpr int WTW = 96, WTH = 64, WRW = WTW + 4 * FUSE, WRH = WTH + 4 * FUSE;   // 128 x 96 window
+static_assert(WRW == 128, "one wave = one window row: 64 lanes x 2 columns");
 constexpr int WLD = WRW / 2;                                                      // row pitch in dwords (64)
 __device__ __forceinline__ uint32_t sc_lane_prev(uint32_t v) {   // lane-1's value (0 for lane 0): DPP wave_shr:1
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
