@@ -49,6 +49,67 @@ def test_oracle_flat_gray_scene(oracle):
         assert np.all(out[c] == out[c, 0, 0])  # flat in, flat out (sharpening of a constant is the constant)
 
 
+
+def _numpy_camera_pipe(raw, matrix, curve, strength, out_w, out_h):
+    """Independent restatement of the integer stages (generator :14-33, :47-152, :240-299, :346-404, :406-413) with numpy
+    rolls on the whole raw frame; wrapped borders never reach the output region (>= 5 quads of margin, <= 4 of reach).
+    matrix, curve and strength are the set-up values (checked separately in test_oracle_setup_values)."""
+    u16, u32, i32 = np.uint16, np.uint32, np.int32
+    R = raw.astype(u16)
+    sh = lambda a, dx, dy: np.roll(a, (-dy, -dx), (0, 1))                 # sh(a, dx, dy)[y, x] = a[y + dy, x + dx]
+    avg = lambda a, b: ((a.astype(u32) + b + 1) // 2).astype(a.dtype)
+    absd = lambda a, b: np.where(a > b, a - b, b - a).astype(u16)
+    a = np.maximum(np.maximum(sh(R, -2, 0), sh(R, 2, 0)), np.maximum(sh(R, 0, -2), sh(R, 0, 2)))
+    den = np.minimum(R, a)                                                # clamp(input, 0, a), :246
+    g_gr, r_r, b_b, g_gb = den[0::2, 0::2], den[0::2, 1::2], den[1::2, 0::2], den[1::2, 1::2]
+    g_r = np.where(absd(sh(g_gr, 1, 0), g_gr) < absd(sh(g_gb, 0, -1), g_gb), avg(sh(g_gr, 1, 0), g_gr), avg(sh(g_gb, 0, -1), g_gb))
+    g_b = np.where(absd(sh(g_gb, -1, 0), g_gb) < absd(sh(g_gr, 0, 1), g_gr), avg(sh(g_gb, -1, 0), g_gb), avg(sh(g_gr, 0, 1), g_gr))
+    r_gr = (g_gr - avg(g_r, sh(g_r, -1, 0))) + avg(sh(r_r, -1, 0), r_r)   # u16 arithmetic wraps
+    b_gr = (g_gr - avg(g_b, sh(g_b, 0, -1))) + avg(b_b, sh(b_b, 0, -1))
+    r_gb = (g_gb - avg(g_r, sh(g_r, 0, 1))) + avg(r_r, sh(r_r, 0, 1))
+    b_gb = (g_gb - avg(g_b, sh(g_b, 1, 0))) + avg(b_b, sh(b_b, 1, 0))
+    rp = (g_b - avg(g_r, sh(g_r, -1, 1))) + avg(r_r, sh(r_r, -1, 1))
+    rn = (g_b - avg(sh(g_r, -1, 0), sh(g_r, 0, 1))) + avg(sh(r_r, -1, 0), sh(r_r, 0, 1))
+    r_b = np.where(absd(r_r, sh(r_r, -1, 1)) < absd(sh(r_r, -1, 0), sh(r_r, 0, 1)), rp, rn)
+    bp = (g_r - avg(g_b, sh(g_b, 1, -1))) + avg(b_b, sh(b_b, 1, -1))
+    bn = (g_r - avg(sh(g_b, 1, 0), sh(g_b, 0, -1))) + avg(sh(b_b, 1, 0), sh(b_b, 0, -1))
+    b_r = np.where(absd(b_b, sh(b_b, 1, -1)) < absd(sh(b_b, 1, 0), sh(b_b, 0, -1)), bp, bn)
+
+    def interleave(gr, r, b, gb):                                         # :24-33, :133-138
+        out = np.empty(R.shape, u16)
+        out[0::2, 0::2], out[0::2, 1::2], out[1::2, 0::2], out[1::2, 1::2] = gr, r, b, gb
+        return out.view(np.int16).astype(i32)                             # reinterpret as signed (:143)
+    ir, ig, ib = interleave(r_gr, r_r, r_b, r_gb), interleave(g_gr, g_r, g_b, g_gb), interleave(b_gr, b_r, b_b, b_gb)
+    m = matrix.astype(i32)
+    curved = []
+    for c in range(3):
+        v = (((m[c, 3] + m[c, 0] * ir) + m[c, 1] * ig) + m[c, 2] * ib) >> 8   # floor division by 256 (:287-289)
+        v = v.astype(np.int16)
+        curved.append(curve[np.clip(v, 0, 1023)].astype(np.uint8))           # :346
+    out = np.zeros((3, out_h, out_w), np.uint8)
+    wrap16 = lambda v: ((v + 32768) % 65536 - 32768)
+    for c in range(3):
+        p = curved[c]
+        uy = avg(avg(sh(p, 0, -1), sh(p, 0, 1)), p)                      # blur121 (:20-22, :386-390)
+        un = avg(avg(sh(uy, -1, 0), sh(uy, 1, 0)), uy)
+        mask = p.astype(i32) - un.astype(i32)
+        q = wrap16(mask * int(strength)) >> 5                             # int16 x uint8 -> int16 wraps; floor / 32
+        v = wrap16(p.astype(i32) + q)
+        out[c] = np.clip(v, 0, 255).astype(np.uint8)[12:12 + out_h, 16:16 + out_w]   # shifted(x, y) = input(x + 16, y + 12)
+    return out
+
+
+@pytest.mark.parametrize("kind,seed", [("scene", 1), ("uniform", 2), ("full", 3)])
+def test_oracle_matches_numpy_restatement(oracle, kind, seed):
+    """The C oracle against a second, array-at-a-time reading of the generator (integer stages, bit for bit).  "full"
+    feeds 16-bit raw values: the correction terms of the demosaic wrap, the matrix product exceeds int16."""
+    raw = _raw(200, 152, seed, kind)
+    m, curve, s = oracle.camera_pipe_setup(M3200, M7000, 3700.0, 2.0, 50.0, 1.0, 25, 1023)
+    want = _numpy_camera_pipe(raw, m, curve, s, 160, 120)
+    got = oracle.camera_pipe(raw, M3200, M7000, 3700.0, 2.0, 50.0, 1.0, 25, 1023, 160, 120)
+    assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} of {got.size} differ"
+
+
 def _run(hl, raw, out_w, out_h, p=PARAMS, in_min=None, out_min=None):
     bi, b3, b7 = hl.Buffer(raw), hl.Buffer(M3200.copy()), hl.Buffer(M7000.copy())
     bo = hl.Buffer(np.zeros((3, out_h, out_w), np.uint8))
