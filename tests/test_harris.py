@@ -25,6 +25,33 @@ def test_oracle_against_float64_reference(oracle):
     assert got.shape == ref.shape and np.max(np.abs(got - ref)) < 1e-6
 
 
+
+def test_oracle_matches_float32_numpy_restatement_bit_for_bit(oracle):
+    """Second reading of the generator (:7-62), array at a time in float32: same operator order, one rounding each."""
+    f32 = np.float32
+    inp = _img(57, 43, 2)
+    h, w = inp.shape[1:]
+    g = (f32(0.299) * inp[0] + f32(0.587) * inp[1]) + f32(0.114) * inp[2]
+    a, b, c, d = f32(-1.0) / f32(12), f32(1.0) / f32(12), f32(-2.0) / f32(12), f32(2.0) / f32(12)
+    G = lambda dx, dy: g[1 + dy:h - 1 + dy, 1 + dx:w - 1 + dx]            # gray(x + dx, y + dy) on the interior
+    iy = ((((G(-1, -1) * a + G(-1, 1) * b) + G(0, -1) * c) + G(0, 1) * d) + G(1, -1) * a) + G(1, 1) * b
+    ix = ((((G(-1, -1) * a + G(1, -1) * b) + G(-1, 0) * c) + G(1, 0) * d) + G(-1, 1) * a) + G(1, 1) * b
+
+    def s3(f):                                                            # sum3x3 (:7-11): x outer, y inner, left to right
+        hh, ww = f.shape
+        F = lambda dx, dy: f[1 + dy:hh - 1 + dy, 1 + dx:ww - 1 + dx]
+        acc = F(-1, -1)
+        for dx, dy in [(-1, 0), (-1, 1), (0, -1), (0, 0), (0, 1), (1, -1), (1, 0), (1, 1)]:
+            acc = acc + F(dx, dy)
+        return acc
+    sxx, syy, sxy = s3(ix * ix), s3(iy * iy), s3(ix * iy)
+    trace = sxx + syy
+    want = (sxx * syy - sxy * sxy) - (f32(0.04) * trace) * trace         # output region starts at (2, 2)
+    got = oracle.harris(inp, out_origin=(2, 2), out_size=(w - 4, h - 4))
+    assert got.dtype == np.float32 and want.dtype == np.float32
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"{np.count_nonzero(got != want)} differ"
+
+
 def _run(hl, inp, out_min=(3, 3), out_size=None, in_min=None):
     a = hl.Buffer(inp)
     if in_min:

@@ -30,6 +30,31 @@ def test_oracle_flat_image_maps_to_full_scale(oracle):
     assert (out == 255).all()   # every pixel is in the top cdf bin: eq = 255, chroma offsets are 0 for gray input
 
 
+
+def _numpy_hist(inp):
+    """Second reading of the generator (:13-56), array at a time in float32, one rounding per operator as written."""
+    f32 = np.float32
+    r, g, b = (inp[c].astype(f32) for c in range(3))
+    y = (f32(0.299) * r + f32(0.587) * g) + f32(0.114) * b
+    cr = (r - y) * f32(0.713) + f32(128)
+    cb = (b - y) * f32(0.564) + f32(128)
+    bins = np.clip(y, f32(0), f32(255)).astype(np.int32)                # cast<int>(clamp(Y, 0, 255))
+    cdf = np.cumsum(np.bincount(bins.ravel(), minlength=256)).astype(np.int32)
+    scale = f32(255.0) / f32(inp.shape[1] * inp.shape[2])
+    eq = np.clip(cdf[bins].astype(f32) * scale, f32(0), f32(255))
+    red = np.clip(eq + (cr - f32(128)) * f32(1.4), f32(0), f32(255))
+    green = np.clip((eq - f32(0.343) * (cb - f32(128))) - f32(0.711) * (cr - f32(128)), f32(0), f32(255))
+    blue = np.clip(eq + f32(1.765) * (cb - f32(128)), f32(0), f32(255))
+    return np.stack([red, green, blue]).astype(np.uint8)                # u8(): truncation of values in [0, 255]
+
+
+@pytest.mark.parametrize("kind,seed", [("scene", 5), ("uniform", 6)])
+def test_oracle_matches_numpy_restatement(oracle, kind, seed):
+    inp = _img(90, 70, seed, kind)
+    got, want = oracle.hist(inp), _numpy_hist(inp)
+    assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} of {got.size} differ"
+
+
 def _run(hl, inp, out_min=None, out_size=None):
     a = hl.Buffer(inp)
     ow, oh = out_size if out_size else (inp.shape[2], inp.shape[1])

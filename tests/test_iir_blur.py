@@ -22,6 +22,28 @@ def test_oracle_against_float64_recurrence(oracle):
     assert np.max(np.abs(got - ref)) < 1e-5
 
 
+
+def test_oracle_matches_float32_recurrence_bit_for_bit(oracle):
+    """The same recurrence (generator :18-31, :146-156) row by row in float32: (1 - alpha) is rounded once, every step is
+    one multiply, one multiply, one add."""
+    f32 = np.float32
+    rng = np.random.default_rng(1)
+    inp = rng.random((3, 23, 17), dtype=np.float32)
+    alpha = f32(0.3)
+    c1 = f32(1) - alpha
+
+    def cols_T(a):                            # (H, W) -> blurred columns, transposed (W, H)
+        b = a.copy()
+        for y in range(1, b.shape[0]):
+            b[y] = c1 * b[y - 1] + alpha * a[y]
+        for y in range(b.shape[0] - 2, -1, -1):
+            b[y] = c1 * b[y + 1] + alpha * b[y]
+        return np.ascontiguousarray(b.T)
+    want = np.stack([cols_T(cols_T(ch)) for ch in inp])
+    got = oracle.iir_blur(inp, float(alpha))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"{np.count_nonzero(got != want)} differ"
+
+
 def test_oracle_constant_image_is_a_fixed_point(oracle):
     inp = np.full((3, 20, 30), 0.625, np.float32)
     assert np.array_equal(oracle.iir_blur(inp, 0.5), inp)     # (1-a) v + a v with a = 1/2 and v = 5/8 is exact

@@ -35,6 +35,26 @@ def test_oracle_against_float64_reference(oracle):
     assert np.max(np.abs(got - ref)) < 1e-5
 
 
+
+def test_oracle_matches_float32_numpy_restatement_bit_for_bit(oracle):
+    """Second reading of the generator (:13-52), array at a time in float32, with the folded kernel constants."""
+    f32 = np.float32
+    inp = _img(45, 37, 4)
+    h, w = inp.shape[1:]
+    k = oracle.unsharp_kernel()
+    pad = np.pad(inp, ((0, 0), (3, 3), (3, 3)), mode="edge")              # repeat_edge (:20)
+    g = (f32(0.299) * pad[0] + f32(0.587) * pad[1]) + f32(0.114) * pad[2]
+    gy = lambda d: g[3 + d:3 + d + h, :]                                   # gray(x, y + d) for every padded column
+    by = ((k[0] * gy(0) + k[1] * (gy(-1) + gy(1))) + k[2] * (gy(-2) + gy(2))) + k[3] * (gy(-3) + gy(3))
+    bx_ = lambda d: by[:, 3 + d:3 + d + w]
+    bx = ((k[0] * bx_(0) + k[1] * (bx_(-1) + bx_(1))) + k[2] * (bx_(-2) + bx_(2))) + k[3] * (bx_(-3) + bx_(3))
+    g0 = g[3:3 + h, 3:3 + w]
+    ratio = (f32(2.0) * g0 - bx) / g0
+    want = (ratio[None] * inp).astype(f32)
+    got = oracle.unsharp(inp)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"{np.count_nonzero(got != want)} differ"
+
+
 def _run(hl, inp, out_min=None, out_size=None, in_min=None):
     a = hl.Buffer(inp)
     if in_min:
