@@ -74,6 +74,25 @@ def main():
                           "write_gbs": round(m["write_gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "copy_frac_of_peak": round(m["copy_gbs"] / HBM_PEAK_GBS, 4)}), flush=True)
 
+    # ---- the headline pipeline on the other inputs SURVEY.md §8(d) lists for configs[2] (bench.py uses the smooth synthetic
+    #      frame): uniform full-range noise — the worst case for the data-dependent plane gathers of the up pass — and
+    #      7680x4320; one stream, one frame at a time
+    if not only or "local_laplacian" in only:
+        for tag, (W, H), kind in (("uniform noise 3840x2160", (3840, 2160), "uniform"), ("smooth 7680x4320", (7680, 4320), "smooth"),
+                                  ("uniform noise 7680x4320", (7680, 4320), "uniform")):
+            if kind == "uniform":
+                img = rng.integers(0, 65536, (3, H, W), dtype=np.uint16)
+            else:
+                yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+                base = (np.sin(xx / 311.0) + np.cos(yy / 173.0) + np.sin((xx + yy) / 97.0) + 3.3) / 6.6
+                img = np.clip(np.stack([base * 65535.0, np.roll(base, 64, 1) * 52000.0, base[::-1] * 46000.0]) +
+                              rng.normal(0.0, 900.0, (3, H, W)).astype(np.float32), 0, 65535).astype(np.uint16)
+            a, o = hl.Buffer(img), hl.Buffer(np.zeros_like(img))
+            call = lambda: hl.local_laplacian(a, 8, 1.0 / 7.0, 1.0, o)
+            t = timed(call, o, 20)
+            emit("local_laplacian", f"apps/local_laplacian J=8 levels=8, u16 RGB, {tag}, 1 stream", t, W * H, "hbm",
+                 12.0 * W * H / t / 1e9, HBM_PEAK_GBS, "GB/s", {"alg_bytes": 12 * W * H})
+
     # ---- configs[0]: blur 3x3, u16 1536x2560 (input 1538x2562)
     if not only or "blur" in only:
         W, H = 1536, 2560
