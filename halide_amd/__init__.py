@@ -99,6 +99,8 @@ _tls = threading.local()
 
 def _on_error(_uc, msg):
     _tls.last_error = msg.decode("utf-8", "replace") if msg else ""
+    if threading.current_thread() is not threading.main_thread():
+        _batch_error[:] = [_tls.last_error]
 
 
 _error_cb = _ERR_CB(_on_error)
@@ -427,6 +429,53 @@ def camera_pipe(input, matrix_3200, matrix_7000, color_temp, gamma, contrast, sh
     return _check(_cam(_as_ptr(input), _as_ptr(matrix_3200), _as_ptr(matrix_7000), float(color_temp), float(gamma),
                        float(contrast), float(sharpen_strength), int(black_level), int(white_level),
                        _as_ptr(processed)))
+
+
+def device_count() -> int:
+    """Usable gfx950 devices visible to this process."""
+    lib.hlmi_device_count.restype = C.c_int
+    return lib.hlmi_device_count()
+
+
+def run_batch(name: str, frames, devices=None, streams_per_device: int = 1) -> int:
+    """The in-process frame sharder (`hlmi_run_batch`, include/hlmi_runtime.h): run pipeline `name` once
+    per frame, frames dealt round-robin to one host thread + HIP stream per entry of `devices` (x streams_per_device).
+
+    `frames` is a list of argument tuples in the pipeline's own order (Buffers and Python scalars), exactly what
+    `<name>_argv` receives per call.  Outputs are left device-dirty on the device that produced them; `Buffer.numpy()`
+    brings them back from there.  Returns 0 or raises HalideError with the first failing frame's code."""
+    md = metadata(name)
+    n_args = md.num_arguments
+    fn = getattr(lib, name + "_argv")
+    keep = []          # ctypes objects that must outlive the call
+    argvs = (C.POINTER(C.c_void_p) * max(len(frames), 1))()
+    for i, frame in enumerate(frames):
+        if len(frame) != n_args:
+            raise TypeError(f"{name} takes {n_args} arguments, frame {i} has {len(frame)}")
+        argv = (C.c_void_p * n_args)()
+        for j, v in enumerate(frame):
+            a = md.arguments[j]
+            if a.kind == 0:
+                box = C.c_float(v) if a.type.code == 2 else (C.c_int32(v) if a.type.bits == 32 else C.c_int64(v))
+                keep.append(box)
+                argv[j] = C.cast(C.pointer(box), C.c_void_p)
+            else:
+                argv[j] = C.cast(C.pointer(v.raw), C.c_void_p)
+        keep.append(argv)
+        argvs[i] = C.cast(argv, C.POINTER(C.c_void_p))
+    if devices is None:
+        devices = list(range(max(device_count(), 1)))
+    devs = (C.c_int * len(devices))(*devices)
+    lib.hlmi_run_batch.restype = C.c_int
+    lib.hlmi_run_batch.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_void_p)), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]
+    code = lib.hlmi_run_batch(C.cast(fn, C.c_void_p), argvs, len(frames), devs, len(devices), int(streams_per_device))
+    if code != 0:
+        raise HalideError(code, _batch_error[0] if _batch_error else "")
+    return 0
+
+
+# worker threads of hlmi_run_batch report through the same handler but on their own threads: keep the last message
+_batch_error: list = []
 
 
 def metadata(name: str) -> halide_filter_metadata_t:

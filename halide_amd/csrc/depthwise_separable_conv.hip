@@ -114,7 +114,11 @@ extern "C" int depthwise_separable_conv(halide_buffer_t *input, halide_buffer_t 
         int ci = 32, w = 112, h = 112, n = 4, cm = 1, fw = 3, fh = 3, co = 16;
         if (real(input)) ci = input->dim[0].extent, w = input->dim[1].extent, h = input->dim[2].extent, n = input->dim[3].extent;
         else if (real(output)) w = output->dim[1].extent, h = output->dim[2].extent, n = output->dim[3].extent;
-        if (real(depthwise_filter)) cm = depthwise_filter->dim[0].extent, fw = depthwise_filter->dim[2].extent, fh = depthwise_filter->dim[3].extent;
+        // channel multiplier and filter size ARE the extents of depthwise_filter as passed (:27-29), also in query mode:
+        // RunGen hands over query buffers shaped by the estimates (tools/RunGen.h:362-364), and :86 estimates CI / CO = 2
+        if (real(depthwise_filter) || depthwise_filter->dim[0].extent > 0) cm = depthwise_filter->dim[0].extent;
+        if (real(depthwise_filter) || depthwise_filter->dim[2].extent > 0) fw = depthwise_filter->dim[2].extent;
+        if (real(depthwise_filter) || depthwise_filter->dim[3].extent > 0) fh = depthwise_filter->dim[3].extent;
         if (real(output)) co = output->dim[0].extent;
         else if (real(pointwise_filter)) co = pointwise_filter->dim[0].extent;
         else if (real(bias)) co = bias->dim[0].extent;

@@ -47,20 +47,42 @@ struct BufArg {
     bool is_output;
 };
 
-// step 1 of the entry protocol (src/UnpackBuffers.cpp:148)
+// ---------------------------------------------------------------------------------------------
+// The entry prologue.  The reference emits its argument checks in a fixed order (src/AddImageChecks.cpp:716-760,
+// reverse of the prepend order; buffers in the order of a std::map keyed by buffer name, i.e. alphabetical):
+//   0. null buffer arguments, in signature order                       (src/UnpackBuffers.cpp:148)          -12
+//   1. scalar parameter ranges                                           (src/AddParameterChecks.cpp)         -9 / -10
+//   2. bounds-query mode: rewrite the query buffers, return 0            (:709-713)
+//   3. per buffer: type, then dimensionality                             (asserts_type_checks, :329-347)      -3 / -43
+//   4. per buffer, per dimension: stride / min / extent constraints      (asserts_constrained, :621-645)      -8
+//   5. per buffer, per dimension: required region, then extent >= 0      (asserts_required, :414-418, :466-470) -4 / -28
+//   6. per buffer, per dimension: |extent * stride| and the running product of extents <= 2^31 - 1
+//                                                                        (dims_no_overflow_asserts, :436-462) -5 / -6
+//   7. host pointers                                                     (asserts_host_non_null, :648-655)    -34
+// The pipelines call the check_* helpers below in whatever order is convenient for them; failures of phases 4-6 are
+// not reported on the spot but RECORDED with their (phase, buffer rank, dimension, kind) key, and the one the
+// reference would have hit first is reported by checks_done() — which acquire_device() calls, so no kernel is ever
+// enqueued with unchecked arguments.  tests/test_entry_protocol.py pins the codes and the order.
+// step 0; also (re)starts the recording for this call and ranks the buffers by name
 int check_not_null(void *uc, const BufArg *args, int n);
 // step 2 (src/AddImageChecks.cpp:315-318, HalideRuntime.h:1851-1853)
 bool any_bounds_query(const BufArg *args, int n);
-// steps 3-4 (src/AddImageChecks.cpp:329-347)
+// step 3, reported immediately (everything after it indexes dim[]).  In bounds-query mode the reference skips the
+// type check and rewrites type and dimensions of the query buffers (BufferBuilder, :478-494): here a query buffer gets
+// its type rewritten too, but a wrong dimensionality stays an error (-43) — writing dim[] entries the caller did not
+// provide is not something a drop-in should copy.
 int check_type_and_dims(void *uc, const BufArg *args, int n);
-// step 5a: extents >= 0, dim[0].stride == 1 (src/Parameter.cpp:30-35), sizes < 2^31
-// (src/AddImageChecks.cpp:414-471)
+// steps 4-6 for one buffer: dim[0].stride == 1 (src/Parameter.cpp:30-35), extents >= 0, sizes < 2^31.  Always
+// returns 0 (recorded).
 int check_shape(void *uc, const BufArg &a);
-// step 5b: [min, min+extent) of dimension d must cover [req_min, req_min+req_extent)
-// (src/AddImageChecks.cpp:436-458 -> halide_error_access_out_of_bounds)
+// step 5: [min, min+extent) of dimension d must cover [req_min, req_min+req_extent)
+// (src/AddImageChecks.cpp:393-418 -> halide_error_access_out_of_bounds).  Always returns 0 (recorded).
 int check_covers(void *uc, const BufArg &a, int d, int req_min, int req_extent);
-// pinned constraint helper (halide_error_constraint_violated, src/runtime/errors.cpp:104)
+// step 4, a pinned constraint "<buffer>.<field>.<dim> == expect" (halide_error_constraint_violated,
+// src/runtime/errors.cpp:104); `what` must start with the buffer's name.  Always returns 0 (recorded).
 int check_equal(void *uc, const char *what, int val, const char *expect_what, int expect);
+// report the recorded failure the reference would have hit first (0 if none) and forget the rest
+int checks_done(void *uc);
 // bounds-query answer: rewrite dim[] to a dense planar shape (stride[0]=1) — only if `buf` is itself
 // a query buffer (host==NULL && device==0), as the reference does (AddImageChecks.cpp:480-497).
 void answer_query(halide_buffer_t *buf, const int *mins, const int *extents);
@@ -79,7 +101,10 @@ struct DeviceCtx {
 };
 // choose device (halide_set_gpu_device / HL_GPU_DEVICE / 0), hipSetDevice, choose stream.
 // Fails with -29 when no gfx950 device is usable: there is NO CPU fallback.
-int acquire_device(void *uc, DeviceCtx *ctx);
+// `lock` = take the stream's call lock (pipeline entry points do; copies, syncs and allocations do not: they never
+// touch the scratch arena, and holding the lock across a blocking wait would stall every other caller of the stream).
+// Reports the failure recorded by the check_* helpers first, if there is one.
+int acquire_device(void *uc, DeviceCtx *ctx, bool lock = true);
 // scratch arena owned by (device, stream); contents valid until the next call that asks for a
 // workspace on the same stream (stream order makes reuse across back-to-back calls safe).
 int get_workspace(void *uc, const DeviceCtx &ctx, size_t bytes, void **ptr);

@@ -16,6 +16,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include <dlfcn.h>
 #include <stdlib.h>
 
 #include "hlmi_internal.h"
@@ -45,7 +46,52 @@ static std::atomic<halide_print_t> g_print{default_print};
 static std::atomic<halide_malloc_t> g_malloc{default_malloc};
 static std::atomic<halide_free_t> g_free{default_free};
 
+// ---- recorded check failures (see hlmi_internal.h: the entry prologue) ------------------------------
+struct PendingFailure {
+    bool any = false;
+    uint32_t key = 0;  // (phase << 24) | (buffer rank << 16) | (dimension << 8) | kind — smaller = checked earlier
+    int code = 0;
+    char msg[512];
+};
+static thread_local PendingFailure t_fail;
+static thread_local const BufArg *t_args = nullptr;
+static thread_local int t_nargs = 0;
+static thread_local int t_rank[16];
+
+static int rank_of(const char *name, size_t len) {
+    for (int i = 0; i < t_nargs && i < 16; i++) {
+        if (strlen(t_args[i].name) == len && strncmp(t_args[i].name, name, len) == 0) return t_rank[i];
+    }
+    return 15;
+}
+
+static int record(int phase, int rank, int dim, int kind, int code, const char *fmt, ...) __attribute__((format(printf, 6, 7)));
+static int record(int phase, int rank, int dim, int kind, int code, const char *fmt, ...) {
+    uint32_t key = ((uint32_t)phase << 24) | ((uint32_t)(rank & 0xff) << 16) | ((uint32_t)(dim & 0xff) << 8) | (uint32_t)(kind & 0xff);
+    if (t_fail.any && t_fail.key <= key) return 0;
+    t_fail.any = true, t_fail.key = key, t_fail.code = code;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_fail.msg, sizeof t_fail.msg, fmt, ap);
+    va_end(ap);
+    return 0;
+}
+
+int checks_done(void *uc) {
+    if (!t_fail.any) return 0;
+    t_fail.any = false;
+    halide_error(uc, t_fail.msg);
+    return t_fail.code;
+}
+
 int report(void *uc, int code, const char *fmt, ...) {
+    // a failure recorded earlier in the prologue pre-empts anything found later — except the scalar-parameter range
+    // checks, which the reference performs before every image check (src/Lower.cpp:189 vs :251)
+    if (t_fail.any && code != halide_error_code_param_too_small && code != halide_error_code_param_too_large &&
+        code != halide_error_code_buffer_argument_is_null) {
+        return checks_done(uc);
+    }
+    t_fail.any = false;
     char msg[1024];
     va_list ap;
     va_start(ap, fmt);
@@ -73,11 +119,18 @@ const char *type_name(uint32_t abi, char tmp[16]) {
 // ------------------------------------------------------------------------------------------------
 // argument checks
 int check_not_null(void *uc, const BufArg *args, int n) {
+    t_fail.any = false;
+    t_args = args, t_nargs = n;
     for (int i = 0; i < n; i++) {
         if (!args[i].buf) {
             return report(uc, halide_error_code_buffer_argument_is_null, "Buffer argument %s is nullptr",
                           args[i].name);
         }
+    }
+    for (int i = 0; i < n && i < 16; i++) {
+        int r = 0;
+        for (int j = 0; j < n; j++) r += strcmp(args[j].name, args[i].name) < 0;
+        t_rank[i] = r;
     }
     return 0;
 }
@@ -90,82 +143,101 @@ bool any_bounds_query(const BufArg *args, int n) {
 }
 
 int check_type_and_dims(void *uc, const BufArg *args, int n) {
-    for (int i = 0; i < n; i++) {
-        const BufArg &a = args[i];
-        uint32_t given = buf_type_abi(a.buf);
-        if (given != a.type) {
-            char t0[16], t1[16];
-            return report(uc, halide_error_code_bad_type,
-                          "%s buffer %s has type %s but type of the buffer passed in is %s",
-                          a.is_output ? "Output" : "Input", a.name, type_name(a.type, t0), type_name(given, t1));
-        }
-    }
-    for (int i = 0; i < n; i++) {
-        const BufArg &a = args[i];
-        if (a.buf->dimensions != a.dims) {
-            return report(uc, halide_error_code_bad_dimensions,
-                          "%s buffer %s requires a buffer of exactly %d dimensions, but the buffer passed in has %d "
-                          "dimensions",
-                          a.is_output ? "Output" : "Input", a.name, a.dims, a.buf->dimensions);
-        }
-        if (a.dims > 0 && a.buf->dim == nullptr) {
-            return report(uc, halide_error_code_buffer_is_null, "%s buffer %s has a null dim pointer",
-                          a.is_output ? "Output" : "Input", a.name);
+    const bool query = any_bounds_query(args, n);
+    // buffers in name order; per buffer the type first, then the dimensionality
+    for (int rank = 0; rank < n; rank++) {
+        for (int i = 0; i < n; i++) {
+            if (i < 16 && t_rank[i] != rank) continue;
+            const BufArg &a = args[i];
+            const char *io = a.is_output ? "Output" : "Input";
+            uint32_t given = buf_type_abi(a.buf);
+            if (given != a.type) {
+                if (query) {
+                    if (a.buf->host == nullptr && a.buf->device == 0) memcpy(&a.buf->type, &a.type, 4);
+                } else {
+                    char t0[16], t1[16];
+                    return report(uc, halide_error_code_bad_type,
+                                  "%s buffer %s has type %s but type of the buffer passed in is %s", io, a.name,
+                                  type_name(a.type, t0), type_name(given, t1));
+                }
+            }
+            if (a.buf->dimensions != a.dims) {
+                return report(uc, halide_error_code_bad_dimensions,
+                              "%s buffer %s requires a buffer of exactly %d dimensions, but the buffer passed in has %d "
+                              "dimensions",
+                              io, a.name, a.dims, a.buf->dimensions);
+            }
+            if (a.dims > 0 && a.buf->dim == nullptr) {
+                return report(uc, halide_error_code_buffer_is_null, "%s buffer %s has a null dim pointer", io, a.name);
+            }
         }
     }
     return 0;
 }
 
 int check_shape(void *uc, const BufArg &a) {
+    (void)uc;
     const halide_buffer_t *b = a.buf;
     const char *io = a.is_output ? "Output" : "Input";
+    const int rank = rank_of(a.name, strlen(a.name));
+    if (b->dimensions > 0 && b->dim[0].stride != 1) {
+        record(4, rank, 0, 0, halide_error_code_constraint_violated, "Constraint violated: %s.stride.0 (%d) == 1 (1)",
+               a.name, b->dim[0].stride);
+    }
     int64_t total = 1;
     for (int d = 0; d < b->dimensions; d++) {
         if (b->dim[d].extent < 0) {
-            return report(uc, halide_error_code_buffer_extents_negative,
-                          "The extents for buffer %s dimension %d is negative (%d)", a.name, d, b->dim[d].extent);
+            record(5, rank, d, 1, halide_error_code_buffer_extents_negative,
+                   "The extents for buffer %s dimension %d is negative (%d)", a.name, d, b->dim[d].extent);
         }
-    }
-    if (b->dimensions > 0 && b->dim[0].stride != 1) {
-        char what[96];
-        snprintf(what, sizeof what, "%s.stride.0", a.name);
-        return check_equal(uc, what, b->dim[0].stride, "1", 1);
-    }
-    for (int d = 0; d < b->dimensions; d++) {
-        int64_t span = (int64_t)b->dim[d].extent * (int64_t)(b->dim[d].stride < 0 ? -(int64_t)b->dim[d].stride
-                                                                                : (int64_t)b->dim[d].stride);
+        int64_t span = (int64_t)b->dim[d].extent * (int64_t)b->dim[d].stride;
+        if (span < 0) span = -span;
         if (span > 0x7fffffffLL) {
-            return report(uc, halide_error_code_buffer_allocation_too_large,
-                          "Total allocation for buffer %s %s is %lld, which exceeds the maximum size of %lld", io,
-                          a.name, (long long)span, (long long)0x7fffffffLL);
+            record(6, rank, d, 0, halide_error_code_buffer_allocation_too_large,
+                   "Total allocation for buffer %s %s is %lld, which exceeds the maximum size of %lld", io, a.name,
+                   (long long)span, (long long)0x7fffffffLL);
         }
-        total *= b->dim[d].extent;
-        if (total > 0x7fffffffLL) {
-            return report(uc, halide_error_code_buffer_extents_too_large,
-                          "Product of extents for buffer %s %s is %lld, which exceeds the maximum size of %lld", io,
-                          a.name, (long long)total, (long long)0x7fffffffLL);
+        total *= b->dim[d].extent;  // |total| <= 2^31 * 2^31 at d = 1, checked before it can grow further
+        if (d > 0 && total > 0x7fffffffLL) {
+            record(6, rank, d, 1, halide_error_code_buffer_extents_too_large,
+                   "Product of extents for buffer %s %s is %lld, which exceeds the maximum size of %lld", io, a.name,
+                   (long long)total, (long long)0x7fffffffLL);
+            total = 1;  // keep the running product inside int64 for the remaining dimensions
         }
     }
     return 0;
 }
 
 int check_covers(void *uc, const BufArg &a, int d, int req_min, int req_extent) {
+    (void)uc;
     const halide_dimension_t &dm = a.buf->dim[d];
-    int req_max = req_min + req_extent - 1, have_max = dm.min + dm.extent - 1;
-    if (req_extent > 0 && (req_min < dm.min || req_max > have_max)) {
-        return report(uc, halide_error_code_access_out_of_bounds,
-                      "%s buffer %s is accessed at %d, which is %s the %s (%d) in dimension %d",
-                      a.is_output ? "Output" : "Input", a.name, req_min < dm.min ? req_min : req_max,
-                      req_min < dm.min ? "before" : "beyond", req_min < dm.min ? "min" : "max",
-                      req_min < dm.min ? dm.min : have_max, d);
+    // in int64: a negative or huge extent must not wrap the comparison (the reference compares in int32 after its
+    // own overflow asserts; the outcome for representable values is the same)
+    int64_t req_max = (int64_t)req_min + req_extent - 1, have_max = (int64_t)dm.min + dm.extent - 1;
+    if (req_min < dm.min || req_max > have_max) {
+        const bool before = req_min < dm.min;
+        record(5, rank_of(a.name, strlen(a.name)), d, 0, halide_error_code_access_out_of_bounds,
+               "%s buffer %s is accessed at %lld, which is %s the %s (%lld) in dimension %d",
+               a.is_output ? "Output" : "Input", a.name, (long long)(before ? req_min : req_max),
+               before ? "before" : "beyond", before ? "min" : "max", (long long)(before ? dm.min : have_max), d);
     }
     return 0;
 }
 
 int check_equal(void *uc, const char *what, int val, const char *expect_what, int expect) {
+    (void)uc;
     if (val != expect) {
-        return report(uc, halide_error_code_constraint_violated, "Constraint violated: %s (%d) == %s (%d)", what, val,
-                      expect_what, expect);
+        // what = "<buffer>.<stride|min|extent>.<dim>"
+        const char *dot = strchr(what, '.');
+        int rank = 15, dim = 0, kind = 3;
+        if (dot) {
+            rank = rank_of(what, (size_t)(dot - what));
+            kind = dot[1] == 's' ? 0 : (dot[1] == 'm' ? 1 : 2);
+            const char *dot2 = strchr(dot + 1, '.');
+            if (dot2) dim = atoi(dot2 + 1);
+        }
+        record(4, rank, dim, kind, halide_error_code_constraint_violated, "Constraint violated: %s (%d) == %s (%d)", what,
+               val, expect_what, expect);
     }
     return 0;
 }
@@ -192,13 +264,32 @@ struct Arena {
     std::recursive_mutex call_mu;  // serialises the ENQUEUE of whole pipeline calls on this (device, stream)
 };
 
+// A device allocation made by this runtime.  `last_stream` = the stream the most recent pipeline call, upload or
+// copy that touched it was enqueued on: whoever touches it next from a DIFFERENT stream (or from the host) orders
+// itself after everything enqueued on that stream so far (an event recorded "now" on last_stream is at or after the
+// last use).  The reference keeps the same kind of record for its allocation cache only (src/runtime/cuda.cpp:667-675,
+// :815 "Can only safely re-use on the same stream on which it was freed"); extending it to live buffers is what makes
+// `set_stream(S); pipeline(); set_stream(NULL); copy_to_host()` and cross-stream chaining of pipelines well-defined.
+struct Owned {
+    size_t bytes = 0;
+    hipStream_t last_stream = nullptr;
+};
+struct Cached {
+    void *ptr = nullptr;
+    hipStream_t stream = nullptr;  // stream the freed allocation was last used on
+    hipEvent_t done = nullptr;     // recorded on `stream` at free time (null: never used on a stream)
+};
+
 struct DeviceState {
     bool inited = false;
     bool usable = false;
     hipStream_t stream = nullptr;
-    std::map<hipStream_t, Arena> arenas;             // scratch per stream
-    std::unordered_map<uint64_t, std::pair<void *, size_t>> owned;  // device handle -> (base, bytes)
-    std::multimap<size_t, void *> cache;             // free allocations kept for reuse
+    std::map<hipStream_t, Arena> arenas;   // scratch per stream
+    std::map<uint64_t, Owned> owned;       // base address -> record (ordered: crops resolve to the containing allocation)
+    std::multimap<size_t, Cached> cache;   // free allocations kept for reuse
+    hipEvent_t ring[64] = {};              // short-lived ordering events (record + wait back to back)
+    unsigned ring_next = 0;
+    std::vector<hipEvent_t> graveyard;     // cache events whose wait has been enqueued; destroyed lazily
 };
 
 static std::mutex g_mu;  // guards g_dev[*] bookkeeping (device_copy_mutex analogue, device_interface.cpp:28)
@@ -223,10 +314,15 @@ static int pick_device() {
     return 0;
 }
 
-int acquire_device(void *uc, DeviceCtx *ctx) {
+int acquire_device(void *uc, DeviceCtx *ctx, bool lock) {
+    if (lock) {  // pipeline entry: the recorded argument-check failures come first
+        int r = checks_done(uc);
+        if (r) return r;
+    }
     int dev = pick_device();
+    std::recursive_mutex *mu = nullptr;
     {
-        std::lock_guard<std::mutex> lock(g_mu);
+        std::lock_guard<std::mutex> guard(g_mu);
         int n = device_count_locked();
         if (n <= 0) {
             return report(uc, halide_error_code_gpu_device_error,
@@ -252,15 +348,9 @@ int acquire_device(void *uc, DeviceCtx *ctx) {
         }
         ctx->device = dev;
         ctx->stream = t_stream_override ? t_stream_override : st.stream;
+        if (lock) mu = &st.arenas[ctx->stream].call_mu;  // std::map: the node (and the mutex in it) never moves
     }
-    {
-        std::recursive_mutex *mu;
-        {
-            std::lock_guard<std::mutex> lock(g_mu);
-            mu = &g_dev[dev].arenas[ctx->stream].call_mu;  // std::map: the node (and the mutex in it) never moves
-        }
-        ctx->call_lock = std::unique_lock<std::recursive_mutex>(*mu);  // taken with g_mu released (lock order: call -> g_mu)
-    }
+    if (mu) ctx->call_lock = std::unique_lock<std::recursive_mutex>(*mu);  // taken with g_mu released (lock order: call -> g_mu)
     HLMI_HIP(uc, hipSetDevice(dev));
     return 0;
 }
@@ -283,19 +373,101 @@ int get_workspace(void *uc, const DeviceCtx &ctx, size_t bytes, void **ptr) {
     return 0;
 }
 
-// ---- raw allocation with cache ---------------------------------------------------------------
-static int dev_alloc_locked(void *uc, int dev, size_t bytes, void **out) {
+// ---- stream ordering ---------------------------------------------------------------------------
+// Everything enqueued on `producer` so far happens before whatever is enqueued on `consumer` from now on.  A stream
+// that no longer exists (a caller destroyed it) has no pending work we could wait for: errors are dropped.
+static void order_after_locked(int dev, hipStream_t consumer, hipStream_t producer) {
+    if (!producer || producer == consumer) return;
     DeviceState &st = g_dev[dev];
-    auto it = st.cache.find(bytes);
-    if (it != st.cache.end()) {
-        *out = it->second;
-        st.cache.erase(it);
+    hipEvent_t &ev = st.ring[st.ring_next++ % 64];
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+        ev = nullptr;
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(producer);
+        (void)hipGetLastError();
+        return;
+    }
+    if (hipEventRecord(ev, producer) != hipSuccess || hipStreamWaitEvent(consumer, ev, 0) != hipSuccess) (void)hipGetLastError();
+}
+
+static void bury_locked(DeviceState &st, hipEvent_t ev) {
+    if (!ev) return;
+    st.graveyard.push_back(ev);
+    if (st.graveyard.size() > 256) {
+        for (size_t i = 0; i < 128; i++) {
+            (void)hipEventSynchronize(st.graveyard[i]);
+            (void)hipEventDestroy(st.graveyard[i]);
+        }
+        st.graveyard.erase(st.graveyard.begin(), st.graveyard.begin() + 128);
+        (void)hipGetLastError();
+    }
+}
+
+// the allocation of device `*dev_out` that contains `handle` (crops and slices point into their parent), or null
+static Owned *find_owned_locked(uint64_t handle, int *dev_out) {
+    int n = device_count_locked();
+    for (int d = 0; d < n; d++) {
+        auto &m = g_dev[d].owned;
+        auto it = m.upper_bound(handle);
+        if (it == m.begin()) continue;
+        --it;
+        if (handle >= it->first && handle < it->first + it->second.bytes) {
+            if (dev_out) *dev_out = d;
+            return &it->second;
+        }
+    }
+    return nullptr;
+}
+
+// a pipeline call / copy on ctx.stream is about to touch `handle`
+static int note_use(void *uc, const DeviceCtx &ctx, uint64_t handle, const char *name) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    int dev;
+    Owned *o = find_owned_locked(handle, &dev);
+    if (!o) return 0;  // wrapped native memory: its owner orders the streams (as with halide_cuda_wrap_device_ptr)
+    if (dev != ctx.device) {
+        return report(uc, halide_error_code_incompatible_device_interface,
+                      "Buffer %s lives on GPU device %d but this call runs on device %d (halide_set_gpu_device)", name, dev,
+                      ctx.device);
+    }
+    order_after_locked(dev, ctx.stream, o->last_stream);
+    o->last_stream = ctx.stream;
+    return 0;
+}
+
+// ---- raw allocation with cache ---------------------------------------------------------------
+static int dev_alloc_locked(void *uc, int dev, size_t bytes, hipStream_t for_stream, void **out) {
+    DeviceState &st = g_dev[dev];
+    auto range = st.cache.equal_range(bytes);
+    auto pick = range.second;
+    for (auto it = range.first; it != range.second; ++it) {
+        if (it->second.stream == for_stream || !it->second.done) {  // same stream: stream order is enough
+            pick = it;
+            break;
+        }
+        if (pick == range.second) pick = it;
+    }
+    if (pick != range.second) {
+        Cached c = pick->second;
+        st.cache.erase(pick);
+        if (c.done) {
+            if (c.stream != for_stream && hipStreamWaitEvent(for_stream, c.done, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipEventSynchronize(c.done);
+            }
+            bury_locked(st, c.done);
+        }
+        *out = c.ptr;
         return 0;
     }
     hipError_t e = hipMalloc(out, bytes ? bytes : 1);
     if (e != hipSuccess) {
         // drop the cache and retry once (cuda.cpp does the same on OOM)
-        for (auto &kv : st.cache) (void)hipFree(kv.second);
+        (void)hipDeviceSynchronize();
+        for (auto &kv : st.cache) {
+            (void)hipFree(kv.second.ptr);
+            if (kv.second.done) (void)hipEventDestroy(kv.second.done);
+        }
         st.cache.clear();
         e = hipMalloc(out, bytes ? bytes : 1);
     }
@@ -307,13 +479,35 @@ static int dev_alloc_locked(void *uc, int dev, size_t bytes, void **out) {
     return 0;
 }
 
-static void dev_free_locked(int dev, void *base, size_t bytes) {
+static void dev_free_locked(int dev, void *base, const Owned &rec) {
     DeviceState &st = g_dev[dev];
     if (g_reuse.load()) {
-        st.cache.emplace(bytes, base);
+        Cached c;
+        c.ptr = base, c.stream = rec.last_stream;
+        if (rec.last_stream) {
+            if (hipEventCreateWithFlags(&c.done, hipEventDisableTiming) != hipSuccess ||
+                hipEventRecord(c.done, rec.last_stream) != hipSuccess) {
+                // the stream is gone (destroyed by its owner): nothing of ours can still be pending on it
+                (void)hipGetLastError();
+                if (c.done) (void)hipEventDestroy(c.done);
+                c.done = nullptr;
+            }
+        }
+        st.cache.emplace(rec.bytes, c);
     } else {
         (void)hipFree(base);
     }
+}
+
+static void purge_cache_locked(DeviceState &st) {
+    for (auto &kv : st.cache) {
+        (void)hipFree(kv.second.ptr);
+        if (kv.second.done) (void)hipEventDestroy(kv.second.done);
+    }
+    st.cache.clear();
+    for (hipEvent_t ev : st.graveyard) (void)hipEventDestroy(ev);
+    st.graveyard.clear();
+    (void)hipGetLastError();
 }
 
 // ---- helpers over halide_buffer_t ---------------------------------------------------------------
@@ -412,7 +606,7 @@ static int copy_strided(void *uc, const halide_buffer_t *b, bool to_device, hipS
 static int hip_device_malloc(void *uc, halide_buffer_t *buf) {
     if (buf->device) return 0;  // already allocated (cuda.cpp:601-606)
     DeviceCtx ctx;
-    int r = acquire_device(uc, &ctx);
+    int r = acquire_device(uc, &ctx, false);
     if (r) return r;
     for (int i = 0; i < buf->dimensions; i++) {
         if (buf->dim[i].stride < 0) return report(uc, halide_error_code_unimplemented, "hlmi: negative strides are not supported on the device");
@@ -423,38 +617,34 @@ static int hip_device_malloc(void *uc, halide_buffer_t *buf) {
     if (bytes == 0) bytes = 256;
     void *base = nullptr;
     std::lock_guard<std::mutex> lock(g_mu);
-    r = dev_alloc_locked(uc, ctx.device, bytes, &base);
+    r = dev_alloc_locked(uc, ctx.device, bytes, ctx.stream, &base);
     if (r) return r;
     buf->device = (uint64_t)(uintptr_t)base;
     buf->device_interface = halide_hip_device_interface();
-    g_dev[ctx.device].owned[buf->device] = {base, bytes};
-    return 0;
-}
-
-static int find_owner_locked(uint64_t handle, int *dev_out) {
-    int n = device_count_locked();
-    for (int d = 0; d < n; d++) {
-        if (g_dev[d].owned.count(handle)) {
-            *dev_out = d;
-            return 1;
-        }
-    }
+    Owned rec;
+    rec.bytes = bytes, rec.last_stream = nullptr;  // a reused allocation has been ordered behind its previous life above
+    g_dev[ctx.device].owned[buf->device] = rec;
     return 0;
 }
 
 static int hip_device_free(void *uc, halide_buffer_t *buf) {
+    (void)uc;
     if (buf->device == 0) return 0;
     {
         std::lock_guard<std::mutex> lock(g_mu);
-        int dev;
-        if (find_owner_locked(buf->device, &dev)) {
-            auto rec = g_dev[dev].owned[buf->device];
-            g_dev[dev].owned.erase(buf->device);
-            if (!g_reuse.load()) {
-                (void)hipSetDevice(dev);
-                (void)hipDeviceSynchronize();
-            }
-            dev_free_locked(dev, rec.first, rec.second);
+        int n = device_count_locked();
+        for (int dev = 0; dev < n; dev++) {
+            auto it = g_dev[dev].owned.find(buf->device);
+            if (it == g_dev[dev].owned.end()) continue;
+            Owned rec = it->second;
+            g_dev[dev].owned.erase(it);
+            int cur = -1;
+            (void)hipGetDevice(&cur);
+            if (cur != dev) (void)hipSetDevice(dev);
+            if (!g_reuse.load()) (void)hipDeviceSynchronize();
+            dev_free_locked(dev, (void *)(uintptr_t)buf->device, rec);
+            if (cur >= 0 && cur != dev) (void)hipSetDevice(cur);
+            break;
         }
         // not owned: a wrapped native pointer or a crop — nothing to free
     }
@@ -464,11 +654,44 @@ static int hip_device_free(void *uc, halide_buffer_t *buf) {
     return 0;
 }
 
-static int hip_device_sync(void *uc, halide_buffer_t *) {
+// where the work that last touched `buf` was enqueued: (device, stream).  Falls back to the calling thread's device
+// and stream for memory this runtime does not own (wrapped pointers) and for buf == null.
+static int producer_of(void *uc, const halide_buffer_t *buf, int *dev, hipStream_t *stream) {
     DeviceCtx ctx;
-    int r = acquire_device(uc, &ctx);
+    int r = acquire_device(uc, &ctx, false);
     if (r) return r;
-    HLMI_HIP(uc, hipStreamSynchronize(ctx.stream));
+    *dev = ctx.device, *stream = ctx.stream;
+    if (buf && buf->device) {
+        std::lock_guard<std::mutex> lock(g_mu);
+        int d;
+        Owned *o = find_owned_locked(buf->device, &d);
+        if (o) {
+            *dev = d;
+            if (o->last_stream) *stream = o->last_stream;
+            else if (d != ctx.device) *stream = g_dev[d].stream;
+        }
+    }
+    if (*dev != ctx.device) HLMI_HIP(uc, hipSetDevice(*dev));
+    return 0;
+}
+struct RestoreDevice {  // a buffer that lives on another device than the calling thread's: switch back on scope exit
+    int dev;
+    ~RestoreDevice() { (void)hipSetDevice(dev); }
+};
+
+static int hip_device_sync(void *uc, halide_buffer_t *buf) {
+    int dev;
+    hipStream_t s;
+    int r = producer_of(uc, buf, &dev, &s);
+    if (r) return r;
+    RestoreDevice back{pick_device()};
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        // the producing stream was destroyed by its owner, which completes its work
+        if (e == hipErrorContextIsDestroyed || e == hipErrorInvalidHandle || e == hipErrorInvalidResourceHandle) return 0;
+        return hip_failed(uc, e, "hipStreamSynchronize");
+    }
     return 0;
 }
 
@@ -480,35 +703,42 @@ static int hip_device_release(void *uc) {
         if (!st.inited || !st.usable) continue;
         (void)hipSetDevice(d);
         (void)hipDeviceSynchronize();
-        for (auto &kv : st.cache) (void)hipFree(kv.second);
-        st.cache.clear();
+        purge_cache_locked(st);
+        // The arena NODES stay: a thread entering a pipeline keeps a pointer to the call lock inside its node
+        // (acquire_device), and get_workspace() re-allocates on demand.
         for (auto &kv : st.arenas) {
             if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+            kv.second.ptr = nullptr;
+            kv.second.bytes = 0;
         }
-        st.arenas.clear();
     }
+    (void)hipSetDevice(pick_device());
+    (void)hipGetLastError();
     (void)uc;
     return 0;
 }
 
 static int hip_copy_to_host(void *uc, halide_buffer_t *buf) {
-    DeviceCtx ctx;
-    int r = acquire_device(uc, &ctx);
+    // on the stream that produced the data (NOT necessarily the caller's current one), then wait for it
+    int dev;
+    hipStream_t s;
+    int r = producer_of(uc, buf, &dev, &s);
     if (r) return r;
-    r = copy_strided(uc, buf, false, ctx.stream);
+    RestoreDevice back{pick_device()};
+    r = copy_strided(uc, buf, false, s);
     if (r) return r;
-    HLMI_HIP(uc, hipStreamSynchronize(ctx.stream));
+    HLMI_HIP(uc, hipStreamSynchronize(s));
     return 0;
 }
 
 static int hip_copy_to_device(void *uc, halide_buffer_t *buf) {
     DeviceCtx ctx;
-    int r = acquire_device(uc, &ctx);
+    int r = acquire_device(uc, &ctx, false);
     if (r) return r;
+    if ((r = note_use(uc, ctx, buf->device, "passed to halide_copy_to_device"))) return r;
     r = copy_strided(uc, buf, true, ctx.stream);
     if (r) return r;
-    // host memory is pageable: the runtime has staged it by the time the call returns, but keep the
-    // contract simple and identical to the reference (copy complete on return)
+    // the reference's copy_to_device is complete on return (the host buffer may be rewritten right away)
     HLMI_HIP(uc, hipStreamSynchronize(ctx.stream));
     return 0;
 }
@@ -526,9 +756,11 @@ static int hip_detach_native(void *uc, halide_buffer_t *buf) {
     if (buf->device == 0) return 0;
     {
         std::lock_guard<std::mutex> lock(g_mu);
-        int dev;
-        if (find_owner_locked(buf->device, &dev)) {
-            return report(uc, halide_error_code_device_detach_native_failed, "hlmi: detach_native on a buffer whose device memory is owned by the runtime");
+        int n = device_count_locked();
+        for (int d = 0; d < n; d++) {
+            if (g_dev[d].owned.count(buf->device)) {
+                return report(uc, halide_error_code_device_detach_native_failed, "hlmi: detach_native on a buffer whose device memory is owned by the runtime");
+            }
         }
     }
     buf->device = 0;
@@ -562,6 +794,16 @@ static int hip_device_release_crop(void *uc, halide_buffer_t *buf) {
 }
 
 // ---- pipeline argument protocol -------------------------------------------------------------------
+// true when the DMA engine may still be reading `p` after hipMemcpyAsync returns (pinned / registered host memory)
+static bool host_memory_is_pinned(const void *p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;  // plain pageable memory is unknown to the runtime
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
 int input_to_device(void *uc, const DeviceCtx &ctx, const BufArg &a) {
     halide_buffer_t *b = a.buf;
     int r = validate(uc, b, a.name);
@@ -577,18 +819,21 @@ int input_to_device(void *uc, const DeviceCtx &ctx, const BufArg &a) {
         if (r) return r;
         fresh = true;
     }
+    // order ctx.stream behind the stream that produced / last read this buffer
+    if ((r = note_use(uc, ctx, b->device, a.name))) return r;
     if ((b->flags & halide_buffer_flag_host_dirty) || fresh) {
         if (b->host == nullptr) return report(uc, halide_error_code_host_is_null, "Input buffer %s host pointer is null", a.name);
         r = copy_strided(uc, b, true, ctx.stream);
         if (r) return halide_error_code_copy_to_device_failed;
-        // pageable host memory: the async copy has consumed the host data when it returns
+        // Pageable host memory has been staged by the time the async copy returns; pinned or registered memory is read
+        // by the DMA engine later, and the reference's copy_to_device is complete on return: wait for it then.
+        if (host_memory_is_pinned(b->host)) HLMI_HIP(uc, hipStreamSynchronize(ctx.stream));
         b->flags &= ~(uint64_t)halide_buffer_flag_host_dirty;
     }
     return 0;
 }
 
 int output_on_device(void *uc, const DeviceCtx &ctx, const BufArg &a) {
-    (void)ctx;
     halide_buffer_t *b = a.buf;
     int r = validate(uc, b, a.name);
     if (r) return r;
@@ -600,7 +845,7 @@ int output_on_device(void *uc, const DeviceCtx &ctx, const BufArg &a) {
         r = hip_device_malloc(uc, b);
         if (r) return r;
     }
-    return 0;
+    return note_use(uc, ctx, b->device, a.name);
 }
 
 void mark_output_written(halide_buffer_t *b) {
@@ -655,6 +900,40 @@ halide_error_handler_t halide_set_error_handler(halide_error_handler_t h) {
 }
 void halide_print(void *uc, const char *msg) { g_print.load()(uc, msg); }
 halide_print_t halide_set_custom_print(halide_print_t p) { return g_print.exchange(p ? p : default_print); }
+// the defaults stay reachable for hooks that wrap them (tools/RunGenMain.cpp:220,243 — its allocation tracker)
+void *halide_default_malloc(void *uc, size_t x) { return default_malloc(uc, x); }
+void halide_default_free(void *uc, void *p) { default_free(uc, p); }
+// dlsym / dlopen hooks (src/runtime/posix_get_symbol.cpp): RunGenMain.cpp:531 probes for runtime symbols through them
+static std::atomic<halide_get_symbol_t> g_get_symbol{nullptr};
+static std::atomic<halide_load_library_t> g_load_library{nullptr};
+static std::atomic<halide_get_library_symbol_t> g_get_library_symbol{nullptr};
+void *halide_default_get_symbol(const char *name) { return dlsym(RTLD_DEFAULT, name); }
+void *halide_default_load_library(const char *name) { return dlopen(name, RTLD_LAZY); }
+void *halide_default_get_library_symbol(void *lib, const char *name) { return dlsym(lib, name); }
+void *halide_get_symbol(const char *name) {
+    halide_get_symbol_t f = g_get_symbol.load();
+    return f ? f(name) : halide_default_get_symbol(name);
+}
+void *halide_load_library(const char *name) {
+    halide_load_library_t f = g_load_library.load();
+    return f ? f(name) : halide_default_load_library(name);
+}
+void *halide_get_library_symbol(void *lib, const char *name) {
+    halide_get_library_symbol_t f = g_get_library_symbol.load();
+    return f ? f(lib, name) : halide_default_get_library_symbol(lib, name);
+}
+halide_get_symbol_t halide_set_custom_get_symbol(halide_get_symbol_t f) {
+    halide_get_symbol_t old = g_get_symbol.exchange(f);
+    return old ? old : halide_default_get_symbol;
+}
+halide_load_library_t halide_set_custom_load_library(halide_load_library_t f) {
+    halide_load_library_t old = g_load_library.exchange(f);
+    return old ? old : halide_default_load_library;
+}
+halide_get_library_symbol_t halide_set_custom_get_library_symbol(halide_get_library_symbol_t f) {
+    halide_get_library_symbol_t old = g_get_library_symbol.exchange(f);
+    return old ? old : halide_default_get_library_symbol;
+}
 void *halide_malloc(void *uc, size_t x) { return g_malloc.load()(uc, x); }
 void halide_free(void *uc, void *p) { g_free.load()(uc, p); }
 halide_malloc_t halide_set_custom_malloc(halide_malloc_t m) { return g_malloc.exchange(m ? m : default_malloc); }
@@ -834,8 +1113,10 @@ static int if_buffer_copy(void *uc, halide_buffer_t *src, const halide_device_in
     if (!from_host && src->device == 0) return report(uc, halide_error_code_device_buffer_copy_failed, "buffer_copy: source has no data");
     if (to_host && dst->host == nullptr) return report(uc, halide_error_code_host_is_null, "buffer_copy: destination host is null");
     DeviceCtx ctx;
-    int r = acquire_device(uc, &ctx);
+    int r = acquire_device(uc, &ctx, false);
     if (r) return r;
+    if (!from_host && (r = note_use(uc, ctx, src->device, "src of halide_buffer_copy"))) return r;
+    if (!to_host && (r = note_use(uc, ctx, dst->device, "dst of halide_buffer_copy"))) return r;
     // element-run copies over the overlapping box
     int nd = src->dimensions;
     int lo[16], ext[16];
@@ -924,10 +1205,22 @@ int halide_hip_release_unused_device_allocations(void *uc) {
         if (st.cache.empty()) continue;
         (void)hipSetDevice(d);
         (void)hipDeviceSynchronize();
-        for (auto &kv : st.cache) (void)hipFree(kv.second);
-        st.cache.clear();
+        purge_cache_locked(st);
     }
+    (void)hipSetDevice(pick_device());
+    (void)hipGetLastError();
     return 0;
+}
+
+int hlmi_device_count(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    int n = device_count_locked(), usable = 0;
+    for (int d = 0; d < n; d++) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) usable++;
+    }
+    (void)hipGetLastError();
+    return usable;
 }
 
 void halide_set_gpu_device(int n) { t_gpu_device = n; }
@@ -941,8 +1234,7 @@ void halide_hip_set_stream(void *stream) { t_stream_override = (hipStream_t)stre
 // Streams are created once per (device, part, nparts) and owned by the library.  Returns NULL on failure.
 void *halide_hip_partition_stream(int part, int nparts) {
     DeviceCtx ctx;
-    if (nparts < 1 || part < 0 || part >= nparts || acquire_device(nullptr, &ctx)) return nullptr;
-    ctx.call_lock.unlock();
+    if (nparts < 1 || part < 0 || part >= nparts || acquire_device(nullptr, &ctx, false)) return nullptr;
     std::lock_guard<std::mutex> lock(g_mu);
     static std::map<std::tuple<int, int, int>, hipStream_t> streams;
     auto key = std::make_tuple(ctx.device, part, nparts);
@@ -963,7 +1255,7 @@ void *halide_hip_partition_stream(int part, int nparts) {
 
 void *halide_hip_get_stream(void *uc) {
     DeviceCtx ctx;
-    if (acquire_device(uc, &ctx)) return nullptr;
+    if (acquire_device(uc, &ctx, false)) return nullptr;
     return (void *)ctx.stream;
 }
 

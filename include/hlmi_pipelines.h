@@ -7,15 +7,20 @@
  * object is a drop-in for `<name>.a` + `<name>.h` of the reference.  Return value: 0 or a negative
  * halide_error_code_t; on error `halide_error()` is called first (default handler aborts).
  *
- * Entry protocol, identical for all pipelines (reference: src/UnpackBuffers.cpp:148,
- * src/AddImageChecks.cpp:315-347, 414-471, 591-671, 709-713):
- *   1. a NULL buffer argument            -> -12 (buffer_argument_is_null)
- *   2. any buffer with host==NULL && device==0 -> BOUNDS QUERY: dim[] of every such buffer is
- *      rewritten to the region the pipeline needs/produces, nothing is computed, return 0
- *   3. element type mismatch             -> -3   4. wrong dimensionality -> -43
- *   5. negative extents -> -28; dim[0].stride != 1 (or other pinned constraint) -> -8;
- *      region required > region supplied -> -4; > 2^31-1 elements -> -6 / -5
- *   6. host==NULL with device set but no usable device interface -> -34 / -42
+ * Entry protocol, identical for all pipelines, in the order the reference emits its checks
+ * (src/UnpackBuffers.cpp:148; src/AddParameterChecks.cpp; src/AddImageChecks.cpp:315-347, 393-470, 591-671,
+ * 716-760; buffers are visited in NAME order within each step; pinned by tests/test_entry_protocol.py):
+ *   1. a NULL buffer argument                       -> -12 (buffer_argument_is_null)
+ *   2. a scalar parameter outside its range         -> -9 / -10 (param_too_small / param_too_large)
+ *   3. any buffer with host==NULL && device==0      -> BOUNDS QUERY: dim[] (and type) of every such buffer is
+ *      rewritten to the region the pipeline needs / produces, nothing is computed, return 0
+ *   4. per buffer: element type mismatch -> -3, then wrong dimensionality -> -43
+ *   5. per buffer and dimension: dim[0].stride != 1 or another pinned stride / min / extent -> -8
+ *   6. per buffer and dimension: region required > region supplied -> -4, then a negative extent -> -28
+ *   7. per buffer and dimension: |extent * stride| > 2^31-1 -> -5, product of extents > 2^31-1 -> -6
+ *   8. with the device: both dirty bits -> -37; device handle without interface -> -19 (and vice versa -36); a
+ *      device allocation of another API -> -42; a host-dirty input without host pointer -> -34.  (-44,
+ *      device_dirty_with_no_device_support, is what a HOST-only target reports; a GPU target copies instead.)
  * Device protocol (what the reference emits for a GPU target,
  * src/InjectHostDevBufferCopies.cpp:197-217, 285-304): inputs are brought to the device with
  * halide_copy_to_device (allocation is attached to the caller's buffer and stays there), the

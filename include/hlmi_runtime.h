@@ -40,6 +40,24 @@ void *halide_malloc(void *user_context, size_t x);
 void halide_free(void *user_context, void *ptr);
 halide_malloc_t halide_set_custom_malloc(halide_malloc_t user_malloc);
 halide_free_t halide_set_custom_free(halide_free_t user_free);
+/* the built-in allocator, for hooks that wrap it (src/runtime/HalideRuntime.h:446-447; tools/RunGenMain.cpp:220,243) */
+void *halide_default_malloc(void *user_context, size_t x);
+void halide_default_free(void *user_context, void *ptr);
+
+/* dlsym / dlopen hooks: src/runtime/HalideRuntime.h:465-476, defaults as src/runtime/posix_get_symbol.cpp
+ * (halide_get_symbol(name) = dlsym(RTLD_DEFAULT, name)); tools/RunGenMain.cpp:531 probes the runtime through them. */
+typedef void *(*halide_get_symbol_t)(const char *name);
+typedef void *(*halide_load_library_t)(const char *name);
+typedef void *(*halide_get_library_symbol_t)(void *lib, const char *name);
+void *halide_get_symbol(const char *name);
+void *halide_load_library(const char *name);
+void *halide_get_library_symbol(void *lib, const char *name);
+void *halide_default_get_symbol(const char *name);
+void *halide_default_load_library(const char *name);
+void *halide_default_get_library_symbol(void *lib, const char *name);
+halide_get_symbol_t halide_set_custom_get_symbol(halide_get_symbol_t user_get_symbol);
+halide_load_library_t halide_set_custom_load_library(halide_load_library_t user_load_library);
+halide_get_library_symbol_t halide_set_custom_get_library_symbol(halide_get_library_symbol_t user_get_library_symbol);
 
 /* ---- device bookkeeping (dirty-flag protocol) ------------------------------------------------
  * Declared at src/runtime/HalideRuntime.h:908-1011; semantics follow src/runtime/device_interface.cpp:141-330:
@@ -94,6 +112,23 @@ void *halide_hip_get_stream(void *user_context);
  * (every nparts-th bit of the CU mask; hipExtStreamCreateWithCUMask).  For batches of independent frames: one frame per
  * partition at a time keeps the frames from slowing each other down.  NULL if the device refuses.  No reference counterpart. */
 void *halide_hip_partition_stream(int part, int nparts);
+
+/* ---- in-process frame sharder (no reference counterpart: the reference has no multi-device layer,
+ * its building block is the per-thread halide_set_gpu_device above) ------------------------------------------
+ * Runs `fn(frame_args[i])` for every frame i in [0, n_frames), where `fn` is the `<name>_argv` entry point of a
+ * pipeline (src/CodeGen_C.cpp:688-694: buffers as halide_buffer_t*, scalars as pointers to their values) and
+ * frame_args[i] its argument vector for frame i.  Frames are dealt round-robin to n_devices * streams_per_device
+ * workers — one host thread and one HIP stream each, worker w on devices[w % n_devices]; a device listed twice gets
+ * two workers (that is also how a one-GPU box exercises the path).  With streams_per_device > 1 the workers of a
+ * device own disjoint CU partitions.  Buffers with host data are uploaded to the worker's device; outputs are left
+ * device-dirty THERE (halide_copy_to_host / device_sync find the device and stream that produced them).  There is
+ * no data-path collective: frames are independent.  Returns 0, or the first error code any frame returned; returns
+ * only after every enqueued frame has completed. */
+typedef int (*hlmi_argv_fn)(void **args);
+int hlmi_run_batch(hlmi_argv_fn fn, void ***frame_args, int n_frames, const int *devices, int n_devices,
+                   int streams_per_device);
+/* Number of usable gfx950 devices visible to the process (0 if none). */
+int hlmi_device_count(void);
 
 /* ---- measurement hooks (no reference counterpart; used by bench.py) ---------------------------
  * When enabled, every kernel launch is bracketed by hipEvents on its stream; the report is a

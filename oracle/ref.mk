@@ -14,7 +14,25 @@ TARGETS := $(OUTDIR)/blur_test $(OUTDIR)/local_laplacian_process $(OUTDIR)/bilat
            $(OUTDIR)/nl_means_process $(OUTDIR)/stencil_chain_process $(OUTDIR)/conv_layer_process $(OUTDIR)/camera_pipe_process \
            $(OUTDIR)/depthwise_separable_conv_process $(OUTDIR)/unsharp_filter $(OUTDIR)/max_filter_filter $(OUTDIR)/hist_filter $(OUTDIR)/harris_filter $(OUTDIR)/iir_blur_filter
 
+# The reference's own RunGen (tools/RunGenMain.cpp + RunGen.h, compiled unmodified) linked with the per-pipeline
+# registration unit of tests/cpp/rungen_registration.cpp: the reference's consumer of <name>_argv / <name>_metadata /
+# the bounds-query protocol, one <name>.rungen per pipeline as in the reference's build (apps/*/Makefile, *.rungen).
+RUNGEN_PIPELINES := local_laplacian bilateral_grid halide_blur nl_means stencil_chain conv_layer camera_pipe \
+                    depthwise_separable_conv unsharp max_filter hist harris interpolate iir_blur
+TARGETS += $(patsubst %,$(OUTDIR)/%.rungen,$(RUNGEN_PIPELINES))
+# own test programs that need the reference's headers (tests/cpp/*.cpp; sources are ours, headers the reference's)
+TARGETS += $(OUTDIR)/entry_protocol_ref $(OUTDIR)/device_interface_test
+
 all: $(TARGETS)
+
+$(OUTDIR)/RunGenMain.o: $(TOOLS)/RunGenMain.cpp $(TOOLS)/RunGen.h
+	$(CXX) $(CXXFLAGS) -c $< -o $@
+$(OUTDIR)/%.rungen: $(OUTDIR)/RunGenMain.o $(ROOT)/tests/cpp/rungen_registration.cpp $(LIBDIR)/libhlmi.so
+	$(CXX) $(CXXFLAGS) -DPIPELINE=$* $(OUTDIR)/RunGenMain.o $(ROOT)/tests/cpp/rungen_registration.cpp -o $@ $(LDFLAGS)
+$(OUTDIR)/entry_protocol_ref: $(ROOT)/tests/cpp/entry_protocol_ref.cpp $(LIBDIR)/libhlmi.so
+	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)
+$(OUTDIR)/device_interface_test: $(ROOT)/tests/cpp/device_interface_test.cpp $(LIBDIR)/libhlmi.so
+	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)
 
 # apps/blur/test.cpp: compares halide_blur() with its own scalar + SSE2 loops, prints "Success!"
 $(OUTDIR)/blur_test: $(REF)/apps/blur/test.cpp $(LIBDIR)/libhlmi.so

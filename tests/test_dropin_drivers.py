@@ -1,7 +1,8 @@
 """Drop-in proof: the reference's own app drivers (apps/<app>/process.cpp …), compiled UNMODIFIED from
 /root/reference against libhlmi.so + include/aot/*.h (recipe: oracle/ref.mk, outputs in oracle/_ref/),
 run on the GPU box and produce results identical to the oracle's.  The binaries are prebuilt in the dev
-container (the GPU box has no /root/reference); tests skip if they are absent."""
+container by __graft_entry__.build() (the GPU box has no /root/reference) and travel with the snapshot: a missing
+binary is a FAILURE — a box without them must not go green on skips."""
 import os
 import subprocess
 
@@ -14,8 +15,8 @@ REF_BIN = os.path.join(ROOT, "oracle", "_ref")
 
 def _exe(name):
     p = os.path.join(REF_BIN, name)
-    if not os.path.exists(p):
-        pytest.skip(f"oracle/_ref/{name} not built")
+    assert os.path.exists(p), (f"oracle/_ref/{name} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` where "
+                               "/root/reference is present (make -C oracle ref)")
     return p
 
 
