@@ -91,11 +91,16 @@ __device__ __forceinline__ float down4_tail(float a, float b, float c, float d) 
     return ((a + 3.0f * (b + c)) + d) * 0.015625f;
 }
 
-// gray = 0.299 f0 + 0.587 f1 + 0.114 f2, f = u16 / 65535.0f -> * (1/65535.0f)   (:28-36)
+// gray = 0.299f * floating(0) + 0.587f * floating(1) + 0.114f * floating(2), floating = u16 / 65535.0f (:32, :36), in the
+// form the reference's simplifier leaves it in: x / c0 -> x * fold(1 / c0) (src/Simplify_Div.cpp:204), then
+// (x * c0) * c1 -> x * fold(c0 * c1) (src/Simplify_Mul.cpp:70; constants fold in double and round to float32,
+// src/IRMatch.h:1014-1016) — one multiply per channel by C_c = float(double(float(1.0 / 65535.0)) * double(coef_c)).
+// The three constants are pinned against the oracle's by tests/test_local_laplacian.py.
 __device__ __forceinline__ float gray_from(uint16_t r, uint16_t g, uint16_t b) {
-    const float s = 1.0f / 65535.0f;
-    float f0 = (float)r * s, f1 = (float)g * s, f2 = (float)b * s;
-    return (0.299f * f0 + 0.587f * f1) + 0.114f * f2;
+    constexpr float s = (float)(1.0 / 65535.0);
+    constexpr float C0 = (float)((double)s * (double)0.299f), C1 = (float)((double)s * (double)0.587f),
+                    C2 = (float)((double)s * (double)0.114f);
+    return ((float)r * C0 + (float)g * C1) + (float)b * C2;
 }
 __device__ __forceinline__ int idx_of(float gray, float Km1, int half) {
     return dev::clampi((int)((gray * Km1) * 256.0f), 0, half);  // (:42-43)

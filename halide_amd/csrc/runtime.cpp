@@ -585,6 +585,30 @@ static int copy_strided(void *uc, const halide_buffer_t *b, bool to_device, hipS
     // dimension order[k] becomes the "rows" of a 2-D copy; iterate over the remaining dims
     const int rd = order[k];
     const size_t pitch = (size_t)b->dim[rd].stride * es, rows = (size_t)b->dim[rd].extent;
+    if (pitch < run * es) {
+        // Rows overlap (a row stride smaller than the row: e.g. tools/RunGen.h:787-805 adopts the dense strides a
+        // bounds query proposes for the REQUIRED region while keeping its own larger extents).  Host and device images
+        // share one layout, so for an upload the whole span can go as one block; a download goes row by row in
+        // index order so that aliased elements end up with the value of their last row, as a host loop would leave them.
+        if (to_device) {
+            const size_t span = (size_t)(end_offset(b) - begin_offset(b)) * es;
+            HLMI_HIP(uc, hipMemcpyAsync(d0, h0, span, kind, stream));
+            return 0;
+        }
+        int idx[16] = {0};
+        for (;;) {
+            size_t off = 0;
+            for (int j = k; j < nd; j++) off += (size_t)idx[j] * (size_t)b->dim[order[j]].stride * es;
+            HLMI_HIP(uc, hipMemcpyAsync(h0 + off, d0 + off, run * es, kind, stream));
+            int j = k;
+            for (; j < nd; j++) {
+                if (++idx[j] < b->dim[order[j]].extent) break;
+                idx[j] = 0;
+            }
+            if (j >= nd) break;
+        }
+        return 0;
+    }
     int idx[16] = {0};
     for (;;) {
         size_t off = 0;
@@ -753,16 +777,11 @@ static int hip_wrap_native(void *uc, halide_buffer_t *buf, uint64_t handle) {
 }
 
 static int hip_detach_native(void *uc, halide_buffer_t *buf) {
-    if (buf->device == 0) return 0;
-    {
-        std::lock_guard<std::mutex> lock(g_mu);
-        int n = device_count_locked();
-        for (int d = 0; d < n; d++) {
-            if (g_dev[d].owned.count(buf->device)) {
-                return report(uc, halide_error_code_device_detach_native_failed, "hlmi: detach_native on a buffer whose device memory is owned by the runtime");
-            }
-        }
-    }
+    // Like halide_cuda_detach_device_ptr (src/runtime/cuda.cpp:1240-1249): forget the handle, free nothing.  Ownership
+    // is the CALLER's bookkeeping (Halide::Runtime::Buffer tracks it as BufferDeviceOwnership::WrappedNative,
+    // HalideBuffer.h:346-347); a handle is a plain device address here, so an alias that wraps an address inside one of
+    // the runtime's own allocations is indistinguishable from that allocation and must be detachable.
+    (void)uc;
     buf->device = 0;
     buf->device_interface = nullptr;
     return 0;

@@ -15,6 +15,56 @@
 
 #define LL_MAXJ 20
 
+/* ---- canonicalisation variants ------------------------------------------------------------------------------
+ * What the reference's object computes for the float stages is the generator's expression AFTER Halide's
+ * simplifier, compiled by LLVM with fast-math contraction allowed.  The simplifier part is deterministic and is
+ * restated here as the CANONICAL form (variant 0):
+ *   - x / c0 -> x * fold(1 / c0)                     src/Simplify_Div.cpp:204 (constants fold in double, then round
+ *                                                      to float32: src/IRMatch.h:1014-1016)
+ *   - (x * c0) * c1 -> x * fold(c0 * c1)              src/Simplify_Mul.cpp:70 (not gated on the type) — so
+ *     gray = 0.299f * (u / 65535.0f) + ... is evaluated as u * C0 + ... with C_c = float(double(r) * double(coef_c)),
+ *     r = float(1.0 / 65535.0)                        (generator :32, :36)
+ *   - power-of-two scalings (/8.0f, /4.0f, /256.0f, /2.0f) move freely: exact.
+ * What LLVM may add on top (contraction of mul+add into fma, src/CodeGen_LLVM.cpp:483-500,
+ * src/CodeGen_Internal.cpp:614) is NOT deterministic across targets/LLVM versions; the other variants exist to MEASURE
+ * how far the u16 output moves under the plausible alternatives (tests/test_oracle_variants.py, scripts/
+ * oracle_variants.py):
+ *   LL_VAR_SOURCE  gray in source order, (u * r) * coef (no constant folding)            — round 1's canonical form
+ *   LL_VAR_FMA     every mul that feeds an add is contracted the way LLVM's DAG combiner does it
+ *                  (fadd(fmul(a,b), c) -> fma(a,b,c), first operand first; single-use multiplies only)
+ *   LL_VAR_DIV     floating = u / 65535.0f as a true division (no reciprocal rewrite; implies source order)
+ * Bits combine (FMA | SOURCE etc.). */
+enum { LL_VAR_SOURCE = 1, LL_VAR_FMA = 2, LL_VAR_DIV = 4 };
+static int ll_var = 0;
+void oracle_ll_set_variant(int v) { ll_var = v; }
+int oracle_ll_get_variant(void) { return ll_var; }
+
+/* a * b + c, contracted or not */
+static inline float v_mad(float a, float b, float c) { return (ll_var & LL_VAR_FMA) ? fmaf(a, b, c) : a * b + c; }
+/* a * b + c * d: the DAG combiner contracts the first multiply and keeps the second */
+static inline float v_mad2(float a, float b, float c, float d) { return (ll_var & LL_VAR_FMA) ? fmaf(a, b, c * d) : a * b + c * d; }
+static inline float v_lerp(float zero, float one, float w) { return v_mad2(zero, 1.0f - w, one, w); }
+
+static inline float ll_gray(float u0, float u1, float u2) {
+    if (ll_var & LL_VAR_DIV) {
+        float f0 = u0 / 65535.0f, f1 = u1 / 65535.0f, f2 = u2 / 65535.0f;
+        return v_mad(0.114f, f2, v_mad2(0.299f, f0, 0.587f, f1));
+    }
+    const float r = (float)(1.0 / 65535.0);
+    if (ll_var & LL_VAR_SOURCE) {
+        float f0 = u0 * r, f1 = u1 * r, f2 = u2 * r;
+        return v_mad(0.114f, f2, v_mad2(0.299f, f0, 0.587f, f1));
+    }
+    const float C0 = (float)((double)r * (double)0.299f), C1 = (float)((double)r * (double)0.587f),
+                C2 = (float)((double)r * (double)0.114f);
+    return v_mad(u2, C2, v_mad2(u0, C0, u1, C1));
+}
+/* the folded constants, for the product-side unit test (tests/test_local_laplacian.py) */
+void oracle_ll_gray_constants(float *c) {
+    const float r = (float)(1.0 / 65535.0);
+    c[0] = (float)((double)r * (double)0.299f), c[1] = (float)((double)r * (double)0.587f), c[2] = (float)((double)r * (double)0.114f);
+}
+
 typedef struct {
     int x0, x1, y0, y1; /* inclusive */
     int w, h;
@@ -43,14 +93,14 @@ static void downsample(const plane_t *f, plane_t *out) {
     for (int y = dy.y0; y <= dy.y1; y++) {
         for (int x = dy.x0; x <= dy.x1; x++) {
             float a = P(f, x, 2 * y - 1), b = P(f, x, 2 * y), c = P(f, x, 2 * y + 1), d = P(f, x, 2 * y + 2);
-            *PP(&dy, x, y) = ((a + 3.0f * (b + c)) + d) * 0.125f;
+            *PP(&dy, x, y) = (v_mad(3.0f, b + c, a) + d) * 0.125f;
         }
     }
 #pragma omp parallel for schedule(static)
     for (int y = out->y0; y <= out->y1; y++) {
         for (int x = out->x0; x <= out->x1; x++) {
             float a = P(&dy, 2 * x - 1, y), b = P(&dy, 2 * x, y), c = P(&dy, 2 * x + 1, y), d = P(&dy, 2 * x + 2, y);
-            *PP(out, x, y) = ((a + 3.0f * (b + c)) + d) * 0.125f;
+            *PP(out, x, y) = (v_mad(3.0f, b + c, a) + d) * 0.125f;
         }
     }
     free(dy.p);
@@ -59,11 +109,11 @@ static void downsample(const plane_t *f, plane_t *out) {
 /* upsample (:276-282) evaluated at one point */
 static inline float upx_at(const plane_t *f, int x, int y) {
     float w = (float)(o_fmod(x, 2) * 2 + 1) * 0.25f;
-    return o_lerp(P(f, o_fdiv(x + 1, 2), y), P(f, o_fdiv(x - 1, 2), y), w);
+    return v_lerp(P(f, o_fdiv(x + 1, 2), y), P(f, o_fdiv(x - 1, 2), y), w);
 }
 static inline float up_at(const plane_t *f, int x, int y) {
     float w = (float)(o_fmod(y, 2) * 2 + 1) * 0.25f;
-    return o_lerp(upx_at(f, x, o_fdiv(y + 1, 2)), upx_at(f, x, o_fdiv(y - 1, 2)), w);
+    return v_lerp(upx_at(f, x, o_fdiv(y + 1, 2)), upx_at(f, x, o_fdiv(y - 1, 2)), w);
 }
 
 /* remap LUT (:23-25): remap(i) = alpha * fx * exp(-fx * fx / 2.0f), fx = float(i) / 256.0f */
@@ -112,8 +162,7 @@ int oracle_local_laplacian(const uint16_t *in, int W, int H, int in_sy, int in_s
     float *lut = (float *)malloc(sizeof(float) * (size_t)(2 * half + 1));
     oracle_ll_remap_lut(K, alpha, lut);
 
-    /* gray on G_0 with clamped input coordinates (:28-36).  floating = u16 / 65535.0f -> * (1/65535.0f) */
-    const float r65535 = 1.0f / 65535.0f;
+    /* gray on G_0 with clamped input coordinates (:28-36); see ll_gray for the canonical constants */
     plane_t gray;
     plane_alloc(&gray, Gx0[0], Gx1[0], Gy0[0], Gy1[0]);
 #pragma omp parallel for schedule(static)
@@ -122,9 +171,7 @@ int oracle_local_laplacian(const uint16_t *in, int W, int H, int in_sy, int in_s
         for (int x = gray.x0; x <= gray.x1; x++) {
             int xc = o_clampi(x, X0, X0 + W - 1) - X0;
             size_t o = (size_t)yc * (size_t)in_sy + (size_t)xc;
-            float f0 = (float)in[o] * r65535, f1 = (float)in[o + (size_t)in_sc] * r65535,
-                  f2 = (float)in[o + 2 * (size_t)in_sc] * r65535;
-            *PP(&gray, x, y) = (0.299f * f0 + 0.587f * f1) + 0.114f * f2;
+            *PP(&gray, x, y) = ll_gray((float)in[o], (float)in[o + (size_t)in_sc], (float)in[o + 2 * (size_t)in_sc]);
         }
     }
 
@@ -133,7 +180,7 @@ int oracle_local_laplacian(const uint16_t *in, int W, int H, int in_sy, int in_s
     const float Km1 = (float)(K - 1);
     const float inv_Km1 = 1.0f / Km1; /* (1.0f / (levels - 1)) :41 */
 #define G0_AT(gr, k) \
-    ((beta * ((gr) - (float)(k) * inv_Km1) + (float)(k) * inv_Km1) + \
+    (v_mad(beta, (gr) - (float)(k) * inv_Km1, (float)(k) * inv_Km1) + \
      lut[o_clampi((int)(((gr) * Km1) * 256.0f), 0, half) - 256 * (k) + half])
     for (int k = 0; k < K; k++) {
         plane_t g0;
@@ -185,7 +232,7 @@ int oracle_local_laplacian(const uint16_t *in, int W, int H, int in_sy, int in_s
                     l0 = l0 - up_at(&g[li][j + 1], x, y);
                     l1 = l1 - up_at(&g[li + 1][j + 1], x, y);
                 }
-                float outL = (1.0f - lf) * l0 + lf * l1;
+                float outL = v_mad2(1.0f - lf, l0, lf, l1);
                 *PP(&outG[j], x, y) = (j == J - 1) ? outL : up_at(&outG[j + 1], x, y) + outL;
             }
         }

@@ -72,15 +72,33 @@ def omp_threads() -> int:
     return int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
 
 
-def local_laplacian(inp: np.ndarray, levels: int, alpha: float, beta: float, J: int = 8, origin=(0, 0)) -> np.ndarray:
+# canonicalisation variants of the local_laplacian oracle (oracle/local_laplacian_oracle.c header); 0 = canonical
+LL_VAR_SOURCE, LL_VAR_FMA, LL_VAR_DIV = 1, 2, 4
+_lib.oracle_ll_set_variant.argtypes = [C.c_int]
+_lib.oracle_ll_gray_constants.argtypes = [_f32p]
+
+
+def ll_gray_constants() -> np.ndarray:
+    c = np.zeros(3, np.float32)
+    _lib.oracle_ll_gray_constants(c)
+    return c
+
+
+def local_laplacian(inp: np.ndarray, levels: int, alpha: float, beta: float, J: int = 8, origin=(0, 0),
+                    variant: int = 0) -> np.ndarray:
     """inp: u16 array of shape (3, H, W) (planar). Returns the same shape.  `origin` = (min_x, min_y) of the
-    buffer in the pipeline's absolute coordinate system (the 2x-1 pyramid taps depend on it)."""
+    buffer in the pipeline's absolute coordinate system (the 2x-1 pyramid taps depend on it).  `variant` selects a
+    non-canonical evaluation (LL_VAR_*) for the canonicalisation study only."""
     inp = np.ascontiguousarray(inp, np.uint16)
     c, h, w = inp.shape
     assert c == 3
     out = np.zeros_like(inp)
-    r = _lib.oracle_local_laplacian(inp, w, h, w, w * h, int(origin[0]), int(origin[1]), J, levels, alpha, beta, out,
-                                    w, w * h, -1, None)
+    _lib.oracle_ll_set_variant(int(variant))
+    try:
+        r = _lib.oracle_local_laplacian(inp, w, h, w, w * h, int(origin[0]), int(origin[1]), J, levels, alpha, beta, out,
+                                        w, w * h, -1, None)
+    finally:
+        _lib.oracle_ll_set_variant(0)
     assert r == 0
     return out
 

@@ -23,7 +23,9 @@ def naive_local_laplacian(inp, levels, alpha, beta, J=8):
     K = levels
     lut = oracle_lib.ll_remap_lut(K, alpha)
     half = (K - 1) * 256
-    r = f32(1.0) / f32(65535.0)
+    r = f32(1.0 / 65535.0)
+    # the simplifier's folded constants (src/Simplify_Div.cpp:204, src/Simplify_Mul.cpp:70; oracle header)
+    C0, C1, C2 = (f32(float(r) * float(f32(c))) for c in (0.299, 0.587, 0.114))
     beta = f32(beta)
     Km1 = f32(K - 1)
     inv = f32(1.0) / Km1
@@ -31,8 +33,8 @@ def naive_local_laplacian(inp, levels, alpha, beta, J=8):
     @functools.lru_cache(maxsize=None)
     def gray(x, y):
         xc, yc = min(max(x, 0), W - 1), min(max(y, 0), H - 1)
-        f0, f1, f2 = (f32(inp[c, yc, xc]) * r for c in range(3))
-        return (f32(0.299) * f0 + f32(0.587) * f1) + f32(0.114) * f2
+        u0, u1, u2 = (f32(inp[c, yc, xc]) for c in range(3))
+        return (u0 * C0 + u1 * C1) + u2 * C2
 
     def g0(x, y, k):
         gr = gray(x, y)

@@ -80,16 +80,20 @@ def test_reference_rungen_estimate_all_benchmark(name):
 
 @pytest.mark.gpu
 def test_reference_rungen_output_equals_the_oracle(oracle, tmp_path):
-    """Image in, image out through the reference's RunGen (npy: tools/halide_image_io.h:1183-1400) == oracle."""
+    """Image in, image out through the reference's RunGen == oracle.  The reference's .npy files list the HALIDE
+    extents (dimension 0 first) under 'fortran_order': False while the payload has dimension 0 fastest
+    (tools/halide_image_io.h:1433-1445, :1376-1387): the bytes of a planar (3, H, W) C-order array under the shape
+    label (W, H, 3)."""
     rng = np.random.default_rng(11)
     inp = rng.integers(0, 65536, (3, 96, 160), dtype=np.uint16)
-    np.save(tmp_path / "in.npy", inp)
+    np.save(tmp_path / "in.npy", inp.reshape(160, 96, 3))
     r = _run("local_laplacian.rungen", f"input={tmp_path / 'in.npy'}", "levels=8", "alpha=0.14285714285714285", "beta=1",
              f"output={tmp_path / 'out.npy'}", "--output_extents=[160,96,3]")
     assert r.returncode == 0, r.stdout + r.stderr
     got = np.load(tmp_path / "out.npy")
+    assert got.shape == (160, 96, 3) and got.dtype == np.uint16
     want = oracle.local_laplacian(inp, 8, np.float32(0.14285714285714285), 1.0)
-    assert got.shape == want.shape and np.array_equal(got, want)
+    assert np.array_equal(got.reshape(3, 96, 160), want)
 
 
 @pytest.mark.gpu
