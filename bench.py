@@ -31,11 +31,14 @@ HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 ALG_BYTES_PER_PX = 12         # SURVEY.md §8(d) primary figure: 6 B read + 6 B written per pixel
 
 
-def synth_frame(seed):
-    """Smooth natural-like frame + noise (data-dependent level selection is cache sensitive)."""
+def synth_frame(seed, w=W, h=H, kind="smooth"):
+    """SURVEY.md §8d input variants: (ii) smooth natural-like frame + noise — the headline input; the data-dependent
+    level selection is cache sensitive — and (i) uniform full-range noise, the worst case for the plane gathers."""
     import numpy as np
     rng = np.random.default_rng(seed)
-    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    if kind == "noise":
+        return rng.integers(0, 65536, (C, h, w), dtype=np.uint16)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
     base = (np.sin(xx / 311.0 + seed) + np.cos(yy / 173.0) + np.sin((xx + yy) / 97.0) + 3.3) / 6.6
     img = np.stack([base * 65535.0, np.roll(base, 64, 1) * 52000.0, base[::-1] * 46000.0])
     img += rng.normal(0.0, 900.0, img.shape).astype(np.float32)
@@ -63,9 +66,10 @@ def cpu_baseline(frame):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=250, help="timed steps (default: about 0.25 s of GPU time)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra input variants (uniform noise, 7680x4320)")
     ap.add_argument("--partitions", type=int, default=int(os.environ.get("HLMI_BENCH_PARTITIONS", "4")),
                     help="frames of a step are spread over this many CU-partitioned streams (halide_hip_partition_stream: "
                          "disjoint quarters of the chip by default), one frame per partition at a time: frames are "
@@ -87,10 +91,15 @@ def main():
     torch.cuda.set_device(local_rank)
     hl.set_gpu_device(local_rank)
     dist = None
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # proof that RCCL really spans `world` ranks (one per GPU): every rank contributes 1 to a sum over xGMI
+        ones = torch.ones(1, dtype=torch.int32, device="cuda")
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
 
     # --- synthetic frames, resident in HBM before the timed region
     from halide_amd import sharding
@@ -102,6 +111,31 @@ def main():
     for a, o in zip(ins, outs):  # first call uploads the input and allocates the output on the device
         hl.local_laplacian(a, LEVELS, ALPHA, BETA, o)
     outs[-1].device_sync()
+
+    def run_variant(w, h, kind, nframes, steps):
+        """Mpx/s of the same call on another input variant of configs[2], same stream scheduling, inputs
+        resident; untimed with respect to the headline figure (runs after it)."""
+        fr = [synth_frame(100 + i, w, h, kind) for i in range(nframes)]
+        vi, vo = [hl.Buffer(f) for f in fr], [hl.Buffer(np.zeros_like(f)) for f in fr]
+
+        def vstep():
+            for i, (a, o) in enumerate(zip(vi, vo)):
+                if streams:
+                    hl.set_stream(streams[i % len(streams)])
+                hl.local_laplacian(a, LEVELS, ALPHA, BETA, o)
+            if streams:
+                hl.set_stream(None)
+        for _ in range(3):
+            vstep()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            vstep()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        for b in vi + vo:
+            b.device_free()
+        return round(nframes * steps * w * h / dt / 1e6, 1)
 
     streams, keep, mode = [], [], "1 stream"
     if args.partitions > 1:
@@ -157,6 +191,12 @@ def main():
         except hl.HalideError:   # e.g. no room for two 1 GiB buffers: the headline line does not depend on it
             copy_ceiling = None
 
+    variants = None
+    if rank == 0 and world == 1 and not args.no_variants:
+        variants = {"unit": "Mpx/s", "uniform_noise_3840x2160": run_variant(W, H, "noise", 8, 40),
+                    "smooth_7680x4320": run_variant(2 * W, 2 * H, "smooth", 4, 20),
+                    "uniform_noise_7680x4320": run_variant(2 * W, 2 * H, "noise", 4, 20)}
+
     if rank == 0:
         px_per_step = world * FRAMES_PER_STEP * W * H
         value = px_per_step * args.steps / elapsed / 1e6
@@ -189,6 +229,9 @@ def main():
                        "frames_per_step_per_gpu": FRAMES_PER_STEP, "frame_ms": round(frame_ms, 4),
                        "streams_per_gpu": max(1, len(streams)), "frame_scheduling": mode,
                        "boundary": "C ABI local_laplacian(halide_buffer_t*,int32,float,float,halide_buffer_t*)",
+                       "input": "smooth natural-like frames (SURVEY.md §8d (ii)); other variants under `variants`",
+                       "variants": variants,
+                       "rccl_ranks": rccl_ranks,
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -204,6 +247,9 @@ def main():
                          "hbm_copy_ceiling_gbs": None if copy_ceiling is None else round(copy_ceiling, 1),
                          "pipeline_traffic_frac_of_copy_ceiling": None if (frame_traffic is None or not copy_ceiling) else
                          round(frame_traffic / (frame_ms * 1e-3) / 1e9 / copy_ceiling, 4),
+                         # ... and against the float4-copy figure MI355X_MICROARCH.md measured (6.29 TB/s)
+                         "pipeline_traffic_frac_of_guide_copy_6290": None if frame_traffic is None else
+                         round(frame_traffic / (frame_ms * 1e-3) / 1e9 / 6290.0, 4),
                          "kernel_ms_per_frame": {k: round(v, 5) for k, v in per_frame.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -19,7 +19,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhlmi.so")
+# HLMI_LIB: an alternative build of the same library (A/B measurements of compile-time switches, csrc/Makefile VARIANT=)
+LIB_PATH = os.environ.get("HLMI_LIB") or os.path.join(_HERE, "lib", "libhlmi.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

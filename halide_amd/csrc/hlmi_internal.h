@@ -113,6 +113,11 @@ int get_workspace(void *uc, const DeviceCtx &ctx, size_t bytes, void **ptr);
 int input_to_device(void *uc, const DeviceCtx &ctx, const BufArg &a);
 int output_on_device(void *uc, const DeviceCtx &ctx, const BufArg &a);
 void mark_output_written(halide_buffer_t *buf);  // device_dirty = 1, host_dirty = 0
+// A number that changes whenever the device contents of `buf` may have changed through this runtime (upload of a
+// host-dirty buffer, use as a pipeline output or copy target, re-allocation); unique across allocations, so
+// (device handle, version) identifies contents.  0 = memory this runtime does not own (wrapped native pointers: their
+// owner can rewrite them behind our back) — callers must not cache anything derived from such a buffer.
+uint64_t buffer_version(const halide_buffer_t *buf);
 
 template<typename T>
 inline T *dev_ptr(const halide_buffer_t *b) { return reinterpret_cast<T *>((uintptr_t)b->device); }

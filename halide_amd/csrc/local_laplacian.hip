@@ -176,6 +176,40 @@ __device__ __forceinline__ T pick4(T x, T y, T z, T w, int s) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The u16 frames are touched exactly twice (input: ll_down0 and ll_up0; output: written once) and never again, while the
+// pyramid planes in between are re-read within tens of microseconds.  HLMI_LL_NT=1 (compile-time; csrc/Makefile
+// VARIANT) marks the frame accesses non-temporal so that they do not displace the planes from L2 / Infinity Cache.
+#ifndef HLMI_LL_NT
+#define HLMI_LL_NT 0
+#endif
+typedef unsigned short us4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ushort4 ld_frame4(const uint16_t *p) {
+#if HLMI_LL_NT
+    us4_t v = __builtin_nontemporal_load(reinterpret_cast<const us4_t *>(p));
+    return make_ushort4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const ushort4 *>(p);
+#endif
+}
+__device__ __forceinline__ ushort2 ld_frame2(const void *sbase, uint32_t byte_off) {
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(sbase) + byte_off);
+#if HLMI_LL_NT
+    const uint32_t w = __builtin_nontemporal_load(q);
+#else
+    const uint32_t w = *q;
+#endif
+    return make_ushort2((uint16_t)(w & 0xffffu), (uint16_t)(w >> 16));
+}
+__device__ __forceinline__ void st_frame2(void *p, uint16_t a, uint16_t b) {
+    const uint32_t w = (uint32_t)a | ((uint32_t)b << 16);
+#if HLMI_LL_NT
+    __builtin_nontemporal_store(w, reinterpret_cast<uint32_t *>(p));
+#else
+    *reinterpret_cast<uint32_t *>(p) = w;
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------
 // level 0 -> level 1
 struct Raw {
     ushort4 c0, c1, c2;  // the lane's 4 columns of the three (clamped) colour channels of one input row
@@ -188,9 +222,9 @@ template<bool VEC>
 __device__ __forceinline__ void load_raw(Raw &r, const uint16_t *__restrict__ rp, long co0, long co1, long co2,
                                          int oq, const int (&xo)[4]) {
     if (VEC) {
-        r.c0 = *reinterpret_cast<const ushort4 *>(rp + co0 + oq);
-        r.c1 = *reinterpret_cast<const ushort4 *>(rp + co1 + oq);
-        r.c2 = *reinterpret_cast<const ushort4 *>(rp + co2 + oq);
+        r.c0 = ld_frame4(rp + co0 + oq);
+        r.c1 = ld_frame4(rp + co1 + oq);
+        r.c2 = ld_frame4(rp + co2 + oq);
     } else {
         r.c0 = make_ushort4(rp[co0 + xo[0]], rp[co0 + xo[1]], rp[co0 + xo[2]], rp[co0 + xo[3]]);
         r.c1 = make_ushort4(rp[co1 + xo[0]], rp[co1 + xo[1]], rp[co1 + xo[2]], rp[co1 + xo[3]]);
@@ -837,6 +871,12 @@ struct Up0Args {
     int ox0, oy0, ow, oh, nc, RU;
     int same_ch;             // the colour channels are exactly the gray channels: load once
     float beta;
+    // level 2, for the fused collapse of level 1 (ll_up0f<.., .., true>): outGPyramid[1] is then produced per workgroup
+    // tile in LDS instead of by an ll_up:1 launch
+    const float *g2, *out2;
+    int lox2, loy2, ws2;
+    size_t ps2;
+    int rx1_1;               // right end of R_1 (the tiles of the last workgroup column stop there)
 };
 
 template<bool VEC, bool LUT_LDS>
@@ -978,13 +1018,36 @@ __global__ void ll_div3_check(const float *n, const float *d, int count, int *ba
     }
 }
 
-template<bool LUT_LDS, bool B1>
+//   * FUSE1: outGPyramid[1] on the part of R_1 this workgroup's 256 x 2 RU outputs read (130 coarse columns x up to
+//     RU + 2 coarse rows) is computed HERE, into LDS, by the very device functions ll_up uses (bit-identical), instead
+//     of by an ll_up:1 launch that writes it to memory for this kernel to gather back: one launch, the write and the
+//     re-read of the plane, and a second pass over level 1's planes less.  The tile halo costs (130 x (RU + 2)) /
+//     (128 x RU) - 1 recomputed values (16 % at RU = 16).
+constexpr int U0_TW = 130, U0_TS = 131;  // coarse columns of a workgroup's tile / its LDS row stride
+template<bool LUT_LDS, bool B1, bool FUSE1>
 __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
     extern __shared__ float slut[];
+    float *s_out1 = slut + (LUT_LDS ? ((2 * gm.half + 2) & ~1) : 0);
     if (LUT_LDS) {
         for (int i = threadIdx.x; i <= 2 * gm.half; i += 256) slut[i] = p.lut_g[i];
-        __syncthreads();
     }
+    int cx0 = 0, cy0 = 0;
+    if (FUSE1) {
+        const int X0 = p.ox0 + (int)blockIdx.x * 256;                       // even
+        const int Yw0 = p.oy0 + (int)blockIdx.y * (2 * p.RU);
+        const int Yw1 = min(Yw0 + 2 * p.RU, p.oy0 + p.oh) - 1;
+        cx0 = (X0 >> 1) - 1, cy0 = dev::fdiv2(Yw0 - 1);
+        const int th = dev::fdiv2(Yw1 + 1) - cy0 + 1;
+        for (int e = threadIdx.x; e < U0_TW * th; e += 256) {
+            const int ty = e / U0_TW, tx = e - ty * U0_TW;
+            const int cx = cx0 + tx, cy = cy0 + ty;
+            if (cx > p.rx1_1) continue;
+            // outGPyramid[1] = upsample(outGPyramid[2]) + outLPyramid[1]   (:76-79), exactly as ll_up computes it
+            const float outL = outl_value(p.g1, p.ws1, p.ps1, p.lox1, p.loy1, p.g2, p.ws2, p.ps2, p.lox2, p.loy2, cx, cy, gm.K, gm.Km1);
+            s_out1[ty * U0_TS + tx] = up_at(p.out2, p.lox2, p.loy2, p.ws2, cx, cy) + outL;
+        }
+    }
+    if (LUT_LDS || FUSE1) __syncthreads();
     const float *lut = LUT_LDS ? slut : p.lut_g;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int x = blockIdx.x * 256 + (wave & 1) * 128 + 2 * lane;  // output storage column of the lane's pair
@@ -1003,17 +1066,25 @@ __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
         const int Y = p.oy0 + y;
         const uint16_t *irow = p.in + (long)(Y - gm.iy0) * p.in_sy;
         uint16_t *orow = p.out + (long)y * p.out_sy;
-        const ushort2 c0 = ld_su<ushort2>(irow + p.gco[0], inb), c1 = ld_su<ushort2>(irow + p.gco[1], inb),
-                      c2 = ld_su<ushort2>(irow + p.gco[2], inb);
+        const ushort2 c0 = ld_frame2(irow + p.gco[0], inb), c1 = ld_frame2(irow + p.gco[1], inb),
+                      c2 = ld_frame2(irow + p.gco[2], inb);
         const int ya = dev::fdiv2(Y + 1) - p.loy1, yb = dev::fdiv2(Y - 1) - p.loy1;
         const bool yodd = dev::fmod2(Y) != 0;  // wave-uniform
         // lerp(ua, ub, wy) (:280), ua from coarse row ya, ub from yb: wy = 3/4 for odd Y, 1/4 for even Y.  The row
         // whose weight is 1/4 (an exact product) is called q, the other t — a scalar choice of row pointers.
         const int yq = yodd ? ya : yb, yt = yodd ? yb : ya;
         const float *ga = p.g1 + (size_t)yq * p.ws1, *gb = p.g1 + (size_t)yt * p.ws1;
-        const float *oa = p.out1 + (size_t)yq * p.ws1, *ob = p.out1 + (size_t)yt * p.ws1;
         auto vl = [&](float uq, float ut) { return __builtin_fmaf(uq, 0.25f, ut * 0.75f); };
-        const F3U OA = ld_su<F3U>(oa, colb), OB = ld_su<F3U>(ob, colb);
+        F3U OA, OB;
+        if (FUSE1) {  // rows of the workgroup's LDS tile; column c - 1 - cx0 = 64 (wave & 1) + lane
+            const float *oa = s_out1 + (yq + p.loy1 - cy0) * U0_TS + (wave & 1) * 64 + lane;
+            const float *ob = s_out1 + (yt + p.loy1 - cy0) * U0_TS + (wave & 1) * 64 + lane;
+            OA.x = oa[0], OA.y = oa[1], OA.z = oa[2];
+            OB.x = ob[0], OB.y = ob[1], OB.z = ob[2];
+        } else {
+            const float *oa = p.out1 + (size_t)yq * p.ws1, *ob = p.out1 + (size_t)yt * p.ws1;
+            OA = ld_su<F3U>(oa, colb), OB = ld_su<F3U>(ob, colb);
+        }
         const float uo[2] = {vl(hl0(OA.x, OA.y), hl0(OB.x, OB.y)), vl(hl1(OA.y, OA.z), hl1(OB.y, OB.z))};
         const uint16_t ch[3][2] = {{c0.x, c0.y}, {c1.x, c1.y}, {c2.x, c2.y}};
         uint16_t res[3][2];
@@ -1048,10 +1119,7 @@ __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
             for (int c = 0; c < 3; c++) res[c][i] = (uint16_t)__builtin_amdgcn_fmed3f(q[c], 0.0f, 65535.0f);  // q is never NaN
         }
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            *reinterpret_cast<ushort2 *>(reinterpret_cast<char *>(orow + (long)c * p.out_sc) + outb) =
-                make_ushort2(res[c][0], res[c][1]);
-        }
+        for (int c = 0; c < 3; c++) st_frame2(reinterpret_cast<char *>(orow + (long)c * p.out_sc) + outb, res[c][0], res[c][1]);
     }
 }
 
@@ -1092,6 +1160,9 @@ int cu_count(int dev) {
 // last call's level table, for hlmi_debug_local_laplacian_outg (tests only)
 thread_local Level t_dbg_lv[J];
 thread_local hipStream_t t_dbg_stream = nullptr;
+thread_local bool t_dbg_out1_pending = false;  // the last call fused level 1's collapse: outGPyramid[1] was never stored
+thread_local int t_dbg_K = 0;
+thread_local float t_dbg_Km1 = 0;
 
 }  // namespace
 
@@ -1317,19 +1388,11 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         HLMI_LAUNCH(uc, "ll_top", st, ll_top, dim3((rw + 63) / 64, rh), dim3(64), 0, t.g, t.ws, t.ps, t.lox, t.loy, t.rx0,
                     t.ry0, rw, rh, levels, gm.Km1, t.out);
     }
-    for (int j = min(SU, J - 1) - 1; j >= 1; j--) {
-        const Level &a = lv[j], &c = lv[j + 1];
-        int rw = a.rx1 - a.rx0 + 1, rh = a.ry1 - a.ry0 + 1;
-        char nm[32];
-        snprintf(nm, sizeof nm, "ll_up:%d", j);
-        // per output: 2 planes of g_j + inG_j read, outG_j written; per coarse pixel: 2 planes of g_{j+1} + outG_{j+1}
-        timing_note_bytes(4.0 * (4.0 * rw * rh + 3.0 * (c.rx1 - c.rx0 + 1) * (c.ry1 - c.ry0 + 1)));
-        HLMI_LAUNCH(uc, nm, st, ll_up, dim3((rw + 255) / 256, rh), dim3(256), 0, a.g, a.ws, a.ps, a.lox, a.loy, c.g,
-                    c.out, c.ws, c.ps, c.lox, c.loy, a.rx0, a.ry0, rw, rh, levels, gm.Km1, a.out);
-    }
+    // ---- level 0 arguments first: whether the level-1 collapse is fused into ll_up0f decides if ll_up:1 is launched
+    Up0Args p;
+    bool vec, fast, fuse1;
     {
         const Level &c = lv[1];
-        Up0Args p;
         p.in = din, p.in_sy = in_sy;
         const int oc0 = output->dim[2].min;
         bool same = (nc == 3);
@@ -1343,23 +1406,55 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         p.lox1 = c.lox, p.loy1 = c.loy, p.ws1 = c.ws, p.ps1 = c.ps;
         p.out = dout, p.out_sy = out_sy, p.out_sc = out_sc;
         p.ox0 = output->dim[0].min, p.oy0 = output->dim[1].min, p.ow = ow, p.oh = oh, p.nc = nc;
-        p.RU = max(1, env_int("HLMI_LL_RU", 8));
         p.beta = beta;
-        bool vec = ((uintptr_t)din % 4 == 0) && ((uintptr_t)dout % 4 == 0) && in_sy % 2 == 0 && out_sy % 2 == 0 &&
-                   out_sc % 2 == 0 && ((p.ox0 - gm.ix0) % 2 == 0) && !env_int("HLMI_LL_NO_VEC", 0);
+        p.g2 = lv[2].g, p.out2 = lv[2].out, p.lox2 = lv[2].lox, p.loy2 = lv[2].loy, p.ws2 = lv[2].ws, p.ps2 = lv[2].ps;
+        p.rx1_1 = c.rx1;
+        vec = ((uintptr_t)din % 4 == 0) && ((uintptr_t)dout % 4 == 0) && in_sy % 2 == 0 && out_sy % 2 == 0 &&
+              out_sc % 2 == 0 && ((p.ox0 - gm.ix0) % 2 == 0) && !env_int("HLMI_LL_NO_VEC", 0);
         for (int ch = 0; ch < 3; ch++) vec = vec && p.gco[ch] % 2 == 0 && p.cco[ch] % 2 == 0;
+        fast = vec && same && nc == 3 && (ow & 1) == 0 && (p.ox0 & 1) == 0 &&
+               (double)(levels + 1) * (4.0 * (double)c.ps) < 4.0e9 && !env_int("HLMI_LL_UP0_OLD", 0);
+        // the fused collapse needs level 2 to be a stored level of its own (SU >= 2 always holds: SU >= S >= 4 or the
+        // opt-in up-chain, which starts at >= 1 and then owns level 1 itself)
+        fuse1 = fast && SU >= 2 && env_int("HLMI_LL_FUSE_UP1", 1);
+        p.RU = max(1, env_int("HLMI_LL_RU", fuse1 ? 16 : 8));
+    }
+    for (int j = min(SU, J - 1) - 1; j >= (fuse1 ? 2 : 1); j--) {
+        const Level &a = lv[j], &c = lv[j + 1];
+        int rw = a.rx1 - a.rx0 + 1, rh = a.ry1 - a.ry0 + 1;
+        char nm[32];
+        snprintf(nm, sizeof nm, "ll_up:%d", j);
+        // per output: 2 planes of g_j + inG_j read, outG_j written; per coarse pixel: 2 planes of g_{j+1} + outG_{j+1}
+        timing_note_bytes(4.0 * (4.0 * rw * rh + 3.0 * (c.rx1 - c.rx0 + 1) * (c.ry1 - c.ry0 + 1)));
+        HLMI_LAUNCH(uc, nm, st, ll_up, dim3((rw + 255) / 256, rh), dim3(256), 0, a.g, a.ws, a.ps, a.lox, a.loy, c.g,
+                    c.out, c.ws, c.ps, c.lox, c.loy, a.rx0, a.ry0, rw, rh, levels, gm.Km1, a.out);
+    }
+    t_dbg_out1_pending = fuse1;
+    t_dbg_K = levels, t_dbg_Km1 = gm.Km1;
+    {
+        const Level &c = lv[1];
         dim3 grid((ow + 255) / 256, (oh + 2 * p.RU - 1) / (2 * p.RU)), block(256);
-        // input read + output written (u16 x nc channels), 2 selected planes of g_1 + outG_1 read
-        const double u0_bytes = 2.0 * (3 + nc) * ow * oh + 4.0 * 3.0 * (c.rx1 - c.rx0 + 1) * (c.ry1 - c.ry0 + 1);
+        // input read + output written (u16 x nc channels), 2 selected planes of g_1 read; unfused: + outG_1 read;
+        // fused: + inG_1 and, per level-2 pixel, 2 planes of g_2 + outG_2
+        const double n1 = (double)(c.rx1 - c.rx0 + 1) * (c.ry1 - c.ry0 + 1), n2 = (double)(lv[2].rx1 - lv[2].rx0 + 1) * (lv[2].ry1 - lv[2].ry0 + 1);
+        const double u0_bytes = 2.0 * (3 + nc) * ow * oh + 4.0 * 3.0 * n1 + (fuse1 ? 4.0 * 3.0 * n2 : 0.0);
         timing_note_bytes(u0_bytes);
-        const bool fast = vec && same && nc == 3 && (ow & 1) == 0 && (p.ox0 & 1) == 0 &&
-                          (double)(levels + 1) * (4.0 * (double)c.ps) < 4.0e9 && !env_int("HLMI_LL_UP0_OLD", 0);
         if (fast) {
             const bool b1 = (beta == 1.0f);
-            if (lut_lds && b1) HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0f<true, true>), grid, block, lut_sh, p, gm);
-            else if (lut_lds) HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0f<true, false>), grid, block, lut_sh, p, gm);
-            else if (b1) HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0f<false, true>), grid, block, lut_sh, p, gm);
-            else HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0f<false, false>), grid, block, lut_sh, p, gm);
+            const size_t sh = lut_sh + (fuse1 ? ((lut_lds && (nlut & 1)) ? 4 : 0) + sizeof(float) * U0_TS * (p.RU + 2) : 0);
+#define LL_U0(L, B, F) HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0f<L, B, F>), grid, block, sh, p, gm)
+            if (fuse1) {
+                if (lut_lds && b1) LL_U0(true, true, true);
+                else if (lut_lds) LL_U0(true, false, true);
+                else if (b1) LL_U0(false, true, true);
+                else LL_U0(false, false, true);
+            } else {
+                if (lut_lds && b1) LL_U0(true, true, false);
+                else if (lut_lds) LL_U0(true, false, false);
+                else if (b1) LL_U0(false, true, false);
+                else LL_U0(false, false, false);
+            }
+#undef LL_U0
         } else if (vec) {
             if (lut_lds) HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0<true, true>), grid, block, lut_sh, p, gm);
             else HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0<true, false>), grid, block, lut_sh, p, gm);
@@ -1424,6 +1519,15 @@ extern "C" int hlmi_debug_local_laplacian_outg(int level, float *dst, int cap_fl
     if (rh_out) *rh_out = rh;
     if (!dst) return 0;
     if ((long)rw * rh > cap_floats) return -1;
+    if (level == 1 && t_dbg_out1_pending) {
+        // the fused ll_up0f kept outGPyramid[1] in LDS: produce the plane now with the stand-alone kernel (its inputs are
+        // still in the arena) so that the tests can compare every level
+        const Level &a = t_dbg_lv[1], &c = t_dbg_lv[2];
+        hipLaunchKernelGGL(ll_up, dim3((rw + 255) / 256, rh), dim3(256), 0, t_dbg_stream, a.g, a.ws, a.ps, a.lox, a.loy, c.g, c.out,
+                           c.ws, c.ps, c.lox, c.loy, a.rx0, a.ry0, rw, rh, t_dbg_K, t_dbg_Km1, a.out);
+        if (hipGetLastError() != hipSuccess) return -1;
+        t_dbg_out1_pending = false;
+    }
     if (hipStreamSynchronize(t_dbg_stream) != hipSuccess) return -1;
     const float *src = L.out + (size_t)(L.ry0 - L.loy) * L.ws + (L.rx0 - L.lox);
     if (hipMemcpy2D(dst, sizeof(float) * rw, src, sizeof(float) * L.ws, sizeof(float) * rw, rh, hipMemcpyDeviceToHost) !=

@@ -273,7 +273,9 @@ struct Arena {
 struct Owned {
     size_t bytes = 0;
     hipStream_t last_stream = nullptr;
+    uint64_t version = 0;  // changes whenever the contents may have changed (upload, use as an output, copy target)
 };
+static std::atomic<uint64_t> g_version_counter{0};
 struct Cached {
     void *ptr = nullptr;
     hipStream_t stream = nullptr;  // stream the freed allocation was last used on
@@ -420,7 +422,7 @@ static Owned *find_owned_locked(uint64_t handle, int *dev_out) {
 }
 
 // a pipeline call / copy on ctx.stream is about to touch `handle`
-static int note_use(void *uc, const DeviceCtx &ctx, uint64_t handle, const char *name) {
+static int note_use(void *uc, const DeviceCtx &ctx, uint64_t handle, const char *name, bool written = false) {
     std::lock_guard<std::mutex> lock(g_mu);
     int dev;
     Owned *o = find_owned_locked(handle, &dev);
@@ -432,7 +434,15 @@ static int note_use(void *uc, const DeviceCtx &ctx, uint64_t handle, const char 
     }
     order_after_locked(dev, ctx.stream, o->last_stream);
     o->last_stream = ctx.stream;
+    if (written) o->version = ++g_version_counter;
     return 0;
+}
+
+uint64_t buffer_version(const halide_buffer_t *buf) {
+    if (!buf || !buf->device) return 0;
+    std::lock_guard<std::mutex> lock(g_mu);
+    Owned *o = find_owned_locked(buf->device, nullptr);
+    return o ? o->version : 0;
 }
 
 // ---- raw allocation with cache ---------------------------------------------------------------
@@ -646,6 +656,7 @@ static int hip_device_malloc(void *uc, halide_buffer_t *buf) {
     buf->device = (uint64_t)(uintptr_t)base;
     buf->device_interface = halide_hip_device_interface();
     Owned rec;
+    rec.version = ++g_version_counter;
     rec.bytes = bytes, rec.last_stream = nullptr;  // a reused allocation has been ordered behind its previous life above
     g_dev[ctx.device].owned[buf->device] = rec;
     return 0;
@@ -759,7 +770,7 @@ static int hip_copy_to_device(void *uc, halide_buffer_t *buf) {
     DeviceCtx ctx;
     int r = acquire_device(uc, &ctx, false);
     if (r) return r;
-    if ((r = note_use(uc, ctx, buf->device, "passed to halide_copy_to_device"))) return r;
+    if ((r = note_use(uc, ctx, buf->device, "passed to halide_copy_to_device", true))) return r;
     r = copy_strided(uc, buf, true, ctx.stream);
     if (r) return r;
     // the reference's copy_to_device is complete on return (the host buffer may be rewritten right away)
@@ -839,8 +850,9 @@ int input_to_device(void *uc, const DeviceCtx &ctx, const BufArg &a) {
         fresh = true;
     }
     // order ctx.stream behind the stream that produced / last read this buffer
-    if ((r = note_use(uc, ctx, b->device, a.name))) return r;
-    if ((b->flags & halide_buffer_flag_host_dirty) || fresh) {
+    const bool upload = (b->flags & halide_buffer_flag_host_dirty) || fresh;
+    if ((r = note_use(uc, ctx, b->device, a.name, upload))) return r;
+    if (upload) {
         if (b->host == nullptr) return report(uc, halide_error_code_host_is_null, "Input buffer %s host pointer is null", a.name);
         r = copy_strided(uc, b, true, ctx.stream);
         if (r) return halide_error_code_copy_to_device_failed;
@@ -864,7 +876,7 @@ int output_on_device(void *uc, const DeviceCtx &ctx, const BufArg &a) {
         r = hip_device_malloc(uc, b);
         if (r) return r;
     }
-    return note_use(uc, ctx, b->device, a.name);
+    return note_use(uc, ctx, b->device, a.name, true);
 }
 
 void mark_output_written(halide_buffer_t *b) {
@@ -1135,7 +1147,7 @@ static int if_buffer_copy(void *uc, halide_buffer_t *src, const halide_device_in
     int r = acquire_device(uc, &ctx, false);
     if (r) return r;
     if (!from_host && (r = note_use(uc, ctx, src->device, "src of halide_buffer_copy"))) return r;
-    if (!to_host && (r = note_use(uc, ctx, dst->device, "dst of halide_buffer_copy"))) return r;
+    if (!to_host && (r = note_use(uc, ctx, dst->device, "dst of halide_buffer_copy", true))) return r;
     // element-run copies over the overlapping box
     int nd = src->dimensions;
     int lo[16], ext[16];

@@ -112,6 +112,37 @@ def test_hip_bf16_lane_mapping_with_asymmetric_operands(hl, oracle):
 
 
 @pytest.mark.gpu
+def test_hip_bf16_filter_image_follows_the_filter_contents(hl, oracle):
+    """The re-ordered bf16 image of the filter is cached per (filter allocation, version): a resident filter is
+    re-ordered once; a filter the caller rewrites and marks host_dirty (the reference's protocol for changed inputs,
+    src/runtime/HalideRuntime.h:1699-1702) must be re-read; so must a new allocation that lands on the same address."""
+    inp, filt, bias = _data(2, 6, 10, 64, 128, seed=8)
+    bi, bf, bb = hl.Buffer(inp), hl.Buffer(filt), hl.Buffer(bias)
+
+    def run():
+        out = np.zeros((2, 6, 10, 128), np.float32)
+        bo = hl.Buffer(out)
+        hl.conv_layer_bf16(bi, bf, bb, bo)
+        return bo.numpy().copy()
+    first, again = run(), run()                   # second call: cached image
+    assert np.array_equal(first, again)
+    want, mag = oracle.conv_layer_bf16(inp, filt, bias)
+    assert (np.abs(first - want) <= 2e-6 * mag + 1e-6).all()
+    filt[...] = -filt                              # rewrite the SAME host array, tell the library
+    bf.set_host_dirty()
+    changed = run()
+    want2, mag2 = oracle.conv_layer_bf16(inp, filt, bias)
+    assert (np.abs(changed - want2) <= 2e-6 * mag2 + 1e-6).all() and not np.array_equal(changed, first)
+    # a different filter buffer of the same size, allocated after the first one was freed (same address is likely)
+    bf.device_free()
+    filt3 = (filt * np.float32(0.5)).astype(np.float32)
+    bf = hl.Buffer(filt3)
+    third = run()
+    want3, mag3 = oracle.conv_layer_bf16(inp, filt3, bias)
+    assert (np.abs(third - want3) <= 2e-6 * mag3 + 1e-6).all()
+
+
+@pytest.mark.gpu
 def test_hip_rejects_non_dense_layout(hl):
     inp, filt, bias = _data(1, 4, 4, 32, 128, 0)
     bi, bf, bb = hl.Buffer(inp), hl.Buffer(filt), hl.Buffer(bias)

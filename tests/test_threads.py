@@ -13,10 +13,10 @@ import pytest
 @pytest.mark.parametrize("own_streams", [False, True])
 def test_concurrent_calls_from_host_threads(hl, oracle, own_streams):
     # NB: round 1's "224 s" of this test on the shared stream was the first `import torch` of the session on a fresh box
-    # (the image pages in for 1-2 minutes) plus the oracle, not the library: scripts/thread_diag.py times the same 4-thread
-    # loop at 20 ms.  torch is only needed for the caller-owned streams.
-    if own_streams:
-        import torch
+    # (the image pages in for minutes) plus the oracle, not the library: scripts/thread_diag.py times the same 4-thread
+    # loop at 20 ms.  The caller-owned streams are therefore made with the HIP runtime directly, not through torch.
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
     rng = np.random.default_rng(7)
     frames = [rng.integers(0, 65536, (3, 200 + 16 * i, 320), dtype=np.uint16) for i in range(4)]
     gray = [rng.random((180, 250 + 8 * i), dtype=np.float32) for i in range(4)]
@@ -26,9 +26,11 @@ def test_concurrent_calls_from_host_threads(hl, oracle, own_streams):
 
     def worker(i):
         try:
-            stream = torch.cuda.Stream() if own_streams else None
-            if stream is not None:
-                hl.set_stream(stream.cuda_stream)
+            stream = None
+            if own_streams:
+                stream = ctypes.c_void_p()
+                assert hip.hipStreamCreateWithFlags(ctypes.byref(stream), 1) == 0  # hipStreamNonBlocking
+                hl.set_stream(stream.value)
             for rep in range(6):
                 a, o = hl.Buffer(frames[i]), hl.Buffer(np.zeros_like(frames[i]))
                 hl.local_laplacian(a, 8, 1.0 / 7.0, 1.0, o)
@@ -40,6 +42,7 @@ def test_concurrent_calls_from_host_threads(hl, oracle, own_streams):
                     errors.append(f"thread {i} rep {rep}: bilateral_grid differs")
             if stream is not None:
                 hl.set_stream(None)
+                assert hip.hipStreamSynchronize(stream) == 0  # kept alive: the runtime's caches may still name it
         except Exception as e:  # noqa: BLE001
             errors.append(f"thread {i}: {e!r}")
 
