@@ -57,6 +57,20 @@ struct Level {
     int nsx;                 // strips per row
 };
 
+// HLMI_LL_PROBE=1 (compile-time, csrc/Makefile VARIANT): s_memrealtime stamps (10 ns ticks) of the phases of the two big kernels, summed over
+// workgroups into g_probe; hlmi_debug_ll_probe prints and clears them.  Timing experiments only.
+#ifndef HLMI_LL_PROBE
+#define HLMI_LL_PROBE 0
+#endif
+#if HLMI_LL_PROBE
+__device__ unsigned long long g_probe[32];
+#define LL_PROBE_T(var) const unsigned long long var = wall_clock64()   // s_memrealtime: constant 100 MHz
+#define LL_PROBE_ADD(slot, val) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_probe[slot], (unsigned long long)(val)); } while (0)   // only at the very end of a kernel: the atomics are VMEM traffic
+#else
+#define LL_PROBE_T(var)
+#define LL_PROBE_ADD(slot, val)
+#endif
+
 struct Geometry {
     int K, half;             // levels, (K-1)*256
     float Km1, inv_Km1;
@@ -177,14 +191,15 @@ __device__ __forceinline__ T pick4(T x, T y, T z, T w, int s) {
 
 // ---------------------------------------------------------------------------------------------------
 // The u16 frames are touched exactly twice (input: ll_down0 and ll_up0; output: written once) and never again, while the
-// pyramid planes in between are re-read within tens of microseconds.  HLMI_LL_NT=1 (compile-time; csrc/Makefile
-// VARIANT) marks the frame accesses non-temporal so that they do not displace the planes from L2 / Infinity Cache.
+// pyramid planes in between are re-read within tens of microseconds.  HLMI_LL_NT (compile-time bit mask; csrc/Makefile
+// VARIANT) marks frame accesses non-temporal so that they do not displace the planes from L2 / Infinity Cache:
+// 1 = the input read of ll_down0* (first touch), 2 = the input read of ll_up0* (last touch), 4 = the output stores.
 #ifndef HLMI_LL_NT
 #define HLMI_LL_NT 0
 #endif
 typedef unsigned short us4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ ushort4 ld_frame4(const uint16_t *p) {
-#if HLMI_LL_NT
+#if HLMI_LL_NT & 1
     us4_t v = __builtin_nontemporal_load(reinterpret_cast<const us4_t *>(p));
     return make_ushort4(v.x, v.y, v.z, v.w);
 #else
@@ -193,7 +208,7 @@ __device__ __forceinline__ ushort4 ld_frame4(const uint16_t *p) {
 }
 __device__ __forceinline__ ushort2 ld_frame2(const void *sbase, uint32_t byte_off) {
     const uint32_t *q = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(sbase) + byte_off);
-#if HLMI_LL_NT
+#if HLMI_LL_NT & 2
     const uint32_t w = __builtin_nontemporal_load(q);
 #else
     const uint32_t w = *q;
@@ -202,7 +217,7 @@ __device__ __forceinline__ ushort2 ld_frame2(const void *sbase, uint32_t byte_of
 }
 __device__ __forceinline__ void st_frame2(void *p, uint16_t a, uint16_t b) {
     const uint32_t w = (uint32_t)a | ((uint32_t)b << 16);
-#if HLMI_LL_NT
+#if HLMI_LL_NT & 4
     __builtin_nontemporal_store(w, reinterpret_cast<uint32_t *>(p));
 #else
     *reinterpret_cast<uint32_t *>(p) = w;
@@ -581,6 +596,347 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down0f(const uint16_t *__res
         if (++t > t1) break;
         step(t, p2, p3, p0, p1, a2, b2, a, b);
         ++t;
+    }
+    };  // walk
+    if (edge_wave) walk(std::true_type{});
+    else walk(std::false_type{});
+}
+
+// ---- ll_down01f: ll_down0f that ALSO produces level 2 (all K+1 planes) in the same walk — the ll_down_strip:1 launch, its
+// read of the level-1 planes (75 MB at 4K) and its launch latency disappear.
+//   * A unit owns n level-2 rows [A, B] and the level-1 rows [2A, 2B+1] under them.  gPyramid[2] row Y needs level-1 rows
+//     2Y-1 .. 2Y+2, so the walk computes level-1 rows 2A-1 .. 2B+2 — one more above and below than it stores (its
+//     vertical neighbours compute the same two rows with the same operations; nothing is exchanged between units).
+//     Rows or columns of level 1 outside its box are simply computed from the clamped input: level 1 is constant
+//     beyond its box, which is what a clamped read of the stored plane would have returned.
+//   * EXCH: the two extra rows per unit (+24 % of the walk at 4K, where a unit is 4-5 level-2 rows) are avoided inside a
+//     workgroup: its four waves own vertically adjacent units of one strip, a unit is shifted to the level-1 rows
+//     [2A-1, 2B], and what it then lacks for its last level-2 row — rows 2B+1 and 2B+2 — are the FIRST two rows of the
+//     wave below, which publishes them in LDS after its first two steps (one workgroup barrier); only the bottom wave of
+//     a workgroup walks the two extra rows itself, and gets one level-2 row less to own, so that all four walk 2 n rows.
+//   * Vertical 1-3-3-1 of level 1 -> 2 incrementally, in the association of down4_raw: on odd steps pc = a + 3 (b + c),
+//     on even steps pc + d.  The two live values per (plane, column) sit in wave-private LDS (the walk has no registers
+//     left), moved as float2 = both columns of the lane.
+//   * Horizontal pass: the lane's level-1 pair is columns (P, P+1); with P odd (ODD1) the level-2 column (P+1)/2 takes
+//     (own.x, own.y, next.x, next.y), with P even column P/2 takes (prev.y, own.x, own.y, next.x): two DPP moves, one
+//     level-2 value per lane.  A strip therefore advances by S2 = 62 level-2 columns (61 when both origins are even: lane
+//     63's pair is incomplete), i.e. 2 S2 level-1 columns, and starts at Pbase <= so1 far enough left for column so2.
+struct D01Args {
+    const uint16_t *in;
+    long in_sy, co0, co1, co2;
+    float beta;
+    const float *lut_g;
+    float *g1;
+    int so1, loy1, w1, h1, ws1;
+    size_t ps1;
+    float *g2;
+    int so2, loy2, w2, h2, ws2;
+    size_t ps2;
+    int Pbase, S2, nsx, nsy, nunits;
+    unsigned nsy_magic;        // floor(2^32 / nsy) + 1: x / nsy == umulhi(x, magic) for x * nsy < 2^32; 0 when nsy == 1
+    int rows_base, rows_rem;   // h2 / nsy, h2 % nsy
+};
+constexpr int D01_STATE = 2 * (KCH + 1) * 64;  // float2 slots of one wave's level-1 -> 2 window state (and of the two rows it publishes)
+
+#ifndef HLMI_D01_ABL
+#define HLMI_D01_ABL 0   // timing experiments only (csrc/Makefile VARIANT): 1 no LUT gathers, 2 no level-1 stores, 4 no level-2 stores, 8 no input loads
+#endif
+#ifndef HLMI_D01_LSGPR
+#define HLMI_D01_LSGPR 0
+#endif
+template<bool ODD0, bool ODD1, bool B1, bool EXCH>
+__global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry gm, Levels lev) {
+    extern __shared__ float slut[];
+    LL_PROBE_T(pt0);
+    for (int i = threadIdx.x; i <= 2 * gm.half; i += D0_THREADS) slut[i] = p.lut_g[i];
+    __syncthreads();
+    LL_PROBE_T(pt1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int sx, A, B;              // strip; level-2 rows [A, B] owned
+    bool self_halo = true;     // the walk itself continues over the two rows below the unit
+    bool publish = false;      // first two rows go to LDS for the wave above
+    if (EXCH) {
+        // nsy = workgroups per strip; the workgroup's rows [GA, GB] are cut into 4 runs of n (the last one shorter)
+        // no integer divisions here: every wave of the launch runs this before its first load (the host passes the
+        // reciprocal of nsy and the quotient / remainder of h2 / nsy; rows are dealt base + 1 to the first `rem` groups)
+        const int wg = xcd_block();
+        sx = p.nsy_magic ? (int)__umulhi((unsigned)wg, p.nsy_magic) : wg;
+        const int gy = wg - sx * p.nsy;
+        const int GA = p.loy2 + gy * p.rows_base + min(gy, p.rows_rem);
+        const int GB = GA + p.rows_base + (gy < p.rows_rem ? 1 : 0) - 1;
+        const int n = (GB - GA + 1 + 1 + 3) >> 2;
+        A = GA + wave * n, B = min(A + n - 1, GB);
+        if (A > GB) {          // no rows left for this wave: it only keeps the barrier count
+            __syncthreads();
+            return;
+        }
+        self_halo = !(wave < 3 && A + n <= GB);
+        publish = wave > 0;
+    } else {
+        const int unit = xcd_block() * (D0_THREADS / 64) + wave;
+        if (unit >= p.nunits) return;
+        sx = p.nsy_magic ? (int)__umulhi((unsigned)unit, p.nsy_magic) : unit;
+        const int sy = unit - sx * p.nsy;
+        A = p.loy2 + sy * p.rows_base + min(sy, p.rows_rem);
+        B = A + p.rows_base + (sy < p.rows_rem ? 1 : 0) - 1;
+    }
+    const int P = p.Pbase + 2 * p.S2 * sx + 2 * lane;   // absolute level-1 column of the lane's pair
+    const int q0 = ODD0 ? 2 * P - 1 : 2 * P - 2;
+    const int iw = gm.ix1 - gm.ix0 + 1, ih = gm.iy1 - gm.iy0;
+    const QuadSel qs = quad_sel(q0 - gm.ix0, iw);
+    int xo[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) xo[i] = qs.oq + qs.sel[i];
+    const bool edge_wave = __any(!qs.plain);
+    // level-1 rows [T0, T1] computed, [Ts0, Ts1] stored
+    const int T0 = 2 * A - 1, T1 = self_halo ? 2 * B + 2 : 2 * B;
+    const int Ts0 = max(EXCH ? 2 * A - 1 : 2 * A, p.loy1), Ts1 = min(EXCH ? 2 * B : 2 * B + 1, p.loy1 + p.h1 - 1);
+    const int off1 = P - p.so1;
+    const bool st1_ok = lane < p.S2 && off1 >= 0 && off1 < p.w1;
+    const int X2 = ODD1 ? (P + 1) >> 1 : P >> 1;
+    const int off2 = X2 - p.so2;
+    const bool st2_ok = (ODD1 ? lane < p.S2 : (lane >= 1 && lane <= p.S2)) && off2 >= 0 && off2 < p.w2;
+    float2 *st2 = reinterpret_cast<float2 *>(slut + ((2 * gm.half + 2) & ~1)) + wave * D01_STATE + lane;
+    float2 *pub_all = reinterpret_cast<float2 *>(slut + ((2 * gm.half + 2) & ~1)) + (D0_THREADS / 64) * D01_STATE + lane;
+    float2 *pub_mine = pub_all + (wave - 1) * D01_STATE, *pub_next = pub_all + wave * D01_STATE;   // [row][plane][64]
+    const int lbase = gm.half - 256 * (KCH - 1);
+    // level_k in VECTOR registers: a VALU instruction with an SGPR operand does not pair with the other wave's
+    // (1.8 instead of 1.1 ns per instruction at two waves per SIMD, scripts/ubench/valu_dep.hip)
+    float level[KCH];
+#pragma unroll
+    for (int kk = 0; kk < KCH; kk++) {
+        level[kk] = lev.v[kk];
+#if HLMI_D01_LSGPR
+        asm volatile("" : "+s"(level[kk]));
+#else
+        asm volatile("" : "+v"(level[kk]));
+#endif
+    }
+    auto walk = [&](auto edge_tag) {
+    constexpr bool EDGE = decltype(edge_tag)::value;
+#if HLMI_LL_PROBE
+    unsigned long long pr_a0 = 0, pr_a = 0, pr_3 = 0;
+#endif
+    auto load_row = [&](Raw &r, int y_abs) {
+        const uint16_t *rp = p.in + (long)(dev::clampi(y_abs - gm.iy0, 0, ih)) * p.in_sy;
+        load_raw<true>(r, rp, p.co0, p.co1, p.co2, qs.oq, xo);
+    };
+    auto u16s = [&](const ushort4 &c, uint16_t (&o)[4]) {
+        const uint2 w = __builtin_bit_cast(uint2, c);
+        o[0] = (uint16_t)(w.x & 0xffffu), o[1] = (uint16_t)(w.x >> 16);
+        o[2] = (uint16_t)(w.y & 0xffffu), o[3] = (uint16_t)(w.y >> 16);
+    };
+    struct Row {
+        float g[4];
+        int l[4];
+    };
+    auto prep_row = [&](const Raw &r, Row &o) {
+        uint16_t rr[4], gg[4], bb[4];
+        u16s(r.c0, rr), u16s(r.c1, gg), u16s(r.c2, bb);
+#pragma unroll
+        for (int i = 0; i < 4; i++) o.g[i] = gray_from(rr[i], gg[i], bb[i]);
+        if (EDGE) {
+            const float g0 = o.g[0], g1v = o.g[1], g2v = o.g[2], g3 = o.g[3];
+#pragma unroll
+            for (int i = 0; i < 4; i++) o.g[i] = pick4(g0, g1v, g2v, g3, qs.sel[i]);
+        }
+        // l = LDS byte offset of the LUT entry of plane KCH-1; made opaque so that the per-plane constant 1024 (KCH-1-k)
+        // stays a separate addend and lands in the ds_read offset field instead of costing one v_add per gather
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            o.l[i] = (min((int)((o.g[i] * gm.Km1) * 256.0f), gm.half) + lbase) * 4;
+            asm volatile("" : "+v"(o.l[i]));
+        }
+    };
+    auto lut_issue = [&](int kk, const Row &r0, const Row &r1, float (&dst)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#if HLMI_D01_ABL & 1
+            dst[i] = __builtin_bit_cast(float, r0.l[i] + kk);
+            dst[4 + i] = __builtin_bit_cast(float, r1.l[i] + kk);
+#else
+            dst[i] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(slut) + r0.l[i] + 1024 * (KCH - 1 - kk));
+            dst[4 + i] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(slut) + r1.l[i] + 1024 * (KCH - 1 - kk));
+#endif
+        }
+    };
+    // In passes over the 8 pixels (not pixel by pixel): a wave issues dependent VALU instructions only every ~3.7 ns but
+    // independent ones every ~2.2 ns (scripts/ubench/valu_dep.hip), and with two waves per SIMD nothing else hides it.
+    auto plane_vals = [&](int kk, const Row &r0, const Row &r1, const float (&lv)[8], float (&v0)[4], float (&v1)[4]) {
+        if (kk < KCH) {
+            const float L = level[kk < KCH ? kk : 0];
+            float t[8];
+#pragma unroll
+            for (int i = 0; i < 4; i++) t[i] = r0.g[i] - L, t[4 + i] = r1.g[i] - L;
+            if (!B1) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) t[i] = p.beta * t[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) t[i] = t[i] + L;
+#pragma unroll
+            for (int i = 0; i < 4; i++) v0[i] = t[i] + lv[i], v1[i] = t[4 + i] + lv[4 + i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) v0[i] = r0.g[i], v1[i] = r1.g[i];
+        }
+    };
+    auto vpass = [&](const float (&ia)[4], const float (&ib)[4], const float (&c)[4], const float (&d)[4], float (&o)[4]) {
+        float t[4];   // down4_raw, column-parallel
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[i] = ib[i] + c[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[i] = 3.0f * t[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[i] = ia[i] + t[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = t[i] + d[i];
+    };
+
+    float a[KCH + 1][4], b[KCH + 1][4], a2[KCH + 1][4], b2[KCH + 1][4];
+    Raw rc, rd;
+    {
+        // all four rows of the first step are requested at once: every wave of the launch starts here at the same time
+        // and the first (cold) round trip to memory is the longest of the walk
+        Raw ra, rb;
+        load_row(ra, 2 * T0 - 1);
+        load_row(rb, 2 * T0);
+        load_row(rc, 2 * T0 + 1);
+        load_row(rd, 2 * T0 + 2);
+#if HLMI_LL_PROBE
+        LL_PROBE_T(ptA0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LL_PROBE_T(ptA);
+        pr_a0 = ptA0, pr_a = ptA;
+#endif
+        Row r0, r1;
+        prep_row(ra, r0);
+        prep_row(rb, r1);
+        float lv[2][8];
+        lut_issue(0, r0, r1, lv[0]);
+#pragma unroll
+        for (int kk = 0; kk <= KCH; kk++) {
+            if (kk + 1 < KCH) lut_issue(kk + 1, r0, r1, lv[(kk + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            plane_vals(kk, r0, r1, lv[kk & 1], a[kk], b[kk]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // One level-1 row T.  PH = 0: T odd relative to the unit (rows "a"/"c" of the level-2 window), PH = 1: rows "b"/"d" —
+    // the step that completes level-2 row (T - 2) / 2.
+    auto step = [&](auto ph_tag, int T, const Row &c0, const Row &c1, Row &n0, Row &n1, float (&ia)[KCH + 1][4],
+                    float (&ib)[KCH + 1][4], float (&oa)[KCH + 1][4], float (&ob)[KCH + 1][4], float2 *pub) {
+        constexpr int PH = decltype(ph_tag)::value;
+        float lv[2][8], dy[2][4];
+        float2 res[KCH + 1];
+        float2 sa, sb;  // level-2 window state of the plane whose level-1 row is being finished
+        const bool out2 = PH == 1 && T >= 2 * A + 2;   // wave-uniform
+        float *d2 = p.g2 + (size_t)(((T - 2) >> 1) - p.loy2) * p.ws2 + off2;
+        auto level2 = [&](int k) {
+            const float2 c = res[k];
+            if (PH == 0) {
+                float2 pc;
+                pc.x = sa.x + 3.0f * (sb.x + c.x);
+                pc.y = sa.y + 3.0f * (sb.y + c.y);
+                st2[(2 * k + 1) * 64] = pc;
+                st2[(2 * k) * 64] = c;
+            } else {
+                const float rx = sb.x + c.x, ry = sb.y + c.y;   // down4_raw of the lane's two level-1 columns
+                float o;
+                if (ODD1) {
+                    const float nx = lane_next(rx), ny = lane_next(ry);
+                    o = down4_tail(rx, ry, nx, ny);
+                } else {
+                    const float py = lane_prev(ry), nx = lane_next(rx);
+                    o = down4_tail(py, rx, ry, nx);
+                }
+                if (out2 && st2_ok && !(HLMI_D01_ABL & 4 && p.nunits > 0)) d2[(size_t)k * p.ps2] = o;
+                st2[(2 * k + 1) * 64] = c;
+            }
+        };
+        auto state_issue = [&](int k) {
+            if (PH == 0) sa = st2[(2 * k) * 64];
+            sb = st2[(2 * k + 1) * 64];
+        };
+        lut_issue(0, c0, c1, lv[0]);
+#pragma unroll
+        for (int kk = 0; kk <= KCH; kk++) {
+            if (kk > 0) state_issue(kk - 1);   // before the gathers: LDS returns in order, the state must not wait for them
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 1 < KCH) lut_issue(kk + 1, c0, c1, lv[(kk + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            plane_vals(kk, c0, c1, lv[kk & 1], oa[kk], ob[kk]);
+            vpass(ia[kk], ib[kk], oa[kk], ob[kk], dy[kk & 1]);
+            if (kk > 0) {
+                res[kk - 1] = hpair<ODD0>(dy[(kk - 1) & 1]);
+                level2(kk - 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        state_issue(KCH);
+        res[KCH] = hpair<ODD0>(dy[KCH & 1]);
+        level2(KCH);
+        // unconditional: after the last row rc / rd still hold the previous (valid) rows and the result is unused
+        prep_row(rc, n0);
+        prep_row(rd, n1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (T >= Ts0 && T <= Ts1 && !(HLMI_D01_ABL & 2 && p.nunits > 0)) {
+            float *drow = p.g1 + (size_t)(T - p.loy1) * p.ws1 + off1;
+            if (st1_ok) {
+#pragma unroll
+                for (int kk = 0; kk <= KCH; kk++) *reinterpret_cast<float2 *>(drow + (size_t)kk * p.ps1) = res[kk];
+            }
+        }
+        if (EXCH && pub) {
+#pragma unroll
+            for (int kk = 0; kk <= KCH; kk++) pub[kk * 64] = res[kk];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (T + 1 < T1 && !(HLMI_D01_ABL & 8 && p.nunits > 0)) {
+            load_row(rc, 2 * T + 5);
+            load_row(rd, 2 * T + 6);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    Row p0, p1, p2, p3;
+    prep_row(rc, p0);
+    prep_row(rd, p1);
+    load_row(rc, 2 * T0 + 3);   // T0 < T1 always: a unit walks at least 2 rows
+    load_row(rd, 2 * T0 + 4);
+    LL_PROBE_T(pt2);
+    for (int T = T0; T <= T1; T += 2) {
+        const bool first = EXCH && T == T0;
+        step(std::integral_constant<int, 0>{}, T, p0, p1, p2, p3, a, b, a2, b2, first && publish ? pub_mine : nullptr);
+        step(std::integral_constant<int, 1>{}, T + 1, p2, p3, p0, p1, a2, b2, a, b,
+             first && publish ? pub_mine + (KCH + 1) * 64 : nullptr);
+        if (first) __syncthreads();   // every wave of the workgroup that has rows passes here exactly once
+#if HLMI_LL_PROBE
+        if (first) { LL_PROBE_T(pt3); pr_3 = pt3; }
+#endif
+    }
+    LL_PROBE_T(pt4);
+    LL_PROBE_ADD(0, pt1 - pt0); LL_PROBE_ADD(1, 1); LL_PROBE_ADD(2, pt2 - pt1); LL_PROBE_ADD(3, pr_3 - pt2);
+    LL_PROBE_ADD(16, pr_a - pr_a0); LL_PROBE_ADD(17, pr_a0 - pt1);
+    LL_PROBE_ADD(4, pt4 - pt2); LL_PROBE_ADD(5, (T1 - T0 + 1)); LL_PROBE_ADD(6, pt4 - pt0);
+    if (EXCH && !self_halo) {
+        // level-2 row B: rows "c" (2B+1) and "d" (2B+2) are the first two rows of the wave below
+        float *d2 = p.g2 + (size_t)(B - p.loy2) * p.ws2 + off2;
+#pragma unroll
+        for (int k = 0; k <= KCH; k++) {
+            const float2 sa = st2[(2 * k) * 64], sb = st2[(2 * k + 1) * 64];
+            const float2 c = pub_next[k * 64], d = pub_next[(KCH + 1 + k) * 64];
+            const float rx = (sa.x + 3.0f * (sb.x + c.x)) + d.x, ry = (sa.y + 3.0f * (sb.y + c.y)) + d.y;
+            float o;
+            if (ODD1) {
+                const float nx = lane_next(rx), ny = lane_next(ry);
+                o = down4_tail(rx, ry, nx, ny);
+            } else {
+                const float py = lane_prev(ry), nx = lane_next(rx);
+                o = down4_tail(py, rx, ry, nx);
+            }
+            if (st2_ok) d2[(size_t)k * p.ps2] = o;
+        }
     }
     };  // walk
     if (edge_wave) walk(std::true_type{});
@@ -1027,6 +1383,7 @@ constexpr int U0_TW = 130, U0_TS = 131;  // coarse columns of a workgroup's tile
 template<bool LUT_LDS, bool B1, bool FUSE1>
 __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
     extern __shared__ float slut[];
+    LL_PROBE_T(pt0);
     float *s_out1 = slut + (LUT_LDS ? ((2 * gm.half + 2) & ~1) : 0);
     if (LUT_LDS) {
         for (int i = threadIdx.x; i <= 2 * gm.half; i += 256) slut[i] = p.lut_g[i];
@@ -1047,7 +1404,9 @@ __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
             s_out1[ty * U0_TS + tx] = up_at(p.out2, p.lox2, p.loy2, p.ws2, cx, cy) + outL;
         }
     }
+    LL_PROBE_T(pt1);
     if (LUT_LDS || FUSE1) __syncthreads();
+    LL_PROBE_T(pt2);
     const float *lut = LUT_LDS ? slut : p.lut_g;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int x = blockIdx.x * 256 + (wave & 1) * 128 + 2 * lane;  // output storage column of the lane's pair
@@ -1062,65 +1421,119 @@ __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
     // an fma rounds exactly like the separate multiply and add of the definition (one instruction less per lerp)
     auto hl0 = [](float rm, float r0) { return __builtin_fmaf(rm, 0.25f, r0 * 0.75f); };  // lerp(f[c], f[c-1], 1/4): X even
     auto hl1 = [](float r0, float rp) { return __builtin_fmaf(rp, 0.25f, r0 * 0.75f); };  // lerp(f[c+1], f[c], 3/4): X odd
-    for (int y = y0; y < y1; y++) {
-        const int Y = p.oy0 + y;
-        const uint16_t *irow = p.in + (long)(Y - gm.iy0) * p.in_sy;
-        uint16_t *orow = p.out + (long)y * p.out_sy;
-        const ushort2 c0 = ld_frame2(irow + p.gco[0], inb), c1 = ld_frame2(irow + p.gco[1], inb),
-                      c2 = ld_frame2(irow + p.gco[2], inb);
+    // The row loop is software-pipelined over three rows: a row needs two dependent round trips to memory (its pixels
+    // -> which planes to gather from -> the gathers), ~2 us per row if taken one after the other, and a wave walks RU
+    // rows — the launch used to last as long as that chain (52 % of all wave-cycles waiting, SQ_WAIT_ANY).  Now, while
+    // row y is finished (stage 2), the gathers of row y+1 are in flight (issued by its stage 1) and the pixels of row
+    // y+2 are being loaded.  Two register sets per stage, swapped by unrolling (never copied: copying the target of a
+    // load in flight would wait for it); rows past the end are clamped (loaded and prepared again, never stored).
+    struct Frame {
+        ushort2 c0, c1, c2;
+    };
+    struct Prep {                 // what stage 2 needs of a row besides the gathers
+        float chf[3][2];          // colour channels as float
+        float gray[2], lf[2], lev0[2], lev1[2];
+        float lut0[2], lut1[2];   // remap values of the two planes
+        F3U OA, OB;               // outGPyramid[1] rows (q: weight 1/4, t: weight 3/4), columns c-1, c, c+1
+    };
+    struct Gath {
+        F2U A0[2], B0[2], A1[2], Bp[2];
+    };
+    auto load_frame = [&](int y, Frame &f) {
+        const uint16_t *irow = p.in + (long)(p.oy0 + min(y, y1 - 1) - gm.iy0) * p.in_sy;
+        f.c0 = ld_frame2(irow + p.gco[0], inb), f.c1 = ld_frame2(irow + p.gco[1], inb), f.c2 = ld_frame2(irow + p.gco[2], inb);
+    };
+    auto vl = [](float uq, float ut) { return __builtin_fmaf(uq, 0.25f, ut * 0.75f); };
+    auto stage1 = [&](int yy, const Frame &f, Prep &s, Gath &g) {
+        const int Y = p.oy0 + min(yy, y1 - 1);
         const int ya = dev::fdiv2(Y + 1) - p.loy1, yb = dev::fdiv2(Y - 1) - p.loy1;
         const bool yodd = dev::fmod2(Y) != 0;  // wave-uniform
         // lerp(ua, ub, wy) (:280), ua from coarse row ya, ub from yb: wy = 3/4 for odd Y, 1/4 for even Y.  The row
         // whose weight is 1/4 (an exact product) is called q, the other t — a scalar choice of row pointers.
         const int yq = yodd ? ya : yb, yt = yodd ? yb : ya;
         const float *ga = p.g1 + (size_t)yq * p.ws1, *gb = p.g1 + (size_t)yt * p.ws1;
-        auto vl = [&](float uq, float ut) { return __builtin_fmaf(uq, 0.25f, ut * 0.75f); };
-        F3U OA, OB;
-        if (FUSE1) {  // rows of the workgroup's LDS tile; column c - 1 - cx0 = 64 (wave & 1) + lane
-            const float *oa = s_out1 + (yq + p.loy1 - cy0) * U0_TS + (wave & 1) * 64 + lane;
-            const float *ob = s_out1 + (yt + p.loy1 - cy0) * U0_TS + (wave & 1) * 64 + lane;
-            OA.x = oa[0], OA.y = oa[1], OA.z = oa[2];
-            OB.x = ob[0], OB.y = ob[1], OB.z = ob[2];
-        } else {
-            const float *oa = p.out1 + (size_t)yq * p.ws1, *ob = p.out1 + (size_t)yt * p.ws1;
-            OA = ld_su<F3U>(oa, colb), OB = ld_su<F3U>(ob, colb);
-        }
-        const float uo[2] = {vl(hl0(OA.x, OA.y), hl0(OB.x, OB.y)), vl(hl1(OA.y, OA.z), hl1(OB.y, OB.z))};
-        const uint16_t ch[3][2] = {{c0.x, c0.y}, {c1.x, c1.y}, {c2.x, c2.y}};
-        uint16_t res[3][2];
+        const uint16_t ch[3][2] = {{f.c0.x, f.c0.y}, {f.c1.x, f.c1.y}, {f.c2.x, f.c2.y}};
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const float gray = gray_from(ch[0][i], ch[1][i], ch[2][i]);
             const float level = gray * gm.Km1;
             // gray >= 0: the lower bounds of clamp(.., 0, ..) (:43, :66) can never bind
             const int li = min((int)level, gm.K - 2);
-            const float lif = (float)li, lf = level - lif;
+            const float lif = (float)li;
             const int idx = min((int)(level * 256.0f), gm.half);
             const float *lp = lut + (idx - 256 * li + gm.half);
-            const float lev0 = lif * gm.inv_Km1, lev1 = (lif + 1.0f) * gm.inv_Km1;
             const uint32_t pb = (uint32_t)li * psb + colb + 4u * i;
-            const F2U A0 = ld_su<F2U>(ga, pb), B0 = ld_su<F2U>(gb, pb);
-            const F2U A1 = ld_su<F2U>(ga, pb + psb), B1v = ld_su<F2U>(gb, pb + psb);
+            g.A0[i] = ld_su<F2U>(ga, pb), g.B0[i] = ld_su<F2U>(gb, pb);
+            g.A1[i] = ld_su<F2U>(ga, pb + psb), g.Bp[i] = ld_su<F2U>(gb, pb + psb);
+            s.lut0[i] = lp[0], s.lut1[i] = lp[-256];
+            s.gray[i] = gray, s.lf[i] = level - lif;
+            s.lev0[i] = lif * gm.inv_Km1, s.lev1[i] = (lif + 1.0f) * gm.inv_Km1;
+#pragma unroll
+            for (int c = 0; c < 3; c++) s.chf[c][i] = (float)ch[c][i];
+        }
+        if (FUSE1) {  // rows of the workgroup's LDS tile; column c - 1 - cx0 = 64 (wave & 1) + lane
+            const float *oa = s_out1 + (yq + p.loy1 - cy0) * U0_TS + (wave & 1) * 64 + lane;
+            const float *ob = s_out1 + (yt + p.loy1 - cy0) * U0_TS + (wave & 1) * 64 + lane;
+            s.OA.x = oa[0], s.OA.y = oa[1], s.OA.z = oa[2];
+            s.OB.x = ob[0], s.OB.y = ob[1], s.OB.z = ob[2];
+        } else {
+            const float *oa = p.out1 + (size_t)yq * p.ws1, *ob = p.out1 + (size_t)yt * p.ws1;
+            s.OA = ld_su<F3U>(oa, colb), s.OB = ld_su<F3U>(ob, colb);
+        }
+    };
+    auto stage2 = [&](int y, const Prep &s, const Gath &g) {
+        const float uo[2] = {vl(hl0(s.OA.x, s.OA.y), hl0(s.OB.x, s.OB.y)), vl(hl1(s.OA.y, s.OA.z), hl1(s.OB.y, s.OB.z))};
+        uint16_t res[3][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
             float u0, u1;
             if (i == 0) {
-                u0 = vl(hl0(A0.x, A0.y), hl0(B0.x, B0.y)), u1 = vl(hl0(A1.x, A1.y), hl0(B1v.x, B1v.y));
+                u0 = vl(hl0(g.A0[i].x, g.A0[i].y), hl0(g.B0[i].x, g.B0[i].y)), u1 = vl(hl0(g.A1[i].x, g.A1[i].y), hl0(g.Bp[i].x, g.Bp[i].y));
             } else {
-                u0 = vl(hl1(A0.x, A0.y), hl1(B0.x, B0.y)), u1 = vl(hl1(A1.x, A1.y), hl1(B1v.x, B1v.y));
+                u0 = vl(hl1(g.A0[i].x, g.A0[i].y), hl1(g.B0[i].x, g.B0[i].y)), u1 = vl(hl1(g.A1[i].x, g.A1[i].y), hl1(g.Bp[i].x, g.Bp[i].y));
             }
-            const float l0 = g0_val<B1>(gray, lev0, p.beta, lp[0]) - u0;
-            const float l1 = g0_val<B1>(gray, lev1, p.beta, lp[-256]) - u1;
-            const float outL = (1.0f - lf) * l0 + lf * l1;
+            const float l0 = g0_val<B1>(s.gray[i], s.lev0[i], p.beta, s.lut0[i]) - u0;
+            const float l1 = g0_val<B1>(s.gray[i], s.lev1[i], p.beta, s.lut1[i]) - u1;
+            const float outL = (1.0f - s.lf[i]) * l0 + s.lf[i] * l1;
             const float og = (uo[i] + outL) + 0.01f;
-            const float gr = gray + 0.01f;
-            const float n[3] = {(float)ch[0][i] * og, (float)ch[1][i] * og, (float)ch[2][i] * og};
+            const float gr = s.gray[i] + 0.01f;
+            const float n[3] = {s.chf[0][i] * og, s.chf[1][i] * og, s.chf[2][i] * og};
             float q[3];
             div3_by(n, gr, q);
 #pragma unroll
             for (int c = 0; c < 3; c++) res[c][i] = (uint16_t)__builtin_amdgcn_fmed3f(q[c], 0.0f, 65535.0f);  // q is never NaN
         }
+        if (y < y1) {
+            uint16_t *orow = p.out + (long)y * p.out_sy;
 #pragma unroll
-        for (int c = 0; c < 3; c++) st_frame2(reinterpret_cast<char *>(orow + (long)c * p.out_sc) + outb, res[c][0], res[c][1]);
+            for (int c = 0; c < 3; c++) st_frame2(reinterpret_cast<char *>(orow + (long)c * p.out_sc) + outb, res[c][0], res[c][1]);
+        }
+    };
+    Frame f0, f1;
+    Prep s0, s1;
+    Gath g0, g1;
+    load_frame(y0, f0);
+    load_frame(y0 + 1, f1);
+    stage1(y0, f0, s0, g0);
+    for (int y = y0; y < y1; y += 2) {
+        // the scheduling barriers keep the order loads -> gathers of the next row -> arithmetic of this row; left
+        // alone the scheduler moves the arithmetic up and the gathers down to where they are needed
+        load_frame(y + 2, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        stage1(y + 1, f1, s1, g1);
+        __builtin_amdgcn_sched_barrier(0);
+        stage2(y, s0, g0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frame(y + 3, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        stage1(y + 2, f0, s0, g0);
+        __builtin_amdgcn_sched_barrier(0);
+        stage2(y + 1, s1, g1);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    LL_PROBE_T(pt3);
+    LL_PROBE_ADD(8, pt1 - pt0); LL_PROBE_ADD(9, pt2 - pt1); LL_PROBE_ADD(10, 1);
+    LL_PROBE_ADD(11, pt3 - pt2); LL_PROBE_ADD(12, pt3 - pt0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1266,6 +1679,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     const size_t lut_sh = lut_lds ? sizeof(float) * nlut : 0;
 
     HLMI_LAUNCH(uc, "ll_remap_lut", st, ll_remap_lut, dim3((nlut + 255) / 256), dim3(256), 0, lut, gm.half, alpha);
+    bool fuse_d2 = false;
     {
         const Level &d = lv[1];
         // two waves per SIMD with (almost) equal row counts: the kernel is VALU-bound, so balance is what counts
@@ -1294,7 +1708,63 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     case ((O ? 8 : 0) | (V ? 4 : 0) | (L ? 2 : 0) | (B ? 1 : 0)):      \
         r = launch_d0(&ll_down0<O, V, L, B>);                         \
         break;
-        if (levels == KCH && vec && lut_lds && env_int("HLMI_LL_D0F", 1)) {
+        fuse_d2 = levels == KCH && vec && lut_lds && env_int("HLMI_LL_D0F", 1) && env_int("HLMI_LL_FUSE_D2", 1);
+        if (fuse_d2) {
+            // ---- levels 1 AND 2 from the input in one walk (ll_down01f); the ll_down_strip:1 launch below is skipped
+            const Level &e = lv[2];
+            D01Args a;
+            a.in = din, a.in_sy = in_sy, a.co0 = gco[0], a.co1 = gco[1], a.co2 = gco[2], a.beta = beta, a.lut_g = lut;
+            a.g1 = d.g, a.so1 = d.lox, a.loy1 = d.loy, a.w1 = d.w, a.h1 = d.h, a.ws1 = d.ws, a.ps1 = d.ps;
+            a.g2 = e.g, a.so2 = e.lox, a.loy2 = e.loy, a.w2 = e.w, a.h2 = e.h, a.ws2 = e.ws, a.ps2 = e.ps;
+            const bool odd0 = d.odd, odd1 = e.odd;   // e.odd == (d.lox & 1)
+            a.S2 = (odd0 || odd1) ? 62 : 61;
+            const int lim = odd1 ? 2 * e.lox - 1 : 2 * e.lox - 2;    // leftmost pair must reach level-2 column so2
+            a.Pbase = min(d.lox, lim);                                // same parity as so1 in either case
+            const int hi1 = d.lox + d.w - 1, hi2 = e.lox + e.w - 1;
+            const int x2_first = odd1 ? (a.Pbase + 1) / 2 + 0 : a.Pbase / 2 + 1;   // Pbase + 1 (resp. Pbase) is even: exact
+            a.nsx = max((hi2 - x2_first + a.S2) / a.S2, (hi1 - a.Pbase + 2 * a.S2) / (2 * a.S2));
+            const int target2 = env_int("HLMI_LL_UNITS0", 8 * cu_count(ctx.device));
+            // EXCH: a workgroup = 4 vertically adjacent units exchanging their seam rows through LDS.  With n level-2 rows
+            // per wave a workgroup owns R = 4 n - 1 rows (the bottom wave walks the two seam rows of the next workgroup
+            // itself and owns one row less); n = the smallest that keeps the launch within `target2` resident waves.
+            bool exch = env_int("HLMI_LL_D01_EXCH", 1) != 0;
+            int nwy = 0;
+            auto ceil_div = [](int x, int y) { return (x + y - 1) / y; };
+            if (exch) {
+                const int nwy_max = max(1, target2 / (WPB * a.nsx));
+                const int n = max(2, (ceil_div(e.h, nwy_max) + 1 + 3) / 4);
+                nwy = ceil_div(e.h, 4 * n - 1);
+                exch = e.h / nwy >= 4;     // every workgroup gets at least 4 rows; smaller images take the plain units
+            }
+            if (exch) {
+                a.nsy = nwy;
+                a.nunits = a.nsx * nwy * WPB;
+            } else {
+                a.nsy = max(1, min(max(target2 / a.nsx, (e.h + 31) / 32), e.h));
+                a.nunits = a.nsx * a.nsy;
+            }
+            a.nsy_magic = a.nsy == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)a.nsy + 1ull);   // 0: nsy == 1
+            a.rows_base = e.h / a.nsy, a.rows_rem = e.h % a.nsy;
+            dim3 grid2((a.nunits + WPB - 1) / WPB);
+            const size_t sh2 = sizeof(float) * ((nlut + 1) & ~1) + sizeof(float2) * D01_STATE * (WPB + (exch ? WPB - 1 : 0));
+            timing_note_bytes(d0_bytes + 4.0 * (levels + 1) * e.w * e.h);
+#define LL_D01(O0, O1, B)                                                                                              \
+    do {                                                                                                               \
+        if (exch) HLMI_LAUNCH(uc, "ll_down01", st, (ll_down01f<O0, O1, B, true>), grid2, block, sh2, a, gm, lev);      \
+        else HLMI_LAUNCH(uc, "ll_down01", st, (ll_down01f<O0, O1, B, false>), grid2, block, sh2, a, gm, lev);          \
+    } while (0)
+            switch ((odd0 ? 4 : 0) | (odd1 ? 2 : 0) | (b1 ? 1 : 0)) {
+                case 0: LL_D01(false, false, false); break;
+                case 1: LL_D01(false, false, true); break;
+                case 2: LL_D01(false, true, false); break;
+                case 3: LL_D01(false, true, true); break;
+                case 4: LL_D01(true, false, false); break;
+                case 5: LL_D01(true, false, true); break;
+                case 6: LL_D01(true, true, false); break;
+                default: LL_D01(true, true, true); break;
+            }
+#undef LL_D01
+        } else if (levels == KCH && vec && lut_lds && env_int("HLMI_LL_D0F", 1)) {
             if (d.odd) r = b1 ? launch_d0(&ll_down0f<true, true>) : launch_d0(&ll_down0f<true, false>);
             else r = b1 ? launch_d0(&ll_down0f<false, true>) : launch_d0(&ll_down0f<false, false>);
         } else {
@@ -1339,6 +1809,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             else HLMI_LAUNCH(uc, nm, st, (ll_down_multi<1>), grid, block, 0, ca, ntx, nty);
             break;
         }
+        if (j == 1 && fuse_d2) continue;   // level 2 came out of ll_down01f
         const Level &s = lv[j], &d = lv[j + 1];
         // enough waves to fill the chip on the big levels, short strips on the small ones
         const int cols = d.nsx * (levels + 1);
@@ -1479,6 +1950,19 @@ extern "C" int local_laplacian_auto_schedule(halide_buffer_t *input, int32_t lev
 
 // Test hook: runs the DPP wave-shift probe on the current device; 1 = wave_shr:1 / wave_shl:1 behave as the
 // strip kernels assume, 0 = they do not, < 0 = HIP error.
+extern "C" int hlmi_debug_ll_probe(unsigned long long *out32) {
+#if HLMI_LL_PROBE
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_probe), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    unsigned long long zero[32] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_probe), zero, sizeof zero) != hipSuccess) return -1;
+    return 1;
+#else
+    (void)out32;
+    return 0;
+#endif
+}
+
 extern "C" int hlmi_debug_dpp_probe(void) {
     int *flag = nullptr, h = 0;
     if (hipMalloc(&flag, sizeof(int)) != hipSuccess) return -1;

@@ -11,7 +11,7 @@ echo "== bench"; timeout 900 python bench.py 2>&1 | tail -1 | tee $OUT/bench.jso
 echo "== bench_apps"; timeout 900 python bench_apps.py 2>/dev/null | grep pipeline | tee $OUT/bench_apps.jsonl
 echo "== bench 1 stream"; timeout 900 python bench.py --partitions 0 --streams 1 --no-cpu-baseline 2>&1 | tail -1 | tee $OUT/bench_1stream.json
 cd /tmp
-CMD="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --partitions 0 --streams 1"
+CMD="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-variants --partitions 0 --streams 1"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $CMD > $OUT/kt.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- $CMD > $OUT/pmc_$c.log 2>&1

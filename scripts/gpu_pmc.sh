@@ -3,7 +3,7 @@
 TAG=$1; shift
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp; cd /tmp
-CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --partitions 0 --streams 1"
+CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants --partitions 0 --streams 1"
 i=0
 for set in "$@"; do
   i=$((i+1))

@@ -4,7 +4,7 @@
 TAG=${1:-prof}; PMC=${2:-1}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp; cd /tmp
-CMD="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --partitions 0 --streams 1"
+CMD="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-variants --partitions 0 --streams 1"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $CMD > $OUT/kt.log 2>&1
 f=$(find $OUT/kt -name "*kernel_stats.csv" | head -1); echo "== kernel stats ($f)"; cut -d, -f1-4,6,7 "$f" | sed -E 's/\(anonymous namespace\):://g; s/\([^"]*\)//' | head -24
 if [ "$PMC" = "1" ]; then

@@ -59,16 +59,21 @@ if rows:
         w.writerows(rows)
     # name the launches the way libhlmi's timing report does: strips and ups by descending grid size
     per = {}
+    # level 1 -> 2 comes out of ll_down01f when that kernel ran (then the strips start at level 2); the level-1 collapse
+    # is part of ll_up0f when only two ll_up launches ran (levels 3 and 2)
     strips = sorted([r for r in rows if r[0].startswith("ll_down_strip")], key=lambda r: -r[5])
+    first_strip = 2 if any(r[0].startswith("ll_down01f") for r in rows) else 1
     for i, r in enumerate(strips):
-        per[f"ll_down_strip:{i + 1}"] = r[5]
+        per[f"ll_down_strip:{i + first_strip}"] = r[5]
     ups = sorted([r for r in rows if r[0] == "ll_up"], key=lambda r: -r[5])
+    first_up = 2 if len(ups) == 2 else 1
     for i, r in enumerate(ups):
-        per[f"ll_up:{i + 1}"] = r[5]
+        per[f"ll_up:{i + first_up}"] = r[5]
     for r in rows:
-        for base in ("ll_down0", "ll_up0", "ll_top", "ll_remap_lut"):
+        for base, name in (("ll_down01f", "ll_down01"), ("ll_down0f", "ll_down0"), ("ll_down0<", "ll_down0"), ("ll_up0", "ll_up0"),
+                           ("ll_top", "ll_top"), ("ll_remap_lut", "ll_remap_lut")):
             if r[0].startswith(base):
-                per[base] = r[5]
+                per[name] = r[5]
         # the multi-level kernels are reported as ll_down_multi:<S> / ll_up_multi:<S>; one instantiation each per run
         for base, depth_to_s in (("ll_down_multi", lambda d: 7 - d), ("ll_up_multi", lambda d: 7 - d)):
             if r[0].startswith(base + "<"):

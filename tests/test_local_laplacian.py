@@ -241,6 +241,35 @@ def test_hip_pyramid_levels_match_oracle(hl, oracle, monkeypatch, w, h, origin, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("exch,units", [(1, 0), (0, 0), (1, 48), (1, 4096), (0, 300)])
+@pytest.mark.parametrize("w,h,origin", [(256, 200, (0, 0)), (256, 200, (1, 0)), (512, 131, (2, 5)), (260, 97, (3, -7)),
+                                        (1024, 64, (-2, 1)), (128, 333, (-1, -1)), (8, 40, (0, 3)), (2048, 36, (4, 2))])
+def test_hip_fused_levels_1_and_2_match_oracle(hl, oracle, monkeypatch, w, h, origin, exch, units):
+    """ll_down01f (levels 1 AND 2 from the input in one walk) on vectorisable inputs (width % 4 == 0): every parity
+    of the level-0 / level-1 storage origins (origin x = 0..3 mod 4), both seam treatments (HLMI_LL_D01_EXCH: rows
+    exchanged through LDS inside a workgroup / every unit walks its own two extra rows) and several unit heights
+    (HLMI_LL_UNITS0 = resident-wave target; small = tall units, large = 2-row units and idle waves).  All outGPyramid
+    levels and the result must equal the oracle's bit for bit."""
+    monkeypatch.setenv("HLMI_LL_D01_EXCH", str(exch))
+    if units:
+        monkeypatch.setenv("HLMI_LL_UNITS0", str(units))
+    inp = _rand_image(w, h, seed=3 * w + h + origin[0], kind="smooth" if (w + h) & 1 else "uniform")
+    a = hl.Buffer(inp).set_min(origin[0], origin[1], 0)
+    o = hl.Buffer(np.zeros_like(inp)).set_min(origin[0], origin[1], 0)
+    hl.local_laplacian(a, 8, 1.0 / 7, 1.0, o)
+    bad = []
+    for level in range(4, 0, -1):
+        got = hl.debug_local_laplacian_outg(level)
+        want = oracle.local_laplacian_outg(inp, 8, 1.0 / 7, 1.0, level, origin=origin)
+        assert got.shape == want.shape
+        if not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
+            ys, xs = np.nonzero(got.view(np.uint32) != want.view(np.uint32))
+            bad.append((level, len(ys), int(xs.min()), int(xs.max()), int(ys.min()), int(ys.max())))
+    assert not bad, f"(level, #bad, xmin, xmax, ymin, ymax): {bad}"
+    assert np.array_equal(o.numpy(), oracle.local_laplacian(inp, 8, 1.0 / 7, 1.0, origin=origin))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("alpha,beta", [(0.0, 1.0), (1.0, 1.0), (0.4, 0.0), (-0.3, 1.7), (2.0, 0.5)])
 def test_hip_matches_oracle_parameter_sweep(hl, oracle, alpha, beta):
     inp = _rand_image(301, 203, seed=5, kind="smooth")
