@@ -31,10 +31,11 @@ constexpr int P = 7, SA = 7, HALF = 3;
 constexpr int TW = 58;                           // output tile width; the height TH is a template parameter (64 or 80)
 constexpr int IW = TW + 4 * HALF, IWP = 71;      // input window (halo 3 patch + 3 search), padded pitch
 constexpr int BWP = 65;                          // blur_d_y tile: TW + 6 = 64 columns, padded pitch
-constexpr int NT = 1024;                         // threads per workgroup (the window allows one workgroup per CU: 4 waves
-                                                 // per SIMD hide the LDS latency of the walks)
-constexpr int GROUPS = NT / 64;                  // phase-1 row groups
-constexpr size_t lds_bytes(int th) { return sizeof(float) * ((size_t)3 * (th + 4 * HALF) * IWP + (size_t)th * BWP); }
+// Threads per workgroup NT = 16 TH: a thread owns 4 rows of a blur_d_y column in phase 1 (ROWS1) and 4 pixels of a row in
+// phase 2 (SEG).  TH = 64 (1024 threads, 81 KB: one workgroup per CU) leaves a third of the chip idle at 1920 x 1080 —
+// 578 tiles on 256 CUs run as three rounds of ~95 us (scripts/nlm_scale.py) — TH = 16 (256 threads, 28 KB, five
+// workgroups per CU that interleave their phases) has 2312 tiles that back-fill the CUs as they finish.
+constexpr size_t lds_bytes(int th) { return sizeof(float) * ((size_t)3 * (th + 4 * HALF) * IWP + (size_t)th * BWP + 4); }  // + 4: phase 2 reads whole SEG + 6 windows
 
 struct NGeom {
     int ix0, ix1, iy0, iy1, ic0, ic1;  // clamp box of the input (absolute)
@@ -43,10 +44,11 @@ struct NGeom {
 };
 
 // TH: tile height (a multiple of GROUPS).  Phase 2 is thread <-> (row r2 = tid % TH, x segment s2 = tid / TH).
-template<int TH>
+template<int TH, int NT>
 __global__ __launch_bounds__(NT) void nlm_7x7(const float *__restrict__ in, long in_sy, long in_sc, NGeom g,
                                               float *__restrict__ out, long out_sy, long out_sc) {
     constexpr int IH = TH + 4 * HALF;
+    constexpr int GROUPS = NT / 64;                  // phase-1 row groups
     constexpr int ROWS1 = TH / GROUPS;               // rows of blur_d_y a phase-1 thread produces
     constexpr int NSEG = NT / TH;                    // phase-2 x segments
     constexpr int SEG = (TW + NSEG - 1) / NSEG;      // pixels per segment (the last one shorter)
@@ -77,60 +79,87 @@ __global__ __launch_bounds__(NT) void nlm_7x7(const float *__restrict__ in, long
 #pragma unroll
     for (int j = 0; j < SEG; j++) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f;
 
+    // The kernel is bound by LDS instruction issue (one ds_read_b32 = 2 LDS cycles per wave, 16 waves on one LDS pipe),
+    // so everything that does not change with the offset stays in registers:
+    //   * phase 1: the UNSHIFTED operand of d — the thread's ROWS1 + 6 rows x 3 channels at its own column — is read
+    //     once, before the offset loops (half of the phase-1 reads)
+    //   * both phases issue all their LDS reads first and compute afterwards (the dx loop is unrolled: every offset is a
+    //     compile-time constant folded into the read instructions)
+    const int col = cx + HALF;            // window column of abs x
+    const int row0 = ROWS1 * g1 + HALF;   // window row of abs y = ty0 + ROWS1*g1 - 3
+    constexpr bool HOIST = ROWS1 <= 4;   // taller row segments: both operands are read per offset (registers)
+    float u[HOIST ? ROWS1 + 6 : 1][3];
+    if (HOIST) {
+#pragma unroll
+        for (int i = 0; i < ROWS1 + 6; i++) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) u[i][c] = sin[(c * IH + row0 + i) * IWP + col];
+        }
+    }
+    const float *unshifted = sin + row0 * IWP + col;
+
+    const float *brow = sbdy + r2 * BWP + xb;
 #pragma unroll 1
     for (int dy = -HALF; dy <= HALF; dy++) {
-#pragma unroll 1
-        for (int dx = -HALF; dx <= HALF; dx++) {
-            // ---- phase 1: d -> blur_d_y
+        const float *shifted = sin + (row0 + dy) * IWP + col;
+        const float *srow = sin + (r2 + 2 * HALF + dy) * IWP + xb + HALF;
+#pragma unroll
+        for (int dxi = 0; dxi < SA; dxi++) {
+            const int dx = dxi - HALF;
+            // ---- phase 1: d -> blur_d_y.  All reads first, then the arithmetic row-parallel: a wave that reads three
+            // values and waits for them ten times over exposes the LDS latency ten times.
             {
-                const int col = cx + HALF;            // window column of abs x
-                const int row0 = ROWS1 * g1 + HALF;   // window row of abs y = ty0 + ROWS1*g1 - 3
-                float dwin[7];
+                float sh[ROWS1 + 6][3], uu[HOIST ? 1 : ROWS1 + 6][3];
 #pragma unroll
                 for (int i = 0; i < ROWS1 + 6; i++) {
-                    const int r = row0 + i;
-                    float d = 0.0f;
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
-                        float t = sin[(c * IH + r) * IWP + col] - sin[(c * IH + r + dy) * IWP + col + dx];
-                        d = d + t * t;
+                        sh[i][c] = shifted[(c * IH + i) * IWP + dx];
+                        if (!HOIST) uu[i][c] = unshifted[(c * IH + i) * IWP];
                     }
-                    if (i < 7) {
-                        dwin[i] = d;
-                    } else {
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                float d[ROWS1 + 6];
 #pragma unroll
-                        for (int q = 0; q < 6; q++) dwin[q] = dwin[q + 1];
-                        dwin[6] = d;
-                    }
-                    if (i >= 6) {
-                        float s = 0.0f;
+                for (int i = 0; i < ROWS1 + 6; i++) {
+                    float dd = 0.0f;
 #pragma unroll
-                        for (int q = 0; q < 7; q++) s = s + dwin[q];
-                        sbdy[(ROWS1 * g1 + i - 6) * BWP + cx] = s;
+                    for (int c = 0; c < 3; c++) {
+                        const float t = (HOIST ? u[i][c] : uu[i][c]) - sh[i][c];
+                        dd = dd + t * t;
                     }
+                    d[i] = dd;
+                }
+#pragma unroll
+                for (int o = 0; o < ROWS1; o++) {
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 7; q++) sum = sum + d[o + q];
+                    sbdy[(ROWS1 * g1 + o) * BWP + cx] = sum;
                 }
             }
             __syncthreads();
             // ---- phase 2: blur_d, weight, accumulate
             if (npx > 0) {
-                const float *brow = sbdy + r2 * BWP + xb;
-                float bwin[7];
+                float bw[SEG + 6], sv[3][SEG];
 #pragma unroll
-                for (int q = 0; q < 6; q++) bwin[q] = brow[q];
+                for (int q = 0; q < SEG + 6; q++) bw[q] = brow[q];   // q < npx + 6 is what is used; the rest stays inside the tile's LDS
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+#pragma unroll
+                    for (int j = 0; j < SEG; j++) sv[c][j] = srow[c * IH * IWP + j + dxi];
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < SEG; j++) {
                     if (j < npx) {
-                        bwin[6] = brow[j + 6];
-                        float s = 0.0f;
+                        float sum = 0.0f;
 #pragma unroll
-                        for (int q = 0; q < 7; q++) s = s + bwin[q];
-                        float w = dev::fast_exp(s * g.inv);
-                        const int ir = r2 + 2 * HALF + dy, ic = xb + j + 2 * HALF + dx;
+                        for (int q = 0; q < 7; q++) sum = sum + bw[j + q];
+                        const float w = dev::fast_exp(sum * g.inv);
 #pragma unroll
-                        for (int c = 0; c < 3; c++) acc[j][c] = acc[j][c] + w * sin[(c * IH + ir) * IWP + ic];
+                        for (int c = 0; c < 3; c++) acc[j][c] = acc[j][c] + w * sv[c][j];
                         acc[j][3] = acc[j][3] + w * 1.0f;
-#pragma unroll
-                        for (int q = 0; q < 6; q++) bwin[q] = bwin[q + 1];
                     }
                 }
             }
@@ -252,18 +281,22 @@ extern "C" int nl_means(halide_buffer_t *input, int32_t patch_size, int32_t sear
     const long in_sy = input->dim[1].stride, in_sc = input->dim[2].stride;
     const long out_sy = output->dim[1].stride, out_sc = output->dim[2].stride;
     if (patch_size == P && search_area == SA) {
-        // tile height 64; HLMI_NLM_TH=80 selects the taller tile (fewer, larger workgroups: measured 3 % slower at 1080p)
+        // tile height: 16 by default (see NT above); HLMI_NLM_TH = 32 / 64 / 80 select the larger workgroups (A/B)
         const char *e = getenv("HLMI_NLM_TH");
-        const int th = e ? atoi(e) : 64;
-        if (th == 80) {
-            HLMI_HIP(uc, hipFuncSetAttribute((const void *)nlm_7x7<80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(80)));
-            dim3 grid((ow + TW - 1) / TW, (oh + 79) / 80);
-            HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, nlm_7x7<80>, grid, dim3(NT), lds_bytes(80), din, in_sy, in_sc, g, dout, out_sy, out_sc);
-        } else {
-            HLMI_HIP(uc, hipFuncSetAttribute((const void *)nlm_7x7<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(64)));
-            dim3 grid((ow + TW - 1) / TW, (oh + 63) / 64);
-            HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, nlm_7x7<64>, grid, dim3(NT), lds_bytes(64), din, in_sy, in_sc, g, dout, out_sy, out_sc);
-        }
+        const int th = e ? atoi(e) : 16;
+#define NLM_LAUNCH(TH_, NT_)                                                                                                  \
+    do {                                                                                                                      \
+        HLMI_HIP(uc, hipFuncSetAttribute((const void *)nlm_7x7<TH_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize,           \
+                                         (int)lds_bytes(TH_)));                                                               \
+        dim3 grid((ow + TW - 1) / TW, (oh + TH_ - 1) / TH_);                                                                  \
+        HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, (nlm_7x7<TH_, NT_>), grid, dim3(NT_), lds_bytes(TH_), din, in_sy, in_sc, g, dout, \
+                    out_sy, out_sc);                                                                                          \
+    } while (0)
+        if (th == 80) NLM_LAUNCH(80, 1024);
+        else if (th == 64) NLM_LAUNCH(64, 1024);
+        else if (th == 32) NLM_LAUNCH(32, 512);
+        else NLM_LAUNCH(16, 256);
+#undef NLM_LAUNCH
     } else {
         HLMI_LAUNCH(uc, "nlm_generic", ctx.stream, nlm_generic, dim3((ow + 255) / 256, oh), dim3(256), 0, din, in_sy, in_sc, g,
                     patch_size, search_area, dout, out_sy, out_sc);
