@@ -4,7 +4,8 @@
 // boundary: `int bilateral_grid(halide_buffer_t *input, float r_sigma, halide_buffer_t *bilateral_grid)`
 // (:10-12, :203).  HBM-bound at 8 B/px (4 read + 4 written); the grid (~3 MB at 1080p) lives in L2/MALL.
 //
-// Kernels (same decomposition as the reference's GPU schedule, :85-119):
+// Kernels (the decomposition of the reference's GPU schedule, :85-119; for grids of at most 16 planes the last three stages
+// run as ONE launch, bg_blur_slice, with the blurred cells of a pixel tile in LDS):
 //   bg_histogram_blurz  one thread per grid cell: zero an LDS histogram, accumulate its 8x8 pixels SERIALLY in
 //                       RDom order (float sums are order-sensitive, :28-29), blur in z, write float2 {value, weight}
 //   bg_blurx, bg_blury  5-tap [1 4 6 4 1], left-to-right association (:38-47)
@@ -163,6 +164,59 @@ __global__ __launch_bounds__(256) void bg_slice(const float *__restrict__ in, lo
     out[(long)y * out_sy + x] = r.x / r.y;
 }
 
+// ---- bg_blur_slice: blurx + blury + slice in ONE launch (grids of at most 16 planes).  A workgroup owns 64 x 32 output
+// pixels; the blury cells they interpolate between (at most 10 x 6 x ZD), the blurx rows under those (10 x 10) and the
+// blurz cells under those (14 x 10) are produced in LDS by the same blur5 chains the separate kernels run — two launches
+// and the write + re-read of two grids less (the pipeline is launch-latency bound: 4 launches took 30 us for 16 MB).
+constexpr int FPX = 64, FPY = 32, FCX = 10, FCY = 6, FZ = 16;
+__global__ __launch_bounds__(256) void bg_blur_slice(const float *__restrict__ in, long in_sy, BGeom g, const float2 *__restrict__ bz,
+                                                    float *__restrict__ out, long out_sy, int ox0, int oy0, int ow, int oh) {
+    __shared__ float2 s_bz[FZ][FCY + 4][FCX + 4], s_bx[FZ][FCY + 4][FCX], s_by[FZ][FCY][FCX];
+    const int t = threadIdx.x;
+    const int x0 = blockIdx.x * FPX, y0 = blockIdx.y * FPY;
+    const int cxa = dev::fdiv8(ox0 + x0) - g.gx0, cya = dev::fdiv8(oy0 + y0) - g.gy0;   // first blury cell of the tile
+    for (int e = t; e < g.ZD * (FCY + 4) * (FCX + 4); e += 256) {
+        const int z = e / ((FCY + 4) * (FCX + 4)), rem = e - z * ((FCY + 4) * (FCX + 4)), j = rem / (FCX + 4), i = rem - j * (FCX + 4);
+        const int hx = min(cxa + i, g.HX - 1), hy = min(cya + j, g.HY - 1);     // cells past the grid are never interpolated
+        s_bz[z][j][i] = bz[((size_t)z * g.HY + hy) * g.HX + hx];
+    }
+    __syncthreads();
+    for (int e = t; e < g.ZD * (FCY + 4) * FCX; e += 256) {
+        const int z = e / ((FCY + 4) * FCX), rem = e - z * ((FCY + 4) * FCX), j = rem / FCX, i = rem - j * FCX;
+        const float2 a = s_bz[z][j][i], b = s_bz[z][j][i + 1], c = s_bz[z][j][i + 2], d = s_bz[z][j][i + 3], q = s_bz[z][j][i + 4];
+        s_bx[z][j][i] = make_float2(blur5(a.x, b.x, c.x, d.x, q.x), blur5(a.y, b.y, c.y, d.y, q.y));
+    }
+    __syncthreads();
+    for (int e = t; e < g.ZD * FCY * FCX; e += 256) {
+        const int z = e / (FCY * FCX), rem = e - z * (FCY * FCX), j = rem / FCX, i = rem - j * FCX;
+        const float2 a = s_bx[z][j][i], b = s_bx[z][j + 1][i], c = s_bx[z][j + 2][i], d = s_bx[z][j + 3][i], q = s_bx[z][j + 4][i];
+        s_by[z][j][i] = make_float2(blur5(a.x, b.x, c.x, d.x, q.x), blur5(a.y, b.y, c.y, d.y, q.y));
+    }
+    __syncthreads();
+    const int x = x0 + (t & 63);
+    if (x >= ow) return;
+    const int ax = ox0 + x;
+    const float xf = (float)dev::fmod8(ax) * 0.125f;
+    const int xi = dev::fdiv8(ax) - g.gx0 - cxa;
+#pragma unroll
+    for (int k = 0; k < FPY / 4; k++) {
+        const int y = y0 + (t >> 6) + 4 * k;
+        if (y >= oh) break;
+        const int ay = oy0 + y;
+        const float val = dev::clampf(in[(long)(ay - g.iy0) * in_sy + (ax - g.ix0)], 0.0f, 1.0f);
+        const float zv = val * g.inv_r;
+        const int zi = (int)zv;
+        const float zf = zv - (float)zi;
+        const float yf = (float)dev::fmod8(ay) * 0.125f;
+        const int yi = dev::fdiv8(ay) - g.gy0 - cya;
+        const float2 a = lerp2(lerp2(s_by[zi][yi][xi], s_by[zi][yi][xi + 1], xf), lerp2(s_by[zi][yi + 1][xi], s_by[zi][yi + 1][xi + 1], xf), yf);
+        const float2 b = lerp2(lerp2(s_by[zi + 1][yi][xi], s_by[zi + 1][yi][xi + 1], xf),
+                               lerp2(s_by[zi + 1][yi + 1][xi], s_by[zi + 1][yi + 1][xi + 1], xf), yf);
+        const float2 r = lerp2(a, b, zf);
+        out[(long)y * out_sy + x] = r.x / r.y;
+    }
+}
+
 const int64_t e0 = 0, ew = 1536, eh = 2560;
 const int64_t *const est[4] = {&e0, &ew, &e0, &eh};
 const halide_scalar_value_t est_rs = [] { halide_scalar_value_t v{}; v.u.f32 = 0.1f; return v; }();
@@ -237,10 +291,15 @@ extern "C" int bilateral_grid(halide_buffer_t *input, float r_sigma, halide_buff
         size_t sh = (size_t)g.ZH * 2 * T * sizeof(float);
         HLMI_LAUNCH(uc, "bg_histogram_blurz", st, bg_histogram_blurz, dim3((g.HX + T - 1) / T, g.HY), dim3(T), sh, din, in_sy, g, bz);
     }
-    HLMI_LAUNCH(uc, "bg_blurx", st, bg_blurx, dim3((g.GX + 63) / 64, g.HY, g.ZD), dim3(64), 0, bz, g, bx);
-    HLMI_LAUNCH(uc, "bg_blury", st, bg_blury, dim3((g.GX + 63) / 64, g.GY, g.ZD), dim3(64), 0, bx, g, by);
-    HLMI_LAUNCH(uc, "bg_slice", st, bg_slice, dim3((ow + 255) / 256, oh), dim3(256), 0, din, in_sy, g, by, dev_ptr<float>(output),
-                out_sy, ox0, oy0, ow);
+    if (g.ZD <= FZ && !getenv("HLMI_BG_UNFUSED")) {
+        HLMI_LAUNCH(uc, "bg_blur_slice", st, bg_blur_slice, dim3((ow + FPX - 1) / FPX, (oh + FPY - 1) / FPY), dim3(256), 0, din, in_sy, g, bz,
+                    dev_ptr<float>(output), out_sy, ox0, oy0, ow, oh);
+    } else {
+        HLMI_LAUNCH(uc, "bg_blurx", st, bg_blurx, dim3((g.GX + 63) / 64, g.HY, g.ZD), dim3(64), 0, bz, g, bx);
+        HLMI_LAUNCH(uc, "bg_blury", st, bg_blury, dim3((g.GX + 63) / 64, g.GY, g.ZD), dim3(64), 0, bx, g, by);
+        HLMI_LAUNCH(uc, "bg_slice", st, bg_slice, dim3((ow + 255) / 256, oh), dim3(256), 0, din, in_sy, g, by, dev_ptr<float>(output),
+                    out_sy, ox0, oy0, ow);
+    }
     mark_output_written(output);
     return 0;
 }

@@ -11,6 +11,9 @@
 //   cp_demosaic one thread per Bayer quad: 10x10 raw window -> hot-pixel clamp -> 3x3x4 deinterleaved values in
 //               registers -> demosaic 4 pixels -> matrix -> curve -> u8 planes on [-1, W] x [-1, H]
 //   cp_sharpen  one thread per output pixel, 3 channels
+#include <mutex>
+#include <string.h>
+
 #include "hlmi_device_math.h"
 #include "hlmi_internal.h"
 
@@ -401,6 +404,30 @@ const halide_filter_argument_t cp_args[10] = {
 };
 const halide_filter_metadata_t cp_md = {1, 10, cp_args, kTargetString, "camera_pipe"};
 
+// ---- cache of set-up blocks ---------------------------------------------------------------------------------------
+// cp_setup's output (matrix, curve, strength) is a function of the two matrix buffers' contents and six scalars; a video
+// stream calls with the same ones frame after frame.  The block is kept per (matrix allocations and versions, scalars) in
+// memory of its own (the per-stream arena is shared with other pipelines) and the launch is skipped when nothing changed.
+// Matrices in memory the runtime does not own (version 0) are never cached.
+struct SetupKey {
+    int device;
+    uint64_t h3, v3, h7, v7;
+    long s3, s7, o3, o7;
+    float color_temp, gamma, contrast, sharpen;
+    int black, white;
+};
+struct SetupImage {
+    SetupKey key;
+    bool valid = false;
+    CPSetup *dev = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ready = nullptr;
+    uint64_t used = 0;
+};
+std::mutex g_si_mu;
+SetupImage g_si[4];
+uint64_t g_si_clock = 0;
+
 }  // namespace
 
 extern "C" int camera_pipe(halide_buffer_t *input, halide_buffer_t *matrix_3200, halide_buffer_t *matrix_7000, float color_temp,
@@ -457,10 +484,60 @@ extern "C" int camera_pipe(halide_buffer_t *input, halide_buffer_t *matrix_3200,
     CPSetup *setup = (CPSetup *)ws;
     uint8_t *cv = (uint8_t *)ws + setup_bytes;
     hipStream_t st = ctx.stream;
-    const float *m3 = dev_ptr<float>(matrix_3200) - ((long)matrix_3200->dim[1].min * matrix_3200->dim[1].stride + matrix_3200->dim[0].min);
-    const float *m7 = dev_ptr<float>(matrix_7000) - ((long)matrix_7000->dim[1].min * matrix_7000->dim[1].stride + matrix_7000->dim[0].min);
-    HLMI_LAUNCH(uc, "cp_setup", st, cp_setup, dim3(1), dim3(1024), 0, m3, (long)matrix_3200->dim[1].stride, m7,
-                (long)matrix_7000->dim[1].stride, color_temp, gamma, contrast, sharpen_strength, blackLevel, whiteLevel, setup);
+    const long mo3 = (long)matrix_3200->dim[1].min * matrix_3200->dim[1].stride + matrix_3200->dim[0].min;
+    const long mo7 = (long)matrix_7000->dim[1].min * matrix_7000->dim[1].stride + matrix_7000->dim[0].min;
+    const float *m3 = dev_ptr<float>(matrix_3200) - mo3;
+    const float *m7 = dev_ptr<float>(matrix_7000) - mo7;
+    bool have_setup = false;
+    SetupKey key;
+    memset(&key, 0, sizeof key);
+    key.device = ctx.device;
+    key.h3 = matrix_3200->device, key.v3 = buffer_version(matrix_3200), key.h7 = matrix_7000->device, key.v7 = buffer_version(matrix_7000);
+    key.s3 = matrix_3200->dim[1].stride, key.s7 = matrix_7000->dim[1].stride, key.o3 = mo3, key.o7 = mo7;
+    key.color_temp = color_temp, key.gamma = gamma, key.contrast = contrast, key.sharpen = sharpen_strength;
+    key.black = blackLevel, key.white = whiteLevel;
+    const bool cacheable = key.v3 != 0 && key.v7 != 0 && !getenv("HLMI_CP_NO_SETUP_CACHE");
+    std::unique_lock<std::mutex> si_lock(g_si_mu, std::defer_lock);
+    SetupImage *slot = nullptr;
+    if (cacheable) {
+        si_lock.lock();
+        for (auto &e : g_si) {
+            if (e.valid && memcmp(&e.key, &key, sizeof key) == 0) {
+                e.used = ++g_si_clock;
+                if (e.stream != st) HLMI_HIP(uc, hipStreamWaitEvent(st, e.ready, 0));
+                setup = e.dev, have_setup = true;
+                break;
+            }
+        }
+        if (!have_setup) {
+            slot = &g_si[0];
+            for (auto &e : g_si) {
+                if (!e.dev) { slot = &e; break; }
+                if (e.used < slot->used) slot = &e;
+            }
+            slot->valid = false;
+            if (slot->dev && slot->key.device != ctx.device) {
+                (void)hipFree(slot->dev);
+                slot->dev = nullptr;
+            }
+            if (!slot->dev) HLMI_HIP(uc, hipMalloc((void **)&slot->dev, setup_bytes));
+            else HLMI_HIP(uc, hipDeviceSynchronize());   // evicting a block (rare): launches on any stream may still read it
+            if (!slot->ready) HLMI_HIP(uc, hipEventCreateWithFlags(&slot->ready, hipEventDisableTiming));
+            slot->key = key, slot->stream = st, slot->used = ++g_si_clock;
+            setup = slot->dev;
+        } else {
+            si_lock.unlock();
+        }
+    }
+    if (!have_setup) {
+        HLMI_LAUNCH(uc, "cp_setup", st, cp_setup, dim3(1), dim3(1024), 0, m3, (long)matrix_3200->dim[1].stride, m7,
+                    (long)matrix_7000->dim[1].stride, color_temp, gamma, contrast, sharpen_strength, blackLevel, whiteLevel, setup);
+        if (slot) {
+            HLMI_HIP(uc, hipEventRecord(slot->ready, st));
+            slot->valid = true;
+            si_lock.unlock();
+        }
+    }
     // shifted(x, y) = input(x + 16, y + 12) in ABSOLUTE coordinates; output pixel (ox, oy) is X = 0 of the kernels
     const long in_sy = input->dim[1].stride;
     const uint16_t *raw = dev_ptr<uint16_t>(input) + (long)(oy + 12 - input->dim[1].min) * in_sy + (ox + 16 - input->dim[0].min);

@@ -149,6 +149,38 @@ def test_hip_parameter_sweep(hl, oracle, p):
 
 
 @pytest.mark.gpu
+def test_hip_setup_block_follows_the_matrices_and_scalars(hl, oracle):
+    """The set-up block (colour matrix, curve, strength) is cached per (matrix allocations + versions, scalars): resident
+    matrices and unchanged scalars skip cp_setup; a matrix the caller rewrites and marks host_dirty, other scalars, or a
+    re-allocated matrix at the same address must produce the new result."""
+    raw = _raw(200, 150, seed=11)
+    bi = hl.Buffer(raw)
+    m3, m7 = M3200.copy(), M7000.copy()
+    b3, b7 = hl.Buffer(m3), hl.Buffer(m7)
+
+    def run(p):
+        bo = hl.Buffer(np.zeros((3, 120, 160), np.uint8))
+        hl.camera_pipe(bi, b3, b7, p["color_temp"], p["gamma"], p["contrast"], p["sharpen"], p["black"], p["white"], bo)
+        return bo.numpy().copy()
+
+    def want(p, a3, a7):
+        return oracle.camera_pipe(raw, a3, a7, p["color_temp"], p["gamma"], p["contrast"], p["sharpen"], p["black"], p["white"], 160, 120)
+    first, again = run(PARAMS), run(PARAMS)            # second call: cached block
+    assert np.array_equal(first, again) and np.array_equal(first, want(PARAMS, m3, m7))
+    p2 = dict(PARAMS, gamma=1.4, sharpen=3.0)
+    assert np.array_equal(run(p2), want(p2, m3, m7))   # other scalars
+    assert np.array_equal(run(PARAMS), first)          # and back: the first block is still cached
+    m3[...] = m3 * np.float32(0.75)                     # rewrite the SAME host array, tell the library
+    b3.set_host_dirty()
+    changed = run(PARAMS)
+    assert np.array_equal(changed, want(PARAMS, m3, m7)) and not np.array_equal(changed, first)
+    b7.device_free()                                    # a new allocation, most likely at the same address
+    m7b = (m7 * np.float32(1.25)).astype(np.float32)
+    b7 = hl.Buffer(m7b)
+    assert np.array_equal(run(PARAMS), want(PARAMS, m3, m7b))
+
+
+@pytest.mark.gpu
 def test_hip_odd_output_size_and_out_of_bounds(hl, oracle):
     raw = _raw(120, 90, seed=9)
     assert np.array_equal(_run(hl, raw, 97, 71), _oracle(oracle, raw, 97, 71))
