@@ -193,6 +193,29 @@ def test_harris_filter_cpp(tmp_path):
 
 
 @pytest.mark.gpu
+def test_interpolate_filter_cpp(tmp_path, oracle):
+    """apps/interpolate/filter.cpp wants an RGBA image; without libpng in this image it is fed (and writes) MATLAB level-5
+    ".mat" files, the one format of tools/halide_image_io.h (:1759-1915 load_mat, :1916-2060 save_mat) that carries a
+    3-dimensional float image without libpng — which also keeps the result exact: the saved output must be the oracle's
+    bit for bit."""
+    import scipy.io
+    exe = _exe("interpolate_filter")
+    rng = np.random.default_rng(12)
+    rgba = rng.random((4, 96, 160), dtype=np.float32)
+    rgba[3] = (rng.random((96, 160)) > 0.7).astype(np.float32) * rgba[3]     # sparse alpha: the pull-push has holes to fill
+    src, dst = str(tmp_path / "rgba.mat"), str(tmp_path / "result.mat")
+    # MATLAB arrays are column-major: an array of shape (W, H, C) stores x fastest, then y, then c — Halide's planar layout
+    scipy.io.savemat(src, {"rgba": np.asfortranarray(rgba.transpose(2, 1, 0))}, format="5", do_compression=False)
+    r = subprocess.run([exe, src, dst], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Success!" in r.stdout, r.stdout + r.stderr
+    saved = scipy.io.loadmat(dst)
+    (name,) = [k for k in saved if not k.startswith("__")]
+    got = np.ascontiguousarray(saved[name].transpose(2, 1, 0))
+    want = oracle.interpolate(rgba)
+    assert got.dtype == np.float32 and got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
 def test_iir_blur_filter_cpp(tmp_path):
     exe = _exe("iir_blur_filter")
     img8 = _scene8(192, 130, 9, 3)
