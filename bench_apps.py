@@ -121,13 +121,21 @@ def main():
         o = hl.Buffer(np.zeros((H, W), np.uint16))
         call = lambda: hl.stencil_chain(a, o)
         t = timed(call, o, 20)
-        # 4 B/px compulsory HBM traffic against 32 stages x 25 taps = 1600 u16 multiply-adds per pixel (400 op/B): the bound
-        # is the packed 16-bit integer VALU rate (v_pk_mad_u16: 2 MACs per lane and clock = the packed-f32 figure), priced on
-        # the ALGORITHMIC op count — the kernel's separable 5 + 5 factorisation executes 2.5x fewer
-        ops = 2.0 * 1600 * W * H
-        emit("stencil_chain", "apps/stencil_chain 32 stages 5x5, u16 1536x2560", t, W * H, "valu", ops / t / 1e12,
-             VALU_F32_PEAK_TF, "TOP/s (u16, packed)", {"alg_ops": ops, "alg_bytes": 4 * W * H, "hbm_gbs": 4.0 * W * H / t / 1e9,
-                                                      "kernels_ms": kernels(call, o)})
+        # Priced on the operations the kernel EXECUTES: the separable 5 + 5 form is 10 u16 multiply-adds per pixel and stage
+        # (the reference's 25-tap form would be 2.5x more), over the 128 x 96 window of a tile whose 8 fused stages leave
+        # 96 x 64 outputs (2.0x halo recomputation) = 640 executed multiply-adds per output pixel; bound: the packed 16-bit
+        # integer VALU rate (v_pk_mad_u16: 2 MACs per lane and clock = the packed-f32 figure).  Next to it the figure on the
+        # ALGORITHMIC count (32 stages x 25 taps = 1600 MACs per pixel) and the fraction of the HBM roofline SURVEY.md
+        # §8(d) assigns the pipeline (4 B/px: read + write once).
+        halo = (128.0 * 96.0) / (96.0 * 64.0)
+        ops_exec = 2.0 * 32 * 10 * halo * W * H
+        ops_alg = 2.0 * 1600 * W * H
+        emit("stencil_chain", "apps/stencil_chain 32 stages 5x5, u16 1536x2560", t, W * H, "valu", ops_exec / t / 1e12,
+             VALU_F32_PEAK_TF, "TOP/s (u16, packed, executed)",
+             {"executed_ops": ops_exec, "halo_recompute": halo, "alg_ops": ops_alg,
+              "alg_ops_frac": round(ops_alg / t / 1e12 / VALU_F32_PEAK_TF, 4), "alg_bytes": 4 * W * H,
+              "hbm_gbs": 4.0 * W * H / t / 1e9, "hbm_frac": round(4.0 * W * H / t / 1e9 / HBM_PEAK_GBS, 4),
+              "kernels_ms": kernels(call, o)})
 
     # ---- camera_pipe 2592x1968 raw -> 2560x1920x3 u8
     if not only or "camera_pipe" in only:
