@@ -118,6 +118,8 @@ void mark_output_written(halide_buffer_t *buf);  // device_dirty = 1, host_dirty
 // (device handle, version) identifies contents.  0 = memory this runtime does not own (wrapped native pointers: their
 // owner can rewrite them behind our back) — callers must not cache anything derived from such a buffer.
 uint64_t buffer_version(const halide_buffer_t *buf);
+// compute units a launch on `stream` can use (a CU-partitioned stream of halide_hip_partition_stream: its share)
+int stream_cu_count(int device, hipStream_t stream);
 
 template<typename T>
 inline T *dev_ptr(const halide_buffer_t *b) { return reinterpret_cast<T *>((uintptr_t)b->device); }

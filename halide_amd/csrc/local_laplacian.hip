@@ -31,7 +31,9 @@
 #include "hlmi_internal.h"
 
 #include <atomic>
+#include <mutex>
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 using namespace hlmi;
@@ -1560,22 +1562,28 @@ int env_int(const char *name, int dflt) {
     return (e && *e) ? atoi(e) : dflt;
 }
 
-int cu_count(int dev) {
-    static std::atomic<int> cached[64];
-    int c = cached[dev & 63].load();
-    if (c <= 0) {
-        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
-        cached[dev & 63].store(c);
-    }
-    return c;
-}
-
 // last call's level table, for hlmi_debug_local_laplacian_outg (tests only)
 thread_local Level t_dbg_lv[J];
 thread_local hipStream_t t_dbg_stream = nullptr;
 thread_local bool t_dbg_out1_pending = false;  // the last call fused level 1's collapse: outGPyramid[1] was never stored
 thread_local int t_dbg_K = 0;
 thread_local float t_dbg_Km1 = 0;
+
+// ---- cache of remap tables: the LUT is a function of (levels, alpha) only — a video stream calls with the same pair frame
+// after frame — so it is kept in memory of its own per (device, levels, alpha) and ll_remap_lut runs when the pair is new
+// (one 4.5 us launch less per frame).  An entry is used by other streams behind the event recorded after its launch.
+struct LutImage {
+    int device = -1, levels = 0;
+    uint32_t alpha_bits = 0;
+    bool valid = false;
+    float *dev = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ready = nullptr;
+    uint64_t used = 0;
+};
+std::mutex g_lut_mu;
+LutImage g_lut[8];
+uint64_t g_lut_clock = 0;
 
 }  // namespace
 
@@ -1678,12 +1686,45 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     const int nlut = 2 * gm.half + 1;
     const size_t lut_sh = lut_lds ? sizeof(float) * nlut : 0;
 
-    HLMI_LAUNCH(uc, "ll_remap_lut", st, ll_remap_lut, dim3((nlut + 255) / 256), dim3(256), 0, lut, gm.half, alpha);
+    if (!env_int("HLMI_LL_NO_LUT_CACHE", 0)) {
+        uint32_t abits;
+        memcpy(&abits, &alpha, 4);
+        std::unique_lock<std::mutex> lock(g_lut_mu);
+        LutImage *hit = nullptr, *slot = &g_lut[0];
+        for (auto &e : g_lut) {
+            if (e.valid && e.device == ctx.device && e.levels == levels && e.alpha_bits == abits) hit = &e;
+        }
+        if (hit) {
+            hit->used = ++g_lut_clock;
+            if (hit->stream != st) HLMI_HIP(uc, hipStreamWaitEvent(st, hit->ready, 0));
+            lut = hit->dev;
+        } else {
+            for (auto &e : g_lut) {
+                if (!e.dev) { slot = &e; break; }
+                if (e.used < slot->used) slot = &e;
+            }
+            slot->valid = false;
+            if (slot->dev) {   // evicting (more than 8 (levels, alpha) pairs in use): launches on any stream may still read it
+                HLMI_HIP(uc, hipDeviceSynchronize());
+                (void)hipFree(slot->dev);
+                slot->dev = nullptr;
+            }
+            HLMI_HIP(uc, hipMalloc((void **)&slot->dev, sizeof(float) * ((size_t)nlut + 64)));
+            if (!slot->ready) HLMI_HIP(uc, hipEventCreateWithFlags(&slot->ready, hipEventDisableTiming));
+            slot->device = ctx.device, slot->levels = levels, slot->alpha_bits = abits, slot->stream = st, slot->used = ++g_lut_clock;
+            lut = slot->dev;
+            HLMI_LAUNCH(uc, "ll_remap_lut", st, ll_remap_lut, dim3((nlut + 255) / 256), dim3(256), 0, lut, gm.half, alpha);
+            HLMI_HIP(uc, hipEventRecord(slot->ready, st));
+            slot->valid = true;
+        }
+    } else {
+        HLMI_LAUNCH(uc, "ll_remap_lut", st, ll_remap_lut, dim3((nlut + 255) / 256), dim3(256), 0, lut, gm.half, alpha);
+    }
     bool fuse_d2 = false;
     {
         const Level &d = lv[1];
         // two waves per SIMD with (almost) equal row counts: the kernel is VALU-bound, so balance is what counts
-        const int target = env_int("HLMI_LL_UNITS0", 8 * cu_count(ctx.device));
+        const int target = env_int("HLMI_LL_UNITS0", 8 * stream_cu_count(ctx.device, nullptr));
         const int nsy = max(1, min(max(target / d.nsx, (d.h + 63) / 64), max(1, d.h / 2)));
         const int nunits = d.nsx * nsy;
         const int iw = gm.ix1 - gm.ix0 + 1;
@@ -1723,7 +1764,9 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             const int hi1 = d.lox + d.w - 1, hi2 = e.lox + e.w - 1;
             const int x2_first = odd1 ? (a.Pbase + 1) / 2 + 0 : a.Pbase / 2 + 1;   // Pbase + 1 (resp. Pbase) is even: exact
             a.nsx = max((hi2 - x2_first + a.S2) / a.S2, (hi1 - a.Pbase + 2 * a.S2) / (2 * a.S2));
-            const int target2 = env_int("HLMI_LL_UNITS0", 8 * cu_count(ctx.device));
+            // sized for the whole device even on a CU-partitioned stream: units sized for the partition's 64 CUs (one round
+            // of 18-row units) measured 2-3 % slower than 3.6 rounds of 5-row units (101.5 vs 98.9 us per frame)
+            const int target2 = env_int("HLMI_LL_UNITS0", 8 * stream_cu_count(ctx.device, nullptr));
             // EXCH: a workgroup = 4 vertically adjacent units exchanging their seam rows through LDS.  With n level-2 rows
             // per wave a workgroup owns R = 4 n - 1 rows (the bottom wave walks the two seam rows of the next workgroup
             // itself and owns one row less); n = the smallest that keeps the launch within `target2` resident waves.
@@ -1813,7 +1856,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         const Level &s = lv[j], &d = lv[j + 1];
         // enough waves to fill the chip on the big levels, short strips on the small ones
         const int cols = d.nsx * (levels + 1);
-        const int target = env_int("HLMI_LL_UNITSB", 16 * cu_count(ctx.device));
+        const int target = env_int("HLMI_LL_UNITSB", 16 * stream_cu_count(ctx.device, nullptr));
         const int nsy = max(1, min(max(target / cols, (d.h + 31) / 32), max(1, d.h / 2)));
         const int nunits = cols * nsy;
         dim3 grid((nunits + 3) / 4), block(256);

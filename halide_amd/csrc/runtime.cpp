@@ -438,6 +438,25 @@ static int note_use(void *uc, const DeviceCtx &ctx, uint64_t handle, const char 
     return 0;
 }
 
+static std::map<std::tuple<int, int, int>, hipStream_t> g_part_streams;   // (device, part, nparts) -> stream (under g_mu)
+static std::unordered_map<hipStream_t, int> g_part_cus;                    // partition stream -> its number of CUs
+
+// compute units a launch on `stream` can use: the partition's share for a library-owned partition stream, else the device's
+int stream_cu_count(int device, hipStream_t stream) {
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        auto it = g_part_cus.find(stream);
+        if (it != g_part_cus.end()) return it->second;
+    }
+    static std::atomic<int> cached[64];
+    int c = cached[device & 63].load();
+    if (c <= 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c <= 0) c = 256;
+        cached[device & 63].store(c);
+    }
+    return c;
+}
+
 uint64_t buffer_version(const halide_buffer_t *buf) {
     if (!buf || !buf->device) return 0;
     std::lock_guard<std::mutex> lock(g_mu);
@@ -1267,7 +1286,7 @@ void *halide_hip_partition_stream(int part, int nparts) {
     DeviceCtx ctx;
     if (nparts < 1 || part < 0 || part >= nparts || acquire_device(nullptr, &ctx, false)) return nullptr;
     std::lock_guard<std::mutex> lock(g_mu);
-    static std::map<std::tuple<int, int, int>, hipStream_t> streams;
+    auto &streams = g_part_streams;
     auto key = std::make_tuple(ctx.device, part, nparts);
     auto it = streams.find(key);
     if (it != streams.end()) return (void *)it->second;
@@ -1281,8 +1300,10 @@ void *halide_hip_partition_stream(int part, int nparts) {
         return nullptr;
     }
     streams[key] = s;
+    g_part_cus[s] = (ncu - part + nparts - 1) / nparts;
     return (void *)s;
 }
+
 
 void *halide_hip_get_stream(void *uc) {
     DeviceCtx ctx;
