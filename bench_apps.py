@@ -229,6 +229,22 @@ def main():
              {"alg_bytes": 24 * W * H, "kernels_ms": kernels(call, o),
               "note": "bound by the sequential recurrence: 2 (W + H) dependent multiply-add steps per scan line"})
 
+    # ---- lens_blur u8 stereo pair 768x1280 (the size of apps/images/rgb.png the reference's Makefile feeds process.cpp), 32 slices, 32 samples
+    if not only or "lens_blur" in only:
+        W, H = 768, 1280
+        left = rng.integers(0, 256, (3, H, W), dtype=np.uint8)
+        right = np.roll(left, 7, 2)
+        a, b = hl.Buffer(left), hl.Buffer(right)
+        o = hl.Buffer(np.zeros((3, H, W), np.float32))
+        call = lambda: hl.lens_blur(a, b, 32, 13, 0.5, 32, o)
+        t = timed(call, o, 5)
+        # traffic of the straightforward decomposition: the 2 x 32-plane level 0 of the push pyramid written once and read twice
+        # (down, depth), 4/3 of that again for the coarser push + pull levels: ~ (3 + 4/3) * 256 B per pixel
+        bytes_px = (3.0 + 4.0 / 3.0) * 2 * 32 * 4
+        emit("lens_blur", "apps/lens_blur 32 slices, 32 aperture samples, u8 768x1280x3 stereo pair -> f32", t, W * H, "hbm",
+             bytes_px * W * H / t / 1e9, HBM_PEAK_GBS, "GB/s", {"alg_bytes": bytes_px * W * H, "kernels_ms": kernels(call, o),
+                                                              "note": "coverage pipeline: one thread per element, untuned"})
+
     # ---- depthwise_separable_conv at the driver's shape (MobileNet-v2 layer 2, process.cpp:13)
     if not only or "depthwise_separable_conv" in only:
         N, Hh, Ww, CI, CO = 4, 112, 112, 32, 16

@@ -339,6 +339,7 @@ _hist = _bind("hist", [_BP, _BP])
 _harris = _bind("harris", [_BP, _BP])
 _interp = _bind("interpolate", [_BP, _BP])
 _iir = _bind("iir_blur", [_BP, C.c_float, _BP])
+_lens = _bind("lens_blur", [_BP, _BP, C.c_int32, C.c_int32, C.c_float, C.c_int32, _BP])
 _cam = _bind("camera_pipe", [_BP, _BP, _BP, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _BP])
 
 
@@ -423,6 +424,11 @@ def interpolate(input, output) -> int:
 
 def iir_blur(input, alpha, output) -> int:
     return _check(_iir(_as_ptr(input), float(alpha), _as_ptr(output)))
+
+
+def lens_blur(left_im, right_im, slices, focus_depth, blur_radius_scale, aperture_samples, final) -> int:
+    return _check(_lens(_as_ptr(left_im), _as_ptr(right_im), int(slices), int(focus_depth), float(blur_radius_scale),
+                        int(aperture_samples), _as_ptr(final)))
 
 
 def camera_pipe(input, matrix_3200, matrix_7000, color_temp, gamma, contrast, sharpen_strength, black_level,

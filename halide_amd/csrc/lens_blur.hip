@@ -1,0 +1,366 @@
+// lens_blur.hip — gfx950 implementation of the reference's lens_blur AOT pipeline (adjacent app, same
+// boundary).  Algorithm: /root/reference/apps/lens_blur/lens_blur_generator.cpp:24-152 (downsample :279-285, upsample
+// :288-294); boundary: `int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, int32_t slices, int32_t
+// focus_depth, float blur_radius_scale, int32_t aperture_samples, halide_buffer_t *final)` (:12-21, :301).
+//
+// Stages (one launch each unless noted; every Func is evaluated on the box its consumers read, as the oracle does —
+// oracle/lens_blur_oracle.c has the derivation of the boxes D, P_i, E):
+//   lb_cost     per pixel of E: the `slices` stereo costs, their confidence (variance across the stack) and
+//               cost_pyramid_push[0] = {cost * confidence, confidence}                                  (:30-56)
+//   lb_down     cost_pyramid_push[i], i = 1..7: 1-3-3-1 in x then in y of the level above, clamped box (:57-63)
+//   lb_pull     cost_pyramid_pull[i], i = 7..1: lerp(upsample(pull[i+1]), push[i], 1/2) on P_i         (:65-71)
+//   lb_depth    pull[0] on the fly, filtered_cost, argmin over the slices -> depth, bokeh radius on D   (:73-89)
+//   lb_wcy      vertical running maximum of the bokeh radius                                           (:94-99)
+//   lb_final    horizontal maximum, the aperture samples, weights, accumulation, normalisation         (:99-152)
+// Float operations are in the generator's order with one rounding each (-ffp-contract=off).  The sample positions come
+// from Halide's random_float(): a fixed hash (src/Random.cpp:20-104) of (call id, definition tag, s, y, x); the call ids
+// are 0 and 1, the definition tag is a compile-time counter of the reference's compiler that cannot be observed here —
+// it defaults to the count derived in the oracle's header (71) and is settable: hlmi_lens_blur_set_random_tag().
+//
+// Layout: push[i] / pull[i] are float [slices][2][box_h][box_w] (x fastest); nothing is tiled or fused beyond lb_depth:
+// this pipeline is here for coverage of the boundary (the reference's driver runs unmodified), not tuned.
+#include "hlmi_device_math.h"
+#include "hlmi_internal.h"
+
+#include <atomic>
+
+using namespace hlmi;
+
+namespace {
+
+constexpr int LV = 8;
+std::atomic<int> g_rand_tag{71};
+
+struct Box {
+    int x0, y0, w, h;   // origin (absolute), extents
+};
+struct LBGeom {
+    int lx0, lx1, ly0, ly1;      // clamp box of left_im (absolute)
+    int rx0, rx1, ry0, ry1;      // clamp box of right_im
+    long l_sy, l_sc, r_sy, r_sc; // strides (elements); channel index clamped by the caller: offsets below
+    long l_c[3], r_c[3];         // element offsets of the (clamped) channels 0..2
+    int slices, focus, samples, R, tag;
+    float scale, fslices;
+};
+
+__device__ __forceinline__ size_t at(const Box &b, int slices_unused, int z, int c, int x, int y) {
+    return (((size_t)z * 2 + c) * b.h + (y - b.y0)) * b.w + (x - b.x0);
+}
+
+// cost(x, y, z) (:30-39): integer-valued float
+__device__ __forceinline__ float cost_at(const uint8_t *__restrict__ L, const uint8_t *__restrict__ Rr, const LBGeom &g, int x, int y,
+                                         int z) {
+    const long lo = (long)(dev::clampi(y, g.ly0, g.ly1) - g.ly0) * g.l_sy + (dev::clampi(x, g.lx0, g.lx1) - g.lx0);
+    const long ro = (long)(dev::clampi(y, g.ry0, g.ry1) - g.ry0) * g.r_sy;
+    const long r0 = ro + (dev::clampi(x + 2 * z, g.rx0, g.rx1) - g.rx0), r1 = ro + (dev::clampi(x + 2 * z + 1, g.rx0, g.rx1) - g.rx0);
+    float cz = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int l = L[lo + g.l_c[c]], a = Rr[r0 + g.r_c[c]], b = Rr[r1 + g.r_c[c]];
+        const int d0 = l > a ? l - a : a - l, d1 = l > b ? l - b : b - l;
+        const float d = (float)min(d0, d1);
+        cz = (c == 0) ? d * d : cz + d * d;
+    }
+    return cz;
+}
+
+__global__ __launch_bounds__(256) void lb_cost(const uint8_t *__restrict__ L, const uint8_t *__restrict__ Rr, LBGeom g, Box E,
+                                              float *__restrict__ push0) {
+    const int xi = blockIdx.x * 256 + threadIdx.x, yi = blockIdx.y;
+    if (xi >= E.w) return;
+    const int x = E.x0 + xi, y = E.y0 + yi;
+    float sa = 0.0f, sb = 0.0f;
+    for (int z = 0; z < g.slices; z++) {
+        const float cz = cost_at(L, Rr, g, x, y, z);
+        sa = sa + cz * cz;
+        sb = sb + cz / g.fslices;
+    }
+    const float conf = sa / g.fslices - sb * sb;
+    for (int z = 0; z < g.slices; z++) {
+        const float cz = cost_at(L, Rr, g, x, y, z);
+        push0[at(E, 0, z, 0, x, y)] = cz * conf;
+        push0[at(E, 0, z, 1, x, y)] = conf;
+    }
+}
+
+// src level as the total function the generator defines: clamped to its box for levels >= 1 (:62), direct for level 0
+template<bool CLAMP>
+__device__ __forceinline__ float src_at(const float *__restrict__ s, const Box &b, int zc, int x, int y) {
+    if (CLAMP) x = dev::clampi(x, b.x0, b.x0 + b.w - 1), y = dev::clampi(y, b.y0, b.y0 + b.h - 1);
+    return s[((size_t)zc * b.h + (y - b.y0)) * b.w + (x - b.x0)];
+}
+
+template<bool SRC_CLAMP>
+__global__ __launch_bounds__(256) void lb_down(const float *__restrict__ src, Box sb, float *__restrict__ dst, Box db) {
+    const int xi = blockIdx.x * 256 + threadIdx.x, y = db.y0 + blockIdx.y, zc = blockIdx.z;
+    if (xi >= db.w) return;
+    const int x = db.x0 + xi;
+    float dx[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int yy = 2 * y - 1 + k;
+        dx[k] = (src_at<SRC_CLAMP>(src, sb, zc, 2 * x - 1, yy) +
+                 3.0f * (src_at<SRC_CLAMP>(src, sb, zc, 2 * x, yy) + src_at<SRC_CLAMP>(src, sb, zc, 2 * x + 1, yy)) +
+                 src_at<SRC_CLAMP>(src, sb, zc, 2 * x + 2, yy)) * 0.125f;
+    }
+    dst[((size_t)zc * db.h + (y - db.y0)) * db.w + xi] = (dx[0] + 3.0f * (dx[1] + dx[2]) + dx[3]) * 0.125f;
+}
+
+// upsample(f)(x, y) (:288-294) of a pull level stored on box b
+__device__ __forceinline__ float up_at(const float *__restrict__ f, const Box &b, int zc, int x, int y) {
+    const int xa = (x >> 1) - 1 + 2 * (x & 1), xb = x >> 1, ya = (y >> 1) - 1 + 2 * (y & 1), yb = y >> 1;
+    const float *p = f + (size_t)zc * b.h * b.w;
+    const float *ra = p + (size_t)(ya - b.y0) * b.w - b.x0, *rb = p + (size_t)(yb - b.y0) * b.w - b.x0;
+    const float ua = 0.25f * ra[xa] + 0.75f * ra[xb];
+    const float ub = 0.25f * rb[xa] + 0.75f * rb[xb];
+    return 0.25f * ua + 0.75f * ub;
+}
+
+// pull[i] on P_i: TOP: pull[7] = push[7]; else lerp(upsample(pull[i+1]), push[i], 0.5)
+template<bool TOP>
+__global__ __launch_bounds__(256) void lb_pull(const float *__restrict__ push, Box pb, const float *__restrict__ coarse, Box cb,
+                                              float *__restrict__ dst, Box db) {
+    const int xi = blockIdx.x * 256 + threadIdx.x, y = db.y0 + blockIdx.y, zc = blockIdx.z;
+    if (xi >= db.w) return;
+    const int x = db.x0 + xi;
+    const float p = src_at<true>(push, pb, zc, x, y);
+    float v = p;
+    if (!TOP) v = dev::lerpf(up_at(coarse, cb, zc, x, y), p, 0.5f);
+    dst[((size_t)zc * db.h + (y - db.y0)) * db.w + xi] = v;
+}
+
+__global__ __launch_bounds__(256) void lb_depth(const float *__restrict__ push0, Box E, const float *__restrict__ pull1, Box P1, LBGeom g,
+                                               Box D, int *__restrict__ depth, float *__restrict__ br) {
+    const int xi = blockIdx.x * 256 + threadIdx.x, yi = blockIdx.y;
+    if (xi >= D.w) return;
+    const int x = D.x0 + xi, y = D.y0 + yi;
+    int best_i = 0;
+    float best = 3.402823466e38f;
+    for (int z = 0; z < g.slices; z++) {
+        const float v0 = dev::lerpf(up_at(pull1, P1, 2 * z, x, y), push0[at(E, 0, z, 0, x, y)], 0.5f);
+        const float v1 = dev::lerpf(up_at(pull1, P1, 2 * z + 1, x, y), push0[at(E, 0, z, 1, x, y)], 0.5f);
+        const float fc = v0 / v1;
+        if (fc < best) best = fc, best_i = z;
+    }
+    const size_t o = (size_t)yi * D.w + xi;
+    depth[o] = best_i;
+    const int ad = best_i - g.focus;
+    br[o] = (float)(unsigned)(ad < 0 ? -ad : ad) * g.scale;
+}
+
+__global__ __launch_bounds__(256) void lb_wcy(const float *__restrict__ br, Box D, int R, int oy0, int oh, float *__restrict__ wcy) {
+    const int xi = blockIdx.x * 256 + threadIdx.x, yo = blockIdx.y;   // yo: output row
+    if (xi >= D.w) return;
+    const int y = oy0 + yo;
+    float m = -INFINITY;
+    for (int r = -R; r <= R; r++) m = fmaxf(m, br[(size_t)(y + r - D.y0) * D.w + xi]);
+    wcy[(size_t)yo * D.w + xi] = m;
+}
+
+// random_float() of the reference: src/Random.cpp:20-104 with args {id, tag, s, y, x}
+__device__ __forceinline__ uint32_t rng32(uint32_t x) { return ((1040796640u * x) + 1121052041u) * x + 576942909u; }
+__device__ __forceinline__ float rand_float(uint32_t seeded, int s, int y, int x) {   // seeded = rng32(rng32(id) + tag)
+    uint32_t r = rng32(seeded + (uint32_t)s);
+    r = rng32(r + (uint32_t)y);
+    r = rng32(r + (uint32_t)x);
+    r = r ^ (r >> 16);
+    return dev::clampf(__uint_as_float((127u << 23) | (r >> 9)) - 1.0f, 0.0f, 1.0f);
+}
+
+__global__ __launch_bounds__(256) void lb_final(const uint8_t *__restrict__ L, LBGeom g, const int *__restrict__ depth,
+                                               const float *__restrict__ br, const float *__restrict__ wcy, Box D, int ox0, int oy0,
+                                               int ow, int nc, float *__restrict__ out, long out_sy, long out_sc) {
+    const int xo = blockIdx.x * 256 + threadIdx.x, yo = blockIdx.y;
+    if (xo >= ow) return;
+    const int x = ox0 + xo, y = oy0 + yo;
+    float worst = -INFINITY;
+    for (int r = -g.R; r <= g.R; r++) worst = fmaxf(worst, wcy[(size_t)yo * D.w + (x + r - D.x0)]);
+    auto left_at = [&](int xx, int yy, int c) -> float {
+        return (float)L[(long)(dev::clampi(yy, g.ly0, g.ly1) - g.ly0) * g.l_sy + (dev::clampi(xx, g.lx0, g.lx1) - g.lx0) + g.l_c[c]];
+    };
+    float acc[4] = {left_at(x, y, 0), left_at(x, y, 1), left_at(x, y, 2), 255.0f};
+    const size_t o = (size_t)(y - D.y0) * D.w + (x - D.x0);
+    const float brs = br[o] * br[o];
+    const int dxy = depth[o];
+    const uint32_t seed_u = rng32(rng32(0u) + (uint32_t)g.tag), seed_v = rng32(rng32(1u) + (uint32_t)g.tag);
+    for (int s = 0; s < g.samples; s++) {
+        const float fu = ((rand_float(seed_u, s, y, x) - 0.5f) * 2.0f) * worst;
+        const float fv = ((rand_float(seed_v, s, y, x) - 0.5f) * 2.0f) * worst;
+        const int u = dev::clampi((int)fu, -g.R, g.R), v = dev::clampi((int)fv, -g.R, g.R);
+        const int sx = x + u, sy = y + v;
+        const size_t so = (size_t)(sy - D.y0) * D.w + (sx - D.x0);
+        const float r2 = (float)(u * u + v * v);
+        const float bs = br[so];
+        const bool take = ((r2 < brs) || (depth[so] < dxy)) && (r2 < bs * bs);
+        const float wgt = take ? 1.0f : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc[c] = acc[c] + wgt * left_at(sx, sy, c);
+        acc[3] = acc[3] + wgt * 255.0f;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        if (c < nc) out[(long)yo * out_sy + xo + (long)c * out_sc] = acc[c] / acc[3];
+    }
+}
+
+const int64_t e0 = 0, e192 = 192, e320 = 320, e3 = 3;
+const int64_t *const est_im[6] = {&e0, &e192, &e0, &e320, &e0, &e3};
+halide_scalar_value_t mk_i(int v) { halide_scalar_value_t s{}; s.u.i32 = v; return s; }
+halide_scalar_value_t mk_f(float v) { halide_scalar_value_t s{}; s.u.f32 = v; return s; }
+// defaults / ranges / estimates: generator :14-19, :158-166
+const halide_scalar_value_t s32 = mk_i(32), s13 = mk_i(13), s1 = mk_i(1), s64 = mk_i(64), fhalf = mk_f(0.5f), f0 = mk_f(0.0f), f1 = mk_f(1.0f);
+const halide_type_t ty_u8 = {(decltype(halide_type_t::code))1, 8, 0};
+const halide_type_t ty_i32 = {(decltype(halide_type_t::code))0, 32, 0};
+const halide_type_t ty_f32 = {(decltype(halide_type_t::code))2, 32, 0};
+const halide_filter_argument_t lb_args[7] = {
+    {"left_im", halide_argument_kind_input_buffer, 3, ty_u8, nullptr, nullptr, nullptr, nullptr, est_im},
+    {"right_im", halide_argument_kind_input_buffer, 3, ty_u8, nullptr, nullptr, nullptr, nullptr, est_im},
+    {"slices", halide_argument_kind_input_scalar, 0, ty_i32, &s32, &s1, &s64, &s32, nullptr},
+    {"focus_depth", halide_argument_kind_input_scalar, 0, ty_i32, &s13, &s1, &s32, &s13, nullptr},
+    {"blur_radius_scale", halide_argument_kind_input_scalar, 0, ty_f32, &fhalf, &f0, &f1, &fhalf, nullptr},
+    {"aperture_samples", halide_argument_kind_input_scalar, 0, ty_i32, &s32, &s1, &s64, &s32, nullptr},
+    {"final", halide_argument_kind_output_buffer, 3, ty_f32, nullptr, nullptr, nullptr, nullptr, est_im},
+};
+const halide_filter_metadata_t lb_md = {1, 7, lb_args, kTargetString, "lens_blur"};
+
+}  // namespace
+
+extern "C" void hlmi_lens_blur_set_random_tag(int tag) { g_rand_tag.store(tag); }
+extern "C" int hlmi_lens_blur_get_random_tag(void) { return g_rand_tag.load(); }
+
+extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, int32_t slices, int32_t focus_depth,
+                         float blur_radius_scale, int32_t aperture_samples, halide_buffer_t *final_) {
+    void *uc = nullptr;
+    BufArg args[3] = {{"left_im", left_im, T_U8, 3, false}, {"right_im", right_im, T_U8, 3, false}, {"final", final_, T_F32, 3, true}};
+    int r = check_not_null(uc, args, 3);
+    if (r) return r;
+    // scalar ranges are checked before the image checks (src/Lower.cpp:189 vs :251); generator :14-19
+    struct { const char *name; double v, lo, hi; } pr[4] = {{"slices", (double)slices, 1, 64}, {"focus_depth", (double)focus_depth, 1, 32},
+                                                            {"blur_radius_scale", (double)blur_radius_scale, 0, 1},
+                                                            {"aperture_samples", (double)aperture_samples, 1, 64}};
+    for (auto &p : pr) {
+        if (!(p.v >= p.lo)) return report(uc, halide_error_code_param_too_small, "Parameter %s is %g but must be at least %g", p.name, p.v, p.lo);
+        if (!(p.v <= p.hi)) return report(uc, halide_error_code_param_too_large, "Parameter %s is %g but must be at most %g", p.name, p.v, p.hi);
+    }
+    if ((r = check_type_and_dims(uc, args, 3))) return r;
+    if (any_bounds_query(args, 3)) {
+        // every tap of the inputs is clamped (:27-28); propose the output's x / y region and the three channels
+        int mins[3] = {final_->dim[0].min, final_->dim[1].min, 0}, ext[3] = {final_->dim[0].extent, final_->dim[1].extent, 3};
+        answer_query(left_im, mins, ext);
+        answer_query(right_im, mins, ext);
+        answer_query(final_, mins, ext);
+        return 0;
+    }
+    for (int i = 0; i < 3; i++)
+        if ((r = check_shape(uc, args[i]))) return r;
+    if ((r = check_equal(uc, "final.min.2", final_->dim[2].min, "0", 0))) return r;
+    if (final_->dim[2].extent > 3) {
+        return report(uc, halide_error_code_constraint_violated, "Output buffer final has %d channels, at most 3 are defined", final_->dim[2].extent);
+    }
+    const int ow = final_->dim[0].extent, oh = final_->dim[1].extent, nc = final_->dim[2].extent;
+    if (ow > 0 && oh > 0 && nc > 0) {
+        for (int i = 0; i < 2; i++) {
+            const halide_buffer_t *b = args[i].buf;
+            if (b->dim[0].extent < 1 || b->dim[1].extent < 1 || b->dim[2].extent < 1) {
+                return report(uc, halide_error_code_access_out_of_bounds, "Input buffer %s is empty but is accessed (clamped)", args[i].name);
+            }
+        }
+    }
+    DeviceCtx ctx;
+    if ((r = acquire_device(uc, &ctx))) return r;
+    if ((r = input_to_device(uc, ctx, args[0])) || (r = input_to_device(uc, ctx, args[1]))) return r;
+    if ((r = output_on_device(uc, ctx, args[2]))) return r;
+    if (ow == 0 || oh == 0 || nc == 0) {
+        mark_output_written(final_);
+        return 0;
+    }
+    LBGeom g;
+    auto box_of = [](const halide_buffer_t *b, int &x0, int &x1, int &y0, int &y1) {
+        x0 = b->dim[0].min, x1 = x0 + b->dim[0].extent - 1, y0 = b->dim[1].min, y1 = y0 + b->dim[1].extent - 1;
+    };
+    box_of(left_im, g.lx0, g.lx1, g.ly0, g.ly1);
+    box_of(right_im, g.rx0, g.rx1, g.ry0, g.ry1);
+    g.l_sy = left_im->dim[1].stride, g.l_sc = left_im->dim[2].stride, g.r_sy = right_im->dim[1].stride, g.r_sc = right_im->dim[2].stride;
+    for (int c = 0; c < 3; c++) {
+        auto cl = [](const halide_buffer_t *b, int c) { const int lo = b->dim[2].min, hi = lo + b->dim[2].extent - 1; return (c < lo ? lo : (c > hi ? hi : c)) - lo; };
+        g.l_c[c] = (long)cl(left_im, c) * g.l_sc, g.r_c[c] = (long)cl(right_im, c) * g.r_sc;
+    }
+    g.slices = slices, g.focus = focus_depth, g.samples = aperture_samples, g.scale = blur_radius_scale, g.fslices = (float)slices;
+    g.R = (int)((float)(slices - focus_depth > focus_depth ? slices - focus_depth : focus_depth) * blur_radius_scale);
+    g.tag = g_rand_tag.load();
+    const int ox0 = final_->dim[0].min, oy0 = final_->dim[1].min;
+
+    // ---- boxes (oracle/lens_blur_oracle.c); the pyramids' clamp extents come from left_im's extents (:57-61)
+    Box D = {ox0 - g.R, oy0 - g.R, ow + 2 * g.R, oh + 2 * g.R};
+    Box P[LV], PB[LV];
+    P[0] = D;
+    for (int i = 1; i < LV; i++) {
+        const int x0 = floor_div(P[i - 1].x0, 2) - 1, x1 = floor_div(P[i - 1].x0 + P[i - 1].w - 1, 2) + 1;
+        const int y0 = floor_div(P[i - 1].y0, 2) - 1, y1 = floor_div(P[i - 1].y0 + P[i - 1].h - 1, 2) + 1;
+        P[i] = {x0, y0, x1 - x0 + 1, y1 - y0 + 1};
+    }
+    int w = left_im->dim[0].extent, h = left_im->dim[1].extent;
+    for (int i = 1; i < LV; i++) {
+        w /= 2, h /= 2;
+        PB[i] = {0, 0, w > 1 ? w : 1, h > 1 ? h : 1};
+    }
+    {
+        int x0 = min(P[0].x0, -1), y0 = min(P[0].y0, -1);
+        int x1 = max(P[0].x0 + P[0].w - 1, 2 * PB[1].w), y1 = max(P[0].y0 + P[0].h - 1, 2 * PB[1].h);
+        PB[0] = {x0, y0, x1 - x0 + 1, y1 - y0 + 1};
+    }
+    const Box E = PB[0];
+    // ---- workspace
+    auto al = [](size_t n) { return (n + 63) & ~(size_t)63; };
+    size_t off_push[LV], off_pull[LV], total = 0;
+    for (int i = 0; i < LV; i++) off_push[i] = total, total += al((size_t)2 * slices * PB[i].w * PB[i].h);
+    for (int i = 1; i < LV; i++) off_pull[i] = total, total += al((size_t)2 * slices * P[i].w * P[i].h);
+    const size_t off_depth = total;
+    total += al((size_t)D.w * D.h);
+    const size_t off_br = total;
+    total += al((size_t)D.w * D.h);
+    const size_t off_wcy = total;
+    total += al((size_t)D.w * oh);
+    void *ws = nullptr;
+    if ((r = get_workspace(uc, ctx, total * sizeof(float), &ws))) return r;
+    float *wsf = (float *)ws;
+    float *push[LV], *pull[LV];
+    for (int i = 0; i < LV; i++) push[i] = wsf + off_push[i];
+    for (int i = 1; i < LV; i++) pull[i] = wsf + off_pull[i];
+    pull[0] = nullptr;
+    int *depth = (int *)(wsf + off_depth);
+    float *br = wsf + off_br, *wcy = wsf + off_wcy;
+
+    const uint8_t *dl = dev_ptr<uint8_t>(left_im), *dr = dev_ptr<uint8_t>(right_im);
+    hipStream_t st = ctx.stream;
+    const unsigned zc = 2u * (unsigned)slices;
+    HLMI_LAUNCH(uc, "lb_cost", st, lb_cost, dim3((E.w + 255) / 256, E.h), dim3(256), 0, dl, dr, g, E, push[0]);
+    for (int i = 1; i < LV; i++) {
+        char nm[24];
+        snprintf(nm, sizeof nm, "lb_down:%d", i);
+        if (i == 1) HLMI_LAUNCH(uc, nm, st, lb_down<false>, dim3((PB[i].w + 255) / 256, PB[i].h, zc), dim3(256), 0, push[0], PB[0], push[i], PB[i]);
+        else HLMI_LAUNCH(uc, nm, st, lb_down<true>, dim3((PB[i].w + 255) / 256, PB[i].h, zc), dim3(256), 0, push[i - 1], PB[i - 1], push[i], PB[i]);
+    }
+    for (int i = LV - 1; i >= 1; i--) {
+        char nm[24];
+        snprintf(nm, sizeof nm, "lb_pull:%d", i);
+        if (i == LV - 1) HLMI_LAUNCH(uc, nm, st, lb_pull<true>, dim3((P[i].w + 255) / 256, P[i].h, zc), dim3(256), 0, push[i], PB[i], (const float *)nullptr, P[i], pull[i], P[i]);
+        else HLMI_LAUNCH(uc, nm, st, lb_pull<false>, dim3((P[i].w + 255) / 256, P[i].h, zc), dim3(256), 0, push[i], PB[i], pull[i + 1], P[i + 1], pull[i], P[i]);
+    }
+    HLMI_LAUNCH(uc, "lb_depth", st, lb_depth, dim3((D.w + 255) / 256, D.h), dim3(256), 0, push[0], E, pull[1], P[1], g, D, depth, br);
+    HLMI_LAUNCH(uc, "lb_wcy", st, lb_wcy, dim3((D.w + 255) / 256, oh), dim3(256), 0, br, D, g.R, oy0, oh, wcy);
+    HLMI_LAUNCH(uc, "lb_final", st, lb_final, dim3((ow + 255) / 256, oh), dim3(256), 0, dl, g, depth, br, wcy, D, ox0, oy0, ow, nc,
+                dev_ptr<float>(final_), (long)final_->dim[1].stride, (long)final_->dim[2].stride);
+    mark_output_written(final_);
+    return 0;
+}
+
+extern "C" int lens_blur_argv(void **a) {
+    return lens_blur((halide_buffer_t *)a[0], (halide_buffer_t *)a[1], *(int32_t *)a[2], *(int32_t *)a[3], *(float *)a[4], *(int32_t *)a[5],
+                     (halide_buffer_t *)a[6]);
+}
+extern "C" const halide_filter_metadata_t *lens_blur_metadata(void) { return &lb_md; }
+extern "C" int lens_blur_auto_schedule(halide_buffer_t *left_im, halide_buffer_t *right_im, int32_t slices, int32_t focus_depth,
+                                       float blur_radius_scale, int32_t aperture_samples, halide_buffer_t *final_) {
+    return lens_blur(left_im, right_im, slices, focus_depth, blur_radius_scale, aperture_samples, final_);
+}

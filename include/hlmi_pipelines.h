@@ -121,6 +121,20 @@ HLMI_DECLARE_AUX(interpolate)
 int iir_blur(struct halide_buffer_t *input, float alpha, struct halide_buffer_t *output);
 HLMI_DECLARE_AUX(iir_blur)
 
+/* apps/lens_blur/lens_blur_generator.cpp:12-21,301 — u8 [W,H,3] planar stereo pair in, f32 [W,H,3] out: depth from
+ * stereo (cost volume of `slices` disparities, confidence-weighted 8-level push-pull), depth-dependent bokeh from
+ * `aperture_samples` pseudo-random samples per pixel.  Adjacent app, same boundary.  The sample
+ * positions are Halide's random_float(): a fixed hash whose "definition tag" is a counter of the reference's COMPILER that
+ * cannot be observed without it — see hlmi_lens_blur_set_random_tag below and oracle/lens_blur_oracle.c. */
+int lens_blur(struct halide_buffer_t *left_im, struct halide_buffer_t *right_im, int32_t slices, int32_t focus_depth,
+              float blur_radius_scale, int32_t aperture_samples, struct halide_buffer_t *final);
+HLMI_DECLARE_AUX(lens_blur)
+/* The tag the random_float() calls of lens_blur's sample_locations were lowered with (src/Function.cpp:640-648: the number
+ * of pure Func definitions the generator process made before it).  Default 71 = the count derived in
+ * oracle/lens_blur_oracle.c; a maintainer who can run the reference's compiler sets the observed value. */
+void hlmi_lens_blur_set_random_tag(int tag);
+int hlmi_lens_blur_get_random_tag(void);
+
 /* apps/camera_pipe/camera_pipe_generator.cpp:219-228,622 — raw u16 Bayer -> u8 [W,H,3]. */
 int camera_pipe(struct halide_buffer_t *input, struct halide_buffer_t *matrix_3200,
                 struct halide_buffer_t *matrix_7000, float color_temp, float gamma, float contrast,
@@ -148,6 +162,9 @@ int hist_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *ou
 int harris_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);
 int interpolate_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *output);
 int iir_blur_auto_schedule(struct halide_buffer_t *input, float alpha, struct halide_buffer_t *output);
+int lens_blur_auto_schedule(struct halide_buffer_t *left_im, struct halide_buffer_t *right_im, int32_t slices,
+                            int32_t focus_depth, float blur_radius_scale, int32_t aperture_samples,
+                            struct halide_buffer_t *final);
 int camera_pipe_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *matrix_3200,
                               struct halide_buffer_t *matrix_7000, float color_temp, float gamma, float contrast,
                               float sharpen_strength, int32_t blackLevel, int32_t whiteLevel,

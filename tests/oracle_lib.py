@@ -352,3 +352,36 @@ def camera_pipe_setup(m3200, m7000, color_temp, gamma, contrast, sharpen, black,
     _lib.oracle_camera_pipe_setup(np.ascontiguousarray(m3200, np.float32), np.ascontiguousarray(m7000, np.float32), color_temp,
                                   gamma, contrast, sharpen, black, white, matrix, curve, s)
     return matrix.reshape(3, 4), curve, int(s[0])
+
+
+# ---- lens_blur
+_lib.oracle_lens_blur.argtypes = [_u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _f32p,
+                                  C.c_void_p]
+_lib.oracle_lens_blur.restype = C.c_int
+_lib.oracle_lens_blur_random.argtypes = [C.c_int] * 5
+_lib.oracle_lens_blur_random.restype = C.c_float
+_lib.oracle_lens_blur_default_tag.restype = C.c_int
+
+
+def lens_blur_default_tag() -> int:
+    return _lib.oracle_lens_blur_default_tag()
+
+
+def lens_blur_random(call_id, tag, s, y, x) -> float:
+    return float(_lib.oracle_lens_blur_random(call_id, tag, s, y, x))
+
+
+def lens_blur(left: np.ndarray, right: np.ndarray, slices=32, focus_depth=13, blur_radius_scale=0.5, aperture_samples=32, tag=None,
+              return_depth=False):
+    """left / right: u8 (3, H, W) planar -> f32 (3, H, W); optionally also depth on the image grown by R on every side."""
+    left, right = np.ascontiguousarray(left, np.uint8), np.ascontiguousarray(right, np.uint8)
+    _, h, w = left.shape
+    _, rh, rw = right.shape
+    out = np.zeros((3, h, w), np.float32)
+    md = max(slices - focus_depth, focus_depth)
+    R = int(np.float32(md) * np.float32(blur_radius_scale))
+    depth = np.zeros((h + 2 * R, w + 2 * R), np.int32)
+    t = lens_blur_default_tag() if tag is None else tag
+    assert _lib.oracle_lens_blur(left, w, h, right, rw, rh, slices, focus_depth, blur_radius_scale, aperture_samples, t, out,
+                                 depth.ctypes.data) == 0
+    return (out, depth) if return_depth else out

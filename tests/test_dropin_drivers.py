@@ -216,6 +216,24 @@ def test_interpolate_filter_cpp(tmp_path, oracle):
 
 
 @pytest.mark.gpu
+def test_lens_blur_process_cpp(tmp_path, oracle):
+    """apps/lens_blur/process.cpp:16-58: the same image as left and right view (process.cpp:26-27), result saved as .mat
+    (exact float32): must be the oracle's bit for bit (with the random tag both sides default to)."""
+    import scipy.io
+    exe = _exe("lens_blur_process")
+    img8 = _scene8(160, 100, 21, 3)
+    src, dst = str(tmp_path / "in.ppm"), str(tmp_path / "result.mat")
+    write_ppm8(src, img8)
+    r = subprocess.run([exe, src, "32", "13", "0.5", "32", "2", dst], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Success!" in r.stdout, r.stdout + r.stderr
+    saved = scipy.io.loadmat(dst)
+    (name,) = [k for k in saved if not k.startswith("__")]
+    got = np.ascontiguousarray(saved[name].transpose(2, 1, 0))
+    want = oracle.lens_blur(img8, img8, 32, 13, 0.5, 32)
+    assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
 def test_iir_blur_filter_cpp(tmp_path):
     exe = _exe("iir_blur_filter")
     img8 = _scene8(192, 130, 9, 3)

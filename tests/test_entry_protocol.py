@@ -38,8 +38,10 @@ SPEC = {
     "interpolate": dict(out=(64, 48, 3), scalars=[]),
     "iir_blur": dict(out=(64, 48, 3), scalars=[0.5]),
     "camera_pipe": dict(out=(64, 32, 3), scalars=[3700.0, 2.0, 50.0, 1.0, 25, 1023]),
+    "lens_blur": dict(out=(48, 40, 3), scalars=[32, 13, 0.5, 32]),
 }
 PIPELINES = sorted(SPEC)
+PRIMARY = {"lens_blur": "left_im"}   # the image input the generic cases perturb ("input" everywhere else)
 # pipelines whose generator pins mins / extents / strides of its buffers (conv_layer_generator.cpp:35-50,
 # nl_means_generator.cpp:68, …): a malformed shape trips a constraint (-8) before the generic shape checks
 PINNED = {"conv_layer", "conv_layer_bf16"}
@@ -50,7 +52,7 @@ TIED = PINNED | {"iir_blur", "interpolate"}
 # pipelines that read their input ONLY through repeat_edge (stencil_chain_generator.cpp:20, nl_means_generator.cpp:28,
 # max_filter_generator.cpp:22): bounds inference clamps the required region to whatever was passed, so no input
 # is ever too small
-CLAMPED = {"stencil_chain", "nl_means", "max_filter"}
+CLAMPED = {"stencil_chain", "nl_means", "max_filter", "lens_blur"}   # lens_blur_generator.cpp:27-28
 
 
 def _np_type(t):
@@ -181,7 +183,7 @@ def test_input_too_small_is_out_of_bounds(calls, name):
     """error_codes_aottest.cpp:49-57.  Only for the buffer named `input`: the filters / matrices of a pipeline have
     pinned extents (a constraint, -8)."""
     c = calls(name)
-    i = c.names.index("input")
+    i = c.names.index(PRIMARY.get(name, "input"))
     c.buf(i).dim(0).extent -= 1
     if name in TIED:
         assert c.code() == -8 and "Constraint violated" in c.hl.last_error()
@@ -206,7 +208,7 @@ def test_negative_extent(calls, name):
 def test_too_large(calls, name):
     """error_codes_aottest.cpp:73-92: a product of extents beyond 2^31-1 (-6) and |extent * stride| beyond it (-5)."""
     c = calls(name)
-    i = c.names.index("input")
+    i = c.names.index(PRIMARY.get(name, "input"))
     b = c.buf(i)
     keep = [(b.dim(d).min, b.dim(d).extent, b.dim(d).stride) for d in range(2)]
     b.dim(0).min, b.dim(1).min = min(keep[0][0], 0), min(keep[1][0], 0)

@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported(hl):
 
 def test_metadata_of_every_pipeline(hl):
     expect = {"local_laplacian": 5, "bilateral_grid": 3, "halide_blur": 2, "nl_means": 5, "stencil_chain": 2,
-              "conv_layer": 4, "conv_layer_bf16": 4, "depthwise_separable_conv": 5, "unsharp": 2, "max_filter": 2, "hist": 2, "harris": 2, "interpolate": 2, "iir_blur": 3, "camera_pipe": 10}
+              "conv_layer": 4, "conv_layer_bf16": 4, "depthwise_separable_conv": 5, "unsharp": 2, "max_filter": 2, "hist": 2, "harris": 2, "interpolate": 2, "iir_blur": 3, "camera_pipe": 10, "lens_blur": 7}
     for name, n in expect.items():
         md = hl.metadata(name)
         assert md.version == 1 and md.num_arguments == n and md.name.decode() == name
