@@ -35,7 +35,7 @@ constexpr int BWP = 65;                          // blur_d_y tile: TW + 6 = 64 c
 // phase 2 (SEG).  TH = 64 (1024 threads, 81 KB: one workgroup per CU) leaves a third of the chip idle at 1920 x 1080 —
 // 578 tiles on 256 CUs run as three rounds of ~95 us (scripts/nlm_scale.py) — TH = 16 (256 threads, 28 KB, five
 // workgroups per CU that interleave their phases) has 2312 tiles that back-fill the CUs as they finish.
-constexpr size_t lds_bytes(int th) { return sizeof(float) * ((size_t)3 * (th + 4 * HALF) * IWP + (size_t)th * BWP + 4); }  // + 4: phase 2 reads whole SEG + 6 windows
+constexpr size_t lds_bytes(int th) { return sizeof(float) * ((size_t)3 * (th + 4 * HALF) * IWP + (size_t)2 * th * BWP + 4); }  // + 4: phase 2 reads whole SEG + 6 windows
 
 struct NGeom {
     int ix0, ix1, iy0, iy1, ic0, ic1;  // clamp box of the input (absolute)
@@ -55,7 +55,8 @@ __global__ __launch_bounds__(NT) void nlm_7x7(const float *__restrict__ in, long
     static_assert(TH % GROUPS == 0 && NSEG * SEG >= TW, "tile shape");
     extern __shared__ float lds[];
     float *sin = lds;                       // [3][IH][IWP]
-    float *sbdy = lds + 3 * IH * IWP;       // [TH][BWP]
+    float *sbdy0 = lds + 3 * IH * IWP;      // [2][TH][BWP]: blur_d_y of even / odd offsets — one barrier per offset instead of two
+                                            // (phase 1 of offset k+1 writes the buffer whose last readers finished before barrier k)
     const int tid = threadIdx.x;
     const int tx0 = g.ox0 + blockIdx.x * TW, ty0 = g.oy0 + blockIdx.y * TH;  // absolute coords of the tile
 
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(NT) void nlm_7x7(const float *__restrict__ in, long
     }
     const float *unshifted = sin + row0 * IWP + col;
 
-    const float *brow = sbdy + r2 * BWP + xb;
+    int parity = 0;
 #pragma unroll 1
     for (int dy = -HALF; dy <= HALF; dy++) {
         const float *shifted = sin + (row0 + dy) * IWP + col;
@@ -106,6 +107,9 @@ __global__ __launch_bounds__(NT) void nlm_7x7(const float *__restrict__ in, long
 #pragma unroll
         for (int dxi = 0; dxi < SA; dxi++) {
             const int dx = dxi - HALF;
+            float *sbdy = sbdy0 + parity * (TH * BWP);
+            const float *brow = sbdy + r2 * BWP + xb;
+            parity ^= 1;
             // ---- phase 1: d -> blur_d_y.  All reads first, then the arithmetic row-parallel: a wave that reads three
             // values and waits for them ten times over exposes the LDS latency ten times.
             {
@@ -163,7 +167,6 @@ __global__ __launch_bounds__(NT) void nlm_7x7(const float *__restrict__ in, long
                     }
                 }
             }
-            __syncthreads();
         }
     }
     // ---- normalise + store
@@ -281,9 +284,9 @@ extern "C" int nl_means(halide_buffer_t *input, int32_t patch_size, int32_t sear
     const long in_sy = input->dim[1].stride, in_sc = input->dim[2].stride;
     const long out_sy = output->dim[1].stride, out_sc = output->dim[2].stride;
     if (patch_size == P && search_area == SA) {
-        // tile height: 16 by default (see NT above); HLMI_NLM_TH = 32 / 64 / 80 select the larger workgroups (A/B)
+        // tile height: 32 by default (512 threads, two or three workgroups per CU; see NT above); HLMI_NLM_TH = 16 / 64 / 80 for A/B
         const char *e = getenv("HLMI_NLM_TH");
-        const int th = e ? atoi(e) : 16;
+        const int th = e ? atoi(e) : 32;
 #define NLM_LAUNCH(TH_, NT_)                                                                                                  \
     do {                                                                                                                      \
         HLMI_HIP(uc, hipFuncSetAttribute((const void *)nlm_7x7<TH_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize,           \
@@ -294,8 +297,8 @@ extern "C" int nl_means(halide_buffer_t *input, int32_t patch_size, int32_t sear
     } while (0)
         if (th == 80) NLM_LAUNCH(80, 1024);
         else if (th == 64) NLM_LAUNCH(64, 1024);
-        else if (th == 32) NLM_LAUNCH(32, 512);
-        else NLM_LAUNCH(16, 256);
+        else if (th == 16) NLM_LAUNCH(16, 256);
+        else NLM_LAUNCH(32, 512);
 #undef NLM_LAUNCH
     } else {
         HLMI_LAUNCH(uc, "nlm_generic", ctx.stream, nlm_generic, dim3((ow + 255) / 256, oh), dim3(256), 0, din, in_sy, in_sc, g,
