@@ -17,6 +17,8 @@
 // each pixel from LDS (thread <-> (pixel, output channel)), with both filters staged in LDS once per workgroup.
 #include "hlmi_internal.h"
 
+#include <stdlib.h>
+
 using namespace hlmi;
 
 namespace {
@@ -77,6 +79,85 @@ __global__ __launch_bounds__(256) void dsc_fused(const float *__restrict__ in, c
         const float *m = s_mid + px * g.IC;
         for (int rc = 0; rc < g.IC; rc++) acc = __builtin_fmaf(s_pw[rc * g.CO + c], m[rc], acc);
         out[(long)n * g.out_sn + (long)y * g.out_sy + (long)(x0 + px) * g.out_sx + c] = acc > 0.0f ? acc : 0.0f;
+    }
+}
+
+// ---- dsc_fused_t: the same two phases with the filter shape, IC, CO compile-time (channel multiplier 1) and a wider tile.
+// The generic kernel spends its time in run-time index arithmetic (five div / mod per staged filter element, per tap
+// address chains) and in two LATENCY-bound fma chains per thread; here every index folds, a thread owns TPX IC / 256
+// depthwise values and TPX CO / 256 outputs and walks their fma chains interleaved (independent accumulators), so that the
+// dependent-issue latency of one chain hides behind the others.  Same operations in the same order: bit-identical.
+template<int FW, int FH, int IC, int CO, int TPX>
+__global__ __launch_bounds__(256) void dsc_fused_t(const float *__restrict__ in, const float *__restrict__ dw, const float *__restrict__ pw,
+                                                  const float *__restrict__ bias, float *__restrict__ out, DGeom g) {
+    __shared__ float s_mid[TPX * IC], s_dw[FH * FW * IC], s_pw[IC * CO];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TPX, y = blockIdx.y, n = blockIdx.z;
+    for (int i = tid; i < FH * FW * IC; i += 256) {
+        const int d = i % IC, rx = (i / IC) % FW, ry = i / (IC * FW);
+        s_dw[i] = dw[d * g.d_s1 + rx * g.d_sx + ry * g.d_sy];
+    }
+    for (int i = tid; i < IC * CO; i += 256) s_pw[i] = pw[(i % CO) + (long)(i / CO) * g.p_s1];
+    __syncthreads();
+    constexpr int padw = FW / 2, padh = FH / 2;
+    const int Y = g.oy0 + y;
+    // ---- phase 1: thread <-> (pixels px0 + k * (256 / IC), channel d)
+    constexpr int PPT = 256 / IC, N1 = (TPX + PPT - 1) / PPT;   // pixels per pass, passes
+    {
+        const int d = tid % IC, pxo = tid / IC;
+        float acc[N1];
+#pragma unroll
+        for (int k = 0; k < N1; k++) acc[k] = 0.0f;
+#pragma unroll
+        for (int ry = 0; ry < FH; ry++) {
+            const int yy = Y + ry - padh;
+            const bool yin = yy >= 0 && yy < g.H;
+            const float *rowp = in + (long)n * g.in_sn + (long)(min(max(yy, 0), g.iy0 + g.H - 1) - g.iy0) * g.in_sy + d;
+#pragma unroll
+            for (int rx = 0; rx < FW; rx++) {
+                const float f = s_dw[(ry * FW + rx) * IC + d];
+#pragma unroll
+                for (int k = 0; k < N1; k++) {
+                    const int px = pxo + k * PPT;
+                    const int xx = g.ox0 + x0 + px + rx - padw;
+                    const bool inb = yin && xx >= 0 && xx < g.W;                      // (:36-43): zero padding by the EXTENTS
+                    const int cx = min(max(xx, 0), g.ix0 + g.W - 1) - g.ix0;           // the read itself is clamped
+                    const float v = inb ? rowp[(long)cx * g.in_sx] : 0.0f;
+                    if (px < TPX && x0 + px < g.ow) acc[k] = __builtin_fmaf(f, v, acc[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < N1; k++) {
+            const int px = pxo + k * PPT;
+            if (px < TPX) s_mid[px * IC + d] = acc[k];
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: thread <-> (pixels pxo + k * (256 / CO), output channel c)
+    constexpr int QPT = 256 / CO, N2 = (TPX + QPT - 1) / QPT;
+    {
+        const int c = tid % CO, pxo = tid / CO;
+        float acc[N2];
+        const float b = bias[c];
+#pragma unroll
+        for (int k = 0; k < N2; k++) acc[k] = b;
+#pragma unroll 8
+        for (int rc = 0; rc < IC; rc++) {
+            const float w = s_pw[rc * CO + c];
+#pragma unroll
+            for (int k = 0; k < N2; k++) {
+                const int px = min(pxo + k * QPT, TPX - 1);
+                acc[k] = __builtin_fmaf(w, s_mid[px * IC + rc], acc[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < N2; k++) {
+            const int px = pxo + k * QPT;
+            if (px < TPX && x0 + px < g.ow) {
+                out[(long)n * g.out_sn + (long)y * g.out_sy + (long)(x0 + px) * g.out_sx + c] = acc[k] > 0.0f ? acc[k] : 0.0f;
+            }
+        }
     }
 }
 
@@ -181,9 +262,15 @@ extern "C" int depthwise_separable_conv(halide_buffer_t *input, halide_buffer_t 
         const float *d_pw = dev_ptr<float>(pointwise_filter) + (long)(output->dim[0].min - pointwise_filter->dim[0].min) +
                             (long)(0 - pointwise_filter->dim[1].min) * g.p_s1;
         const float *d_b = dev_ptr<float>(bias) + (long)(output->dim[0].min - bias->dim[0].min);
-        dim3 grid((g.ow + TP - 1) / TP, g.oh, g.N);
         timing_note_bytes(4.0 * ((double)g.CI * g.W * g.H * g.N + (double)g.CO * g.ow * g.oh * g.N));
-        HLMI_LAUNCH(uc, "dsc_fused", ctx.stream, dsc_fused, grid, dim3(256), sh, d_in, d_dw, d_pw, d_b, dev_ptr<float>(output), g);
+        if (g.FW == 3 && g.FH == 3 && g.IC == 32 && g.CO == 16 && g.CM == 1 && !getenv("HLMI_DSC_GENERIC")) {
+            constexpr int TPX = 56;   // the driver's MobileNet-v2 layer (process.cpp:13): two tiles per 112-pixel row
+            HLMI_LAUNCH(uc, "dsc_fused", ctx.stream, (dsc_fused_t<3, 3, 32, 16, TPX>), dim3((g.ow + TPX - 1) / TPX, g.oh, g.N), dim3(256), 0,
+                        d_in, d_dw, d_pw, d_b, dev_ptr<float>(output), g);
+        } else {
+            dim3 grid((g.ow + TP - 1) / TP, g.oh, g.N);
+            HLMI_LAUNCH(uc, "dsc_fused", ctx.stream, dsc_fused, grid, dim3(256), sh, d_in, d_dw, d_pw, d_b, dev_ptr<float>(output), g);
+        }
     }
     mark_output_written(output);
     return 0;
