@@ -53,21 +53,6 @@ __global__ __launch_bounds__(256) void hist_count(const uint8_t *__restrict__ in
     if (s) atomicAdd(&ghist[tid], s);
 }
 
-// one wave: cdf[b] = hist[0] + .. + hist[b]; lane l owns bins 4l .. 4l+3
-__global__ __launch_bounds__(64) void hist_cdf(const unsigned *__restrict__ ghist, int *__restrict__ cdf) {
-    const int lane = threadIdx.x;
-    const uint4 h = reinterpret_cast<const uint4 *>(ghist)[lane];
-    const unsigned s0 = h.x, s1 = s0 + h.y, s2 = s1 + h.z, s3 = s2 + h.w;
-    unsigned run = s3;                       // inclusive scan of the lane totals across the wave
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned up = __shfl_up(run, d, 64);
-        if (lane >= d) run += up;
-    }
-    const unsigned base = run - s3;
-    reinterpret_cast<int4 *>(cdf)[lane] = make_int4((int)(base + s0), (int)(base + s1), (int)(base + s2), (int)(base + s3));
-}
-
 struct HGeom {
     int ox0, oy0, ow, oh;
     long in_sy, in_sc, out_sy, out_sc;
@@ -75,10 +60,27 @@ struct HGeom {
 };
 
 template<bool VEC>
-__global__ __launch_bounds__(256) void hist_apply(const uint8_t *__restrict__ in, const int *__restrict__ cdf,
+__global__ __launch_bounds__(256) void hist_apply(const uint8_t *__restrict__ in, const unsigned *__restrict__ ghist,
                                                  uint8_t *__restrict__ out, HGeom g) {
+    // the cdf is a 256-term integer prefix sum of the histogram (exact, order-free): every workgroup forms it itself from
+    // the 1 KB histogram (L2-resident) instead of waiting for a one-workgroup hist_cdf launch in between
     __shared__ int s_cdf[256];
-    s_cdf[threadIdx.x] = cdf[threadIdx.x];
+    __shared__ unsigned s_wsum[4];
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        unsigned run = ghist[threadIdx.x];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned up = __shfl_up(run, d, 64);
+            if (lane >= d) run += up;
+        }
+        if (lane == 63) s_wsum[wv] = run;
+        __syncthreads();
+        unsigned base = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) base += (k < wv) ? s_wsum[k] : 0u;
+        s_cdf[threadIdx.x] = (int)(base + run);
+    }
     __syncthreads();
     const int y = blockIdx.y;
     const uint8_t *r0 = in + (long)(g.oy0 + y) * g.in_sy + g.ox0, *r1 = r0 + g.in_sc, *r2 = r0 + 2 * g.in_sc;
@@ -159,7 +161,6 @@ extern "C" int hist(halide_buffer_t *input, halide_buffer_t *output) {
         void *ws = nullptr;
         if ((r = get_workspace(uc, ctx, 2 * 256 * sizeof(int), &ws))) return r;
         unsigned *ghist = (unsigned *)ws;
-        int *cdf = (int *)ws + 256;
         hipStream_t st = ctx.stream;
         const long in_sy = input->dim[1].stride, in_sc = input->dim[2].stride;
         // element (0, 0, 0) of the input
@@ -171,7 +172,6 @@ extern "C" int hist(halide_buffer_t *input, halide_buffer_t *output) {
         timing_note_bytes(3.0 * W * H);
         if (vec_in && W % 4 == 0) HLMI_LAUNCH(uc, "hist_count", st, hist_count<true>, dim3(nblk), dim3(256), 0, din, in_sy, in_sc, W, H, rpb, ghist);
         else HLMI_LAUNCH(uc, "hist_count", st, hist_count<false>, dim3(nblk), dim3(256), 0, din, in_sy, in_sc, W, H, rpb, ghist);
-        HLMI_LAUNCH(uc, "hist_cdf", st, hist_cdf, dim3(1), dim3(64), 0, ghist, cdf);
         HGeom g;
         g.ox0 = output->dim[0].min, g.oy0 = output->dim[1].min, g.ow = ow, g.oh = oh;
         g.in_sy = in_sy, g.in_sc = in_sc, g.out_sy = output->dim[1].stride, g.out_sc = output->dim[2].stride;
@@ -179,8 +179,8 @@ extern "C" int hist(halide_buffer_t *input, halide_buffer_t *output) {
         uint8_t *dout = dev_ptr<uint8_t>(output);
         const bool vec = vec_in && g.ox0 % 4 == 0 && ow % 4 == 0 && (uintptr_t)dout % 4 == 0 && g.out_sy % 4 == 0 && g.out_sc % 4 == 0;
         timing_note_bytes(6.0 * ow * oh);
-        if (vec) HLMI_LAUNCH(uc, "hist_apply", st, hist_apply<true>, dim3((ow / 4 + 255) / 256, oh), dim3(256), 0, din, cdf, dout, g);
-        else HLMI_LAUNCH(uc, "hist_apply", st, hist_apply<false>, dim3((ow + 255) / 256, oh), dim3(256), 0, din, cdf, dout, g);
+        if (vec) HLMI_LAUNCH(uc, "hist_apply", st, hist_apply<true>, dim3((ow / 4 + 255) / 256, oh), dim3(256), 0, din, ghist, dout, g);
+        else HLMI_LAUNCH(uc, "hist_apply", st, hist_apply<false>, dim3((ow + 255) / 256, oh), dim3(256), 0, din, ghist, dout, g);
     }
     mark_output_written(output);
     return 0;
