@@ -22,6 +22,10 @@ RUNGEN_PIPELINES := local_laplacian bilateral_grid halide_blur nl_means stencil_
 TARGETS += $(patsubst %,$(OUTDIR)/%.rungen,$(RUNGEN_PIPELINES))
 # own test programs that need the reference's headers (tests/cpp/*.cpp; sources are ours, headers the reference's)
 TARGETS += $(OUTDIR)/entry_protocol_ref $(OUTDIR)/device_interface_test
+# the PNG path of tools/halide_image_io.h: two drivers built WITHOUT -DHALIDE_NO_PNG against tests/cpp/png_shim/png.h (the libpng
+# calls the reference makes, over zlib)
+PNGFLAGS := $(filter-out -DHALIDE_NO_PNG,$(CXXFLAGS)) -I$(ROOT)/tests/cpp/png_shim
+TARGETS += $(OUTDIR)/interpolate_filter_png $(OUTDIR)/local_laplacian_process_png
 
 all: $(TARGETS)
 
@@ -67,6 +71,10 @@ $(OUTDIR)/iir_blur_filter: $(REF)/apps/iir_blur/filter.cpp $(LIBDIR)/libhlmi.so
 	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)
 $(OUTDIR)/lens_blur_process: $(REF)/apps/lens_blur/process.cpp $(LIBDIR)/libhlmi.so
 	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)
+$(OUTDIR)/interpolate_filter_png: $(REF)/apps/interpolate/filter.cpp $(ROOT)/tests/cpp/png_shim/png.h $(LIBDIR)/libhlmi.so
+	$(CXX) $(PNGFLAGS) $< -o $@ $(LDFLAGS) -lz
+$(OUTDIR)/local_laplacian_process_png: $(REF)/apps/local_laplacian/process.cpp $(ROOT)/tests/cpp/png_shim/png.h $(LIBDIR)/libhlmi.so
+	$(CXX) $(PNGFLAGS) $< -o $@ $(LDFLAGS) -lz
 # RGBA input: without libpng the driver is fed the reference's own 4-dimensional ".tmp" format (tools/halide_image_io.h:1630-1720)
 $(OUTDIR)/interpolate_filter: $(REF)/apps/interpolate/filter.cpp $(LIBDIR)/libhlmi.so
 	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)

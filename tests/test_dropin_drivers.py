@@ -233,6 +233,101 @@ def test_lens_blur_process_cpp(tmp_path, oracle):
     assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+# ---- the PNG path of tools/halide_image_io.h (load_png :856-940, save_png :952-1040), libpng calls over zlib (tests/cpp/png_shim)
+def write_png(path, img, bit_depth=8):
+    """img: (C, H, W) integer array, C in 1..4.  Scanline filters cycle through all five types (clause 9 of the PNG spec)."""
+    import struct
+    import zlib
+    c, h, w = img.shape
+    bps = bit_depth // 8
+    rows = np.ascontiguousarray(img.transpose(1, 2, 0)).astype(">u2" if bps == 2 else np.uint8).reshape(h, -1).view(np.uint8)
+    bpp, raw, prev = c * bps, bytearray(), np.zeros(rows.shape[1], np.int32)
+    for y in range(h):
+        cur = rows[y].astype(np.int32)
+        left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+        upleft = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+        ft = y % 5
+        if ft == 0:
+            pred = np.zeros_like(cur)
+        elif ft == 1:
+            pred = left
+        elif ft == 2:
+            pred = prev
+        elif ft == 3:
+            pred = (left + prev) >> 1
+        else:
+            pp = left + prev - upleft
+            pa, pb, pc = np.abs(pp - left), np.abs(pp - prev), np.abs(pp - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+        raw.append(ft)
+        raw += bytes(((cur - pred) & 255).astype(np.uint8))
+        prev = cur
+
+    def chunk(t, b):
+        return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b))
+    color = {1: 0, 2: 4, 3: 2, 4: 6}[c]
+    z = zlib.compress(bytes(raw), 6)
+    with open(path, "wb") as f:   # two IDAT chunks: the reader must concatenate them
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, bit_depth, color, 0, 0, 0)) +
+                chunk(b"IDAT", z[:len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:]) + chunk(b"IEND", b""))
+
+
+def read_png(path):
+    """-> (C, H, W) uint8 / uint16."""
+    import struct
+    import zlib
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, z = 8, b""
+    while pos < len(data):
+        n, t = struct.unpack(">I", data[pos:pos + 4])[0], data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + n]
+        assert zlib.crc32(t + body) == struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0]
+        if t == b"IHDR":
+            w, h, depth, color = struct.unpack(">IIBB", body[:10])
+        elif t == b"IDAT":
+            z += body
+        pos += 12 + n
+    c, bps = {0: 1, 4: 2, 2: 3, 6: 4}[color], depth // 8
+    raw = np.frombuffer(zlib.decompress(z), np.uint8).reshape(h, 1 + w * c * bps)
+    assert not raw[:, 0].any()       # the shim writes filter type 0
+    px = raw[:, 1:].copy().view(">u2" if bps == 2 else np.uint8).reshape(h, w, c)
+    return px.transpose(2, 0, 1).astype(np.uint16 if bps == 2 else np.uint8)
+
+
+@pytest.mark.gpu
+def test_local_laplacian_process_cpp_through_png(tmp_path, oracle):
+    """The reference's driver built WITHOUT -DHALIDE_NO_PNG: 8-bit RGB PNG in (all five scanline filters, split IDAT), 16-bit
+    PNG out (process.cpp:22, :50), through the reference's own load_png / save_png."""
+    exe = _exe("local_laplacian_process_png")
+    img8 = _scene8(200, 120, 31, 3)
+    src, dst = str(tmp_path / "in.png"), str(tmp_path / "out.png")
+    write_png(src, img8)
+    r = subprocess.run([exe, src, "8", "1", "1", "2", dst], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Success!" in r.stdout, r.stdout + r.stderr
+    got = read_png(dst)
+    want = oracle.local_laplacian(img8.astype(np.uint16) * 0x0101, 8, float(np.float32(1.0) / np.float32(7)), 1.0)
+    assert got.dtype == np.uint16 and np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_interpolate_filter_cpp_through_png(tmp_path, oracle):
+    """apps/interpolate/filter.cpp with the RGBA PNG it was written for (16-bit here), result saved as PNG."""
+    exe = _exe("interpolate_filter_png")
+    rng = np.random.default_rng(13)
+    rgba = rng.integers(0, 65536, (4, 72, 100)).astype(np.uint16)
+    rgba[3][rng.random((72, 100)) < 0.6] = 0
+    src, dst = str(tmp_path / "rgba.png"), str(tmp_path / "out.png")
+    write_png(src, rgba, 16)
+    r = subprocess.run([exe, src, dst], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Success!" in r.stdout, r.stdout + r.stderr
+    got = read_png(dst)
+    inp = (rgba.astype(np.float32) / np.float32(65535))          # load_and_convert_image: u16 -> float (halide_image_io.h:186-189)
+    want = oracle.interpolate(inp)
+    maxval = 65535 if got.dtype == np.uint16 else 255
+    assert np.array_equal(got, _quantise(want, maxval).astype(got.dtype))
+
+
 @pytest.mark.gpu
 def test_iir_blur_filter_cpp(tmp_path):
     exe = _exe("iir_blur_filter")
