@@ -8,8 +8,13 @@
 // recurrence — a dependent multiply + add per row, ~16 cycles.  With a single wave doing everything (the first version:
 // 0.74 ms) each step also paid its share of a ~1 us HBM round trip, because one wave cannot keep more than 63 vector-memory
 // operations in flight.  So the memory traffic moves to eight helper waves and the scanner only ever touches LDS:
-//   tile p = 64 rows x 64 columns, three LDS slots in rotation:  slot (p+1)%3 is being filled with tile p+1 (its rows were
-//   requested three iterations earlier and waited for in registers), slot p%3 is scanned in place, slot (p-1)%3 is written out
+//   tile p = 64 rows x 64 columns, four LDS slots in rotation:  slot (p+2)%4 is being filled with tile p+2 (its rows were
+//   requested four iterations earlier and waited for in registers), slot (p+1)%4 is complete and is READ by the scanner while
+//   it scans slot p%4 in place — the reads ride in the issue slots the dependent multiply-add chain leaves empty
+//   (reading a tile's 64 values BEFORE its chain, as round 1 did, cost as much again per tile) — and slot (p-1)%4 is
+//   written out.  The steady-state scanner loop is now nothing but the chain: 128 dependent VALU operations and 32 LDS
+//   instructions per tile, 7.8 ns per row against the 7.4 ns two dependent operations cost a lone wave
+//   (scripts/ubench/valu_dep.hip).  Floor of this decomposition: 2 directions x (2560 + 1536) rows x 7.4 ns = 61 us.
 //   forward   b = (1-a) b + a in(x, y), top to bottom; tiles go to a scratch plane as 64-float rows
 //   backward  b = (1-a) b + a scratch(x, y), bottom to top; tiles are written out TRANSPOSED (the generator transposes
 //             after each column blur, :31): lane = y, 64 consecutive floats per store
@@ -22,15 +27,35 @@ using namespace hlmi;
 
 namespace {
 
-constexpr int TR = 64, TP = 65;          // tile rows, LDS pitch (odd: the transposed reads are conflict-free)
-constexpr int NHELP = 8, HR = TR / NHELP; // helper waves and the tile rows each of them moves
+#ifndef HLMI_IIR_PROBE
+#define HLMI_IIR_PROBE 0
+#endif
+#if HLMI_IIR_PROBE
+__device__ unsigned long long g_iprobe[16];
+#define IP_T(v) const unsigned long long v = wall_clock64()
+#define IP_ACC(a, d) a += (d)
+#else
+#define IP_T(v)
+#define IP_ACC(a, d)
+#endif
+constexpr int TR = 64;                    // tile rows
+// LDS tile layout: groups of 4 rows, a lane's 4 values of a group contiguous (one ds_*_b128), groups 260 floats apart:
+//   at(r, l) = (r / 4) * TG + 4 l + (r % 4).  The scanner — the critical path: it may have only 15 LDS operations in
+// flight (lgkmcnt), and with one dword per row it spent more time waiting on that counter than on the recurrence — moves
+// a group per instruction (32 LDS instructions per tile instead of 128); the transposed reads of the backward pass
+// (lane = row, fixed column) fall on bank (4 j + lane) mod 32: conflict-free because TG = 4 (mod 32).
+constexpr int TG = 260, TSZ = (TR / 4) * TG;
+__device__ __forceinline__ int at(int r, int l) { return (r >> 2) * TG + 4 * l + (r & 3); }
+constexpr int NHELP = 8, NLOAD = 4, LR = TR / NLOAD, SR = TR / (NHELP - NLOAD);   // helper waves: loaders / storers and the tile rows each moves
 constexpr int NSET = 4;                   // tiles a helper has requested and not yet put into LDS (+1 being filled)
+constexpr int SLOTS = 4;                  // LDS tile slots
 
 // src: [C][Hd][Wd] (row stride s_sy, plane stride s_sc); scratch: same shape, dense; dst: [C][Wd][Hd] (d_sy, d_sc)
 __global__ __launch_bounds__(64 * (1 + NHELP)) void iir_cols_T(const float *__restrict__ src, long s_sy, long s_sc, int Wd, int Hd,
                                                                float alpha, float *__restrict__ scratch, float *__restrict__ dst,
                                                                long d_sy, long d_sc) {
-    __shared__ float tiles[3][TR * TP];
+    extern __shared__ __attribute__((aligned(16))) float tiles_raw[];   // [SLOTS][TSZ]: 66.5 KB, above the static limit
+    auto tiles = reinterpret_cast<float (*)[TSZ]>(tiles_raw);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x0 = blockIdx.x * 64, c = blockIdx.y;
     const int x = min(x0 + lane, Wd - 1);                    // lanes past the edge shadow the last column (never stored)
@@ -39,9 +64,7 @@ __global__ __launch_bounds__(64 * (1 + NHELP)) void iir_cols_T(const float *__re
     float *t = scratch + ((long)c * Hd) * Wd + x;
     float *dcol = dst + (long)c * d_sc;
     const int NT = (Hd + TR - 1) / TR;
-    const int h0 = (wave - 1) * HR;                          // helper: first tile row it moves
     float b = 0.0f;                                          // scanner: the recurrence state
-    float set[NSET][HR];                                     // helper: rows of NSET tiles in flight
 
     // one pass over the column: tile p (processing order) holds steps 0..n-1; forward: step st = row 64p + st of `s`,
     // backward: row Hd-1 - 64p - st of the scratch plane.  The scanner and the helpers run DIFFERENT loops that meet at the
@@ -54,105 +77,187 @@ __global__ __launch_bounds__(64 * (1 + NHELP)) void iir_cols_T(const float *__re
         auto row_at = [&](int p, int st) { return BACK ? Hd - 1 - p * TR - st : p * TR + st; };
         if (wave == 0) {
             // ---- the scanner: b = c1 * b + (alpha * in), in place in the tile's LDS slot
-            __syncthreads();
-            for (int p = 0; p < NT; p++) {
-                float *tl = tiles[p % 3] + lane;
+            auto slow = [&](int p) {                         // first tile (its first row is taken as it is, :21, :26-28) and a short last tile
+                float *tl = tiles[p % SLOTS];
                 const int n = rows_of(p);
-                if (n == TR && p != 0) {                     // a full tile: all 64 reads in flight before the chain starts
-                    float u[TR];
-#pragma unroll
-                    for (int k = 0; k < TR; k++) u[k] = tl[k * TP];
-#pragma unroll
-                    for (int k = 0; k < TR; k++) {
-                        b = c1 * b + u[k];
-                        tl[k * TP] = b;
-                    }
-                } else {
-                    int st = 0;
-                    if (p == 0) {                            // the first row of a pass is taken as it is (:21, :26-28)
-                        b = tl[0];
-                        st = 1;
-                    }
-                    for (; st < n; st++) {
-                        b = c1 * b + tl[st * TP];
-                        tl[st * TP] = b;
-                    }
+                int st = 0;
+                if (p == 0) {
+                    b = tl[at(0, lane)];
+                    st = 1;
                 }
+                for (; st < n; st++) {
+                    b = c1 * b + tl[at(st, lane)];
+                    tl[at(st, lane)] = b;
+                }
+            };
+            // a full tile whose 64 inputs are already in registers; the NEXT tile's inputs are read meanwhile
+            auto fast = [&](int p, const float4 (&ucur)[TR / 4], float4 (&unxt)[TR / 4]) {
+                float4 *tl = reinterpret_cast<float4 *>(tiles[p % SLOTS] + 4 * lane);
+                const float4 *tn = reinterpret_cast<const float4 *>(tiles[(p + 1) % SLOTS] + 4 * lane);
+#pragma unroll
+                for (int gq = 0; gq < TR / 4; gq++) {
+                    float4 r;
+                    b = c1 * b + ucur[gq].x, r.x = b;
+                    b = c1 * b + ucur[gq].y, r.y = b;
+                    b = c1 * b + ucur[gq].z, r.z = b;
+                    b = c1 * b + ucur[gq].w, r.w = b;
+                    tl[gq * (TG / 4)] = r;
+                    unxt[gq] = tn[gq * (TG / 4)];
+                }
+            };
+            float4 ua[TR / 4], ub[TR / 4];
+            __syncthreads();
+            slow(0);
+            if (NT > 2) {                                    // tile 1 is full and was filled before the barrier above
+                const float4 *tn = reinterpret_cast<const float4 *>(tiles[1] + 4 * lane);
+#pragma unroll
+                for (int gq = 0; gq < TR / 4; gq++) ua[gq] = tn[gq * (TG / 4)];
+            }
+            __syncthreads();
+            int p = 1;
+#if HLMI_IIR_PROBE
+            unsigned long long pr_chain = 0, pr_bar = 0;
+#endif
+            while (p <= NT - 2) {                            // tiles 1 .. NT-2 are full
+                IP_T(q0);
+                fast(p, ua, ub);
+                IP_T(q1);
+                __syncthreads();
+                IP_T(q2);
+                IP_ACC(pr_chain, q1 - q0); IP_ACC(pr_bar, q2 - q1);
+                if (++p > NT - 2) break;
+                IP_T(q3);
+                fast(p, ub, ua);
+                IP_T(q4);
+                __syncthreads();
+                IP_T(q5);
+                IP_ACC(pr_chain, q4 - q3); IP_ACC(pr_bar, q5 - q4);
+                ++p;
+            }
+#if HLMI_IIR_PROBE
+            if (lane == 0) atomicAdd(&g_iprobe[0], pr_chain), atomicAdd(&g_iprobe[1], pr_bar), atomicAdd(&g_iprobe[2], 1ull);
+#endif
+            if (NT > 1) {
+                slow(NT - 1);
                 __syncthreads();
             }
             __syncthreads();
             return;
         }
-        // ---- the helpers
-        auto issue = [&](int p, float (&v)[HR]) {            // p past the end re-reads the last tile, rows past a short tile its last row
-            const int pc = min(p, NT - 1), last = rows_of(pc) - 1;
+        // ---- the helpers: waves 1..NLOAD only LOAD (global -> registers -> LDS), the others only STORE (LDS -> global).  A wave
+        // that does both has to wait for loads it issued four tiles ago with stores of the last tiles still in flight, and the
+        // one in-order vmcnt counter of gfx9 turns that into "wait for (almost) everything": the memory round trip came back
+        // into every iteration (~0.9 us per tile against a 0.33 us recurrence).  Loaders wait for loads only; storers never wait.
+        if (wave <= NLOAD) {
+            const int l0 = (wave - 1) * LR;                  // first tile row this loader moves
+            float set[NSET][LR];                             // rows of NSET tiles in flight
+            auto issue = [&](int p, float (&v)[LR]) {        // p past the end re-reads the last tile, rows past a short tile its last row
+                const int pc = min(p, NT - 1), last = rows_of(pc) - 1;
 #pragma unroll
-            for (int i = 0; i < HR; i++) {
-                const int r = row_at(pc, min(h0 + i, last));
-                v[i] = BACK ? t[(long)r * Wd] : s[(long)r * s_sy];
+                for (int i = 0; i < LR; i++) {
+                    const int r = row_at(pc, min(l0 + i, last));
+                    v[i] = BACK ? t[(long)r * Wd] : s[(long)r * s_sy];
+                }
+            };
+            // the loaders also do the recurrence's independent product: LDS holds alpha * in (the pass's very first row stays
+            // raw).  Filling a slot for a tile past the end is harmless: that slot's tile has been written out already.
+            auto fill = [&](int p, const float (&v)[LR]) {
+                float4 *tl = reinterpret_cast<float4 *>(tiles[p % SLOTS] + at(l0, lane));   // l0 is a multiple of 4
+#pragma unroll
+                for (int gq = 0; gq < LR / 4; gq++) {
+                    float4 w;
+                    w.x = (p == 0 && l0 + 4 * gq == 0) ? v[4 * gq] : alpha * v[4 * gq];
+                    w.y = alpha * v[4 * gq + 1], w.z = alpha * v[4 * gq + 2], w.w = alpha * v[4 * gq + 3];
+                    tl[gq * (TG / 4)] = w;
+                }
+            };
+#if HLMI_IIR_PROBE
+            unsigned long long pr_fill = 0, pr_issue = 0, pr_lbar = 0;
+#endif
+            auto iter = [&](int p, auto ph_tag) {            // steady state, 1 <= p: no branches
+                constexpr int PH = decltype(ph_tag)::value;  // p % NSET: the register set indices must be compile-time
+                IP_T(q0);
+                fill(p + 2, set[(PH + 2) % NSET]);
+                IP_T(q1);
+                issue(p + 2 + NSET, set[(PH + 2) % NSET]);
+                IP_T(q2);
+                __syncthreads();
+                IP_T(q3);
+                IP_ACC(pr_fill, q1 - q0); IP_ACC(pr_issue, q2 - q1); IP_ACC(pr_lbar, q3 - q2);
+            };
+            static_assert(NSET == 4 && SLOTS == 4, "the unrolled tile loop below names the phases");
+            issue(0, set[0]);
+            issue(1, set[1]);
+            issue(2, set[2]);
+            issue(3, set[3]);
+            fill(0, set[0]);
+            issue(4, set[0]);
+            fill(1, set[1]);
+            issue(5, set[1]);
+            __syncthreads();
+            fill(2, set[2]);
+            issue(6, set[2]);
+            __syncthreads();
+            int p = 1;
+            for (; p + 3 < NT; p += 4) {
+                iter(p, std::integral_constant<int, 1>{});
+                iter(p + 1, std::integral_constant<int, 2>{});
+                iter(p + 2, std::integral_constant<int, 3>{});
+                iter(p + 3, std::integral_constant<int, 0>{});
             }
-        };
-        // the helpers also do the recurrence's independent product: LDS holds alpha * in (the pass's very first row stays
-        // raw).  Filling a slot for a tile past the end is harmless: that slot's tile has been written out already.
-        auto fill = [&](int p, const float (&v)[HR]) {
-            float *tl = tiles[p % 3];
-#pragma unroll
-            for (int i = 0; i < HR; i++) tl[(h0 + i) * TP + lane] = (p == 0 && h0 + i == 0) ? v[i] : alpha * v[i];
-        };
+            if (p < NT) iter(p++, std::integral_constant<int, 1>{});
+            if (p < NT) iter(p++, std::integral_constant<int, 2>{});
+            if (p < NT) iter(p++, std::integral_constant<int, 3>{});
+            __syncthreads();                                 // the storers' last tile
+#if HLMI_IIR_PROBE
+            if (lane == 0 && wave == 1) atomicAdd(&g_iprobe[4], pr_fill), atomicAdd(&g_iprobe[5], pr_issue), atomicAdd(&g_iprobe[6], pr_lbar), atomicAdd(&g_iprobe[7], 1ull);
+#endif
+            return;
+        }
+        const int h0 = (wave - 1 - NLOAD) * SR;              // storer: first tile row (forward) / tile column (backward) it moves
         auto drain_full = [&](int p) {                       // tile p (64 rows) leaves LDS
-            const float *tl = tiles[p % 3];
+            const float *tl = tiles[p % SLOTS];
 #pragma unroll
-            for (int i = 0; i < HR; i++) {
+            for (int i = 0; i < SR; i++) {
                 if (!BACK) {
-                    t[(long)row_at(p, h0 + i) * Wd] = tl[(h0 + i) * TP + lane];
+                    t[(long)row_at(p, h0 + i) * Wd] = tl[at(h0 + i, lane)];
                 } else {
                     // transposed: dst[c][x0 + j][y], y = the row of step `lane` (64 consecutive floats, descending with the
                     // lane); columns past the edge repeat the last one (same value to the same address)
                     const int j = min(h0 + i, Wd - 1 - x0);
-                    dcol[(long)(x0 + j) * d_sy + row_at(p, lane)] = tl[lane * TP + j];
+                    dcol[(long)(x0 + j) * d_sy + row_at(p, lane)] = tl[at(lane, j)];
                 }
             }
         };
         auto drain_last = [&](int p) {                       // the (possibly short) last tile
-            const float *tl = tiles[p % 3];
+            const float *tl = tiles[p % SLOTS];
             const int n = rows_of(p);
 #pragma unroll
-            for (int i = 0; i < HR; i++) {
+            for (int i = 0; i < SR; i++) {
                 if (!BACK) {
-                    if (h0 + i < n) t[(long)row_at(p, h0 + i) * Wd] = tl[(h0 + i) * TP + lane];
+                    if (h0 + i < n) t[(long)row_at(p, h0 + i) * Wd] = tl[at(h0 + i, lane)];
                 } else {
                     const int j = min(h0 + i, Wd - 1 - x0);
-                    if (lane < n) dcol[(long)(x0 + j) * d_sy + row_at(p, lane)] = tl[lane * TP + j];
+                    if (lane < n) dcol[(long)(x0 + j) * d_sy + row_at(p, lane)] = tl[at(lane, j)];
                 }
             }
         };
-        auto iter = [&](int p, auto ph_tag) {                // steady state, 1 <= p: no branches
-            constexpr int PH = decltype(ph_tag)::value;      // p % NSET: the register set indices must be compile-time
-            fill(p + 1, set[(PH + 1) % NSET]);
-            issue(p + NSET, set[PH]);
+        __syncthreads();
+        __syncthreads();                                     // iteration 0: nothing to write out yet
+#if HLMI_IIR_PROBE
+        unsigned long long pr_drain = 0, pr_sbar = 0;
+#endif
+        for (int p = 1; p < NT; p++) {
+            IP_T(q0);
             drain_full(p - 1);
+            IP_T(q1);
             __syncthreads();
-        };
-        static_assert(NSET == 4, "the unrolled tile loop below names the phases");
-        issue(0, set[0]);
-        issue(1, set[1]);
-        issue(2, set[2]);
-        issue(3, set[3]);
-        fill(0, set[0]);
-        __syncthreads();
-        fill(1, set[1]);                                     // iteration 0: nothing to write out yet
-        issue(4, set[0]);
-        __syncthreads();
-        int p = 1;
-        for (; p + 3 < NT; p += 4) {
-            iter(p, std::integral_constant<int, 1>{});
-            iter(p + 1, std::integral_constant<int, 2>{});
-            iter(p + 2, std::integral_constant<int, 3>{});
-            iter(p + 3, std::integral_constant<int, 0>{});
+            IP_T(q2);
+            IP_ACC(pr_drain, q1 - q0); IP_ACC(pr_sbar, q2 - q1);
         }
-        if (p < NT) iter(p++, std::integral_constant<int, 1>{});
-        if (p < NT) iter(p++, std::integral_constant<int, 2>{});
-        if (p < NT) iter(p++, std::integral_constant<int, 3>{});
+#if HLMI_IIR_PROBE
+        if (lane == 0 && wave == NLOAD + 1) atomicAdd(&g_iprobe[8], pr_drain), atomicAdd(&g_iprobe[9], pr_sbar), atomicAdd(&g_iprobe[10], 1ull);
+#endif
         drain_last(NT - 1);
         __syncthreads();                                     // the scratch rows are visible to the whole workgroup
     };
@@ -173,6 +278,19 @@ const halide_filter_argument_t ib_args[3] = {
 const halide_filter_metadata_t ib_md = {1, 3, ib_args, kTargetString, "iir_blur"};
 
 }  // namespace
+
+extern "C" int hlmi_debug_iir_probe(unsigned long long *out16) {
+#if HLMI_IIR_PROBE
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_iprobe), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    unsigned long long zero[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_iprobe), zero, sizeof zero) != hipSuccess) return -1;
+    return 1;
+#else
+    (void)out16;
+    return 0;
+#endif
+}
 
 extern "C" int iir_blur(halide_buffer_t *input, float alpha, halide_buffer_t *output) {
     void *uc = nullptr;
@@ -210,13 +328,15 @@ extern "C" int iir_blur(halide_buffer_t *input, float alpha, halide_buffer_t *ou
         if ((r = get_workspace(uc, ctx, 2 * (size_t)C * plane * sizeof(float), &ws))) return r;
         float *scratch = (float *)ws, *t1 = scratch + (size_t)C * plane;
         hipStream_t st = ctx.stream;
+        constexpr size_t lds = sizeof(float) * SLOTS * TSZ;
+        HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(iir_cols_T), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         timing_note_bytes(16.0 * W * H * C);
         // columns of the input -> t1 = transpose [C][W rows of H]
-        HLMI_LAUNCH(uc, "iir_cols_T:1", st, iir_cols_T, dim3((W + 63) / 64, C), dim3(64 * (1 + NHELP)), 0, dev_ptr<float>(input),
+        HLMI_LAUNCH(uc, "iir_cols_T:1", st, iir_cols_T, dim3((W + 63) / 64, C), dim3(64 * (1 + NHELP)), lds, dev_ptr<float>(input),
                     (long)input->dim[1].stride, (long)input->dim[2].stride, W, H, alpha, scratch, t1, (long)H, (long)W * H);
         timing_note_bytes(16.0 * W * H * C);
         // columns of t1 (= rows of the input) -> output [C][H rows of W]
-        HLMI_LAUNCH(uc, "iir_cols_T:2", st, iir_cols_T, dim3((H + 63) / 64, C), dim3(64 * (1 + NHELP)), 0, t1, (long)H, (long)W * H, H, W, alpha,
+        HLMI_LAUNCH(uc, "iir_cols_T:2", st, iir_cols_T, dim3((H + 63) / 64, C), dim3(64 * (1 + NHELP)), lds, t1, (long)H, (long)W * H, H, W, alpha,
                     scratch, dev_ptr<float>(output), (long)output->dim[1].stride, (long)output->dim[2].stride);
     }
     mark_output_written(output);
