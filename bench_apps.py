@@ -245,6 +245,21 @@ def main():
              bytes_px * W * H / t / 1e9, HBM_PEAK_GBS, "GB/s", {"alg_bytes": bytes_px * W * H, "kernels_ms": kernels(call, o),
                                                               "note": "coverage pipeline: one thread per element, untuned"})
 
+    # ---- bgu at the generator's estimates (bgu_generator.cpp:674-687): 192x320 low-res pair, 1536x2560 full-res image
+    if not only or "bgu" in only:
+        W, H = 1536, 2560
+        yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+        hi = np.stack([(np.sin(xx / (91.0 + 7 * c)) + np.cos(yy / (133.0 - 9 * c))) * 0.22 + 0.5 for c in range(3)]).astype(np.float32)
+        hi += rng.random((3, H, W), dtype=np.float32) * 0.06
+        lo = hi.reshape(3, H // 8, 8, W // 8, 8).mean(axis=(2, 4)).astype(np.float32)
+        val = (lo * lo * (3 - 2 * lo)).astype(np.float32)
+        bl, bv, bh = hl.Buffer(lo), hl.Buffer(val), hl.Buffer(hi)
+        o = hl.Buffer(np.zeros((3, H, W), np.float32))
+        call = lambda: hl.bgu(1.0 / 8.0, 16, bl, bv, bh, o)
+        t = timed(call, o, 20)
+        emit("bgu", "apps/bgu r_sigma=1/8 s_sigma=16, f32 192x320x3 pair -> 1536x2560x3", t, W * H, "hbm", 24.0 * W * H / t / 1e9,
+             HBM_PEAK_GBS, "GB/s", {"alg_bytes": 24 * W * H, "kernels_ms": kernels(call, o)})
+
     # ---- depthwise_separable_conv at the driver's shape (MobileNet-v2 layer 2, process.cpp:13)
     if not only or "depthwise_separable_conv" in only:
         N, Hh, Ww, CI, CO = 4, 112, 112, 32, 16

@@ -340,6 +340,7 @@ _harris = _bind("harris", [_BP, _BP])
 _interp = _bind("interpolate", [_BP, _BP])
 _iir = _bind("iir_blur", [_BP, C.c_float, _BP])
 _lens = _bind("lens_blur", [_BP, _BP, C.c_int32, C.c_int32, C.c_float, C.c_int32, _BP])
+_bgu = _bind("bgu", [C.c_float, C.c_int32, _BP, _BP, _BP, _BP])
 _cam = _bind("camera_pipe", [_BP, _BP, _BP, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _BP])
 
 
@@ -429,6 +430,11 @@ def iir_blur(input, alpha, output) -> int:
 def lens_blur(left_im, right_im, slices, focus_depth, blur_radius_scale, aperture_samples, final) -> int:
     return _check(_lens(_as_ptr(left_im), _as_ptr(right_im), int(slices), int(focus_depth), float(blur_radius_scale),
                         int(aperture_samples), _as_ptr(final)))
+
+
+def bgu(r_sigma, s_sigma, splat_loc, values, slice_loc, output) -> int:
+    """apps/bgu: low-res f32 pair (splat_loc -> values) fitted per bilateral-grid cell, applied to the full-res slice_loc."""
+    return _check(_bgu(float(r_sigma), int(s_sigma), _as_ptr(splat_loc), _as_ptr(values), _as_ptr(slice_loc), _as_ptr(output)))
 
 
 def camera_pipe(input, matrix_3200, matrix_7000, color_temp, gamma, contrast, sharpen_strength, black_level,

@@ -135,6 +135,15 @@ HLMI_DECLARE_AUX(lens_blur)
 void hlmi_lens_blur_set_random_tag(int tag);
 int hlmi_lens_blur_get_random_tag(void);
 
+/* apps/bgu/bgu_generator.cpp:252-266,698 — bilateral-guided upsampling: fits a 3x4 affine colour transform per cell of
+ * a bilateral grid (cells of s_sigma x s_sigma low-res pixels x r_sigma of luma) from the low-res pair splat_loc ->
+ * values, and applies the trilinearly sliced transforms to the full-res slice_loc.  f32 [W,H,3] planar everywhere; the
+ * low-res pair is edge-clamped (:270-271).  Adjacent app, same boundary.  fast_inverse (:170) is the
+ * correctly rounded 1/x of the reference's CUDA path (src/runtime/ptx_dev.ll:61-66), not x86's rcpss estimate. */
+int bgu(float r_sigma, int32_t s_sigma, struct halide_buffer_t *splat_loc, struct halide_buffer_t *values,
+        struct halide_buffer_t *slice_loc, struct halide_buffer_t *output);
+HLMI_DECLARE_AUX(bgu)
+
 /* apps/camera_pipe/camera_pipe_generator.cpp:219-228,622 — raw u16 Bayer -> u8 [W,H,3]. */
 int camera_pipe(struct halide_buffer_t *input, struct halide_buffer_t *matrix_3200,
                 struct halide_buffer_t *matrix_7000, float color_temp, float gamma, float contrast,
@@ -165,6 +174,8 @@ int iir_blur_auto_schedule(struct halide_buffer_t *input, float alpha, struct ha
 int lens_blur_auto_schedule(struct halide_buffer_t *left_im, struct halide_buffer_t *right_im, int32_t slices,
                             int32_t focus_depth, float blur_radius_scale, int32_t aperture_samples,
                             struct halide_buffer_t *final);
+int bgu_auto_schedule(float r_sigma, int32_t s_sigma, struct halide_buffer_t *splat_loc, struct halide_buffer_t *values,
+                      struct halide_buffer_t *slice_loc, struct halide_buffer_t *output);
 int camera_pipe_auto_schedule(struct halide_buffer_t *input, struct halide_buffer_t *matrix_3200,
                               struct halide_buffer_t *matrix_7000, float color_temp, float gamma, float contrast,
                               float sharpen_strength, int32_t blackLevel, int32_t whiteLevel,

@@ -12,13 +12,13 @@ LDFLAGS  := -L$(LIBDIR) -lhlmi -Wl,-rpath,'$$ORIGIN/../../halide_amd/lib' -lpthr
 
 TARGETS := $(OUTDIR)/blur_test $(OUTDIR)/local_laplacian_process $(OUTDIR)/bilateral_grid_filter \
            $(OUTDIR)/nl_means_process $(OUTDIR)/stencil_chain_process $(OUTDIR)/conv_layer_process $(OUTDIR)/camera_pipe_process \
-           $(OUTDIR)/depthwise_separable_conv_process $(OUTDIR)/unsharp_filter $(OUTDIR)/max_filter_filter $(OUTDIR)/hist_filter $(OUTDIR)/harris_filter $(OUTDIR)/iir_blur_filter $(OUTDIR)/interpolate_filter $(OUTDIR)/lens_blur_process
+           $(OUTDIR)/depthwise_separable_conv_process $(OUTDIR)/unsharp_filter $(OUTDIR)/max_filter_filter $(OUTDIR)/hist_filter $(OUTDIR)/harris_filter $(OUTDIR)/iir_blur_filter $(OUTDIR)/interpolate_filter $(OUTDIR)/lens_blur_process $(OUTDIR)/bgu_filter
 
 # The reference's own RunGen (tools/RunGenMain.cpp + RunGen.h, compiled unmodified) linked with the per-pipeline
 # registration unit of tests/cpp/rungen_registration.cpp: the reference's consumer of <name>_argv / <name>_metadata /
 # the bounds-query protocol, one <name>.rungen per pipeline as in the reference's build (apps/*/Makefile, *.rungen).
 RUNGEN_PIPELINES := local_laplacian bilateral_grid halide_blur nl_means stencil_chain conv_layer camera_pipe \
-                    depthwise_separable_conv unsharp max_filter hist harris interpolate iir_blur lens_blur
+                    depthwise_separable_conv unsharp max_filter hist harris interpolate iir_blur lens_blur bgu
 TARGETS += $(patsubst %,$(OUTDIR)/%.rungen,$(RUNGEN_PIPELINES))
 # own test programs that need the reference's headers (tests/cpp/*.cpp; sources are ours, headers the reference's)
 TARGETS += $(OUTDIR)/entry_protocol_ref $(OUTDIR)/device_interface_test
@@ -70,6 +70,8 @@ $(OUTDIR)/harris_filter: $(REF)/apps/harris/filter.cpp $(LIBDIR)/libhlmi.so
 $(OUTDIR)/iir_blur_filter: $(REF)/apps/iir_blur/filter.cpp $(LIBDIR)/libhlmi.so
 	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)
 $(OUTDIR)/lens_blur_process: $(REF)/apps/lens_blur/process.cpp $(LIBDIR)/libhlmi.so
+	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)
+$(OUTDIR)/bgu_filter: $(REF)/apps/bgu/filter.cpp $(LIBDIR)/libhlmi.so
 	$(CXX) $(CXXFLAGS) $< -o $@ $(LDFLAGS)
 $(OUTDIR)/interpolate_filter_png: $(REF)/apps/interpolate/filter.cpp $(ROOT)/tests/cpp/png_shim/png.h $(LIBDIR)/libhlmi.so
 	$(CXX) $(PNGFLAGS) $< -o $@ $(LDFLAGS) -lz

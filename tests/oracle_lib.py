@@ -385,3 +385,34 @@ def lens_blur(left: np.ndarray, right: np.ndarray, slices=32, focus_depth=13, bl
     assert _lib.oracle_lens_blur(left, w, h, right, rw, rh, slices, focus_depth, blur_radius_scale, aperture_samples, t, out,
                                  depth.ctypes.data) == 0
     return (out, depth) if return_depth else out
+
+
+# ---- bgu
+BGU_CANONICAL, BGU_X86_RCP = 0, 1
+_lib.oracle_bgu.argtypes = [C.c_float, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int,
+                            C.c_int, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_void_p, C.c_void_p]
+_lib.oracle_bgu.restype = C.c_int
+
+
+def bgu(r_sigma, s_sigma, splat_loc: np.ndarray, values: np.ndarray, slice_loc: np.ndarray, region=None, variant=BGU_CANONICAL,
+        return_line=False):
+    """splat_loc / values: f32 (C, h, w) planar low-res pair; slice_loc: f32 (3, H, W) -> f32 (3, oh, ow) on
+    region = (x0, y0, ow, oh) (default: all of slice_loc); optionally also the fitted transforms (ncy, ncx, nz, 12) and
+    (cx0, cy0, ncx, ncy, nz, big_sigma)."""
+    splat_loc, values = np.ascontiguousarray(splat_loc, np.float32), np.ascontiguousarray(values, np.float32)
+    slice_loc = np.ascontiguousarray(slice_loc, np.float32)
+    _, H, W = slice_loc.shape
+    x0, y0, ow, oh = region if region is not None else (0, 0, W, H)
+    out = np.zeros((3, oh, ow), np.float32)
+    dims = (C.c_int * 6)()
+    lc, lh, lw = splat_loc.shape
+    vc, vh, vw = values.shape
+    args = [np.float32(r_sigma), s_sigma, splat_loc, lw, lh, lc, values, vw, vh, vc, slice_loc, W, H, x0, y0, ow, oh, out, variant]
+    if not return_line:
+        assert _lib.oracle_bgu(*args, None, None) == 0
+        return out
+    assert _lib.oracle_bgu(*args, None, C.cast(dims, C.c_void_p)) == 0
+    cx0, cy0, ncx, ncy, nz, big = list(dims)
+    line = np.zeros((ncy, ncx, nz, 12), np.float32)
+    assert _lib.oracle_bgu(*args, line.ctypes.data, C.cast(dims, C.c_void_p)) == 0
+    return out, line, (cx0, cy0, ncx, ncy, nz, big)

@@ -233,6 +233,55 @@ def test_lens_blur_process_cpp(tmp_path, oracle):
     assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+def _bgu_filter_cpp_low_res_pair(hi):
+    """apps/bgu/filter.cpp:37-87 in float32, operator by operator: the 8x8 box downsample (sy outer, sx inner) and the
+    "straw-man" sharpen + smoothstep + vignette it wants transferred to full resolution."""
+    f32 = np.float32
+    _, H, W = hi.shape
+    lw, lh = W // 8, H // 8
+    lo = np.zeros((3, lh, lw), f32)
+    for sy in range(8):
+        for sx in range(8):
+            lo = lo + hi[:, sy::8, sx::8][:, :lh, :lw]
+    lo = lo / f32(64)
+    p = np.pad(lo, ((0, 0), (1, 1), (1, 1)), mode="edge")
+    nb = ((p[:, 1:-1, :-2] + p[:, 1:-1, 2:]) + p[:, :-2, 1:-1]) + p[:, 2:, 1:-1]
+    val = f32(2) * lo - nb / f32(4)
+    yy, xx = np.mgrid[0:lh, 0:lw]
+    edge = (xx == 0) | (xx == lw - 1) | (yy == 0) | (yy == lh - 1)
+    val = np.where(edge[None], lo, val).astype(f32)
+    boosted = (val * val) * (f32(3) - f32(2) * val)
+    r = f32(min(W // 16, H // 16))
+    mx, my = (xx - W // 16).astype(f32) / r, (yy - H // 16).astype(f32) / r
+    mask = np.sqrt(mx * mx + my * my).astype(f32)[None]
+    val = val * mask + boosted * (f32(1) - mask)
+    val = val * ((f32(2) - mask) / f32(2))
+    return lo, np.maximum(np.minimum(val, f32(1)), f32(0)).astype(f32)
+
+
+@pytest.mark.gpu
+def test_bgu_filter_cpp(tmp_path, oracle):
+    """apps/bgu/filter.cpp:17-108 unmodified: it builds the low-res pair itself on the host, calls bgu() and
+    bgu_auto_schedule() under the benchmark harness and saves the full-res result — here as .mat (exact float32), which
+    must be the oracle's result for the same pair, bit for bit."""
+    import scipy.io
+    exe = _exe("bgu_filter")
+    img8 = _scene8(256, 192, 31, 3)
+    src, dst = str(tmp_path / "in.ppm"), str(tmp_path / "result.mat")
+    write_ppm8(src, img8)
+    r = subprocess.run([exe, src, dst], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Success!" in r.stdout, r.stdout + r.stderr
+    assert "Manually-tuned time" in r.stdout and "Auto-scheduled time" in r.stdout
+    saved = scipy.io.loadmat(dst)
+    (name,) = [k for k in saved if not k.startswith("__")]
+    got = np.ascontiguousarray(saved[name].transpose(2, 1, 0))
+    hi = img8.astype(np.float32) / np.float32(255.0)              # tools/halide_image_io.h:610-612
+    lo, lo_out = _bgu_filter_cpp_low_res_pair(hi)
+    want = oracle.bgu(1.0 / 8.0, 16, lo, lo_out, hi)
+    assert got.dtype == np.float32 and got.shape == want.shape
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"{np.count_nonzero(got != want)} of {got.size} differ"
+
+
 # ---- the PNG path of tools/halide_image_io.h (load_png :856-940, save_png :952-1040), libpng calls over zlib (tests/cpp/png_shim)
 def write_png(path, img, bit_depth=8):
     """img: (C, H, W) integer array, C in 1..4.  Scanline filters cycle through all five types (clause 9 of the PNG spec)."""

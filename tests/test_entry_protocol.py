@@ -39,9 +39,10 @@ SPEC = {
     "iir_blur": dict(out=(64, 48, 3), scalars=[0.5]),
     "camera_pipe": dict(out=(64, 32, 3), scalars=[3700.0, 2.0, 50.0, 1.0, 25, 1023]),
     "lens_blur": dict(out=(48, 40, 3), scalars=[32, 13, 0.5, 32]),
+    "bgu": dict(out=(64, 48, 3), scalars=[0.125, 16]),
 }
 PIPELINES = sorted(SPEC)
-PRIMARY = {"lens_blur": "left_im"}   # the image input the generic cases perturb ("input" everywhere else)
+PRIMARY = {"lens_blur": "left_im", "bgu": "slice_loc"}   # the image input the generic cases perturb ("input" everywhere else)
 # pipelines whose generator pins mins / extents / strides of its buffers (conv_layer_generator.cpp:35-50,
 # nl_means_generator.cpp:68, …): a malformed shape trips a constraint (-8) before the generic shape checks
 PINNED = {"conv_layer", "conv_layer_bf16"}
@@ -191,7 +192,7 @@ def test_input_too_small_is_out_of_bounds(calls, name):
         assert c.code() in (0, -29)                        # passes every argument check (-29: this box has no GPU)
     else:
         assert c.code() == -4                              # halide_error_code_access_out_of_bounds
-        assert "input" in c.hl.last_error()
+        assert c.names[i] in c.hl.last_error()
 
 
 @pytest.mark.parametrize("name", [n for n in PIPELINES if n not in TIED | {"nl_means", "depthwise_separable_conv"}])

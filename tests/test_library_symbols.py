@@ -31,13 +31,13 @@ def test_every_declared_symbol_is_exported(hl):
 
 def test_metadata_of_every_pipeline(hl):
     expect = {"local_laplacian": 5, "bilateral_grid": 3, "halide_blur": 2, "nl_means": 5, "stencil_chain": 2,
-              "conv_layer": 4, "conv_layer_bf16": 4, "depthwise_separable_conv": 5, "unsharp": 2, "max_filter": 2, "hist": 2, "harris": 2, "interpolate": 2, "iir_blur": 3, "camera_pipe": 10, "lens_blur": 7}
+              "conv_layer": 4, "conv_layer_bf16": 4, "depthwise_separable_conv": 5, "unsharp": 2, "max_filter": 2, "hist": 2, "harris": 2, "interpolate": 2, "iir_blur": 3, "camera_pipe": 10, "lens_blur": 7, "bgu": 6}
     for name, n in expect.items():
         md = hl.metadata(name)
         assert md.version == 1 and md.num_arguments == n and md.name.decode() == name
         assert b"hip" in md.target
         kinds = [md.arguments[i].kind for i in range(n)]
-        assert kinds[-1] == 2 and kinds[0] == 1  # inputs first, the output buffer last
+        assert kinds[-1] == 2 and kinds[0] == (0 if name == "bgu" else 1)  # inputs in declaration order (bgu: its two scalars), the output buffer last
 
 
 def test_no_gpu_means_loud_failure_not_fallback(hl):

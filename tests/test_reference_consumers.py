@@ -67,7 +67,7 @@ RUNGEN_KEYS = {"BEST_TIME_MSEC_PER_ITER", "SAMPLES", "ITERATIONS", "TIMING_ACCUR
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["local_laplacian", "bilateral_grid", "halide_blur", "nl_means", "stencil_chain", "conv_layer",
                                   "camera_pipe", "depthwise_separable_conv", "unsharp", "max_filter", "hist", "harris",
-                                  "interpolate", "iir_blur", "lens_blur"])
+                                  "interpolate", "iir_blur", "lens_blur", "bgu"])
 def test_reference_rungen_estimate_all_benchmark(name):
     """tools/RunGen.h:1285-1298: the parsable benchmark lines; inputs and extents from the metadata's estimates."""
     r = _run(f"{name}.rungen", "--estimate_all", "--benchmarks=all", "--parsable_output", "--benchmark_min_time=0.05")
