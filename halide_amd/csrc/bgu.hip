@@ -6,15 +6,15 @@
 // no defined order.  Here the float sums run in the serial order of the CPU schedule (oracle/bgu_oracle.c), which
 // makes the result reproducible bit for bit, and the pipeline is three launches:
 //   bgu_hist   one workgroup per grid cell: the cell's s_sigma^2 low-res samples are staged in LDS, then one thread per
-//              (intensity bin, Gram-matrix term) walks them in order and adds the ones that land in its bin
-//   bgu_fit    one workgroup per (32 cells of a grid row, intensity plane): the 7-tap blurs in z, y, x through LDS
-//              (blurz is recomputed for the 7 rows a workgroup needs: the grid is a few hundred KB), then one thread
-//              per cell runs the 4x4 sqrt-free LDL' solve with its three right-hand sides in registers
+//              (intensity bin, Gram-matrix term) walks them in order and adds the ones that land in its bin; the cell's
+//              histogram stays in LDS and leaves the kernel already blurred in z
+//   bgu_fit    one workgroup per (32 cells of a grid row, intensity plane): the 7-tap blurs in y (rows straight from
+//              L2) and x (LDS), then one thread per (cell, right-hand side) runs the 4x4 sqrt-free LDL' solve in registers
 //   bgu_slice  the only stage that touches the full-resolution image (2 x 47 MB at 1536 x 2560): a workgroup owns a
 //              256-pixel-wide strip of rows inside ONE grid row; the two rows of transforms it needs live in LDS, per
 //              image row they are interpolated in y once (the reference's interpolated_matrix_y) into a table
-//              [z][cell][12] that every pixel then reads at its own (z, z+1) with ds_read_b128 — the table's z stride
-//              is padded to an odd number of 16-byte groups so that lanes with different z hit different banks
+//              [cell][z][12] that every pixel then reads at its own (z, z+1) with ds_read_b128; the x and z lerps run two
+//              channels per instruction (v_pk_mul_f32 / v_pk_add_f32)
 // fast_inverse (:170) is 1/x correctly rounded, as on the reference's CUDA path (src/runtime/ptx_dev.ll:61-66).
 #include "hlmi_device_math.h"
 #include "hlmi_internal.h"
@@ -28,7 +28,7 @@ constexpr int NC = 22;    // accumulated terms per cell and bin (:307-315)
 constexpr int CH = 256;   // samples staged per pass of bgu_hist
 constexpr int XT = 32;    // cells per bgu_fit workgroup
 constexpr int TW = 256;   // pixels per bgu_slice workgroup row
-constexpr int RB = 16;    // rows per bgu_slice workgroup
+constexpr int RB = 8;     // rows per bgu_slice workgroup
 
 // a low-res input: edge-clamped in EVERY dimension to its own box (BoundaryConditions::repeat_edge, :270-271)
 struct LowRes {
@@ -54,171 +54,193 @@ __device__ __forceinline__ float lr_at(const LowRes &L, int x, int y, int c) {
 __device__ const unsigned char IA[NC] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 6, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5};
 __device__ const unsigned char IB[NC] = {0, 1, 2, 6, 1, 2, 6, 2, 6, 6, 0, 1, 2, 6, 0, 1, 2, 6, 0, 1, 2, 6};
 
-// hist: [nhy][nhx][nhz][22]
-__global__ __launch_bounds__(256) void bgu_hist(LowRes S, LowRes V, BGeom g, float *__restrict__ hist) {
-    __shared__ float smp[7][CH + 1];   // +1: the seven rows start on different banks
-    __shared__ int zis[CH];
-    const int tid = threadIdx.x;
-    const int cxa = g.cx0 - 3 + (int)blockIdx.x, cya = g.cy0 - 3 + (int)blockIdx.y;
-    const int nsamp = g.s * g.s, npairs = g.nhz * NC;
-    float *hcell = hist + ((long)blockIdx.y * g.nhx + blockIdx.x) * npairs;
-    for (int pb = 0; pb < npairs; pb += 256) {
-        const int p = pb + tid;
-        const int z = p / NC, c = p - z * NC;                   // p >= npairs: z > zmax, never matches
-        const float *ra = smp[IA[c]], *rb = smp[IB[c]];
-        float acc = 0.0f;                                       // :291
-        for (int s0 = 0; s0 < nsamp; s0 += CH) {
-            __syncthreads();
-            const int si = s0 + tid;
-            if (si < nsamp) {                                   // sample (r.x, r.y) = (si % s, si / s): r.x innermost (:529-532)
-                const int ry = si / g.s, rx = si - ry * g.s;
-                const int sx = cxa * g.s + rx - g.s / 2, sy = cya * g.s + ry - g.s / 2;   // :294
-                const float sr = lr_at(S, sx, sy, 0), sg = lr_at(S, sx, sy, 1), sb = lr_at(S, sx, sy, 2);
-                smp[0][tid] = sr, smp[1][tid] = sg, smp[2][tid] = sb;
-                smp[3][tid] = lr_at(V, sx, sy, 0), smp[4][tid] = lr_at(V, sx, sy, 1), smp[5][tid] = lr_at(V, sx, sy, 2);
-                smp[6][tid] = 1.0f;
-                const float pos = clampf(((sr + sg * 2.0f) + sb) * 0.25f, 0.0f, 1.0f);   // :281-284 as the simplifier folds it
-                zis[tid] = (int)__builtin_rintf(pos * g.inv_r);                           // :297, ties to even
-            }
-            __syncthreads();
-            const int n = min(CH, nsamp - s0);
-            for (int s = 0; s < n; s++) {
-                const float t = ra[s] * rb[s];
-                if (zis[s] == z) acc = acc + t;
-            }
-        }
-        if (p < npairs) hcell[p] = acc;
-    }
-}
-
 // the seven-tap filter (:333-359), in the generator's order; the centre weight is 1
 __device__ __forceinline__ float tap7(float a, float b, float c, float d, float e, float f, float h) {
     const float t0 = 1.0f / 64, t1 = 1.0f / 27, t2 = 1.0f / 8;
     return a * t0 + b * t1 + c * t2 + d + e * t2 + f * t1 + h * t0;
 }
 
-// solve_symmetric<4, 3> (:131-238), statement by statement on f = [A | b]
-__device__ __forceinline__ void solve4(float (&f)[4][7]) {
+// bz: [nhy][nhx][nz][22] = blurz on the histogram's box.  The cell's histogram [nhz][22] never leaves LDS (hb, dynamic).
+constexpr int RS = CH + 4;   // row stride of the staged table: rows 16 bytes apart in bank space, so lanes reading different rows with
+                             // ds_read_b128 do not collide
+__global__ __launch_bounds__(256) void bgu_hist(LowRes S, LowRes V, BGeom g, float *__restrict__ bzg) {
+    __shared__ __attribute__((aligned(16))) float smp[7][RS];
+    __shared__ __attribute__((aligned(16))) int zis[CH];
+    extern __shared__ float hb[];
+    const int tid = threadIdx.x;
+    const int cxa = g.cx0 - 3 + (int)blockIdx.x, cya = g.cy0 - 3 + (int)blockIdx.y;
+    const int nsamp = g.s * g.s, npairs = g.nhz * NC;
+    for (int pb = 0; pb < npairs; pb += 256) {
+        const int p = pb + tid;
+        const int z = p / NC, c = p - z * NC;                   // p >= npairs: z > zmax, never matches
+        const float4 *ra = reinterpret_cast<const float4 *>(smp[IA[c]]), *rb = reinterpret_cast<const float4 *>(smp[IB[c]]);
+        const int4 *zq = reinterpret_cast<const int4 *>(zis);
+        float acc = 0.0f;                                       // :291
+        for (int s0 = 0; s0 < nsamp; s0 += CH) {
+            __syncthreads();
+            const int si = s0 + tid;
+            float sr = 0.0f, sg = 0.0f, sb = 0.0f, vr = 0.0f, vg = 0.0f, vb = 0.0f;
+            int zi = -1;                                        // past the last sample: lands in no bin
+            if (si < nsamp) {                                   // sample (r.x, r.y) = (si % s, si / s): r.x innermost (:529-532)
+                const int ry = si / g.s, rx = si - ry * g.s;
+                const int sx = cxa * g.s + rx - g.s / 2, sy = cya * g.s + ry - g.s / 2;   // :294
+                sr = lr_at(S, sx, sy, 0), sg = lr_at(S, sx, sy, 1), sb = lr_at(S, sx, sy, 2);
+                vr = lr_at(V, sx, sy, 0), vg = lr_at(V, sx, sy, 1), vb = lr_at(V, sx, sy, 2);
+                const float pos = clampf(((sr + sg * 2.0f) + sb) * 0.25f, 0.0f, 1.0f);   // :281-284 as the simplifier folds it
+                zi = (int)__builtin_rintf(pos * g.inv_r);                                 // :297, ties to even
+            }
+            smp[0][tid] = sr, smp[1][tid] = sg, smp[2][tid] = sb, smp[3][tid] = vr, smp[4][tid] = vg, smp[5][tid] = vb, smp[6][tid] = 1.0f;
+            zis[tid] = zi;
+            __syncthreads();
+            const int n4 = (min(CH, nsamp - s0) + 3) >> 2;
+#pragma unroll 4
+            for (int q = 0; q < n4; q++) {                      // four samples per LDS instruction, added in order.  The sum is
+                const float4 a = ra[q], b = rb[q];              // never -0 (it starts at +0), so adding +0 for the samples of
+                const int4 zz = zq[q];                          // other bins leaves it as it is
+                acc = acc + (zz.x == z ? a.x * b.x : 0.0f);
+                acc = acc + (zz.y == z ? a.y * b.y : 0.0f);
+                acc = acc + (zz.z == z ? a.z * b.z : 0.0f);
+                acc = acc + (zz.w == z ? a.w * b.w : 0.0f);
+            }
+        }
+        if (p < npairs) hb[p] = acc;
+    }
+    __syncthreads();
+    // blurz (:336-342) for the planes that are sliced, z = 0 .. nb + 1; the histogram is 0 outside 0 .. zmax
+    float *out = bzg + ((long)blockIdx.y * g.nhx + blockIdx.x) * (g.nz * NC);
+    for (int t = tid; t < g.nz * NC; t += 256) {
+        const int z = t / NC, c = t - z * NC;
+        float v[7];
+#pragma unroll
+        for (int d = 0; d < 7; d++) {
+            const int zz = z + d - 3;
+            v[d] = (zz >= 0 && zz <= g.zmax) ? hb[zz * NC + c] : 0.0f;
+        }
+        out[t] = tap7(v[0], v[1], v[2], v[3], v[4], v[5], v[6]);
+    }
+}
+
+// the solve of one cell for ONE of its three right-hand sides: solve_symmetric<4, 3> (:131-238) statement by statement —
+// the LDL' factorisation of A (shared by the three, recomputed by each of the three threads of a cell) and the
+// substitutions for column k.  b: the 22 blurred terms of the cell.
+__device__ __forceinline__ void solve_column(const float *b, int k, float (&x)[4]) {
+    const float lambda = 1e-1f;                                  // :406-414
+    float A[4][4];
+    A[0][0] = b[0] + lambda, A[0][1] = b[1], A[0][2] = b[2], A[0][3] = b[3];
+    A[1][0] = b[1], A[1][1] = b[4] + lambda, A[1][2] = b[5], A[1][3] = b[6];
+    A[2][0] = b[2], A[2][1] = b[5], A[2][2] = b[7] + lambda, A[2][3] = b[8];
+    A[3][0] = b[3], A[3][1] = b[6], A[3][2] = b[8], A[3][3] = b[9] + lambda;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        f[j][j] = 1.0f / f[j][j];
+        const float v = b[10 + 4 * k + j];
+        x[j] = (j == k) ? v + lambda : v;                        // b(0,0), b(1,1), b(2,2) += lambda
+    }
 #pragma unroll
-        for (int i = j + 1; i < 4; i++) f[i][j] = f[i][j] * f[j][j];
+    for (int j = 0; j < 4; j++) {
+        A[j][j] = 1.0f / A[j][j];                                // fast_inverse as on the CUDA path
+#pragma unroll
+        for (int i = j + 1; i < 4; i++) A[i][j] = A[i][j] * A[j][j];
 #pragma unroll
         for (int i = j + 1; i < 4; i++) {
 #pragma unroll
-            for (int k = j + 1; k < 4; k++) {
-                if (k < i) f[i][k] = f[k][i];
-                else f[i][k] = f[i][k] - f[k][j] * f[j][i];
+            for (int kk = j + 1; kk < 4; kk++) {
+                if (kk < i) A[i][kk] = A[kk][i];
+                else A[i][kk] = A[i][kk] - A[kk][j] * A[j][i];
             }
         }
     }
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
+    for (int j = 0; j < 4; j++) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int i = 0; i < j; i++) x[j] = x[j] - A[j][i] * x[i];
+    }
 #pragma unroll
-            for (int i = 0; i < j; i++) f[j][4 + k] = f[j][4 + k] - f[j][i] * f[i][4 + k];
-        }
+    for (int j = 0; j < 4; j++) x[j] = x[j] * A[j][j];
 #pragma unroll
-        for (int j = 0; j < 4; j++) f[j][4 + k] = f[j][4 + k] * f[j][j];
+    for (int j = 3; j >= 0; j--) {
 #pragma unroll
-        for (int j = 3; j >= 0; j--) {
-#pragma unroll
-            for (int i = j + 1; i < 4; i++) f[j][4 + k] = f[j][4 + k] - f[i][j] * f[i][4 + k];
-        }
+        for (int i = j + 1; i < 4; i++) x[j] = x[j] - A[i][j] * x[i];
     }
 }
 
-// line: [ncy][ncx][nz][12]
-__global__ __launch_bounds__(256) void bgu_fit(const float *__restrict__ hist, BGeom g, float *__restrict__ line) {
-    __shared__ float bz[7][XT + 6][NC];
+// line: [ncy][ncx][nz][12].  Small, latency-bound and executed once per compute unit: the code is kept short (rolled
+// loops, one right-hand side per thread) because every instruction is also a cold instruction-cache fetch.
+__global__ __launch_bounds__(512) void bgu_fit(const float *__restrict__ bzg, BGeom g, float *__restrict__ line) {
     __shared__ float by[XT + 6][NC];
     __shared__ float bx[XT][NC + 1];
     const int tid = threadIdx.x;
     const int x0c = blockIdx.x * XT, cyi = blockIdx.y, z = blockIdx.z;
     const int nx = min(XT, g.ncx - x0c);
-    const int npairs = g.nhz * NC;
-    // blurz on rows cyi .. cyi + 6 and columns x0c .. x0c + nx + 5 of the histogram's box
-    for (int it = tid; it < 7 * (nx + 6) * NC; it += 256) {
-        const int c = it % NC, xx = (it / NC) % (nx + 6), dy = it / (NC * (nx + 6));
-        const float *h = hist + ((long)(cyi + dy) * g.nhx + (x0c + xx)) * npairs + c;
-        float v[7];
-#pragma unroll
-        for (int d = 0; d < 7; d++) {
-            const int zz = z + d - 3;
-            v[d] = (zz >= 0 && zz <= g.zmax) ? h[zz * NC] : 0.0f;
-        }
-        bz[dy][xx][c] = tap7(v[0], v[1], v[2], v[3], v[4], v[5], v[6]);
+    const long rs = (long)g.nhx * g.nz * NC;                     // one grid row of bzg
+    for (int it = tid; it < (nx + 6) * NC; it += 512) {          // blury (:343-349): the seven rows straight from L2
+        const int xx = it / NC, c = it - xx * NC;
+        const float *q = bzg + (long)cyi * rs + ((long)(x0c + xx) * g.nz + z) * NC + c;
+        by[xx][c] = tap7(q[0], q[rs], q[2 * rs], q[3 * rs], q[4 * rs], q[5 * rs], q[6 * rs]);
     }
     __syncthreads();
-    for (int it = tid; it < (nx + 6) * NC; it += 256) {
-        const int c = it % NC, xx = it / NC;
-        by[xx][c] = tap7(bz[0][xx][c], bz[1][xx][c], bz[2][xx][c], bz[3][xx][c], bz[4][xx][c], bz[5][xx][c], bz[6][xx][c]);
-    }
-    __syncthreads();
-    for (int it = tid; it < nx * NC; it += 256) {
-        const int c = it % NC, xx = it / NC;
+    for (int it = tid; it < nx * NC; it += 512) {                // blurx (:350-356)
+        const int xx = it / NC, c = it - xx * NC;
         bx[xx][c] = tap7(by[xx][c], by[xx + 1][c], by[xx + 2][c], by[xx + 3][c], by[xx + 4][c], by[xx + 5][c], by[xx + 6][c]);
     }
     __syncthreads();
-    if (tid < nx) {
-        const float *b = bx[tid];
-        const float lambda = 1e-1f;                              // :406-414
-        float f[4][7];
-        f[0][0] = b[0] + lambda, f[0][1] = b[1], f[0][2] = b[2], f[0][3] = b[3];
-        f[1][0] = b[1], f[1][1] = b[4] + lambda, f[1][2] = b[5], f[1][3] = b[6];
-        f[2][0] = b[2], f[2][1] = b[5], f[2][2] = b[7] + lambda, f[2][3] = b[8];
-        f[3][0] = b[3], f[3][1] = b[6], f[3][2] = b[8], f[3][3] = b[9] + lambda;
+    if (tid < 3 * nx) {
+        const int xx = tid / 3, k = tid - 3 * xx;
+        float x[4];
+        solve_column(bx[xx], k, x);
+        float *l = line + (((long)cyi * g.ncx + (x0c + xx)) * g.nz + z) * 12 + 4 * k;   // :417-433: c = 4 k + j
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) f[j][4 + k] = b[10 + 4 * k + j];
-        }
-        f[0][4] = f[0][4] + lambda, f[1][5] = f[1][5] + lambda, f[2][6] = f[2][6] + lambda;
-        solve4(f);
-        float *l = line + (((long)cyi * g.ncx + (x0c + tid)) * g.nz + z) * 12;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) l[4 * k + j] = f[j][4 + k];   // :417-433
-        }
+        for (int j = 0; j < 4; j++) l[j] = x[j];
     }
 }
 
 struct SGeom {
-    int ox0, oy0, ow, oh, nsub, nlc, zs;   // zs: z stride of the LDS tables (floats)
+    int ox0, oy0, ow, oh, nsub, nlc;       // nlc: grid cells a 256-pixel strip can touch
     long s_sy, s_sc, o_sy, o_sc;
 };
 
-__device__ __forceinline__ void slice_pixel(const float *__restrict__ tab, int zs, int xl, float xf, float s0, float s1, float s2, int nb,
+typedef float f2 __attribute__((ext_vector_type(2)));   // v_pk_mul_f32 / v_pk_add_f32: two lerps per instruction, each lane
+                                                         // rounding exactly as the scalar operation does
+__device__ __forceinline__ f2 lerp2(f2 zero, f2 one, float w, float iw) { return zero * iw + one * w; }
+
+__device__ __forceinline__ void slice_pixel(const float *__restrict__ tab, int xs, int xl, float xf, float s0, float s1, float s2, int nb,
                                             float (&o)[3]) {
     const float val = clampf(((s0 + s1 * 2.0f) + s2) * 0.25f, 0.0f, 1.0f);   // :286-289 as folded, :459-460
     const float zv = val * (float)nb;
     const int zi = (int)zv;
     const float zf = zv - (float)zi;
-    const float4 *t0 = reinterpret_cast<const float4 *>(tab + zi * zs + xl * 12);
-    const float4 *t1 = reinterpret_cast<const float4 *>(tab + (zi + 1) * zs + xl * 12);
-    float a[24], b[24];
+    const float4 *t0 = reinterpret_cast<const float4 *>(tab + xl * xs + zi * 12);   // cell xl: planes zi, zi + 1 (24 floats in a row)
+    const float4 *t1 = reinterpret_cast<const float4 *>(tab + (xl + 1) * xs + zi * 12);
+    f2 a[12], b[12];                       // [cell xl: 0..5 | cell xl + 1: 6..11] x channel pairs, planes zi (a) and zi + 1 (b)
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const float4 u = t0[i], w = t1[i];
-        a[4 * i] = u.x, a[4 * i + 1] = u.y, a[4 * i + 2] = u.z, a[4 * i + 3] = u.w;
-        b[4 * i] = w.x, b[4 * i + 1] = w.y, b[4 * i + 2] = w.z, b[4 * i + 3] = w.w;
+    for (int i = 0; i < 3; i++) {
+        const float4 u0 = t0[i], u1 = t0[3 + i], w0 = t1[i], w1 = t1[3 + i];
+        a[2 * i] = f2{u0.x, u0.y}, a[2 * i + 1] = f2{u0.z, u0.w};
+        b[2 * i] = f2{u1.x, u1.y}, b[2 * i + 1] = f2{u1.z, u1.w};
+        a[6 + 2 * i] = f2{w0.x, w0.y}, a[6 + 2 * i + 1] = f2{w0.z, w0.w};
+        b[6 + 2 * i] = f2{w1.x, w1.y}, b[6 + 2 * i + 1] = f2{w1.z, w1.w};
     }
-    float m[12];
+    const float ixf = 1.0f - xf, izf = 1.0f - zf;
+    f2 m[6];
 #pragma unroll
-    for (int c = 0; c < 12; c++) m[c] = lerpf(lerpf(a[c], a[12 + c], xf), lerpf(b[c], b[12 + c], xf), zf);   // :452-455, :467-470
+    for (int i = 0; i < 6; i++) m[i] = lerp2(lerp2(a[i], a[6 + i], xf, ixf), lerp2(b[i], b[6 + i], xf, ixf), zf, izf);   // :452-455, :467-470
+    const f2 s01 = f2{s0, s1}, s2one = f2{s2, 1.0f};
 #pragma unroll
-    for (int c = 0; c < 3; c++) o[c] = clampf(m[4 * c] * s0 + m[4 * c + 1] * s1 + m[4 * c + 2] * s2 + m[4 * c + 3], 0.0f, 1.0f);
+    for (int c = 0; c < 3; c++) {
+        const f2 p = m[2 * c] * s01, q = m[2 * c + 1] * s2one;               // :473-477; m * 1 is m
+        o[c] = clampf(p.x + p.y + q.x + q.y, 0.0f, 1.0f);
+    }
 }
 
-// slice_loc: element (ox0, oy0, 0); out likewise.  grid: (ceil(ow / TW), (ncy - 1) * nsub)
+// slice_loc: element (ox0, oy0, 0); out likewise.  grid: (ceil(ow / TW), (ncy - 1) * nsub).  LDS tables are laid out like
+// `line` itself, [cell][z][12]: filling them is a straight copy, the per-row y interpolation needs no index arithmetic, and
+// a pixel's two planes of a cell are 24 consecutive floats; lanes with different z are 3 z 16-byte groups apart, which
+// never collide (3 is odd).
 __global__ __launch_bounds__(TW) void bgu_slice(const float *__restrict__ line, const float *__restrict__ sl, BGeom g, SGeom q,
                                                 float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *lin = lds;                       // [2][nz * zs]
-    float *tab = lds + 2 * g.nz * q.zs;     // [2][nz * zs], double buffered over rows
+    const int xs = g.nz * 12, tsz = q.nlc * xs;
+    float *lin = lds;                       // [2][nlc][nz][12]: the two grid rows this strip interpolates between
+    float *tab = lds + 2 * tsz;             // [2][nlc][nz][12]: interpolated_matrix_y of one image row, double buffered
     const int tid = threadIdx.x;
     const int ci = blockIdx.y / q.nsub, sub = blockIdx.y - ci * q.nsub;
     const int yi = g.cy0 + ci;
@@ -226,12 +248,13 @@ __global__ __launch_bounds__(TW) void bgu_slice(const float *__restrict__ line, 
     if (ya >= yb) return;
     const int xa = q.ox0 + blockIdx.x * TW, xn = min(TW, q.ox0 + q.ow - xa);
     const int xi_lo = (int)floorf((float)xa / (float)g.big);
-    const int tsz = g.nz * q.zs;
-    // the two grid rows of transforms this strip interpolates between, cells xi_lo .. xi_lo + nlc - 1 (clipped to the grid)
-    for (int it = tid; it < 2 * g.nz * q.nlc * 12; it += TW) {
-        const int c = it % 12, xl = (it / 12) % q.nlc, z = (it / (12 * q.nlc)) % g.nz, dy = it / (12 * q.nlc * g.nz);
-        const int cx = min(xi_lo + xl - g.cx0, g.ncx - 1);
-        lin[dy * tsz + z * q.zs + xl * 12 + c] = line[(((long)(ci + dy) * g.ncx + cx) * g.nz + z) * 12 + c];
+    {   // cells xi_lo .. xi_lo + nlc - 1, clipped to the grid (the clipped ones are never read)
+        const int cxl = xi_lo - g.cx0, n4 = min(q.nlc, g.ncx - cxl) * (xs / 4);
+        for (int dy = 0; dy < 2; dy++) {
+            const float4 *src = reinterpret_cast<const float4 *>(line + ((long)(ci + dy) * g.ncx + cxl) * xs);
+            float4 *dst = reinterpret_cast<float4 *>(lin + dy * tsz);
+            for (int it = tid; it < n4; it += TW) dst[it] = src[it];
+        }
     }
     const int x = xa + tid;
     float xf = (float)x / (float)g.big;                          // :449-451
@@ -244,20 +267,22 @@ __global__ __launch_bounds__(TW) void bgu_slice(const float *__restrict__ line, 
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
     if (live) s0 = sp[0], s1 = sp[q.s_sc], s2 = sp[2 * q.s_sc];
     __syncthreads();
+    const float4 *l0 = reinterpret_cast<const float4 *>(lin), *l1 = reinterpret_cast<const float4 *>(lin + tsz);
     for (int y = ya; y < yb; y++) {
         float yf = (float)y / (float)g.big;                      // :441-443
         yf = yf - (float)(int)floorf(yf);
+        const float iyf = 1.0f - yf;
         float *tb = tab + ((y - ya) & 1) * tsz;
-        for (int it = tid; it < g.nz * q.nlc * 12; it += TW) {   // interpolated_matrix_y for this image row (:444-447)
-            const int i = (it / (12 * q.nlc)) * q.zs + it % (12 * q.nlc);
-            tb[i] = lerpf(lin[i], lin[tsz + i], yf);
+        for (int it = tid; it < tsz / 4; it += TW) {             // interpolated_matrix_y for this image row (:444-447)
+            const float4 u = l0[it], w = l1[it];
+            reinterpret_cast<float4 *>(tb)[it] = float4{u.x * iyf + w.x * yf, u.y * iyf + w.y * yf, u.z * iyf + w.z * yf, u.w * iyf + w.w * yf};
         }
         float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;                   // next row's pixel, in flight across the barrier
         if (live && y + 1 < yb) n0 = sp[q.s_sy], n1 = sp[q.s_sy + q.s_sc], n2 = sp[q.s_sy + 2 * q.s_sc];
         __syncthreads();
         if (live) {
             float o[3];
-            slice_pixel(tb, q.zs, xl, xf, s0, s1, s2, g.nb, o);
+            slice_pixel(tb, xs, xl, xf, s0, s1, s2, g.nb, o);
             op[0] = o[0], op[q.o_sc] = o[1], op[2 * q.o_sc] = o[2];
         }
         s0 = n0, s1 = n1, s2 = n2;
@@ -357,8 +382,8 @@ extern "C" int bgu(float r_sigma, int32_t s_sigma, halide_buffer_t *splat_loc, h
         }
         // arguments the generator gives no meaning to (an empty reduction domain and a division by zero, :292, :441)
         if (s_sigma < 1) return report(uc, halide_error_code_requirement_failed, "bgu: s_sigma is %d but must be at least 1", s_sigma);
-        if (!(r_sigma > 0.0f) || !(1.0f / r_sigma <= 4096.0f)) {
-            return report(uc, halide_error_code_requirement_failed, "bgu: r_sigma is %g but must be in [1/4096, inf)", (double)r_sigma);
+        if (!(r_sigma > 0.0f) || !(1.0f / r_sigma <= 256.0f)) {   // a cell's histogram (22 floats per bin) stays in LDS
+            return report(uc, halide_error_code_requirement_failed, "bgu: r_sigma is %g but must be in [1/256, inf)", (double)r_sigma);
         }
     }
     DeviceCtx ctx;
@@ -397,7 +422,7 @@ extern "C" int bgu(float r_sigma, int32_t s_sigma, halide_buffer_t *splat_loc, h
     };
     const LowRes S = low(splat_loc), V = low(values);
     auto al = [](size_t n) { return (n + 63) & ~(size_t)63; };
-    const size_t n_hist = al((size_t)g.nhy * g.nhx * g.nhz * NC), n_line = al((size_t)g.ncy * g.ncx * g.nz * 12);
+    const size_t n_hist = al((size_t)g.nhy * g.nhx * g.nz * NC), n_line = al((size_t)g.ncy * g.ncx * g.nz * 12);
     if ((n_hist + n_line) * sizeof(float) > ((size_t)1 << 32)) {
         return report(uc, halide_error_code_buffer_allocation_too_large, "bgu: the grid needs %zu bytes", (n_hist + n_line) * sizeof(float));
     }
@@ -405,17 +430,16 @@ extern "C" int bgu(float r_sigma, int32_t s_sigma, halide_buffer_t *splat_loc, h
     if ((r = get_workspace(uc, ctx, (n_hist + n_line) * sizeof(float), &ws))) return r;
     float *hist = (float *)ws, *line = hist + n_hist;
     hipStream_t st = ctx.stream;
-    HLMI_LAUNCH(uc, "bgu_hist", st, bgu_hist, dim3(g.nhx, g.nhy), dim3(256), 0, S, V, g, hist);
-    HLMI_LAUNCH(uc, "bgu_fit", st, bgu_fit, dim3((g.ncx + XT - 1) / XT, g.ncy, g.nz), dim3(256), 0, hist, g, line);
+    HLMI_LAUNCH(uc, "bgu_hist", st, bgu_hist, dim3(g.nhx, g.nhy), dim3(256), (size_t)g.nhz * NC * sizeof(float), S, V, g, hist);
+    HLMI_LAUNCH(uc, "bgu_fit", st, bgu_fit, dim3((g.ncx + XT - 1) / XT, g.ncy, g.nz), dim3(512), 0, hist, g, line);
     SGeom q;
     q.ox0 = ox0, q.oy0 = oy0, q.ow = ow, q.oh = oh;
     q.nsub = (g.big + RB - 1) / RB;
     q.nlc = (TW - 1) / g.big + 3;
-    q.zs = q.nlc * 12 + ((q.nlc * 3) % 2 == 0 ? 4 : 0);   // an odd number of 16-byte groups
     q.s_sy = slice_loc->dim[1].stride, q.s_sc = slice_loc->dim[2].stride, q.o_sy = output->dim[1].stride, q.o_sc = output->dim[2].stride;
     const float *sl = dev_ptr<float>(slice_loc) + (long)(oy0 - slice_loc->dim[1].min) * q.s_sy + (ox0 - slice_loc->dim[0].min) +
                       (long)(0 - slice_loc->dim[2].min) * q.s_sc;
-    const size_t lds = (size_t)4 * g.nz * q.zs * sizeof(float);
+    const size_t lds = (size_t)4 * q.nlc * g.nz * 12 * sizeof(float);
     timing_note_bytes(24.0 * ow * oh);
     static const bool force_direct = getenv("HLMI_BGU_DIRECT") != nullptr;
     if (lds <= 64 * 1024 && !force_direct) {
