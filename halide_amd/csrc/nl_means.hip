@@ -126,19 +126,21 @@ __global__ __launch_bounds__(NT) void nlm_7x7(const float *__restrict__ in, long
                 float d[ROWS1 + 6];
 #pragma unroll
                 for (int i = 0; i < ROWS1 + 6; i++) {
-                    float dd = 0.0f;
+                    // the oracle's sums start from 0; 0 + x is x for every x but -0, and a square or a sum of squares is
+                    // never -0: the first term is taken as it is (18 of 254 VALU instructions per offset)
+                    float dd;
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
                         const float t = (HOIST ? u[i][c] : uu[i][c]) - sh[i][c];
-                        dd = dd + t * t;
+                        dd = c == 0 ? t * t : dd + t * t;
                     }
                     d[i] = dd;
                 }
 #pragma unroll
                 for (int o = 0; o < ROWS1; o++) {
-                    float sum = 0.0f;
+                    float sum = d[o];
 #pragma unroll
-                    for (int q = 0; q < 7; q++) sum = sum + d[o + q];
+                    for (int q = 1; q < 7; q++) sum = sum + d[o + q];
                     sbdy[(ROWS1 * g1 + o) * BWP + cx] = sum;
                 }
             }
@@ -157,9 +159,9 @@ __global__ __launch_bounds__(NT) void nlm_7x7(const float *__restrict__ in, long
 #pragma unroll
                 for (int j = 0; j < SEG; j++) {
                     if (j < npx) {
-                        float sum = 0.0f;
+                        float sum = bw[j];
 #pragma unroll
-                        for (int q = 0; q < 7; q++) sum = sum + bw[j + q];
+                        for (int q = 1; q < 7; q++) sum = sum + bw[j + q];
                         const float w = dev::fast_exp(sum * g.inv);
 #pragma unroll
                         for (int c = 0; c < 3; c++) acc[j][c] = acc[j][c] + w * sv[c][j];
