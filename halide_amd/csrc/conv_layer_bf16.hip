@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // through L1 / LDS than re-staging an im2col slice per tap; B streams from L2 into registers.
 // Positions q with x >= W or y >= H are not outputs (7 % of a 56x56 image): computed, never stored.
 // timing experiments (make VARIANT=_cabl1 EXTRA=-DHLMI_CONV_ABL=1): 1 = no output stores, 2 = no main loop, 3 = only the first
-// A window is loaded, 4 = only the first three taps' B fragments are loaded, 5 = no LDS reads of A after the first tap.  At configs[4]: 29.4 us as built, 28.5 / 9.8 / 27.2 / 24.0 / 29.7 us — the main loop is 19-20 us whatever the A loads
+// A window is loaded, 4 = only the first three taps' B fragments are loaded, 5 = every A fragment read from one LDS address, 6 = no LDS reads of A, 7 = neither A reads nor B loads (MFMAs only).  At configs[4]: 29.4 us as built, 28.5 / 9.8 / 27.2 / 24.0 / 29.7 us — the main loop is 19-20 us whatever the A loads
 // and the stores do, 14 us of it without any B traffic, against 7.7 us of MFMA time per SIMD.  (s_memrealtime stamps inside the tap loop made the kernel 6x slower and were removed.)
 #ifndef HLMI_CONV_ABL
 #define HLMI_CONV_ABL 0
@@ -286,14 +286,19 @@ void conv3x3_bf16_lin(const float *__restrict__ in, const uint16_t *__restrict__
         const uint16_t *pa = sA + (64 * wm + (lane & 31) + ky * Wp + kx) * PL + 8 * (lane >> 5);
 #pragma unroll
         for (int ks = 0; ks < KL / 16; ks++) {
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>((HLMI_CONV_ABL == 5 ? sA + (lane & 31) * PL : pa) + 16 * ks);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>((HLMI_CONV_ABL == 5 ? sA + (lane & 31) * PL : pa + 32 * PL) + 16 * ks);
+            bf16x8 a0, a1;
+            if (HLMI_CONV_ABL == 6 || HLMI_CONV_ABL == 7) {   // no LDS reads: whatever the B registers hold
+                a0 = bs[0][ks], a1 = bs[1][ks];
+            } else {
+                a0 = *reinterpret_cast<const bf16x8 *>((HLMI_CONV_ABL == 5 ? sA + (lane & 31) * PL : pa) + 16 * ks);
+                a1 = *reinterpret_cast<const bf16x8 *>((HLMI_CONV_ABL == 5 ? sA + (lane & 31) * PL : pa + 32 * PL) + 16 * ks);
+            }
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bs[0][ks], acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bs[1][ks], acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bs[0][ks], acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bs[1][ks], acc[1][1], 0, 0, 0);
         }
-        if (t + 3 < ntap && HLMI_CONV_ABL != 4) load_b(t + 3, bs);   // refill the stage just consumed
+        if (t + 3 < ntap && HLMI_CONV_ABL != 4 && HLMI_CONV_ABL != 7) load_b(t + 3, bs);   // refill the stage just consumed
     };
     load_a(0);
     load_b(0, bfr[0]);
