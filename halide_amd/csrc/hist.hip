@@ -3,9 +3,9 @@
 // `int hist(halide_buffer_t *input, halide_buffer_t *output)`, u8 [W,H,3] planar in and out (:9-10).
 //
 //   hist_count   luma histogram of the WHOLE input (:28-36).  Counts are integers — exact and order-free — so this is
-//                where wavefront reductions belong: every wave keeps a private 256-bin histogram in LDS (ds_add_u32 on
-//                its own copy: no cross-wave contention), the four copies of a workgroup are summed and added to the
-//                global histogram with one atomic per bin.  4 pixels per lane per step (aligned dword loads).
+//                where private copies belong: 32 copies of the 256-bin histogram per workgroup in LDS, one per lane
+//                modulo 32 (ds_add_u32 without bank or address collisions, see hist_count), summed per workgroup and
+//                added to the global histogram with one atomic per bin.  4 pixels per lane per step (aligned dword loads).
 //   hist_cdf     one wave: 256-bin inclusive prefix sum, 4 bins per lane, cross-lane scan with DPP row / wave shifts
 //                (__shfl_up): integer, exact
 //   hist_apply   pointwise: luma, Cr, Cb, eq = clamp(float(cdf[bin]) * 255 / (W H)), recolour, u8 — one rounding per
@@ -23,14 +23,19 @@ __device__ __forceinline__ float luma(uint8_t r, uint8_t g, uint8_t b) {
 }
 
 // in: channel 0 of the input's element (0, 0); W x H pixels.  VEC: rows start 4-byte aligned and W % 4 == 0
+// Private copies of the histogram keep the LDS atomics of a wave apart: 32 copies per workgroup, laid out [bin][copy] with
+// copy = lane % 32 — a lane's counter always sits in bank `copy`, whatever the bin, so the 64 ds_add_u32 of a wave instruction
+// never collide on a bank by more than two (lanes l and l + 32), and only those two can hit the same address.  With one
+// copy per wave a smooth image (neighbouring pixels in one bin) serialised all 64 lanes on one address.
+constexpr int HCOPY = 32;
 template<bool VEC>
 __global__ __launch_bounds__(256) void hist_count(const uint8_t *__restrict__ in, long in_sy, long in_sc, int W, int H,
                                                  int rows_per_block, unsigned *__restrict__ ghist) {
-    __shared__ unsigned wh[4][256];
-    const int tid = threadIdx.x, wave = tid >> 6;
-    for (int i = tid; i < 4 * 256; i += 256) (&wh[0][0])[i] = 0;
+    __shared__ unsigned wh[256 * HCOPY];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 256 * HCOPY; i += 256) wh[i] = 0;
     __syncthreads();
-    unsigned *mine = wh[wave];
+    unsigned *mine = wh + (tid & (HCOPY - 1));
     const int y0 = blockIdx.x * rows_per_block, y1 = min(y0 + rows_per_block, H);
     for (int y = y0; y < y1; y++) {
         const uint8_t *r0 = in + (long)y * in_sy, *r1 = r0 + in_sc, *r2 = r0 + 2 * in_sc;
@@ -41,15 +46,17 @@ __global__ __launch_bounds__(256) void hist_count(const uint8_t *__restrict__ in
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const float Y = luma((uint8_t)(a >> (8 * k)), (uint8_t)(b >> (8 * k)), (uint8_t)(c >> (8 * k)));
-                    atomicAdd(&mine[(int)dev::clampf(Y, 0.0f, 255.0f)], 1u);
+                    atomicAdd(&mine[(int)dev::clampf(Y, 0.0f, 255.0f) * HCOPY], 1u);
                 }
             }
         } else {
-            for (int x = tid; x < W; x += 256) atomicAdd(&mine[(int)dev::clampf(luma(r0[x], r1[x], r2[x]), 0.0f, 255.0f)], 1u);
+            for (int x = tid; x < W; x += 256) atomicAdd(&mine[(int)dev::clampf(luma(r0[x], r1[x], r2[x]), 0.0f, 255.0f) * HCOPY], 1u);
         }
     }
     __syncthreads();
-    const unsigned s = wh[0][tid] + wh[1][tid] + wh[2][tid] + wh[3][tid];
+    unsigned s = 0;                                    // thread = bin; the copies are read rotated so that the 64 lanes of a
+#pragma unroll 8                                       // wave read 32 different banks
+    for (int k = 0; k < HCOPY; k++) s += wh[tid * HCOPY + ((k + tid) & (HCOPY - 1))];
     if (s) atomicAdd(&ghist[tid], s);
 }
 
