@@ -121,6 +121,12 @@ uint64_t buffer_version(const halide_buffer_t *buf);
 // compute units a launch on `stream` can use (a CU-partitioned stream of halide_hip_partition_stream: its share)
 int stream_cu_count(int device, hipStream_t stream);
 
+// The stream to name in hipEventRecord / hipStreamWaitEvent for work enqueued on `s`.  hipStreamLegacy (the explicit handle of
+// the NULL stream, which callers on torch's default stream pass to halide_hip_set_stream) launches kernels fine, but an event
+// RECORDED on it crashes the next hipStreamWaitEvent on that event inside the HIP runtime (ROCm 7.2; scripts/
+// legacy_event_probe.py) — the NULL handle names the same stream and does not.
+inline hipStream_t event_stream(hipStream_t s) { return s == hipStreamLegacy ? nullptr : s; }
+
 template<typename T>
 inline T *dev_ptr(const halide_buffer_t *b) { return reinterpret_cast<T *>((uintptr_t)b->device); }
 

@@ -45,12 +45,12 @@ extern "C" int hlmi_membench(size_t bytes, int iters, int blocks, double *out_gb
     (void)hipEventCreate(&e1);
     for (int which = 0; which < 3; which++) {
         for (int it = -2; it < iters; it++) {   // two untimed launches first
-            if (it == 0) (void)hipEventRecord(e0, ctx.stream);
+            if (it == 0) (void)hipEventRecord(e0, event_stream(ctx.stream));
             if (which == 0) hipLaunchKernelGGL(mb_copy, dim3(blocks), dim3(256), 0, ctx.stream, (const f32x4 *)a, (f32x4 *)b, n);
             if (which == 1) hipLaunchKernelGGL(mb_read, dim3(blocks), dim3(256), 0, ctx.stream, (const f32x4 *)a, (float *)b, n);
             if (which == 2) hipLaunchKernelGGL(mb_write, dim3(blocks), dim3(256), 0, ctx.stream, (f32x4 *)b, n);
         }
-        (void)hipEventRecord(e1, ctx.stream);
+        (void)hipEventRecord(e1, event_stream(ctx.stream));
         (void)hipEventSynchronize(e1);
         float ms = 0;
         (void)hipEventElapsedTime(&ms, e0, e1);

@@ -389,7 +389,7 @@ static void order_after_locked(int dev, hipStream_t consumer, hipStream_t produc
         (void)hipGetLastError();
         return;
     }
-    if (hipEventRecord(ev, producer) != hipSuccess || hipStreamWaitEvent(consumer, ev, 0) != hipSuccess) (void)hipGetLastError();
+    if (hipEventRecord(ev, event_stream(producer)) != hipSuccess || hipStreamWaitEvent(event_stream(consumer), ev, 0) != hipSuccess) (void)hipGetLastError();
 }
 
 static void bury_locked(DeviceState &st, hipEvent_t ev) {
@@ -480,7 +480,7 @@ static int dev_alloc_locked(void *uc, int dev, size_t bytes, hipStream_t for_str
         Cached c = pick->second;
         st.cache.erase(pick);
         if (c.done) {
-            if (c.stream != for_stream && hipStreamWaitEvent(for_stream, c.done, 0) != hipSuccess) {
+            if (c.stream != for_stream && hipStreamWaitEvent(event_stream(for_stream), c.done, 0) != hipSuccess) {
                 (void)hipGetLastError();
                 (void)hipEventSynchronize(c.done);
             }
@@ -515,7 +515,7 @@ static void dev_free_locked(int dev, void *base, const Owned &rec) {
         c.ptr = base, c.stream = rec.last_stream;
         if (rec.last_stream) {
             if (hipEventCreateWithFlags(&c.done, hipEventDisableTiming) != hipSuccess ||
-                hipEventRecord(c.done, rec.last_stream) != hipSuccess) {
+                hipEventRecord(c.done, event_stream(rec.last_stream)) != hipSuccess) {
                 // the stream is gone (destroyed by its owner): nothing of ours can still be pending on it
                 (void)hipGetLastError();
                 if (c.done) (void)hipEventDestroy(c.done);
@@ -925,14 +925,14 @@ void timing_begin(const char *name, hipStream_t s) {
     t.alg_bytes = t_next_alg_bytes;
     t_next_alg_bytes = 0;
     if (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess) return;
-    (void)hipEventRecord(t.e0, s);
+    (void)hipEventRecord(t.e0, event_stream(s));
     t_pending_e1 = t.e1;
     std::lock_guard<std::mutex> lock(g_timing_mu);
     g_launches.push_back(t);
 }
 
 void timing_end(hipStream_t s) {
-    if (t_pending_e1) (void)hipEventRecord(t_pending_e1, s);
+    if (t_pending_e1) (void)hipEventRecord(t_pending_e1, event_stream(s));
     t_pending_e1 = nullptr;
 }
 

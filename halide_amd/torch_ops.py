@@ -167,6 +167,55 @@ def camera_pipe(input: torch.Tensor, matrix_3200: torch.Tensor, matrix_7000: tor
     return out
 
 
+@torch.library.custom_op("hlmi::harris", mutates_args=())
+def harris(input: torch.Tensor) -> torch.Tensor:
+    """apps/harris: (3, H, W) float32 -> (H - 6, W - 6) float32 corner response of the interior (the driver's region:
+    output origin (3, 3) in the input's frame, apps/harris/filter.cpp:22-28)."""
+    c, h, w = input.shape
+    out = torch.empty((h - 6, w - 6), dtype=torch.float32, device=input.device)
+    with _Wrapped(input, out) as (a, o):
+        o.set_min(3, 3)
+        hl.harris(a, o)
+    return out
+
+
+@torch.library.custom_op("hlmi::interpolate", mutates_args=())
+def interpolate(input: torch.Tensor) -> torch.Tensor:
+    """apps/interpolate: (4, H, W) float32 RGBA -> (3, H, W) float32, alpha-weighted pull-push."""
+    out = torch.empty((3,) + tuple(input.shape[1:]), dtype=torch.float32, device=input.device)
+    with _Wrapped(input, out) as (a, o):
+        hl.interpolate(a, o)
+    return out
+
+
+@torch.library.custom_op("hlmi::iir_blur", mutates_args=())
+def iir_blur(input: torch.Tensor, alpha: float) -> torch.Tensor:
+    """apps/iir_blur: (C, H, W) float32 -> same, first-order IIR low pass down / up the columns, then along the rows."""
+    out = torch.empty_like(input)
+    with _Wrapped(input, out) as (a, o):
+        hl.iir_blur(a, alpha, o)
+    return out
+
+
+@torch.library.custom_op("hlmi::lens_blur", mutates_args=())
+def lens_blur(left_im: torch.Tensor, right_im: torch.Tensor, slices: int, focus_depth: int, blur_radius_scale: float,
+              aperture_samples: int) -> torch.Tensor:
+    """apps/lens_blur: two (3, H, W) uint8 views -> (3, H, W) float32 (depth from stereo, depth-dependent bokeh)."""
+    out = torch.empty(tuple(left_im.shape), dtype=torch.float32, device=left_im.device)
+    with _Wrapped(left_im, right_im, out) as (a, b, o):
+        hl.lens_blur(a, b, slices, focus_depth, blur_radius_scale, aperture_samples, o)
+    return out
+
+
+@torch.library.custom_op("hlmi::bgu", mutates_args=())
+def bgu(r_sigma: float, s_sigma: int, splat_loc: torch.Tensor, values: torch.Tensor, slice_loc: torch.Tensor) -> torch.Tensor:
+    """apps/bgu: low-res (3, h, w) float32 pair splat_loc -> values, applied to the full-res (3, H, W) slice_loc."""
+    out = torch.empty_like(slice_loc)
+    with _Wrapped(splat_loc, values, slice_loc, out) as (a, b, c, o):
+        hl.bgu(r_sigma, s_sigma, a, b, c, o)
+    return out
+
+
 # shape functions for torch.compile / meta tensors
 @local_laplacian.register_fake
 def _(input, levels, alpha, beta):
@@ -186,3 +235,28 @@ def _(input, patch_size, search_area, sigma):
 @stencil_chain.register_fake
 def _(input):
     return torch.empty_like(input)
+
+
+@harris.register_fake
+def _(input):
+    return input.new_empty((input.shape[1] - 6, input.shape[2] - 6))
+
+
+@interpolate.register_fake
+def _(input):
+    return input.new_empty((3,) + tuple(input.shape[1:]))
+
+
+@iir_blur.register_fake
+def _(input, alpha):
+    return torch.empty_like(input)
+
+
+@lens_blur.register_fake
+def _(left_im, right_im, slices, focus_depth, blur_radius_scale, aperture_samples):
+    return left_im.new_empty(tuple(left_im.shape), dtype=torch.float32)
+
+
+@bgu.register_fake
+def _(r_sigma, s_sigma, splat_loc, values, slice_loc):
+    return torch.empty_like(slice_loc)
