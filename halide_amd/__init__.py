@@ -27,7 +27,43 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
         "(or `make -C halide_amd/csrc`). halide_amd has no pure-Python / CPU fallback.")
 
+
+
+def _preload_torch_hip_runtime() -> str | None:
+    """One HIP runtime per process.  The torch-ROCm wheel bundles its own libamdhip64.so (same SONAME as the system's): a
+    process that loads libhlmi.so first and torch afterwards ends up with TWO runtimes — the system's under libhlmi.so and
+    the bundled one under torch — whose streams and events are not interchangeable (torch streams handed to the library,
+    tests/test_torch_ops.py, then belong to the other runtime: std::bad_variant_access or a segfault inside HIP).  When
+    torch is importable its copy is therefore loaded FIRST, without importing torch, and libhlmi.so binds to it exactly as
+    it does when the caller imported torch first.  HLMI_SYSTEM_HIP=1 keeps the system runtime (torch-free processes)."""
+    if os.environ.get("HLMI_SYSTEM_HIP"):
+        return None
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except Exception:  # noqa: BLE001
+        return None
+    if not spec or not spec.submodule_search_locations:
+        return None
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        return None
+    return path
+
+
+HIP_RUNTIME_PRELOADED = _preload_torch_hip_runtime()
 lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+
+def hip_runtime() -> C.CDLL:
+    """The HIP runtime libhlmi.so is bound to (global symbol scope of the process): callers that create streams or events
+    of their own for the library must use THIS runtime, not whatever dlopen("libamdhip64.so") finds."""
+    return C.CDLL(None)
+
 
 
 # ---------------------------------------------------------------------------------------------------

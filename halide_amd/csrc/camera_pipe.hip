@@ -504,7 +504,7 @@ extern "C" int camera_pipe(halide_buffer_t *input, halide_buffer_t *matrix_3200,
         for (auto &e : g_si) {
             if (e.valid && memcmp(&e.key, &key, sizeof key) == 0) {
                 e.used = ++g_si_clock;
-                if (e.stream != st) HLMI_HIP(uc, hipStreamWaitEvent(event_stream(st), e.ready, 0));
+                if (e.stream != st) HLMI_HIP(uc, wait_done(st, e.ready));
                 setup = e.dev, have_setup = true;
                 break;
             }
@@ -533,7 +533,7 @@ extern "C" int camera_pipe(halide_buffer_t *input, halide_buffer_t *matrix_3200,
         HLMI_LAUNCH(uc, "cp_setup", st, cp_setup, dim3(1), dim3(1024), 0, m3, (long)matrix_3200->dim[1].stride, m7,
                     (long)matrix_7000->dim[1].stride, color_temp, gamma, contrast, sharpen_strength, blackLevel, whiteLevel, setup);
         if (slot) {
-            HLMI_HIP(uc, hipEventRecord(slot->ready, event_stream(st)));
+            HLMI_HIP(uc, record_done(slot->ready, st));
             slot->valid = true;
             si_lock.unlock();
         }

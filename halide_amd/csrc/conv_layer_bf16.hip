@@ -377,7 +377,7 @@ struct FilterFill {
     std::unique_lock<std::mutex> lock;
     FilterImage *slot = nullptr;
     void done(hipStream_t s) {
-        if (slot) (void)hipEventRecord(slot->ready, event_stream(s));
+        if (slot) (void)record_done(slot->ready, s);
         slot = nullptr;
         if (lock.owns_lock()) lock.unlock();
     }
@@ -395,7 +395,7 @@ int filter_image(void *uc, const DeviceCtx &ctx, const halide_buffer_t *filter, 
         for (auto &e : g_fi) {
             if (e.wb && e.device == ctx.device && e.handle == filter->device && e.version == version && e.lin == lin && e.bytes == bytes) {
                 e.used = ++g_fi_clock;
-                if (e.stream != ctx.stream && e.ready) HLMI_HIP(uc, hipStreamWaitEvent(event_stream(ctx.stream), e.ready, 0));
+                if (e.stream != ctx.stream && e.ready) HLMI_HIP(uc, wait_done(ctx.stream, e.ready));
                 *wb = e.wb;
                 return 0;
             }

@@ -121,10 +121,24 @@ uint64_t buffer_version(const halide_buffer_t *buf);
 // compute units a launch on `stream` can use (a CU-partitioned stream of halide_hip_partition_stream: its share)
 int stream_cu_count(int device, hipStream_t stream);
 
-// The stream to name in hipEventRecord / hipStreamWaitEvent for work enqueued on `s`.  hipStreamLegacy (the explicit handle of
-// the NULL stream, which callers on torch's default stream pass to halide_hip_set_stream) launches kernels fine, but an event
-// RECORDED on it crashes the next hipStreamWaitEvent on that event inside the HIP runtime (ROCm 7.2; scripts/
-// legacy_event_probe.py) — the NULL handle names the same stream and does not.
+// ---- events across streams.  The special stream handles (NULL, hipStreamLegacy — which callers on torch's default stream pass
+// to halide_hip_set_stream — and hipStreamPerThread) launch kernels fine, but they are not safe partners for events in ROCm
+// 7.2: an event RECORDED on hipStreamLegacy crashes the next hipStreamWaitEvent on it (scripts/legacy_event_probe.py), and
+// one recorded on the NULL handle and waited for from several host threads at once threw std::bad_variant_access inside the
+// runtime (tests/test_torch_ops.py followed by tests/test_threads.py).  So no event ever names a special stream: work on one
+// is waited for on the host, which leaves the event in its "nothing pending" state.
+inline bool stream_is_special(hipStream_t s) { return s == nullptr || s == hipStreamLegacy || s == hipStreamPerThread; }
+// "everything enqueued on `producer` so far" as an event other streams can wait for
+inline hipError_t record_done(hipEvent_t ev, hipStream_t producer) {
+    if (stream_is_special(producer)) return hipStreamSynchronize(producer == hipStreamLegacy ? nullptr : producer);
+    return hipEventRecord(ev, producer);
+}
+// whatever is enqueued on `consumer` from now on happens after `ev`
+inline hipError_t wait_done(hipStream_t consumer, hipEvent_t ev) {
+    if (stream_is_special(consumer)) return hipEventSynchronize(ev);
+    return hipStreamWaitEvent(consumer, ev, 0);
+}
+// timing events only (never waited for by a stream): hipStreamLegacy is the NULL stream
 inline hipStream_t event_stream(hipStream_t s) { return s == hipStreamLegacy ? nullptr : s; }
 
 template<typename T>

@@ -1696,7 +1696,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         }
         if (hit) {
             hit->used = ++g_lut_clock;
-            if (hit->stream != st) HLMI_HIP(uc, hipStreamWaitEvent(event_stream(st), hit->ready, 0));
+            if (hit->stream != st) HLMI_HIP(uc, wait_done(st, hit->ready));
             lut = hit->dev;
         } else {
             for (auto &e : g_lut) {
@@ -1714,7 +1714,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             slot->device = ctx.device, slot->levels = levels, slot->alpha_bits = abits, slot->stream = st, slot->used = ++g_lut_clock;
             lut = slot->dev;
             HLMI_LAUNCH(uc, "ll_remap_lut", st, ll_remap_lut, dim3((nlut + 255) / 256), dim3(256), 0, lut, gm.half, alpha);
-            HLMI_HIP(uc, hipEventRecord(slot->ready, event_stream(st)));
+            HLMI_HIP(uc, record_done(slot->ready, st));
             slot->valid = true;
         }
     } else {

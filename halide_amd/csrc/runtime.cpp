@@ -389,7 +389,7 @@ static void order_after_locked(int dev, hipStream_t consumer, hipStream_t produc
         (void)hipGetLastError();
         return;
     }
-    if (hipEventRecord(ev, event_stream(producer)) != hipSuccess || hipStreamWaitEvent(event_stream(consumer), ev, 0) != hipSuccess) (void)hipGetLastError();
+    if (record_done(ev, producer) != hipSuccess || wait_done(consumer, ev) != hipSuccess) (void)hipGetLastError();
 }
 
 static void bury_locked(DeviceState &st, hipEvent_t ev) {
@@ -480,7 +480,7 @@ static int dev_alloc_locked(void *uc, int dev, size_t bytes, hipStream_t for_str
         Cached c = pick->second;
         st.cache.erase(pick);
         if (c.done) {
-            if (c.stream != for_stream && hipStreamWaitEvent(event_stream(for_stream), c.done, 0) != hipSuccess) {
+            if (c.stream != for_stream && wait_done(for_stream, c.done) != hipSuccess) {
                 (void)hipGetLastError();
                 (void)hipEventSynchronize(c.done);
             }
@@ -515,7 +515,7 @@ static void dev_free_locked(int dev, void *base, const Owned &rec) {
         c.ptr = base, c.stream = rec.last_stream;
         if (rec.last_stream) {
             if (hipEventCreateWithFlags(&c.done, hipEventDisableTiming) != hipSuccess ||
-                hipEventRecord(c.done, event_stream(rec.last_stream)) != hipSuccess) {
+                record_done(c.done, rec.last_stream) != hipSuccess) {
                 // the stream is gone (destroyed by its owner): nothing of ours can still be pending on it
                 (void)hipGetLastError();
                 if (c.done) (void)hipEventDestroy(c.done);

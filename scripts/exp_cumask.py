@@ -11,7 +11,7 @@ import torch
 import halide_amd as hl
 import bench
 
-hip = C.CDLL("libamdhip64.so")
+hip = hl.hip_runtime()   # the runtime libhlmi.so is bound to
 
 
 def masked_stream(bits):

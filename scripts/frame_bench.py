@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import halide_amd as hl
 import bench
 
-hip = C.CDLL("libamdhip64.so")
+hip = hl.hip_runtime()   # the runtime libhlmi.so is bound to
 nframes = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 nparts = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 fr = [bench.synth_frame(i) for i in range(nframes)]

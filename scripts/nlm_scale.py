@@ -9,7 +9,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import halide_amd as hl
 
-hip = C.CDLL("libamdhip64.so")
+hip = hl.hip_runtime()   # the runtime libhlmi.so is bound to
 rng = np.random.default_rng(0)
 for tx, ty in [(1, 1), (4, 4), (16, 8), (16, 16), (16, 17), (16, 24), (16, 32), (32, 24), (34, 17), (32, 32)]:
     w, h = 58 * tx, 64 * ty

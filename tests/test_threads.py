@@ -16,7 +16,7 @@ def test_concurrent_calls_from_host_threads(hl, oracle, own_streams):
     # (the image pages in for minutes) plus the oracle, not the library: scripts/thread_diag.py times the same 4-thread
     # loop at 20 ms.  The caller-owned streams are therefore made with the HIP runtime directly, not through torch.
     import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
+    hip = hl.hip_runtime()   # the runtime the library is bound to (not dlopen by name: torch bundles another copy)
     rng = np.random.default_rng(7)
     frames = [rng.integers(0, 65536, (3, 200 + 16 * i, 320), dtype=np.uint16) for i in range(4)]
     gray = [rng.random((180, 250 + 8 * i), dtype=np.float32) for i in range(4)]
