@@ -211,13 +211,69 @@ def case_depthwise_separable_conv(rng):
 CASES = {k[5:]: v for k, v in list(globals().items()) if k.startswith("case_")}
 
 
+def stress(args, only):
+    """Host threads calling different pipelines at once: the caches (remap tables, filter images, camera set-up), the
+    allocation cache and the per-stream arenas under contention.  Results must still be the oracle's."""
+    import threading
+    names = [n for n in CASES if not only or n in only]
+    hip = hl.hip_runtime()
+    log, lock = [], threading.Lock()
+    counts = {n: [0, 0, 0] for n in names}
+    t_end = time.time() + args.seconds
+
+    def worker(i):
+        rng = np.random.default_rng(args.seed * 7919 + i)
+        stream = None
+        if i % 2 == 1:
+            import ctypes
+            stream = ctypes.c_void_p()
+            assert hip.hipStreamCreateWithFlags(ctypes.byref(stream), 1) == 0
+            hl.set_stream(stream.value)
+        while time.time() < t_end:
+            name = names[int(rng.integers(0, len(names)))]
+            try:
+                desc, ok = CASES[name](rng)
+                with lock:
+                    counts[name][0] += 1
+                    if not ok:
+                        counts[name][1] += 1
+                        log.append(f"thread {i}: {name}: MISMATCH {desc}")
+            except Exception as e:  # noqa: BLE001
+                with lock:
+                    counts[name][0] += 1
+                    counts[name][2] += 1
+                    log.append(f"thread {i}: {name}: EXCEPTION {type(e).__name__}: {str(e)[:200]}")
+        if stream is not None:
+            hl.set_stream(None)
+            hip.hipStreamSynchronize(stream)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(args.threads)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for line in log[:20]:
+        print("  " + line)
+    bad = 0
+    for n in names:
+        c = counts[n]
+        bad += c[1] + c[2]
+        print(f"{n}: {c[0]} cases, {c[1]} mismatches, {c[2]} exceptions")
+    print(f"STRESS ({args.threads} threads) " + ("CLEAN" if bad == 0 else f"FOUND {bad}"))
+    return 0 if bad == 0 else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=20.0, help="time budget per pipeline")
     ap.add_argument("--only", default="")
+    ap.add_argument("--threads", type=int, default=1, help="> 1: concurrency stress — that many host threads draw random cases of ALL "
+                    "pipelines for --seconds in total, every second thread on a stream of its own")
     args = ap.parse_args()
     only = [s for s in args.only.split(",") if s]
+    if args.threads > 1:
+        return stress(args, only)
     bad = 0
     for name, fn in CASES.items():
         if only and name not in only:
