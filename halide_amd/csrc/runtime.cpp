@@ -289,6 +289,7 @@ struct DeviceState {
     std::map<hipStream_t, Arena> arenas;   // scratch per stream
     std::map<uint64_t, Owned> owned;       // base address -> record (ordered: crops resolve to the containing allocation)
     std::multimap<size_t, Cached> cache;   // free allocations kept for reuse
+    size_t cache_bytes = 0;                // their total (bounded: cache_limit())
     hipEvent_t ring[64] = {};              // short-lived ordering events (record + wait back to back)
     unsigned ring_next = 0;
     std::vector<hipEvent_t> graveyard;     // cache events whose wait has been enqueued; destroyed lazily
@@ -478,6 +479,7 @@ static int dev_alloc_locked(void *uc, int dev, size_t bytes, hipStream_t for_str
     }
     if (pick != range.second) {
         Cached c = pick->second;
+        st.cache_bytes -= min(st.cache_bytes, pick->first);
         st.cache.erase(pick);
         if (c.done) {
             if (c.stream != for_stream && wait_done(for_stream, c.done) != hipSuccess) {
@@ -498,6 +500,7 @@ static int dev_alloc_locked(void *uc, int dev, size_t bytes, hipStream_t for_str
             if (kv.second.done) (void)hipEventDestroy(kv.second.done);
         }
         st.cache.clear();
+        st.cache_bytes = 0;
         e = hipMalloc(out, bytes ? bytes : 1);
     }
     if (e != hipSuccess) {
@@ -506,6 +509,16 @@ static int dev_alloc_locked(void *uc, int dev, size_t bytes, hipStream_t for_str
                       hipGetErrorString(e));
     }
     return 0;
+}
+
+// bytes of freed allocations kept for reuse per device: HLMI_ALLOC_CACHE_MB, default 16 GiB (of 288)
+static size_t cache_limit() {
+    static const size_t lim = [] {
+        const char *e = getenv("HLMI_ALLOC_CACHE_MB");
+        const long mb = (e && *e) ? atol(e) : 16384;
+        return (size_t)(mb < 0 ? 0 : mb) << 20;
+    }();
+    return lim;
 }
 
 static void dev_free_locked(int dev, void *base, const Owned &rec) {
@@ -523,6 +536,19 @@ static void dev_free_locked(int dev, void *base, const Owned &rec) {
             }
         }
         st.cache.emplace(rec.bytes, c);
+        st.cache_bytes += rec.bytes;
+        // The reference's pool (src/runtime/cuda.cpp, halide_reuse_device_allocations) is unbounded; a caller that never
+        // repeats a size would make this one hoard the device.  Beyond the limit the largest blocks go back first.
+        while (st.cache_bytes > cache_limit() && !st.cache.empty()) {
+            auto big = std::prev(st.cache.end());
+            if (big->second.done) {
+                (void)hipEventSynchronize(big->second.done);
+                (void)hipEventDestroy(big->second.done);
+            }
+            (void)hipFree(big->second.ptr);
+            st.cache_bytes -= min(st.cache_bytes, big->first);
+            st.cache.erase(big);
+        }
     } else {
         (void)hipFree(base);
     }
@@ -534,6 +560,7 @@ static void purge_cache_locked(DeviceState &st) {
         if (kv.second.done) (void)hipEventDestroy(kv.second.done);
     }
     st.cache.clear();
+    st.cache_bytes = 0;
     for (hipEvent_t ev : st.graveyard) (void)hipEventDestroy(ev);
     st.graveyard.clear();
     (void)hipGetLastError();
