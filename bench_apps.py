@@ -238,12 +238,13 @@ def main():
         o = hl.Buffer(np.zeros((3, H, W), np.float32))
         call = lambda: hl.lens_blur(a, b, 32, 13, 0.5, 32, o)
         t = timed(call, o, 5)
-        # traffic of the straightforward decomposition: the 2 x 32-plane level 0 of the push pyramid written once and read twice
-        # (down, depth), 4/3 of that again for the coarser push + pull levels: ~ (3 + 4/3) * 256 B per pixel
-        bytes_px = (3.0 + 4.0 / 3.0) * 2 * 32 * 4
+        # traffic of the straightforward decomposition: the 33-plane level 0 of the push pyramid (32 cost planes + the one
+        # confidence plane the generator's 32 copies collapse to) written once and read twice (down, depth), 4/3 of that
+        # again for the coarser push + pull levels: ~ (3 + 4/3) * 132 B per pixel
+        bytes_px = (3.0 + 4.0 / 3.0) * 33 * 4
         emit("lens_blur", "apps/lens_blur 32 slices, 32 aperture samples, u8 768x1280x3 stereo pair -> f32", t, W * H, "hbm",
              bytes_px * W * H / t / 1e9, HBM_PEAK_GBS, "GB/s", {"alg_bytes": bytes_px * W * H, "kernels_ms": kernels(call, o),
-                                                              "note": "coverage pipeline: one thread per element, untuned"})
+                                                              "note": "one thread per element except the LDS-tiled cost and downsample stages"})
 
     # ---- bgu at the generator's estimates (bgu_generator.cpp:674-687): 192x320 low-res pair, 1536x2560 full-res image
     if not only or "bgu" in only:

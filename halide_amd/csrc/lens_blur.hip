@@ -17,7 +17,8 @@
 // are 0 and 1, the definition tag is a compile-time counter of the reference's compiler that cannot be observed here —
 // it defaults to the count derived in the oracle's header (71) and is settable: hlmi_lens_blur_set_random_tag().
 //
-// Layout: push[i] / pull[i] are float [slices][2][box_h][box_w] (x fastest); nothing is tiled or fused beyond lb_depth:
+// Layout: push[i] / pull[i] are float [slices + 1][box_h][box_w] (x fastest; plane `slices` = the confidence, see at());
+// nothing is tiled or fused beyond lb_depth:
 // this pipeline is here for coverage of the boundary (the reference's driver runs unmodified), not tuned.
 #include "hlmi_device_math.h"
 #include "hlmi_internal.h"
@@ -43,44 +44,52 @@ struct LBGeom {
     float scale, fslices;
 };
 
-__device__ __forceinline__ size_t at(const Box &b, int slices_unused, int z, int c, int x, int y) {
-    return (((size_t)z * 2 + c) * b.h + (y - b.y0)) * b.w + (x - b.x0);
+// plane of (z, c): c = 0 (cost x confidence) has one plane per slice, c = 1 (the confidence itself) does not depend on z at
+// any level — the generator carries `slices` identical copies of it through both pyramids (:56-71) — and is kept ONCE, as
+// plane `slices`: half the planes, half the traffic of every stage up to the depth map.
+__device__ __forceinline__ size_t at(const Box &b, int slices, int z, int c, int x, int y) {
+    return ((size_t)(c ? slices : z) * b.h + (y - b.y0)) * b.w + (x - b.x0);
 }
 
-// cost(x, y, z) (:30-39): integer-valued float
-__device__ __forceinline__ float cost_at(const uint8_t *__restrict__ L, const uint8_t *__restrict__ Rr, const LBGeom &g, int x, int y,
-                                         int z) {
-    const long lo = (long)(dev::clampi(y, g.ly0, g.ly1) - g.ly0) * g.l_sy + (dev::clampi(x, g.lx0, g.lx1) - g.lx0);
-    const long ro = (long)(dev::clampi(y, g.ry0, g.ry1) - g.ry0) * g.r_sy;
-    const long r0 = ro + (dev::clampi(x + 2 * z, g.rx0, g.rx1) - g.rx0), r1 = ro + (dev::clampi(x + 2 * z + 1, g.rx0, g.rx1) - g.rx0);
-    float cz = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const int l = L[lo + g.l_c[c]], a = Rr[r0 + g.r_c[c]], b = Rr[r1 + g.r_c[c]];
-        const int d0 = l > a ? l - a : a - l, d1 = l > b ? l - b : b - l;
-        const float d = (float)min(d0, d1);
-        cz = (c == 0) ? d * d : cz + d * d;
-    }
-    return cz;
-}
-
+// One workgroup = 256 consecutive pixels of a row of E.  Every pixel compares itself with the 2 * slices right-image pixels
+// to its right (:33-36), so neighbours share almost all of them: the row segment [x0, x0 + 256 + 2 slices) of the (clamped)
+// right image is staged in LDS once and the left pixel sits in registers — instead of 9 clamped byte loads per (pixel, slice),
+// twice (the costs are needed again after their variance is known).
+constexpr int LB_MAXS = 64;   // generator :14: slices <= 64
 __global__ __launch_bounds__(256) void lb_cost(const uint8_t *__restrict__ L, const uint8_t *__restrict__ Rr, LBGeom g, Box E,
                                               float *__restrict__ push0) {
-    const int xi = blockIdx.x * 256 + threadIdx.x, yi = blockIdx.y;
-    if (xi >= E.w) return;
+    __shared__ uint8_t sr[3][256 + 2 * LB_MAXS];
+    const int tid = threadIdx.x, xi = blockIdx.x * 256 + tid, yi = blockIdx.y;
     const int x = E.x0 + xi, y = E.y0 + yi;
+    {
+        const long ro = (long)(dev::clampi(y, g.ry0, g.ry1) - g.ry0) * g.r_sy;
+        const int xb = E.x0 + blockIdx.x * 256;
+        for (int i = tid; i < 256 + 2 * g.slices; i += 256) {
+            const long o = ro + (dev::clampi(xb + i, g.rx0, g.rx1) - g.rx0);
+#pragma unroll
+            for (int c = 0; c < 3; c++) sr[c][i] = Rr[o + g.r_c[c]];
+        }
+    }
+    __syncthreads();
+    if (xi >= E.w) return;
+    const long lo = (long)(dev::clampi(y, g.ly0, g.ly1) - g.ly0) * g.l_sy + (dev::clampi(x, g.lx0, g.lx1) - g.lx0);
+    const int l0 = L[lo + g.l_c[0]], l1 = L[lo + g.l_c[1]], l2 = L[lo + g.l_c[2]];
+    auto cost = [&](int z) -> float {                     // cost(x, y, z) (:30-39): integer-valued float
+        const int i = tid + 2 * z;
+        const int a0 = sr[0][i], b0 = sr[0][i + 1], a1 = sr[1][i], b1 = sr[1][i + 1], a2 = sr[2][i], b2 = sr[2][i + 1];
+        const float d0 = (float)min(abs(l0 - a0), abs(l0 - b0)), d1 = (float)min(abs(l1 - a1), abs(l1 - b1)),
+                    d2 = (float)min(abs(l2 - a2), abs(l2 - b2));
+        return d0 * d0 + d1 * d1 + d2 * d2;
+    };
     float sa = 0.0f, sb = 0.0f;
     for (int z = 0; z < g.slices; z++) {
-        const float cz = cost_at(L, Rr, g, x, y, z);
+        const float cz = cost(z);
         sa = sa + cz * cz;
         sb = sb + cz / g.fslices;
     }
     const float conf = sa / g.fslices - sb * sb;
-    for (int z = 0; z < g.slices; z++) {
-        const float cz = cost_at(L, Rr, g, x, y, z);
-        push0[at(E, 0, z, 0, x, y)] = cz * conf;
-        push0[at(E, 0, z, 1, x, y)] = conf;
-    }
+    for (int z = 0; z < g.slices; z++) push0[at(E, g.slices, z, 0, x, y)] = cost(z) * conf;
+    push0[at(E, g.slices, 0, 1, x, y)] = conf;
 }
 
 // src level as the total function the generator defines: clamped to its box for levels >= 1 (:62), direct for level 0
@@ -90,20 +99,35 @@ __device__ __forceinline__ float src_at(const float *__restrict__ s, const Box &
     return s[((size_t)zc * b.h + (y - b.y0)) * b.w + (x - b.x0)];
 }
 
+// A workgroup makes a 64 x 16 tile of one plane of the next level: its 130 x 34 source window goes through LDS once (every
+// source value is a tap of four outputs), the 1-3-3-1 pass in x over the 34 rows, then in y — the generator's expressions
+// (:279-285), operand for operand.  Source coordinates are clamped to the source box when staging: that IS the function for
+// levels >= 1 (:62) and only feeds outputs outside the destination box for level 0.
+constexpr int DTW = 64, DTH = 16;
 template<bool SRC_CLAMP>
 __global__ __launch_bounds__(256) void lb_down(const float *__restrict__ src, Box sb, float *__restrict__ dst, Box db) {
-    const int xi = blockIdx.x * 256 + threadIdx.x, y = db.y0 + blockIdx.y, zc = blockIdx.z;
-    if (xi >= db.w) return;
-    const int x = db.x0 + xi;
-    float dx[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int yy = 2 * y - 1 + k;
-        dx[k] = (src_at<SRC_CLAMP>(src, sb, zc, 2 * x - 1, yy) +
-                 3.0f * (src_at<SRC_CLAMP>(src, sb, zc, 2 * x, yy) + src_at<SRC_CLAMP>(src, sb, zc, 2 * x + 1, yy)) +
-                 src_at<SRC_CLAMP>(src, sb, zc, 2 * x + 2, yy)) * 0.125f;
+    __shared__ float s_in[2 * DTH + 2][2 * DTW + 3];
+    __shared__ float s_dx[2 * DTH + 2][DTW + 1];
+    const int tid = threadIdx.x, zc = blockIdx.z;
+    const int tx0 = db.x0 + blockIdx.x * DTW, ty0 = db.y0 + blockIdx.y * DTH;
+    const int ix0 = 2 * tx0 - 1, iy0 = 2 * ty0 - 1;
+    for (int i = tid; i < (2 * DTH + 2) * (2 * DTW + 2); i += 256) {
+        const int r = i / (2 * DTW + 2), c = i - r * (2 * DTW + 2);
+        s_in[r][c] = src_at<true>(src, sb, zc, ix0 + c, iy0 + r);
     }
-    dst[((size_t)zc * db.h + (y - db.y0)) * db.w + xi] = (dx[0] + 3.0f * (dx[1] + dx[2]) + dx[3]) * 0.125f;
+    __syncthreads();
+    for (int i = tid; i < (2 * DTH + 2) * DTW; i += 256) {
+        const int r = i / DTW, xo = i - r * DTW;
+        const float *q = &s_in[r][2 * xo];
+        s_dx[r][xo] = (q[0] + 3.0f * (q[1] + q[2]) + q[3]) * 0.125f;
+    }
+    __syncthreads();
+    for (int i = tid; i < DTH * DTW; i += 256) {
+        const int yo = i / DTW, xo = i - yo * DTW;
+        const int xi = blockIdx.x * DTW + xo, yi = blockIdx.y * DTH + yo;
+        if (xi < db.w && yi < db.h)
+            dst[((size_t)zc * db.h + yi) * db.w + xi] = (s_dx[2 * yo][xo] + 3.0f * (s_dx[2 * yo + 1][xo] + s_dx[2 * yo + 2][xo]) + s_dx[2 * yo + 3][xo]) * 0.125f;
+    }
 }
 
 // upsample(f)(x, y) (:288-294) of a pull level stored on box b
@@ -136,9 +160,9 @@ __global__ __launch_bounds__(256) void lb_depth(const float *__restrict__ push0,
     const int x = D.x0 + xi, y = D.y0 + yi;
     int best_i = 0;
     float best = 3.402823466e38f;
+    const float v1 = dev::lerpf(up_at(pull1, P1, g.slices, x, y), push0[at(E, g.slices, 0, 1, x, y)], 0.5f);   // the same for every z
     for (int z = 0; z < g.slices; z++) {
-        const float v0 = dev::lerpf(up_at(pull1, P1, 2 * z, x, y), push0[at(E, 0, z, 0, x, y)], 0.5f);
-        const float v1 = dev::lerpf(up_at(pull1, P1, 2 * z + 1, x, y), push0[at(E, 0, z, 1, x, y)], 0.5f);
+        const float v0 = dev::lerpf(up_at(pull1, P1, z, x, y), push0[at(E, g.slices, z, 0, x, y)], 0.5f);
         const float fc = v0 / v1;
         if (fc < best) best = fc, best_i = z;
     }
@@ -159,10 +183,9 @@ __global__ __launch_bounds__(256) void lb_wcy(const float *__restrict__ br, Box 
 
 // random_float() of the reference: src/Random.cpp:20-104 with args {id, tag, s, y, x}
 __device__ __forceinline__ uint32_t rng32(uint32_t x) { return ((1040796640u * x) + 1121052041u) * x + 576942909u; }
-__device__ __forceinline__ float rand_float(uint32_t seeded, int s, int y, int x) {   // seeded = rng32(rng32(id) + tag)
-    uint32_t r = rng32(seeded + (uint32_t)s);
-    r = rng32(r + (uint32_t)y);
-    r = rng32(r + (uint32_t)x);
+// the last step of the hash and the conversion to [0, 1): `ry` = the state after the sample index and the row went in
+__device__ __forceinline__ float rand_float_x(uint32_t ry, int x) {
+    uint32_t r = rng32(ry + (uint32_t)x);
     r = r ^ (r >> 16);
     return dev::clampf(__uint_as_float((127u << 23) | (r >> 9)) - 1.0f, 0.0f, 1.0f);
 }
@@ -170,9 +193,17 @@ __device__ __forceinline__ float rand_float(uint32_t seeded, int s, int y, int x
 __global__ __launch_bounds__(256) void lb_final(const uint8_t *__restrict__ L, LBGeom g, const int *__restrict__ depth,
                                                const float *__restrict__ br, const float *__restrict__ wcy, Box D, int ox0, int oy0,
                                                int ow, int nc, float *__restrict__ out, long out_sy, long out_sc) {
+    // the hash consumes (id, tag, sample, y, x) in that order: everything up to the row is the same for the whole workgroup
+    __shared__ uint32_t s_ru[LB_MAXS], s_rv[LB_MAXS];
     const int xo = blockIdx.x * 256 + threadIdx.x, yo = blockIdx.y;
-    if (xo >= ow) return;
     const int x = ox0 + xo, y = oy0 + yo;
+    if ((int)threadIdx.x < g.samples) {
+        const uint32_t seed_u = rng32(rng32(0u) + (uint32_t)g.tag), seed_v = rng32(rng32(1u) + (uint32_t)g.tag);
+        s_ru[threadIdx.x] = rng32(rng32(seed_u + threadIdx.x) + (uint32_t)y);
+        s_rv[threadIdx.x] = rng32(rng32(seed_v + threadIdx.x) + (uint32_t)y);
+    }
+    __syncthreads();
+    if (xo >= ow) return;
     float worst = -INFINITY;
     for (int r = -g.R; r <= g.R; r++) worst = fmaxf(worst, wcy[(size_t)yo * D.w + (x + r - D.x0)]);
     auto left_at = [&](int xx, int yy, int c) -> float {
@@ -182,10 +213,9 @@ __global__ __launch_bounds__(256) void lb_final(const uint8_t *__restrict__ L, L
     const size_t o = (size_t)(y - D.y0) * D.w + (x - D.x0);
     const float brs = br[o] * br[o];
     const int dxy = depth[o];
-    const uint32_t seed_u = rng32(rng32(0u) + (uint32_t)g.tag), seed_v = rng32(rng32(1u) + (uint32_t)g.tag);
     for (int s = 0; s < g.samples; s++) {
-        const float fu = ((rand_float(seed_u, s, y, x) - 0.5f) * 2.0f) * worst;
-        const float fv = ((rand_float(seed_v, s, y, x) - 0.5f) * 2.0f) * worst;
+        const float fu = ((rand_float_x(s_ru[s], x) - 0.5f) * 2.0f) * worst;
+        const float fv = ((rand_float_x(s_rv[s], x) - 0.5f) * 2.0f) * worst;
         const int u = dev::clampi((int)fu, -g.R, g.R), v = dev::clampi((int)fv, -g.R, g.R);
         const int sx = x + u, sy = y + v;
         const size_t so = (size_t)(sy - D.y0) * D.w + (sx - D.x0);
@@ -313,8 +343,8 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
     // ---- workspace
     auto al = [](size_t n) { return (n + 63) & ~(size_t)63; };
     size_t off_push[LV], off_pull[LV], total = 0;
-    for (int i = 0; i < LV; i++) off_push[i] = total, total += al((size_t)2 * slices * PB[i].w * PB[i].h);
-    for (int i = 1; i < LV; i++) off_pull[i] = total, total += al((size_t)2 * slices * P[i].w * P[i].h);
+    for (int i = 0; i < LV; i++) off_push[i] = total, total += al((size_t)(slices + 1) * PB[i].w * PB[i].h);
+    for (int i = 1; i < LV; i++) off_pull[i] = total, total += al((size_t)(slices + 1) * P[i].w * P[i].h);
     const size_t off_depth = total;
     total += al((size_t)D.w * D.h);
     const size_t off_br = total;
@@ -333,13 +363,13 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
 
     const uint8_t *dl = dev_ptr<uint8_t>(left_im), *dr = dev_ptr<uint8_t>(right_im);
     hipStream_t st = ctx.stream;
-    const unsigned zc = 2u * (unsigned)slices;
+    const unsigned zc = (unsigned)slices + 1u;   // planes: cost x confidence per slice + the confidence
     HLMI_LAUNCH(uc, "lb_cost", st, lb_cost, dim3((E.w + 255) / 256, E.h), dim3(256), 0, dl, dr, g, E, push[0]);
     for (int i = 1; i < LV; i++) {
         char nm[24];
         snprintf(nm, sizeof nm, "lb_down:%d", i);
-        if (i == 1) HLMI_LAUNCH(uc, nm, st, lb_down<false>, dim3((PB[i].w + 255) / 256, PB[i].h, zc), dim3(256), 0, push[0], PB[0], push[i], PB[i]);
-        else HLMI_LAUNCH(uc, nm, st, lb_down<true>, dim3((PB[i].w + 255) / 256, PB[i].h, zc), dim3(256), 0, push[i - 1], PB[i - 1], push[i], PB[i]);
+        if (i == 1) HLMI_LAUNCH(uc, nm, st, lb_down<false>, dim3((PB[i].w + DTW - 1) / DTW, (PB[i].h + DTH - 1) / DTH, zc), dim3(256), 0, push[0], PB[0], push[i], PB[i]);
+        else HLMI_LAUNCH(uc, nm, st, lb_down<true>, dim3((PB[i].w + DTW - 1) / DTW, (PB[i].h + DTH - 1) / DTH, zc), dim3(256), 0, push[i - 1], PB[i - 1], push[i], PB[i]);
     }
     for (int i = LV - 1; i >= 1; i--) {
         char nm[24];
