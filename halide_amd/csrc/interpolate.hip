@@ -69,6 +69,33 @@ __global__ __launch_bounds__(256) void ip_down(InGeom g, Lvl src, Lvl dst, int c
     dst.v[(size_t)ys * dst.w + xs] = down_value<FROM_INPUT>(g, src, dst.x0 + xs, dst.y0 + ys, CLAMP4, cw, ch);
 }
 
+// downsampled[1] from the input, tiled: a workgroup makes 32 x 16 cells; their 65 x 33 window of downsampled[0] (the input,
+// premultiplied by alpha, edge-clamped) goes through LDS once — every input pixel is a tap of up to four cells and a planar
+// load of four channels — then the (1 2 1) pass in x and in y, as down_value does them.
+constexpr int I0W = 32, I0H = 16;
+__global__ __launch_bounds__(256) void ip_down0_tile(InGeom g, Lvl dst) {
+    __shared__ float4 s_in[2 * I0H + 1][2 * I0W + 1];
+    __shared__ float4 s_dx[2 * I0H + 1][I0W];
+    const int tid = threadIdx.x;
+    const int tx0 = dst.x0 + blockIdx.x * I0W, ty0 = dst.y0 + blockIdx.y * I0H;
+    const int ix0 = 2 * tx0 - 1, iy0 = 2 * ty0 - 1;
+    for (int i = tid; i < (2 * I0H + 1) * (2 * I0W + 1); i += 256) {
+        const int r = i / (2 * I0W + 1), c = i - r * (2 * I0W + 1);
+        s_in[r][c] = ds0(g, ix0 + c, iy0 + r);
+    }
+    __syncthreads();
+    for (int i = tid; i < (2 * I0H + 1) * I0W; i += 256) {
+        const int r = i / I0W, xo = i - r * I0W;
+        s_dx[r][xo] = tap3(s_in[r][2 * xo], s_in[r][2 * xo + 1], s_in[r][2 * xo + 2]);
+    }
+    __syncthreads();
+    for (int i = tid; i < I0H * I0W; i += 256) {
+        const int yo = i / I0W, xo = i - yo * I0W;
+        const int xs = blockIdx.x * I0W + xo, ys = blockIdx.y * I0H + yo;
+        if (xs < dst.w && ys < dst.h) dst.v[(size_t)ys * dst.w + xs] = tap3(s_dx[2 * yo][xo], s_dx[2 * yo + 1][xo], s_dx[2 * yo + 2][xo]);
+    }
+}
+
 __device__ __forceinline__ float4 interp_value(const float4 d, const Lvl &up, int x, int y) {   // (:61-72)
     const int xa = dev::fdiv2(x), xb = dev::fdiv2(x + 1), ya = dev::fdiv2(y), yb = dev::fdiv2(y + 1);
     const float4 aa = at(up, xa, ya), ba = at(up, xb, ya), ab = at(up, xa, yb), bb = at(up, xb, yb);
@@ -206,7 +233,11 @@ extern "C" int interpolate(halide_buffer_t *input, halide_buffer_t *output) {
         for (int l = 1; l < IL && l < T; l++) {
             dim3 grid((ds[l].w + 255) / 256, ds[l].h), block(256);
             snprintf(nm, sizeof nm, "ip_down:%d", l);
-            if (l == 1) HLMI_LAUNCH(uc, nm, st, (ip_down<true, false>), grid, block, 0, g, ds[1], ds[1], cw, ch);
+            if (l == 1) {
+                static const bool untiled = getenv("HLMI_IP_UNTILED") != nullptr;   // A/B: one thread per cell, 36 loads each
+                if (untiled) HLMI_LAUNCH(uc, nm, st, (ip_down<true, false>), grid, block, 0, g, ds[1], ds[1], cw, ch);
+                else HLMI_LAUNCH(uc, nm, st, ip_down0_tile, dim3((ds[1].w + I0W - 1) / I0W, (ds[1].h + I0H - 1) / I0H), dim3(256), 0, g, ds[1]);
+            }
             else if (l == 4) HLMI_LAUNCH(uc, nm, st, (ip_down<false, true>), grid, block, 0, g, ds[l - 1], ds[l], cw, ch);
             else HLMI_LAUNCH(uc, nm, st, (ip_down<false, false>), grid, block, 0, g, ds[l - 1], ds[l], cw, ch);
         }
