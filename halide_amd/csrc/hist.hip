@@ -6,13 +6,14 @@
 //                where private copies belong: 32 copies of the 256-bin histogram per workgroup in LDS, one per lane
 //                modulo 32 (ds_add_u32 without bank or address collisions, see hist_count), summed per workgroup and
 //                added to the global histogram with one atomic per bin.  4 pixels per lane per step (aligned dword loads).
-//   hist_cdf     one wave: 256-bin inclusive prefix sum, 4 bins per lane, cross-lane scan with DPP row / wave shifts
-//                (__shfl_up): integer, exact
+//                The global histogram itself is kept as 8 copies (workgroup mod 8): same-address atomics serialise in L2.
 //   hist_apply   pointwise: luma, Cr, Cb, eq = clamp(float(cdf[bin]) * 255 / (W H)), recolour, u8 — one rounding per
 //                operator in source order (oracle/hist_oracle.c); cdf in LDS; 4 pixels per lane
 // HBM: 3 B/px read twice + 3 B/px written.
 #include "hlmi_device_math.h"
 #include "hlmi_internal.h"
+
+#include <stdlib.h>
 
 using namespace hlmi;
 
@@ -28,6 +29,7 @@ __device__ __forceinline__ float luma(uint8_t r, uint8_t g, uint8_t b) {
 // never collide on a bank by more than two (lanes l and l + 32), and only those two can hit the same address.  With one
 // copy per wave a smooth image (neighbouring pixels in one bin) serialised all 64 lanes on one address.
 constexpr int HCOPY = 32;
+constexpr int HSUB = 8;    // copies of the global histogram
 template<bool VEC>
 __global__ __launch_bounds__(256) void hist_count(const uint8_t *__restrict__ in, long in_sy, long in_sc, int W, int H,
                                                  int rows_per_block, unsigned *__restrict__ ghist) {
@@ -37,19 +39,36 @@ __global__ __launch_bounds__(256) void hist_count(const uint8_t *__restrict__ in
     __syncthreads();
     unsigned *mine = wh + (tid & (HCOPY - 1));
     const int y0 = blockIdx.x * rows_per_block, y1 = min(y0 + rows_per_block, H);
-    for (int y = y0; y < y1; y++) {
-        const uint8_t *r0 = in + (long)y * in_sy, *r1 = r0 + in_sc, *r2 = r0 + 2 * in_sc;
-        if (VEC) {
-            for (int x = 4 * tid; x < W; x += 4 * 256) {
-                const uint32_t a = *reinterpret_cast<const uint32_t *>(r0 + x), b = *reinterpret_cast<const uint32_t *>(r1 + x),
-                               c = *reinterpret_cast<const uint32_t *>(r2 + x);
+    if (VEC) {
+        // a thread's (row, 1024-pixel column block) slots, eight at a time with all 24 loads in flight: taken one by one, each
+        // slot's loads were a full HBM round trip that nothing overlapped (16 us for 12 MB)
+        const int xiters = (W + 1023) / 1024, slots = (y1 - y0) * xiters;
+        for (int s0 = 0; s0 < slots; s0 += 8) {
+            uint32_t a[8], b[8], c[8];
+            bool ok[8];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const float Y = luma((uint8_t)(a >> (8 * k)), (uint8_t)(b >> (8 * k)), (uint8_t)(c >> (8 * k)));
+            for (int k = 0; k < 8; k++) {
+                const int sl = s0 + k, r = sl / xiters, x = 4 * tid + 1024 * (sl - r * xiters);
+                ok[k] = sl < slots && x < W;
+                if (ok[k]) {
+                    const uint8_t *r0 = in + (long)(y0 + r) * in_sy + x;
+                    a[k] = *reinterpret_cast<const uint32_t *>(r0), b[k] = *reinterpret_cast<const uint32_t *>(r0 + in_sc),
+                    c[k] = *reinterpret_cast<const uint32_t *>(r0 + 2 * in_sc);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (!ok[k]) continue;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float Y = luma((uint8_t)(a[k] >> (8 * j)), (uint8_t)(b[k] >> (8 * j)), (uint8_t)(c[k] >> (8 * j)));
                     atomicAdd(&mine[(int)dev::clampf(Y, 0.0f, 255.0f) * HCOPY], 1u);
                 }
             }
-        } else {
+        }
+    } else {
+        for (int y = y0; y < y1; y++) {
+            const uint8_t *r0 = in + (long)y * in_sy, *r1 = r0 + in_sc, *r2 = r0 + 2 * in_sc;
             for (int x = tid; x < W; x += 256) atomicAdd(&mine[(int)dev::clampf(luma(r0[x], r1[x], r2[x]), 0.0f, 255.0f) * HCOPY], 1u);
         }
     }
@@ -57,7 +76,9 @@ __global__ __launch_bounds__(256) void hist_count(const uint8_t *__restrict__ in
     unsigned s = 0;                                    // thread = bin; the copies are read rotated so that the 64 lanes of a
 #pragma unroll 8                                       // wave read 32 different banks
     for (int k = 0; k < HCOPY; k++) s += wh[tid * HCOPY + ((k + tid) & (HCOPY - 1))];
-    if (s) atomicAdd(&ghist[tid], s);
+    // HSUB copies of the global histogram (hist_apply adds them up): 80 workgroups per address instead of 640 — same-address
+    // global atomics are serialised in L2 and were most of this kernel's time
+    if (s) atomicAdd(&ghist[(blockIdx.x % HSUB) * 256 + tid], s);
 }
 
 struct HGeom {
@@ -75,7 +96,9 @@ __global__ __launch_bounds__(256) void hist_apply(const uint8_t *__restrict__ in
     __shared__ unsigned s_wsum[4];
     {
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        unsigned run = ghist[threadIdx.x];
+        unsigned run = 0;
+#pragma unroll
+        for (int k = 0; k < HSUB; k++) run += ghist[k * 256 + threadIdx.x];
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const unsigned up = __shfl_up(run, d, 64);
@@ -166,16 +189,17 @@ extern "C" int hist(halide_buffer_t *input, halide_buffer_t *output) {
     if ((r = output_on_device(uc, ctx, args[1]))) return r;
     if (ow > 0 && oh > 0 && oc > 0) {
         void *ws = nullptr;
-        if ((r = get_workspace(uc, ctx, 2 * 256 * sizeof(int), &ws))) return r;
+        if ((r = get_workspace(uc, ctx, HSUB * 256 * sizeof(int), &ws))) return r;
         unsigned *ghist = (unsigned *)ws;
         hipStream_t st = ctx.stream;
         const long in_sy = input->dim[1].stride, in_sc = input->dim[2].stride;
         // element (0, 0, 0) of the input
         const uint8_t *din = dev_ptr<uint8_t>(input) + (long)(0 - input->dim[1].min) * in_sy + (0 - input->dim[0].min) +
                              (long)(0 - input->dim[2].min) * in_sc;
-        HLMI_HIP(uc, hipMemsetAsync(ghist, 0, 256 * sizeof(unsigned), st));
+        HLMI_HIP(uc, hipMemsetAsync(ghist, 0, HSUB * 256 * sizeof(unsigned), st));
         const bool vec_in = (uintptr_t)din % 4 == 0 && in_sy % 4 == 0 && in_sc % 4 == 0;
-        const int rpb = 4, nblk = (H + rpb - 1) / rpb;
+        static const int rpb_env = getenv("HLMI_HIST_RPB") ? atoi(getenv("HLMI_HIST_RPB")) : 0;   // A/B
+        const int rpb = rpb_env > 0 ? rpb_env : 4, nblk = (H + rpb - 1) / rpb;
         timing_note_bytes(3.0 * W * H);
         if (vec_in && W % 4 == 0) HLMI_LAUNCH(uc, "hist_count", st, hist_count<true>, dim3(nblk), dim3(256), 0, din, in_sy, in_sc, W, H, rpb, ghist);
         else HLMI_LAUNCH(uc, "hist_count", st, hist_count<false>, dim3(nblk), dim3(256), 0, din, in_sy, in_sc, W, H, rpb, ghist);
