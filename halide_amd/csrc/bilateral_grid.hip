@@ -88,8 +88,8 @@ __global__ void bg_histogram_blurz(const float *__restrict__ in, long in_sy, BGe
 constexpr int HC = 16, HZ = 16;  // cells per workgroup (one grid row segment), bin slots per cell
 __global__ __launch_bounds__(HC * HZ) void bg_histogram_blurz_par(const float *__restrict__ in, long in_sy, BGeom g,
                                                                   float2 *__restrict__ bz) {
-    __shared__ float s_val[HC][S * S];
-    __shared__ int s_zi[HC][S * S];
+    __shared__ __attribute__((aligned(16))) float s_val[HC][S * S];
+    __shared__ __attribute__((aligned(16))) int s_zi[HC][S * S];
     __shared__ float2 s_h[HC][HZ + 4];          // histogram, bins -2 .. HZ+1 (zero padded for the z blur)
     const int t = threadIdx.x, c = t / HZ, z = t % HZ;
     const int cx0 = blockIdx.x * HC, cy = blockIdx.y;
@@ -105,13 +105,19 @@ __global__ __launch_bounds__(HC * HZ) void bg_histogram_blurz_par(const float *_
     }
     for (int i = t; i < HC * (HZ + 4); i += HC * HZ) s_h[i / (HZ + 4)][i % (HZ + 4)] = make_float2(0.0f, 0.0f);
     __syncthreads();
+    // four pixels per LDS instruction; a sum that starts at +0 and only ever adds non-negative terms is never -0, so adding
+    // +0 for the pixels of other bins leaves it bit for bit what the selective add would give
     float hv = 0.0f, hw = 0.0f;
-#pragma unroll 8
-    for (int p = 0; p < S * S; p++) {
-        const bool mine = s_zi[c][p] == z;
-        const float val = s_val[c][p];
-        hv = mine ? hv + val : hv;
-        hw = mine ? hw + 1.0f : hw;
+    const float4 *v4 = reinterpret_cast<const float4 *>(s_val[c]);
+    const int4 *z4 = reinterpret_cast<const int4 *>(s_zi[c]);
+#pragma unroll 4
+    for (int q = 0; q < S * S / 4; q++) {
+        const float4 v = v4[q];
+        const int4 zz = z4[q];
+        hv = hv + (zz.x == z ? v.x : 0.0f), hw = hw + (zz.x == z ? 1.0f : 0.0f);
+        hv = hv + (zz.y == z ? v.y : 0.0f), hw = hw + (zz.y == z ? 1.0f : 0.0f);
+        hv = hv + (zz.z == z ? v.z : 0.0f), hw = hw + (zz.z == z ? 1.0f : 0.0f);
+        hv = hv + (zz.w == z ? v.w : 0.0f), hw = hw + (zz.w == z ? 1.0f : 0.0f);
     }
     if (z < g.ZH) s_h[c][z + 2] = make_float2(hv, hw);
     __syncthreads();
