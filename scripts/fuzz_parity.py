@@ -208,6 +208,32 @@ def case_depthwise_separable_conv(rng):
     return f"n={n} {ww}x{hh} ci={ci} co={co}", same(o.numpy(), oracle.depthwise_separable_conv(inp, dw, pw, bias))
 
 
+def _conv_data(rng, ci_choices=(32, 64, 128, 192)):
+    n, hh, ww = int(rng.integers(1, 4)), rdim(rng, 1, 60), rdim(rng, 1, 130)     # W <= 125: input-linear kernel, wider: im2col kernel
+    ci, co = int(rng.choice(ci_choices)), int(rng.choice([128, 256]))
+    inp = rng.uniform(-1, 1, (n, hh + 2, ww + 2, ci)).astype(f32)
+    filt, bias = rng.uniform(-1, 1, (ci, 3, 3, co)).astype(f32), rng.uniform(-1, 1, (co,)).astype(f32)
+    return n, hh, ww, ci, co, inp, filt, bias
+
+
+def case_conv_layer(rng):
+    n, hh, ww, ci, co, inp, filt, bias = _conv_data(rng)
+    o = hl.Buffer(np.zeros((n, hh, ww, co), f32))
+    hl.conv_layer(hl.Buffer(inp), hl.Buffer(filt), hl.Buffer(bias), o)
+    return f"n={n} {ww}x{hh} ci={ci} co={co}", same(o.numpy(), oracle.conv_layer(inp, filt, bias))
+
+
+def case_conv_layer_bf16(rng):
+    """tolerance, not bit-exactness: bf16 operands, f32 accumulation in hardware order (tests/test_conv_layer.py); the bf16
+    entry point wants input channels in multiples of 64"""
+    n, hh, ww, ci, co, inp, filt, bias = _conv_data(rng, (64, 128, 192))
+    o = hl.Buffer(np.zeros((n, hh, ww, co), f32))
+    hl.conv_layer_bf16(hl.Buffer(inp), hl.Buffer(filt), hl.Buffer(bias), o)
+    want, mag = oracle.conv_layer_bf16(inp, filt, bias)
+    err = np.abs(o.numpy().astype(np.float64) - want.astype(np.float64))
+    return f"n={n} {ww}x{hh} ci={ci} co={co}", bool((err <= 2e-6 * mag.astype(np.float64) + 1e-6).all())
+
+
 CASES = {k[5:]: v for k, v in list(globals().items()) if k.startswith("case_")}
 
 
