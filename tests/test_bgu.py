@@ -246,3 +246,30 @@ def test_rejects_scalars_the_generator_gives_no_meaning_to(hl):
         with pytest.raises(hl.HalideError) as e:
             _run(hl, r_sigma, s_sigma, lo, val, hi)
         assert e.value.code == -27
+
+
+@pytest.mark.gpu
+def test_hip_padded_strides_and_mins_of_every_buffer(hl, oracle):
+    """Row / plane padding of all four buffers, a slice_loc larger than (and offset from) the output, and a low-res pair whose
+    box does not start at 0: coordinates are absolute (the low-res pair is clamped to ITS box, :270-271), padding bytes
+    stay untouched.  The oracle takes boxes at 0, so the shifted low-res pair is given to it edge-extended to the origin —
+    the same function of absolute coordinates — with extents chosen so that the upsampling factor (:275-279) is the same."""
+    W, H, lw, lh, m = 256, 192, 29, 25, 2            # ceil(256 / 29) == ceil(256 / 31) == 9, ceil(192 / 25) == ceil(192 / 27) == 8
+    hi, _, _ = _scene(W, H, seed=21)
+    rng = np.random.default_rng(22)
+    lo = rng.random((3, lh, lw), dtype=np.float32)
+    val = np.clip(lo * 0.8 + 0.1 * rng.random((3, lh, lw), dtype=np.float32), 0, 1).astype(np.float32)
+    pad = lambda a, py, px: np.pad(a, ((0, 0), (0, py), (0, px)), constant_values=np.float32(7))   # noqa: E731
+    big_lo, big_val, big_hi = pad(lo, 3, 5), pad(val, 1, 9), pad(hi, 2, 6)
+    x0, y0, ow, oh = 37, 21, 180, 150
+    big_out = np.full((3, oh + 3, ow + 11), np.float32(-3), np.float32)
+    bl = hl.Buffer(big_lo[:, :lh, :lw]).set_min(m, m, 0)
+    bv = hl.Buffer(big_val[:, :lh, :lw]).set_min(m, m, 0)
+    bh = hl.Buffer(big_hi[:, :H, :W])
+    bo = hl.Buffer(big_out[:, :oh, :ow]).set_min(x0, y0, 0)
+    hl.bgu(1 / 8, 4, bl, bv, bh, bo)
+    bo.copy_to_host()
+    ext = lambda a: np.pad(a, ((0, 0), (m, 0), (m, 0)), mode="edge")   # noqa: E731
+    want = oracle.bgu(1 / 8, 4, ext(lo), ext(val), hi, region=(x0, y0, ow, oh))
+    _same(np.ascontiguousarray(big_out[:, :oh, :ow]), want)
+    assert np.all(big_out[:, oh:, :] == -3) and np.all(big_out[:, :, ow:] == -3)

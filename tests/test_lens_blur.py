@@ -208,3 +208,18 @@ def test_hip_right_image_of_another_size_and_scalar_ranges(hl, oracle):
         with pytest.raises(hl.HalideError) as e:
             _run(hl, left, right, *bad)
         assert e.value.code == code
+
+
+@pytest.mark.gpu
+def test_hip_padded_strides_of_every_buffer(hl, oracle):
+    """Row / plane padding of both inputs and of the output: padding bytes are neither read into the result nor written."""
+    left, right = _pair(70, 46, seed=9)
+    big_l = np.pad(left, ((0, 0), (0, 3), (0, 6)), constant_values=200)
+    big_r = np.pad(right, ((0, 0), (0, 1), (0, 10)), constant_values=13)
+    big_o = np.full((3, 46 + 2, 70 + 5), np.float32(-3), np.float32)
+    bo = hl.Buffer(big_o[:, :46, :70])
+    hl.lens_blur(hl.Buffer(big_l[:, :46, :70]), hl.Buffer(big_r[:, :46, :70]), 16, 5, 0.5, 12, bo)
+    bo.copy_to_host()
+    want = oracle.lens_blur(left, right, 16, 5, 0.5, 12)
+    assert np.array_equal(np.ascontiguousarray(big_o[:, :46, :70]).view(np.uint32), want.view(np.uint32))
+    assert np.all(big_o[:, 46:, :] == -3) and np.all(big_o[:, :, 70:] == -3)
