@@ -153,8 +153,17 @@ __global__ __launch_bounds__(256) void lb_pull(const float *__restrict__ push, B
     dst[((size_t)zc * db.h + (y - db.y0)) * db.w + xi] = v;
 }
 
-__global__ __launch_bounds__(256) void lb_depth(const float *__restrict__ push0, Box E, const float *__restrict__ pull1, Box P1, LBGeom g,
-                                               Box D, int *__restrict__ depth, float *__restrict__ br) {
+__device__ __forceinline__ float bokeh_radius(int depth, const LBGeom &g) {   // :88-89
+    const int ad = depth - g.focus;
+    return (float)(unsigned)(ad < 0 ? -ad : ad) * g.scale;
+}
+
+// depth and bokeh radius on D; `rec` packs what lb_final gathers per aperture sample into ONE word per pixel of D:
+// depth | left(x, y, 0) << 8 | left(.., 1) << 16 | left(.., 2) << 24 (the bokeh radius is a function of the depth, the left
+// image is edge-clamped: both are properties of the sample's position) — one 4-byte gather per sample instead of five.
+__global__ __launch_bounds__(256) void lb_depth(const float *__restrict__ push0, Box E, const float *__restrict__ pull1, Box P1,
+                                               const uint8_t *__restrict__ L, LBGeom g, Box D, uint32_t *__restrict__ rec,
+                                               float *__restrict__ br) {
     const int xi = blockIdx.x * 256 + threadIdx.x, yi = blockIdx.y;
     if (xi >= D.w) return;
     const int x = D.x0 + xi, y = D.y0 + yi;
@@ -167,9 +176,9 @@ __global__ __launch_bounds__(256) void lb_depth(const float *__restrict__ push0,
         if (fc < best) best = fc, best_i = z;
     }
     const size_t o = (size_t)yi * D.w + xi;
-    depth[o] = best_i;
-    const int ad = best_i - g.focus;
-    br[o] = (float)(unsigned)(ad < 0 ? -ad : ad) * g.scale;
+    const long lo = (long)(dev::clampi(y, g.ly0, g.ly1) - g.ly0) * g.l_sy + (dev::clampi(x, g.lx0, g.lx1) - g.lx0);
+    rec[o] = (uint32_t)best_i | (uint32_t)L[lo + g.l_c[0]] << 8 | (uint32_t)L[lo + g.l_c[1]] << 16 | (uint32_t)L[lo + g.l_c[2]] << 24;
+    br[o] = bokeh_radius(best_i, g);
 }
 
 __global__ __launch_bounds__(256) void lb_wcy(const float *__restrict__ br, Box D, int R, int oy0, int oh, float *__restrict__ wcy) {
@@ -190,8 +199,7 @@ __device__ __forceinline__ float rand_float_x(uint32_t ry, int x) {
     return dev::clampf(__uint_as_float((127u << 23) | (r >> 9)) - 1.0f, 0.0f, 1.0f);
 }
 
-__global__ __launch_bounds__(256) void lb_final(const uint8_t *__restrict__ L, LBGeom g, const int *__restrict__ depth,
-                                               const float *__restrict__ br, const float *__restrict__ wcy, Box D, int ox0, int oy0,
+__global__ __launch_bounds__(256) void lb_final(LBGeom g, const uint32_t *__restrict__ rec, const float *__restrict__ wcy, Box D, int ox0, int oy0,
                                                int ow, int nc, float *__restrict__ out, long out_sy, long out_sc) {
     // the hash consumes (id, tag, sample, y, x) in that order: everything up to the row is the same for the whole workgroup
     __shared__ uint32_t s_ru[LB_MAXS], s_rv[LB_MAXS];
@@ -206,25 +214,24 @@ __global__ __launch_bounds__(256) void lb_final(const uint8_t *__restrict__ L, L
     if (xo >= ow) return;
     float worst = -INFINITY;
     for (int r = -g.R; r <= g.R; r++) worst = fmaxf(worst, wcy[(size_t)yo * D.w + (x + r - D.x0)]);
-    auto left_at = [&](int xx, int yy, int c) -> float {
-        return (float)L[(long)(dev::clampi(yy, g.ly0, g.ly1) - g.ly0) * g.l_sy + (dev::clampi(xx, g.lx0, g.lx1) - g.lx0) + g.l_c[c]];
-    };
-    float acc[4] = {left_at(x, y, 0), left_at(x, y, 1), left_at(x, y, 2), 255.0f};
     const size_t o = (size_t)(y - D.y0) * D.w + (x - D.x0);
-    const float brs = br[o] * br[o];
-    const int dxy = depth[o];
+    const uint32_t w0 = rec[o];
+    float acc[4] = {(float)((w0 >> 8) & 255u), (float)((w0 >> 16) & 255u), (float)(w0 >> 24), 255.0f};
+    const int dxy = (int)(w0 & 255u);
+    const float br0 = bokeh_radius(dxy, g), brs = br0 * br0;
     for (int s = 0; s < g.samples; s++) {
         const float fu = ((rand_float_x(s_ru[s], x) - 0.5f) * 2.0f) * worst;
         const float fv = ((rand_float_x(s_rv[s], x) - 0.5f) * 2.0f) * worst;
         const int u = dev::clampi((int)fu, -g.R, g.R), v = dev::clampi((int)fv, -g.R, g.R);
-        const int sx = x + u, sy = y + v;
-        const size_t so = (size_t)(sy - D.y0) * D.w + (sx - D.x0);
+        const uint32_t ws = rec[(size_t)(y + v - D.y0) * D.w + (x + u - D.x0)];
         const float r2 = (float)(u * u + v * v);
-        const float bs = br[so];
-        const bool take = ((r2 < brs) || (depth[so] < dxy)) && (r2 < bs * bs);
+        const int ds = (int)(ws & 255u);
+        const float bs = bokeh_radius(ds, g);
+        const bool take = ((r2 < brs) || (ds < dxy)) && (r2 < bs * bs);
         const float wgt = take ? 1.0f : 0.0f;
-#pragma unroll
-        for (int c = 0; c < 3; c++) acc[c] = acc[c] + wgt * left_at(sx, sy, c);
+        acc[0] = acc[0] + wgt * (float)((ws >> 8) & 255u);
+        acc[1] = acc[1] + wgt * (float)((ws >> 16) & 255u);
+        acc[2] = acc[2] + wgt * (float)(ws >> 24);
         acc[3] = acc[3] + wgt * 255.0f;
     }
 #pragma unroll
@@ -358,7 +365,7 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
     for (int i = 0; i < LV; i++) push[i] = wsf + off_push[i];
     for (int i = 1; i < LV; i++) pull[i] = wsf + off_pull[i];
     pull[0] = nullptr;
-    int *depth = (int *)(wsf + off_depth);
+    uint32_t *depth = (uint32_t *)(wsf + off_depth);
     float *br = wsf + off_br, *wcy = wsf + off_wcy;
 
     const uint8_t *dl = dev_ptr<uint8_t>(left_im), *dr = dev_ptr<uint8_t>(right_im);
@@ -377,9 +384,9 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
         if (i == LV - 1) HLMI_LAUNCH(uc, nm, st, lb_pull<true>, dim3((P[i].w + 255) / 256, P[i].h, zc), dim3(256), 0, push[i], PB[i], (const float *)nullptr, P[i], pull[i], P[i]);
         else HLMI_LAUNCH(uc, nm, st, lb_pull<false>, dim3((P[i].w + 255) / 256, P[i].h, zc), dim3(256), 0, push[i], PB[i], pull[i + 1], P[i + 1], pull[i], P[i]);
     }
-    HLMI_LAUNCH(uc, "lb_depth", st, lb_depth, dim3((D.w + 255) / 256, D.h), dim3(256), 0, push[0], E, pull[1], P[1], g, D, depth, br);
+    HLMI_LAUNCH(uc, "lb_depth", st, lb_depth, dim3((D.w + 255) / 256, D.h), dim3(256), 0, push[0], E, pull[1], P[1], dl, g, D, depth, br);
     HLMI_LAUNCH(uc, "lb_wcy", st, lb_wcy, dim3((D.w + 255) / 256, oh), dim3(256), 0, br, D, g.R, oy0, oh, wcy);
-    HLMI_LAUNCH(uc, "lb_final", st, lb_final, dim3((ow + 255) / 256, oh), dim3(256), 0, dl, g, depth, br, wcy, D, ox0, oy0, ow, nc,
+    HLMI_LAUNCH(uc, "lb_final", st, lb_final, dim3((ow + 255) / 256, oh), dim3(256), 0, g, depth, wcy, D, ox0, oy0, ow, nc,
                 dev_ptr<float>(final_), (long)final_->dim[1].stride, (long)final_->dim[2].stride);
     mark_output_written(final_);
     return 0;
