@@ -56,6 +56,9 @@ __device__ __forceinline__ size_t at(const Box &b, int slices, int z, int c, int
 // right image is staged in LDS once and the left pixel sits in registers — instead of 9 clamped byte loads per (pixel, slice),
 // twice (the costs are needed again after their variance is known).
 constexpr int LB_MAXS = 64;   // generator :14: slices <= 64
+// SB: compile-time bound of `slices` (32 or 64): the costs of a pixel stay in registers between the pass that finds their
+// variance and the pass that writes them scaled by it
+template<int SB>
 __global__ __launch_bounds__(256) void lb_cost(const uint8_t *__restrict__ L, const uint8_t *__restrict__ Rr, LBGeom g, Box E,
                                               float *__restrict__ push0) {
     __shared__ uint8_t sr[3][256 + 2 * LB_MAXS];
@@ -81,14 +84,19 @@ __global__ __launch_bounds__(256) void lb_cost(const uint8_t *__restrict__ L, co
                     d2 = (float)min(abs(l2 - a2), abs(l2 - b2));
         return d0 * d0 + d1 * d1 + d2 * d2;
     };
-    float sa = 0.0f, sb = 0.0f;
-    for (int z = 0; z < g.slices; z++) {
-        const float cz = cost(z);
-        sa = sa + cz * cz;
-        sb = sb + cz / g.fslices;
+    float sa = 0.0f, sb = 0.0f, cz[SB];
+#pragma unroll
+    for (int z = 0; z < SB; z++) {
+        if (z < g.slices) {
+            cz[z] = cost(z);
+            sa = sa + cz[z] * cz[z];
+            sb = sb + cz[z] / g.fslices;
+        }
     }
     const float conf = sa / g.fslices - sb * sb;
-    for (int z = 0; z < g.slices; z++) push0[at(E, g.slices, z, 0, x, y)] = cost(z) * conf;
+#pragma unroll
+    for (int z = 0; z < SB; z++)
+        if (z < g.slices) push0[at(E, g.slices, z, 0, x, y)] = cz[z] * conf;
     push0[at(E, g.slices, 0, 1, x, y)] = conf;
 }
 
@@ -371,7 +379,8 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
     const uint8_t *dl = dev_ptr<uint8_t>(left_im), *dr = dev_ptr<uint8_t>(right_im);
     hipStream_t st = ctx.stream;
     const unsigned zc = (unsigned)slices + 1u;   // planes: cost x confidence per slice + the confidence
-    HLMI_LAUNCH(uc, "lb_cost", st, lb_cost, dim3((E.w + 255) / 256, E.h), dim3(256), 0, dl, dr, g, E, push[0]);
+    if (slices <= 32) HLMI_LAUNCH(uc, "lb_cost", st, lb_cost<32>, dim3((E.w + 255) / 256, E.h), dim3(256), 0, dl, dr, g, E, push[0]);
+    else HLMI_LAUNCH(uc, "lb_cost", st, lb_cost<64>, dim3((E.w + 255) / 256, E.h), dim3(256), 0, dl, dr, g, E, push[0]);
     for (int i = 1; i < LV; i++) {
         char nm[24];
         snprintf(nm, sizeof nm, "lb_down:%d", i);
