@@ -24,6 +24,7 @@
 #include "hlmi_internal.h"
 
 #include <atomic>
+#include <stdlib.h>
 
 using namespace hlmi;
 
@@ -159,6 +160,44 @@ __global__ __launch_bounds__(256) void lb_pull(const float *__restrict__ push, B
     float v = p;
     if (!TOP) v = dev::lerpf(up_at(coarse, cb, zc, x, y), p, 0.5f);
     dst[((size_t)zc * db.h + (y - db.y0)) * db.w + xi] = v;
+}
+
+// The planes of the two pyramids never mix (down- and up-sampling are per plane), so below some level one workgroup can take
+// a plane all the way down and back up with a barrier between levels — its own stores are visible to it after the barrier —
+// instead of one launch per level: levels `from`..7 of the push pyramid, then levels 7..`from` of the pull pyramid.
+struct TailArgs {
+    float *push[LV], *pull[LV];
+    Box PB[LV], P[LV];
+    int from;
+};
+__global__ __launch_bounds__(1024) void lb_tail(TailArgs a) {
+    const int zc = blockIdx.x, tid = threadIdx.x;
+    for (int l = a.from; l < LV; l++) {
+        const Box sb = a.PB[l - 1], db = a.PB[l];
+        const float *src = a.push[l - 1];
+        float *dst = a.push[l];
+        for (int i = tid; i < db.w * db.h; i += 1024) {
+            const int yi = i / db.w, xi = i - yi * db.w, x = db.x0 + xi, y = db.y0 + yi;
+            float dx[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int yy = 2 * y - 1 + k;
+                dx[k] = (src_at<true>(src, sb, zc, 2 * x - 1, yy) + 3.0f * (src_at<true>(src, sb, zc, 2 * x, yy) + src_at<true>(src, sb, zc, 2 * x + 1, yy)) +
+                         src_at<true>(src, sb, zc, 2 * x + 2, yy)) * 0.125f;
+            }
+            dst[(size_t)zc * db.h * db.w + i] = (dx[0] + 3.0f * (dx[1] + dx[2]) + dx[3]) * 0.125f;
+        }
+        __syncthreads();
+    }
+    for (int l = LV - 1; l >= a.from; l--) {
+        const Box pb = a.PB[l], db = a.P[l];
+        for (int i = tid; i < db.w * db.h; i += 1024) {
+            const int yi = i / db.w, xi = i - yi * db.w, x = db.x0 + xi, y = db.y0 + yi;
+            const float p = src_at<true>(a.push[l], pb, zc, x, y);
+            a.pull[l][(size_t)zc * db.h * db.w + i] = (l == LV - 1) ? p : dev::lerpf(up_at(a.pull[l + 1], a.P[l + 1], zc, x, y), p, 0.5f);
+        }
+        __syncthreads();
+    }
 }
 
 __device__ __forceinline__ float bokeh_radius(int depth, const LBGeom &g) {   // :88-89
@@ -381,13 +420,31 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
     const unsigned zc = (unsigned)slices + 1u;   // planes: cost x confidence per slice + the confidence
     if (slices <= 32) HLMI_LAUNCH(uc, "lb_cost", st, lb_cost<32>, dim3((E.w + 255) / 256, E.h), dim3(256), 0, dl, dr, g, E, push[0]);
     else HLMI_LAUNCH(uc, "lb_cost", st, lb_cost<64>, dim3((E.w + 255) / 256, E.h), dim3(256), 0, dl, dr, g, E, push[0]);
-    for (int i = 1; i < LV; i++) {
+    // levels below `tail` (at most 128 x 128 elements per plane) go down and up in ONE launch, a workgroup per plane
+    int tail = LV;
+    for (int i = LV - 1; i >= 2; i--) {
+        if ((long)PB[i - 1].w * PB[i - 1].h <= 128 * 128 * 4 && (long)P[i].w * P[i].h <= 128 * 128) tail = i;
+        else break;
+    }
+    {
+        const char *e = getenv("HLMI_LB_TAIL_FROM");   // A/B: 8 = no tail launch
+        if (e && *e) tail = max(2, min(LV, atoi(e)));
+    }
+    for (int i = 1; i < tail; i++) {
         char nm[24];
         snprintf(nm, sizeof nm, "lb_down:%d", i);
         if (i == 1) HLMI_LAUNCH(uc, nm, st, lb_down<false>, dim3((PB[i].w + DTW - 1) / DTW, (PB[i].h + DTH - 1) / DTH, zc), dim3(256), 0, push[0], PB[0], push[i], PB[i]);
         else HLMI_LAUNCH(uc, nm, st, lb_down<true>, dim3((PB[i].w + DTW - 1) / DTW, (PB[i].h + DTH - 1) / DTH, zc), dim3(256), 0, push[i - 1], PB[i - 1], push[i], PB[i]);
     }
-    for (int i = LV - 1; i >= 1; i--) {
+    if (tail < LV) {
+        TailArgs ta;
+        for (int i = 0; i < LV; i++) ta.push[i] = push[i], ta.pull[i] = pull[i], ta.PB[i] = PB[i], ta.P[i] = P[i];
+        ta.from = tail;
+        char nm[24];
+        snprintf(nm, sizeof nm, "lb_tail:%d", tail);
+        HLMI_LAUNCH(uc, nm, st, lb_tail, dim3(zc), dim3(1024), 0, ta);
+    }
+    for (int i = min(LV - 1, tail - 1); i >= 1; i--) {
         char nm[24];
         snprintf(nm, sizeof nm, "lb_pull:%d", i);
         if (i == LV - 1) HLMI_LAUNCH(uc, nm, st, lb_pull<true>, dim3((P[i].w + 255) / 256, P[i].h, zc), dim3(256), 0, push[i], PB[i], (const float *)nullptr, P[i], pull[i], P[i]);
