@@ -17,9 +17,11 @@
 // are 0 and 1, the definition tag is a compile-time counter of the reference's compiler that cannot be observed here —
 // it defaults to the count derived in the oracle's header (71) and is settable: hlmi_lens_blur_set_random_tag().
 //
-// Layout: push[i] / pull[i] are float [slices + 1][box_h][box_w] (x fastest; plane `slices` = the confidence, see at());
-// nothing is tiled or fused beyond lb_depth:
-// this pipeline is here for coverage of the boundary (the reference's driver runs unmodified), not tuned.
+//   lb_tail     the levels with at most 128 x 128 elements per plane (4..7 at 768 x 1280) of BOTH pyramids in one launch:
+//               planes never mix, so a workgroup takes its plane down and back up with a barrier between levels
+// Layout: push[i] / pull[i] are float [slices + 1][box_h][box_w] (x fastest; plane `slices` = the confidence, see at()).
+// What is shared goes through LDS (the right-image row segment of lb_cost, the source window of lb_down), what a stage needs
+// per sample is packed where it is produced (lb_depth -> lb_final); the rest is one thread per element.
 #include "hlmi_device_math.h"
 #include "hlmi_internal.h"
 
