@@ -53,3 +53,25 @@ def test_no_gpu_means_loud_failure_not_fallback(hl):
         raise AssertionError("expected HalideError")
     except hl.HalideError as e:
         assert e.code == -29
+
+
+def test_one_hip_runtime_per_process_whatever_the_import_order():
+    """The torch wheel bundles its own libamdhip64.so; libhlmi.so loaded first used to bind to the system copy, torch
+    then brought its own, and a torch stream handed to the library belonged to the other runtime (a crash inside HIP that
+    depended on test order).  halide_amd loads torch's copy first when torch is installed: one runtime either way."""
+    import subprocess
+    import sys
+    import importlib.util
+    if importlib.util.find_spec("torch") is None:
+        import pytest
+        pytest.skip("torch is not installed")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n%s\n"
+            "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'amdhip64' in l and 'r-xp' in l})\n"
+            "print('RUNTIMES', len(libs), libs)\n"
+            "import halide_amd as hl\nassert hl.hip_runtime().hipGetDeviceCount\n")
+    for order in ("import halide_amd, torch", "import torch, halide_amd"):
+        r = subprocess.run([sys.executable, "-c", code % (root, order)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        line = [l for l in r.stdout.splitlines() if l.startswith("RUNTIMES")][0]
+        assert line.split()[1] == "1", f"{order}: {line}"
