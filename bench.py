@@ -3,17 +3,25 @@
 
 Workload (BASELINE.json configs[2], the one `metric` is quoted on): apps/local_laplacian, 8 pyramid
 levels (J=8), levels=8, alpha=1/7, beta=1, uint16 RGB planar 3840x2160 in/out, fp32 internal arithmetic.
-A "step" = one pass of the pipeline over a batch of FRAMES_PER_STEP distinct synthetic frames per GPU,
-called through the C ABI (libhlmi.so, `local_laplacian(halide_buffer_t*, ...)`), inputs and outputs
-resident in HBM (uploaded once before the timed region, like apps/local_laplacian/process.cpp:31-39 where
-the first call pays the copies and `benchmark()` times calls + device_sync).
+A "step" = PASSES (default 16) passes of the pipeline over a batch of FRAMES_PER_STEP distinct synthetic frames per GPU
+(128 frames = 1.06 Gpx per GPU and step, so that the driver's `--steps 20` times >= 0.2 s), called through the C ABI
+(libhlmi.so, `local_laplacian(halide_buffer_t*, ...)`), inputs and outputs resident in HBM (uploaded once before the
+timed region, like apps/local_laplacian/process.cpp:31-39 where the first call pays the copies and `benchmark()` times
+calls + device_sync).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+
+`--gpus N` is the whole command for any N: when the script is not already running under a launcher it starts N ranks of
+itself under `python -m torch.distributed.run` (one process per GPU, rendezvous on 127.0.0.1) and refuses when fewer than
+N devices are visible (halide_amd/launcher.py).  The driver's own
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` works the same; a WORLD_SIZE that disagrees
+with --gpus is an error, so `n_gpus` in the output is always the N asked for.
 
 Frames are independent units: ranks shard them with no data-path collective ("scaling": "weak");
 torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the elapsed time.
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  After the timed region rank 0 (N = 1 only) also measures the other BASELINE.json
+configs — bilateral_grid 1920x1080, nl_means 1920x1080x3, conv_layer bf16 N=16 — into `config.other_configs`, each with its
+roofline and a bounded oracle `cpu_baseline`.
 """
 import argparse
 import json
@@ -26,7 +34,8 @@ sys.path.insert(0, ROOT)
 
 W, H, C = 3840, 2160, 3
 LEVELS, ALPHA, BETA = 8, 1.0 / 7.0, 1.0
-FRAMES_PER_STEP = int(os.environ.get("HLMI_BENCH_FRAMES", "8"))  # distinct frames per GPU per step (8 x 99.5 MB of u16 I/O > 256 MB MALL)
+FRAMES_PER_STEP = int(os.environ.get("HLMI_BENCH_FRAMES", "8"))  # distinct frames per GPU and pass (8 x 99.5 MB of u16 I/O > 256 MB MALL)
+PASSES = int(os.environ.get("HLMI_BENCH_PASSES", "16"))           # passes over those frames per step
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 ALG_BYTES_PER_PX = 12         # SURVEY.md §8(d) primary figure: 6 B read + 6 B written per pixel
 
@@ -63,12 +72,41 @@ def cpu_baseline(frame):
             "sample": f"{n} frames of {W}x{H} u16 RGB in {dt:.2f} s (OpenMP, all host threads)"}
 
 
+def stub_main(args, rank, local_rank, world):
+    """Launcher self-test (HLMI_BENCH_STUB=1, tests/test_launcher.py): the rendezvous, barrier, max-over-ranks and JSON path
+    of the real run with the pipeline call replaced by a no-op and gloo instead of RCCL.  Not a measurement: "data": "stub"."""
+    from halide_amd import launcher, sharding
+    dist, device, ranks_seen = launcher.init_process_group(local_rank, world)
+    mine = sharding.shard(world * FRAMES_PER_STEP, rank, world)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-4 * len(mine))
+    barrier()
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dist, device)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test (no pipeline ran)", "value": 0.0, "unit": "Mpx/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "stub",
+                          "config": {"workload": "stub", "rccl_ranks": ranks_seen, "backend": launcher.backend(),
+                                     "frames_of_rank0": mine}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=250, help="timed steps (default: about 0.25 s of GPU time)")
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20, help="timed steps (a step = --passes passes over the frames: 20 steps ≈ 0.27 s of GPU time)")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--passes", type=int, default=PASSES, help="passes over the FRAMES_PER_STEP distinct frames that make one step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the bilateral_grid / nl_means / conv_layer_bf16 leg")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra input variants (uniform noise, 7680x4320)")
     ap.add_argument("--partitions", type=int, default=int(os.environ.get("HLMI_BENCH_PARTITIONS", "4")),
                     help="frames of a step are spread over this many CU-partitioned streams (halide_hip_partition_stream: "
@@ -79,27 +117,22 @@ def main():
                     help="with --partitions 0: plain HIP streams the frames of a step are spread over")
     args = ap.parse_args()
 
+    from halide_amd import launcher
+    launcher.ensure_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:])   # N > 1 and no launcher yet: start N ranks, exit
+    rank, local_rank, world = launcher.check_world(args.gpus)
+    if launcher.stub_mode():
+        return stub_main(args, rank, local_rank, world)
+
     import numpy as np
     import torch
     import halide_amd as hl
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     hl.set_gpu_device(local_rank)
-    dist = None
-    rccl_ranks = 1
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        # proof that RCCL really spans `world` ranks (one per GPU): every rank contributes 1 to a sum over xGMI
-        ones = torch.ones(1, dtype=torch.int32, device="cuda")
-        dist.all_reduce(ones)
-        rccl_ranks = int(ones.item())
+    # one process per GPU over RCCL; rccl_ranks = an all-reduced count of the ranks (proof the backend spans `world` GPUs)
+    dist, _, rccl_ranks = launcher.init_process_group(local_rank, world)
 
     # --- synthetic frames, resident in HBM before the timed region
     from halide_amd import sharding
@@ -147,13 +180,17 @@ def main():
         keep = [torch.cuda.Stream() for _ in range(args.streams)]
         streams, mode = [s.cuda_stream for s in keep], f"{args.streams} streams"
 
-    def step(use_streams=True):
+    def one_pass(use_streams=True):
         for i, (a, o) in enumerate(zip(ins, outs)):
             if streams and use_streams:  # frame i goes to stream i % n
                 hl.set_stream(streams[i % len(streams)])
             hl.local_laplacian(a, LEVELS, ALPHA, BETA, o)
         if streams and use_streams:
             hl.set_stream(None)
+
+    def step():
+        for _ in range(args.passes):
+            one_pass()
 
     def barrier():
         torch.cuda.synchronize()
@@ -176,7 +213,7 @@ def main():
     hl.kernel_timing_reset()
     hl.kernel_timing(True)
     for _ in range(3):
-        step(use_streams=False)
+        one_pass(use_streams=False)
     torch.cuda.synchronize()
     hl.kernel_timing(False)
     kernels = hl.kernel_timing_report()
@@ -184,23 +221,36 @@ def main():
 
     # the practical HBM ceiling of this device, measured live: a float4 copy kernel over 1 GiB buffers (4x the MALL), HIP
     # events over 10 launches (halide_amd/csrc/membench.hip) — what "HBM-bound" can reach at best for mixed read/write traffic
-    copy_ceiling = None
+    copy_ceiling, ceiling_detail = None, None
     if rank == 0:
         try:
-            copy_ceiling = hl.membench(1 << 30, 10)["copy_gbs"]
+            ceiling_detail = hl.membench(1 << 30, 10)
+            copy_ceiling = ceiling_detail["copy_gbs"]
         except hl.HalideError:   # e.g. no room for two 1 GiB buffers: the headline line does not depend on it
             copy_ceiling = None
 
     variants = None
     if rank == 0 and world == 1 and not args.no_variants:
-        variants = {"unit": "Mpx/s", "uniform_noise_3840x2160": run_variant(W, H, "noise", 8, 40),
-                    "smooth_7680x4320": run_variant(2 * W, 2 * H, "smooth", 4, 20),
-                    "uniform_noise_7680x4320": run_variant(2 * W, 2 * H, "noise", 4, 20)}
+        variants = {"unit": "Mpx/s", "uniform_noise_3840x2160": run_variant(W, H, "noise", 8, 100),
+                    "smooth_7680x4320": run_variant(2 * W, 2 * H, "smooth", 4, 40),
+                    "uniform_noise_7680x4320": run_variant(2 * W, 2 * H, "noise", 4, 40)}
+        variants["frame_ms"] = {k: round((4 if "7680" in k else 1) * W * H / v / 1e3, 4) for k, v in variants.items() if k != "unit"}
+
+    other_configs = None
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        # BASELINE.json configs[1], [3], [4] in the same driver-run line: ms per call, the roofline that bounds each, and a
+        # bounded oracle cpu_baseline beside it (bench_apps.py holds the measurement code)
+        for b in ins + outs:
+            b.device_free()
+        import bench_apps
+        other_configs = []
+        bench_apps.run(("bilateral_grid", "nl_means", "conv_layer_bf16"), 3, other_configs.append, cpu=not args.no_cpu_baseline)
 
     if rank == 0:
-        px_per_step = world * FRAMES_PER_STEP * W * H
+        frames_per_step = FRAMES_PER_STEP * args.passes
+        px_per_step = world * frames_per_step * W * H
         value = px_per_step * args.steps / elapsed / 1e6
-        frame_ms = elapsed / (args.steps * FRAMES_PER_STEP) * 1e3
+        frame_ms = elapsed / (args.steps * frames_per_step) * 1e3
         # per-launch view: every launch of the chain is reported under its own name (ll_down_strip:1 ... ll_up:6 ...)
         per_frame = {k["name"]: k["total_ms"] / (3 * FRAMES_PER_STEP) for k in kernels}
         # dominant kernel = the launch with the longest average duration; its ALGORITHMIC bytes (compulsory reads +
@@ -226,11 +276,16 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "apps/local_laplacian J=8 levels=8 alpha=1/7 beta=1, u16 RGB planar 3840x2160",
-                       "frames_per_step_per_gpu": FRAMES_PER_STEP, "frame_ms": round(frame_ms, 4),
+                       "frames_per_step_per_gpu": frames_per_step, "distinct_frames_per_gpu": FRAMES_PER_STEP,
+                       "passes_per_step": args.passes, "frame_ms": round(frame_ms, 4),
+                       # remap(x) depends on (levels, alpha) only: its 3585-entry table is memoised across calls, so 8 of the
+                       # reference's 9 stages run inside the timed region (HLMI_LL_NO_LUT_CACHE=1 re-runs it: +1 launch of ~4 us)
+                       "lut_cached": True,
                        "streams_per_gpu": max(1, len(streams)), "frame_scheduling": mode,
                        "boundary": "C ABI local_laplacian(halide_buffer_t*,int32,float,float,halide_buffer_t*)",
                        "input": "smooth natural-like frames (SURVEY.md §8d (ii)); other variants under `variants`",
                        "variants": variants,
+                       "other_configs": other_configs,
                        "rccl_ranks": rccl_ranks,
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -245,6 +300,7 @@ def main():
                          round(frame_traffic / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          # the same against the measured copy ceiling instead of the 8 TB/s spec figure
                          "hbm_copy_ceiling_gbs": None if copy_ceiling is None else round(copy_ceiling, 1),
+                         "hbm_ceiling_detail": ceiling_detail,
                          "pipeline_traffic_frac_of_copy_ceiling": None if (frame_traffic is None or not copy_ceiling) else
                          round(frame_traffic / (frame_ms * 1e-3) / 1e9 / copy_ceiling, 4),
                          # ... and against the float4-copy figure MI355X_MICROARCH.md measured (6.29 TB/s)

@@ -24,18 +24,46 @@ MFMA_BF16_PEAK_TF = 2500.0     # dense
 MFMA_F32_PEAK_TF = 157.3
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="")
-    ap.add_argument("--samples", type=int, default=5)
-    args = ap.parse_args()
+def cpu_time(fn, budget_s=4.0, max_reps=8):
+    """Bounded timing of one oracle call on the host cores (cpu_baseline leg only): one warm call, then repetitions until
+    `budget_s` is spent.  Returns (seconds per call, calls timed)."""
+    fn()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= max_reps:
+            return dt / n, n
+
+
+def run(only=(), samples=5, sink=None, cpu=False):
+    """Times the pipelines named in `only` (all when empty) and hands one dict per pipeline to `sink` (default: print as a
+    JSON line).  cpu=True adds a bounded `cpu_baseline` (the C oracle, OpenMP, kind "port") beside the BASELINE.json
+    configs (bilateral_grid, nl_means, conv_layer_bf16) — bench.py's `other_configs` leg."""
     import numpy as np
     import torch
     import halide_amd as hl
     if not torch.cuda.is_available():
         raise SystemExit("bench_apps.py needs a HIP device (no CPU fallback)")
     rng = np.random.default_rng(0)
-    only = set(filter(None, args.only.split(",")))
+    only = set(only)
+    if sink is None:
+        sink = lambda d: print(json.dumps(d), flush=True)
+
+    class _A:
+        pass
+    args = _A()
+    args.samples = samples
+
+    def cpu_base(fn, units, unit, what):
+        if not cpu:
+            return {}
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib  # cpu_baseline leg only: the checker timed as the host-CPU reference point
+        sec, n = cpu_time(lambda: fn(oracle_lib))
+        return {"cpu_baseline": {"value": round(units / sec / 1e6, 3), "unit": unit, "cores": os.cpu_count() or 1, "kind": "port",
+                                 "ms_per_call": round(sec * 1e3, 2), "sample": f"{n} calls of {what} (C oracle, OpenMP, all host threads)"}}
 
     def timed(call, sync_buf, iters):
         call()
@@ -61,18 +89,18 @@ def main():
         return {k["name"]: round(k["total_ms"] / 3, 5) for k in rep}
 
     def emit(name, workload, t, mpx, bound, achieved, peak, unit, extra):
-        print(json.dumps({"pipeline": name, "workload": workload, "ms_per_call": round(t * 1e3, 4),
-                          "value": round(mpx / t / 1e6, 1), "unit": "Mpx/s",
-                          "roofline": {"bound": bound, "achieved": round(achieved, 1), "peak": peak, "unit": unit,
-                                       "frac": round(achieved / peak, 4)}, **extra}), flush=True)
+        sink({"pipeline": name, "workload": workload, "ms_per_call": round(t * 1e3, 4),
+              "value": round(mpx / t / 1e6, 1), "unit": "Mpx/s",
+              "roofline": {"bound": bound, "achieved": round(achieved, 1), "peak": peak, "unit": unit,
+                           "frac": round(achieved / peak, 4)}, **extra})
 
     # ---- the practical HBM ceiling: copy / read / write kernels over 1 GiB buffers (4x the MALL)
     if not only or "membench" in only:
         m = hl.membench(1 << 30, 10)
-        print(json.dumps({"pipeline": "membench", "workload": "grid-stride float4 kernels over 1 GiB buffers, HIP events over 10 launches",
-                          "copy_gbs": round(m["copy_gbs"], 1), "read_gbs": round(m["read_gbs"], 1),
-                          "write_gbs": round(m["write_gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "copy_frac_of_peak": round(m["copy_gbs"] / HBM_PEAK_GBS, 4)}), flush=True)
+        sink({"pipeline": "membench", "workload": "grid-stride float4 kernels over 1 GiB buffers, HIP events over 10 launches",
+              "copy_gbs": round(m["copy_gbs"], 1), "read_gbs": round(m["read_gbs"], 1),
+              "write_gbs": round(m["write_gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+              "copy_frac_of_peak": round(m["copy_gbs"] / HBM_PEAK_GBS, 4)})
 
     # ---- the headline pipeline on the other inputs SURVEY.md §8(d) lists for configs[2] (bench.py uses the smooth synthetic
     #      frame): uniform full-range noise — the worst case for the data-dependent plane gathers of the up pass — and
@@ -111,8 +139,11 @@ def main():
         a, o = hl.Buffer(img.astype(np.float32)), hl.Buffer(np.zeros((H, W), np.float32))
         call = lambda: hl.bilateral_grid(a, 0.1, o)
         t = timed(call, o, 50)
+        img32 = img.astype(np.float32)
         emit("bilateral_grid", "apps/bilateral_grid f32 1920x1080 s_sigma=8 r_sigma=0.1", t, W * H, "hbm",
-             8.0 * W * H / t / 1e9, HBM_PEAK_GBS, "GB/s", {"alg_bytes": 8 * W * H, "kernels_ms": kernels(call, o)})
+             8.0 * W * H / t / 1e9, HBM_PEAK_GBS, "GB/s",
+             {"alg_bytes": 8 * W * H, "kernels_ms": kernels(call, o),
+              **cpu_base(lambda ol: ol.bilateral_grid(img32, 0.1), W * H, "Mpx/s", "1920x1080 f32")})
 
     # ---- stencil_chain u16 1536x2560, 32 stages
     if not only or "stencil_chain" in only:
@@ -154,14 +185,16 @@ def main():
     # ---- configs[3]: nl_means 7x7 / 7x7, f32 1920x1080x3 (one frame per call; frames of a batch are independent)
     if not only or "nl_means" in only:
         W, H = 1920, 1080
-        a = hl.Buffer(rng.random((3, H, W), dtype=np.float32))
+        nlm_in = rng.random((3, H, W), dtype=np.float32)
+        a = hl.Buffer(nlm_in)
         o = hl.Buffer(np.zeros((3, H, W), np.float32))
         call = lambda: hl.nl_means(a, 7, 7, 0.12, o)
         t = timed(call, o, 10)
         flops = 2200.0 * W * H       # ~49 offsets x ~45 flops per pixel
         emit("nl_means", "apps/nl_means patch 7 search 7 sigma 0.12, f32 1920x1080x3", t, W * H, "valu",
-             flops / t / 1e12, VALU_F32_PEAK_TF, "TFLOP/s", {"alg_flops": flops, "alg_bytes": 24 * W * H,
-                                                            "kernels_ms": kernels(call, o)})
+             flops / t / 1e12, VALU_F32_PEAK_TF, "TFLOP/s",
+             {"alg_flops": flops, "alg_bytes": 24 * W * H, "kernels_ms": kernels(call, o),
+              **cpu_base(lambda ol: ol.nl_means(nlm_in, 7, 7, 0.12), W * H, "Mpx/s", "1920x1080x3 f32, patch 7 search 7")})
 
     # ---- unsharp f32 1536x2560x3 (generator estimates)
     if not only or "unsharp" in only:
@@ -278,17 +311,33 @@ def main():
         if only and name not in only:
             continue
         N, Hh, Ww, CI, CO = 16, 56, 56, 128, 128
-        inp = hl.Buffer(rng.uniform(-1, 1, (N, Hh + 2, Ww + 2, CI)).astype(np.float32))
-        filt = hl.Buffer(rng.uniform(-1, 1, (CI, 3, 3, CO)).astype(np.float32))
-        bias = hl.Buffer(rng.uniform(-1, 1, CO).astype(np.float32))
+        c_in = rng.uniform(-1, 1, (N, Hh + 2, Ww + 2, CI)).astype(np.float32)
+        c_f = rng.uniform(-1, 1, (CI, 3, 3, CO)).astype(np.float32)
+        c_b = rng.uniform(-1, 1, CO).astype(np.float32)
+        inp, filt, bias = hl.Buffer(c_in), hl.Buffer(c_f), hl.Buffer(c_b)
         o = hl.Buffer(np.zeros((N, Hh, Ww, CO), np.float32))
         f = getattr(hl, fn)
         call = lambda: f(inp, filt, bias, o)
         t = timed(call, o, 50)
         flops = 2.0 * N * Hh * Ww * CI * CO * 9
+        io_bytes = 4 * (N * (Hh + 2) * (Ww + 2) * CI + N * Hh * Ww * CO)   # the reference's f32 input and output, each moved once
+        orc = (lambda ol: ol.conv_layer_bf16(c_in, c_f, c_b)) if "bf16" in name else (lambda ol: ol.conv_layer(c_in, c_f, c_b))
         emit(name, f"apps/conv_layer N=16 CI=CO=128 56x56 k=3 ({'bf16 operands, f32 accumulate' if 'bf16' in name else 'exact f32'})",
              t, N * Hh * Ww, "mfma", flops / t / 1e12, peak, "TFLOP/s",
-             {"alg_flops": flops, "alg_bytes": 4 * (N * (Hh + 2) * (Ww + 2) * CI + N * Hh * Ww * CO), "kernels_ms": kernels(call, o)})
+             {"alg_flops": flops, "alg_bytes": io_bytes, "kernels_ms": kernels(call, o),
+              # the second bound: with f32 I/O the call cannot beat its bytes — reported beside the matrix-core fraction
+              "hbm_bound": {"alg_bytes": io_bytes, "achieved_gbs": round(io_bytes / t / 1e9, 1), "peak": HBM_PEAK_GBS,
+                            "frac": round(io_bytes / t / 1e9 / HBM_PEAK_GBS, 4)},
+              **(cpu_base(orc, flops / 1e6, "TFLOP/s", "N=16 56x56 128->128 k=3") if "bf16" in name else {})})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--samples", type=int, default=5)
+    ap.add_argument("--cpu-baseline", action="store_true", help="time the C oracle beside the BASELINE.json configs")
+    a = ap.parse_args()
+    run(filter(None, a.only.split(",")), a.samples, None, a.cpu_baseline)
 
 
 if __name__ == "__main__":
