@@ -29,6 +29,35 @@ if not os.path.exists(LIB_PATH):
 
 
 
+def _elf_dynamic_strings(path: str, tag: int) -> list:
+    """Values of the string-valued entries `tag` (1 = DT_NEEDED, 14 = DT_SONAME) of a little-endian ELF64 shared object's
+    dynamic section; [] when the file cannot be parsed."""
+    import struct
+    try:
+        with open(path, "rb") as f:
+            data = f.read()
+        if data[:4] != b"\x7fELF" or data[4] != 2 or data[5] != 1:
+            return []
+        shoff, = struct.unpack_from("<Q", data, 0x28)
+        shentsize, shnum = struct.unpack_from("<HH", data, 0x3A)
+        secs = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
+        out = []
+        for sec in secs:
+            if sec[1] != 6:      # SHT_DYNAMIC
+                continue
+            strtab = secs[sec[6]]
+            for off in range(sec[4], sec[4] + sec[5], 16):
+                t, v = struct.unpack_from("<qQ", data, off)
+                if t == 0:
+                    break
+                if t == tag:
+                    a = strtab[4] + v
+                    out.append(data[a:data.index(b"\0", a)].decode())
+        return out
+    except Exception:  # noqa: BLE001
+        return []
+
+
 def _preload_torch_hip_runtime() -> str | None:
     """One HIP runtime per process.  The torch-ROCm wheel bundles its own libamdhip64.so (same SONAME as the system's): a
     process that loads libhlmi.so first and torch afterwards ends up with TWO runtimes — the system's under libhlmi.so and
@@ -48,6 +77,15 @@ def _preload_torch_hip_runtime() -> str | None:
     path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
     if not os.path.exists(path):
         return None
+    # libhlmi.so was linked against the system ROCm; torch's copy is only a safe stand-in when it IS the same ABI: its
+    # SONAME must be the libamdhip64 name libhlmi.so lists as NEEDED.  On a mismatch the system runtime is kept (a
+    # process that then also imports torch has to import torch FIRST) unless HLMI_TORCH_HIP=1 insists.
+    import sys
+    if "torch" not in sys.modules and os.environ.get("HLMI_TORCH_HIP") != "1":
+        needed = [n for n in _elf_dynamic_strings(LIB_PATH, 1) if n.startswith("libamdhip64")]
+        soname = _elf_dynamic_strings(path, 14)
+        if not needed or not soname or soname[0] != needed[0]:
+            return None
     try:
         C.CDLL(path, mode=C.RTLD_GLOBAL)
     except OSError:
@@ -136,8 +174,8 @@ _tls = threading.local()
 
 def _on_error(_uc, msg):
     _tls.last_error = msg.decode("utf-8", "replace") if msg else ""
-    if threading.current_thread() is not threading.main_thread():
-        _batch_error[:] = [_tls.last_error]
+    if _batch_active[0] and not _batch_error:   # a worker thread of hlmi_run_batch: keep the batch's FIRST message
+        _batch_error.append(_tls.last_error)
 
 
 _error_cb = _ERR_CB(_on_error)
@@ -400,15 +438,41 @@ def debug_local_laplacian_outg(level: int) -> np.ndarray:
     return out
 
 
-def membench(nbytes: int = 1 << 30, iters: int = 10, blocks: int = 0) -> dict:
-    """Measurement hook: achieved GB/s of a device copy / read-only / write-only kernel over buffers of `nbytes` (the
-    practical HBM ceiling the pipelines' roofline fractions can be read against)."""
+def membench_naive(nbytes: int = 1 << 30, iters: int = 10, blocks: int = 0) -> dict:
+    """The round-1/2 figure: naive grid-stride float4 copy / read-only / write-only kernels over buffers of `nbytes`."""
     fn = lib.hlmi_membench
     fn.restype = C.c_int
     fn.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double)]
     out = (C.c_double * 3)()
     _check(fn(int(nbytes), int(iters), int(blocks), out))
     return {"copy_gbs": out[0], "read_gbs": out[1], "write_gbs": out[2]}
+
+
+def membench_sweep(nbytes: int = 1 << 30, iters: int = 10) -> dict:
+    """Every (loads in flight, workgroups per CU, temporal policy) variant of the streaming kernels + hipMemcpyDtoD
+    (csrc/membench.hip); the full table, as the library measured it."""
+    import json
+    fn = lib.hlmi_membench_sweep
+    fn.restype = C.c_long
+    fn.argtypes = [C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]
+    n = fn(int(nbytes), int(iters), None, 0)
+    if n < 0:
+        _check(int(n))
+    buf = C.create_string_buffer(n + 16)
+    fn(int(nbytes), int(iters), buf, n + 16)
+    return json.loads(buf.value.decode())
+
+
+def membench(nbytes: int = 1 << 30, iters: int = 10, blocks: int = 0) -> dict:
+    """Measurement hook: the practical HBM ceiling the pipelines' roofline fractions can be read against — the BEST copy /
+    read-only / write-only rate over the sweep of streaming-kernel variants, beside the naive kernel's and hipMemcpyDtoD's."""
+    naive = membench_naive(nbytes, iters, blocks)
+    sw = membench_sweep(nbytes, iters)
+    best = sw["best"]
+    return {"copy_gbs": max(best["copy"]["gbs"], naive["copy_gbs"]), "read_gbs": max(best["read"]["gbs"], naive["read_gbs"]),
+            "write_gbs": max(best["write"]["gbs"], naive["write_gbs"]), "best_variant": best,
+            "naive": {k: round(v, 1) for k, v in naive.items()}, "memcpy_d2d_gbs": sw["memcpy_d2d_gbs"],
+            "bytes_per_buffer": sw["bytes"], "guide_copy_gbs": 6290.0}
 
 
 def bilateral_grid(input, r_sigma, output) -> int:
@@ -517,14 +581,24 @@ def run_batch(name: str, frames, devices=None, streams_per_device: int = 1) -> i
     devs = (C.c_int * len(devices))(*devices)
     lib.hlmi_run_batch.restype = C.c_int
     lib.hlmi_run_batch.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_void_p)), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]
-    code = lib.hlmi_run_batch(C.cast(fn, C.c_void_p), argvs, len(frames), devs, len(devices), int(streams_per_device))
+    with _batch_lock:      # one batch at a time records messages: a HalideError never carries another batch's text
+        del _batch_error[:]
+        _batch_active[0] = True
+        try:
+            code = lib.hlmi_run_batch(C.cast(fn, C.c_void_p), argvs, len(frames), devs, len(devices), int(streams_per_device))
+        finally:
+            _batch_active[0] = False
+        msg = _batch_error[0] if _batch_error else ""
     if code != 0:
-        raise HalideError(code, _batch_error[0] if _batch_error else "")
+        raise HalideError(code, msg)
     return 0
 
 
-# worker threads of hlmi_run_batch report through the same handler but on their own threads: keep the last message
+# worker threads of hlmi_run_batch report through the same handler but on their own threads; messages are recorded only
+# while a batch is running (and cleared when it starts), so unrelated calls on other Python threads leave no stale text
 _batch_error: list = []
+_batch_active = [False]
+_batch_lock = threading.Lock()
 
 
 def metadata(name: str) -> halide_filter_metadata_t:

@@ -41,7 +41,8 @@ using namespace hlmi;
 namespace {
 
 constexpr int J = 8;         // pyramid_levels (local_laplacian_generator.cpp:10)
-constexpr int MAX_K = 32;    // largest `levels` the LUT sizing below admits
+constexpr int MAX_K = 32;    // entries of the `Levels` kernel argument (the levels == KCH fast kernels read the first KCH);
+                             // `levels` itself is unbounded above, as in the reference (generator :13: Input<int> levels, no range)
 constexpr int STRIP = 126;   // level-(j+1) columns one wave produces per row (lanes 0..62 store a float2)
 constexpr int KCH = 8;       // planes of gPyramid one ll_down0 pass keeps in registers
 constexpr int D0_THREADS = 256;  // ll_down0 workgroup: one wave per SIMD, two workgroups per CU (242 VGPRs)
@@ -294,7 +295,10 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down0(const uint16_t *__rest
         float level[KCH];                // level_k of this chunk's planes, pinned in scalar registers
 #pragma unroll
         for (int kk = 0; kk < KCH; kk++) {
-            level[kk] = lev.v[kb + kk];
+            // level_k = k * (1 / (levels - 1)) (:41): the same f32 multiply the host does for `lev`, for any number of planes
+            const float lk = (float)(kb + kk) * gm.inv_Km1;   // uniform, but computed on the vector unit: back to a scalar register
+            level[kk] = kb + kk < MAX_K ? lev.v[kb + kk]
+                                        : __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lk)));
             asm volatile("" : "+s"(level[kk]));
         }
 
@@ -1605,9 +1609,15 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     for (int d = 0; d < 3; d++) {
         if ((r = check_covers(uc, args[0], d, output->dim[d].min, output->dim[d].extent))) return r;
     }
-    if (levels < 2 || levels > MAX_K) {
-        return report(uc, levels < 2 ? halide_error_code_param_too_small : halide_error_code_param_too_large,
-                      "Parameter levels is %d but must be in [2, %d]", levels, MAX_K);
+    // The reference declares `Input<int> levels` without a range (generator :13) and divides by levels - 1 (:41): any value
+    // >= 2 is accepted (the remap table lives in LDS up to 15 levels, in global memory beyond; memory grows with levels + 1
+    // planes per pyramid level and an impossible request fails with device_malloc_failed like any other allocation).  levels
+    // < 2 makes 1 / (levels - 1) infinite or negative — the one value range with no defined result — and is rejected.
+    if (levels < 2) {
+        return report(uc, halide_error_code_param_too_small, "Parameter levels is %d but must be at least 2", levels);
+    }
+    if (levels > (1 << 20)) {   // (levels - 1) * 256 table entries and plane counts must stay inside 32-bit index arithmetic
+        return report(uc, halide_error_code_param_too_large, "Parameter levels is %d but must be at most %d", levels, 1 << 20);
     }
     const int ow = output->dim[0].extent, oh = output->dim[1].extent, nc = output->dim[2].extent;
     if (nc > 3) {

@@ -466,8 +466,11 @@ uint64_t buffer_version(const halide_buffer_t *buf) {
 }
 
 // ---- raw allocation with cache ---------------------------------------------------------------
-static int dev_alloc_locked(void *uc, int dev, size_t bytes, hipStream_t for_stream, void **out) {
+// *prior_life = true when the block is a cached one whose previous owner may still have work in flight: the caller's
+// stream `for_stream` has been ordered behind it (stream order, or an event wait), nobody else has.
+static int dev_alloc_locked(void *uc, int dev, size_t bytes, hipStream_t for_stream, void **out, bool *prior_life = nullptr) {
     DeviceState &st = g_dev[dev];
+    if (prior_life) *prior_life = false;
     auto range = st.cache.equal_range(bytes);
     auto pick = range.second;
     for (auto it = range.first; it != range.second; ++it) {
@@ -487,6 +490,7 @@ static int dev_alloc_locked(void *uc, int dev, size_t bytes, hipStream_t for_str
                 (void)hipEventSynchronize(c.done);
             }
             bury_locked(st, c.done);
+            if (prior_life) *prior_life = true;
         }
         *out = c.ptr;
         return 0;
@@ -697,13 +701,16 @@ static int hip_device_malloc(void *uc, halide_buffer_t *buf) {
     if (bytes == 0) bytes = 256;
     void *base = nullptr;
     std::lock_guard<std::mutex> lock(g_mu);
-    r = dev_alloc_locked(uc, ctx.device, bytes, ctx.stream, &base);
+    bool prior_life = false;
+    r = dev_alloc_locked(uc, ctx.device, bytes, ctx.stream, &base, &prior_life);
     if (r) return r;
     buf->device = (uint64_t)(uintptr_t)base;
     buf->device_interface = halide_hip_device_interface();
     Owned rec;
     rec.version = ++g_version_counter;
-    rec.bytes = bytes, rec.last_stream = nullptr;  // a reused allocation has been ordered behind its previous life above
+    // A reused block has been ordered behind its previous life on ctx.stream ONLY (stream order or the event wait above):
+    // naming ctx.stream as its last stream makes a first use on any other stream order itself behind that too (note_use).
+    rec.bytes = bytes, rec.last_stream = prior_life ? ctx.stream : nullptr;
     g_dev[ctx.device].owned[buf->device] = rec;
     return 0;
 }
@@ -806,6 +813,16 @@ static int hip_copy_to_host(void *uc, halide_buffer_t *buf) {
     int r = producer_of(uc, buf, &dev, &s);
     if (r) return r;
     RestoreDevice back{pick_device()};
+    if (!stream_is_special(s)) {
+        // the producing stream may have been destroyed by its owner (a torch stream that was garbage-collected): that
+        // completes its work, and the download goes on the device's own stream instead (hip_device_sync tolerates the same)
+        const hipError_t q = hipStreamQuery(s);
+        if (q != hipSuccess && q != hipErrorNotReady) {
+            (void)hipGetLastError();
+            std::lock_guard<std::mutex> lock(g_mu);
+            s = g_dev[dev].stream;
+        }
+    }
     r = copy_strided(uc, buf, false, s);
     if (r) return r;
     HLMI_HIP(uc, hipStreamSynchronize(s));

@@ -10,8 +10,9 @@
 // (src/CodeGen_C.cpp:688-694), `<name>_metadata` (HalideRuntime.h:1937-1975), the bounds-query protocol
 // (HalideRuntime.h:1851-1853: buffers with host == device == 0) and `buf->device_interface` for sync / copy_to_host.
 //
-// Differences, all printed by --help: image files are PGM / PPM (8- or 16-bit) and NumPy .npy; PNG and JPG need
-// libpng / libjpeg, which this build does not link.
+// Image files: PNG (8 / 16 bit, gray / gray+alpha / RGB / RGBA, non-interlaced — the formats tools/halide_image_io.h:856-1040
+// reads and writes; own codec over zlib in hlmi_png.h, this image has no libpng), binary PGM / PPM and NumPy .npy.  JPG needs
+// libjpeg, which this build does not link (printed by --help).
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -28,6 +29,8 @@
 #include <random>
 #include <sstream>
 #include <string>
+
+#include "hlmi_png.h"
 #include <vector>
 
 #include "hlmi_abi.h"
@@ -196,6 +199,49 @@ void load_pnm(const std::string &path, Arg &a) {
     });
 }
 
+// PNG: samples convert like the reference's image I/O (convert_sample); a 2-D buffer takes channel 0, a buffer with more
+// channels than the file repeats the last one (RunGen's "adapt the image to the argument" rule, tools/RunGen.h:640-700)
+void load_png(const std::string &path, Arg &a) {
+    hlmi_png::Image im;
+    const std::string err = hlmi_png::read(path, im);
+    if (!err.empty()) fail(err);
+    const int w = (int)im.width, h = (int)im.height, ch = im.channels;
+    std::vector<int> ext = {w, h};
+    if ((int)a.md->dimensions >= 3) ext.push_back(ch);
+    while ((int)ext.size() < a.md->dimensions) ext.push_back(1);
+    a.dims = dense_shape({}, ext);
+    allocate(a);
+    const double file_max = im.bit_depth == 16 ? 65535.0 : 255.0;
+    for_each_element(a, [&](size_t i, const std::vector<int> &c) {
+        const int cc = c.size() >= 3 ? std::min(c[2], ch - 1) : 0;
+        store_value(a, i, convert_sample((double)im.at((uint32_t)c[0], (uint32_t)c[1], cc), file_max, a.md->type));
+    });
+}
+
+void save_png(const std::string &path, const Arg &a) {
+    const int w = a.dims.size() > 0 ? a.dims[0].extent : 1, h = a.dims.size() > 1 ? a.dims[1].extent : 1;
+    const int ch = a.dims.size() > 2 ? a.dims[2].extent : 1;
+    if (ch < 1 || ch > 4) fail(path + ": PNG needs 1 to 4 channels, the buffer has " + std::to_string(ch));
+    const halide_type_t t = a.md->type;
+    hlmi_png::Image im;
+    im.width = (uint32_t)w, im.height = (uint32_t)h, im.channels = ch;
+    im.bit_depth = (t.code == halide_type_float || t.bits > 8) ? 16 : 8;
+    const double maxv = im.bit_depth == 16 ? 65535.0 : 255.0;
+    im.bytes.assign((size_t)w * h * ch * (im.bit_depth / 8), 0);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            for (int c = 0; c < ch; c++) {
+                const size_t i = (size_t)x * a.dims[0].stride + (a.dims.size() > 1 ? (size_t)y * a.dims[1].stride : 0) +
+                                 (a.dims.size() > 2 ? (size_t)c * a.dims[2].stride : 0);
+                double v = load_value(a, i);
+                if (t.code == halide_type_float) v = std::floor(std::min(1.0, std::max(0.0, v)) * maxv + 0.5);
+                else v = std::min(maxv, std::max(0.0, v));
+                im.set((uint32_t)x, (uint32_t)y, c, (unsigned)v);
+            }
+    const std::string err = hlmi_png::write(path, im);
+    if (!err.empty()) fail(err);
+}
+
 void save_pnm(const std::string &path, const Arg &a) {
     const int w = a.dims.size() > 0 ? a.dims[0].extent : 1, h = a.dims.size() > 1 ? a.dims[1].extent : 1;
     const int ch = a.dims.size() > 2 ? a.dims[2].extent : 1;
@@ -306,12 +352,12 @@ void usage() {
         "Usage: hlmi_rungen --name=PIPELINE argument=value [argument=value ...] [flags]\n"
         "   or: PIPELINE.rungen argument=value ... (pipeline = basename of argv[0] up to the first '.')\n\n"
         "Arguments follow the reference's RunGen (tools/RunGenMain.cpp): scalars as literals or `default` / `estimate`;\n"
-        "buffers as a file (.pgm .ppm .npy) or a pseudo-file: zero:[e0,e1,..]  constant:V:[..]  identity:[..]\n"
+        "buffers as a file (.png .pgm .ppm .npy) or a pseudo-file: zero:[e0,e1,..]  constant:V:[..]  identity:[..]\n"
         "random:SEED:[..]; `auto` or `estimate` may stand for the extents.\n\n"
         "Flags: --help --describe --output_extents=[..]|estimate --benchmarks=all --benchmark_min_time=SEC\n"
         "       --parsable_output --estimate_all --default_input_buffers[=V] --default_input_scalars[=V]\n"
         "       --success --verbose --quiet\n\n"
-        "PNG / JPG files are not supported by this build (no libpng / libjpeg): use PGM, PPM or .npy.\n";
+        "PNG: 8 / 16 bit, gray / gray+alpha / RGB / RGBA, non-interlaced.  JPG files are not supported by this build (no libjpeg).\n";
 }
 
 }  // namespace
@@ -454,6 +500,9 @@ int main(int argc, char **argv) {
             a.dims = dense_shape(mins, ext);
             allocate(a);
             a.spec = spec;
+        } else if (ends_with(spec, ".png")) {
+            load_png(spec, a);
+            a.spec.clear();
         } else if (ends_with(spec, ".pgm") || ends_with(spec, ".ppm")) {
             load_pnm(spec, a);
             a.spec.clear();
@@ -461,7 +510,7 @@ int main(int argc, char **argv) {
             load_npy(spec, a);
             a.spec.clear();
         } else {
-            fail("cannot read '" + spec + "': supported are .pgm .ppm .npy and the pseudo-files of --help");
+            fail("cannot read '" + spec + "': supported are .png .pgm .ppm .npy and the pseudo-files of --help");
         }
     }
     // ---- outputs: shape from --output_extents, the estimates, or a bounds query constrained by the inputs
@@ -558,8 +607,9 @@ int main(int argc, char **argv) {
         }
         if (a.out_path.empty()) continue;
         if (ends_with(a.out_path, ".npy")) save_npy(a.out_path, a);
+        else if (ends_with(a.out_path, ".png")) save_png(a.out_path, a);
         else if (ends_with(a.out_path, ".pgm") || ends_with(a.out_path, ".ppm")) save_pnm(a.out_path, a);
-        else fail("cannot write '" + a.out_path + "': supported are .pgm .ppm .npy");
+        else fail("cannot write '" + a.out_path + "': supported are .png .pgm .ppm .npy");
     }
     for (auto &a : args)
         if (a.md->kind != halide_argument_kind_input_scalar && a.buf.device_interface) a.buf.device_interface->device_free(nullptr, &a.buf);

@@ -43,7 +43,7 @@ extern "C" {
     const struct halide_filter_metadata_t *name##_metadata(void);
 
 /* apps/local_laplacian/local_laplacian_generator.cpp:12-16,287 — u16 [W,H,3] planar in/out,
- * pyramid_levels J=8 (compile-time GeneratorParam :10), `levels` K in [2,16] at run time.
+ * pyramid_levels J=8 (compile-time GeneratorParam :10), `levels` K >= 2 at run time (no upper bound, as in the reference).
  * Drivers pass alpha/(levels-1) (apps/local_laplacian/process.cpp:31). */
 int local_laplacian(struct halide_buffer_t *input, int32_t levels, float alpha, float beta,
                     struct halide_buffer_t *output);

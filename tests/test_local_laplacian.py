@@ -202,6 +202,8 @@ def _run_hip(hl, inp, levels, alpha, beta, out_arr=None):
     (1, 1, 8, "uniform"), (2, 3, 8, "uniform"), (37, 23, 8, "uniform"), (128, 16, 8, "uniform"),
     (129, 17, 8, "smooth"), (640, 480, 8, "smooth"), (333, 777, 8, "uniform"), (200, 120, 2, "uniform"),
     (200, 120, 4, "smooth"), (200, 120, 15, "uniform"), (200, 120, 16, "uniform"), (96, 64, 20, "smooth"),
+    # beyond 32: the reference declares no upper bound for `levels` (generator :13)
+    (96, 64, 33, "uniform"), (64, 48, 40, "smooth"),
 ])
 def test_hip_matches_oracle(hl, oracle, w, h, levels, kind):
     inp = _rand_image(w, h, seed=w + 7 * h + levels, kind=kind)

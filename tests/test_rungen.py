@@ -67,3 +67,63 @@ def test_bounds_query_sizes_auto_inputs_and_ppm_output(tmp_path):
     assert "Argument input: [ (0,66,1) (0,50,66) ]" in p.stdout
     with open(tmp_path / "o.pgm", "rb") as f:
         assert f.read(2) == b"P5"
+
+
+# ---- PNG files (halide_amd/tools/hlmi_png.h: the runner's own codec over zlib; reference: tools/halide_image_io.h:856-1040)
+def _png_tool(tmp_path):
+    exe = tmp_path / "png_codec_test"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "halide_amd", "tools"),
+                    os.path.join(ROOT, "tests", "cpp", "png_codec_test.cpp"), "-o", str(exe), "-lz"], check=True)
+    return str(exe)
+
+
+@pytest.mark.parametrize("channels,depth", [(1, 8), (2, 8), (3, 8), (4, 8), (1, 16), (3, 16), (4, 16)])
+def test_png_codec_round_trip(tmp_path, channels, depth):
+    """A file with all five scanline filters and a split IDAT stream (written by the independent Python encoder of
+    tests/test_dropin_drivers.py) decodes to the same samples, and what the codec writes the Python decoder reads back."""
+    from test_dropin_drivers import read_png, write_png
+    rng = np.random.default_rng(channels * 100 + depth)
+    img = rng.integers(0, 1 << depth, (channels, 37, 53)).astype(np.uint16 if depth == 16 else np.uint8)
+    src, dst = str(tmp_path / "in.png"), str(tmp_path / "out.png")
+    write_png(src, img, depth)
+    p = subprocess.run([_png_tool(tmp_path), src, dst], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout.split() == ["53", "37", str(channels), str(depth)]
+    assert np.array_equal(read_png(dst), img)
+
+
+def test_png_codec_rejects_damaged_files(tmp_path):
+    from test_dropin_drivers import write_png
+    tool = _png_tool(tmp_path)
+    src = str(tmp_path / "in.png")
+    write_png(src, np.zeros((3, 8, 8), np.uint8))
+    data = bytearray(open(src, "rb").read())
+    data[40] ^= 0x55                                   # inside the first IDAT chunk: its CRC no longer matches
+    open(src, "wb").write(bytes(data))
+    p = subprocess.run([tool, src, str(tmp_path / "o.png")], capture_output=True, text=True)
+    assert p.returncode == 1 and "CRC" in p.stderr
+    open(src, "wb").write(b"not a png at all")
+    p = subprocess.run([tool, src, str(tmp_path / "o.png")], capture_output=True, text=True)
+    assert p.returncode == 1 and "not a PNG" in p.stderr
+
+
+@pytest.mark.gpu
+def test_png_in_png_out_matches_the_oracle(oracle, tmp_path):
+    """`input=foo.png output=bar.png` — the command the reference's RunGen accepts (tools/RunGenMain.cpp:100-112): 16-bit RGB
+    in, 16-bit RGB out, bit-exact with the oracle on the decoded samples."""
+    from test_dropin_drivers import read_png, write_png
+    rng = np.random.default_rng(11)
+    inp = rng.integers(0, 65536, (3, 90, 160), dtype=np.uint16)
+    write_png(str(tmp_path / "in.png"), inp, 16)
+    _run("--name=local_laplacian", f"input={tmp_path / 'in.png'}", "levels=8", "alpha=0.14285714285714285", "beta=1",
+         f"output={tmp_path / 'out.png'}", "--output_extents=[160,90,3]")
+    got = read_png(str(tmp_path / "out.png"))
+    want = oracle.local_laplacian(inp, 8, np.float32(0.14285714285714285), 1.0)
+    assert got.dtype == np.uint16 and np.array_equal(got, want)
+    # an 8-bit file feeding the u16 input is rescaled x257 like the reference's image I/O (halide_image_io.h:79-240)
+    inp8 = rng.integers(0, 256, (3, 90, 160), dtype=np.uint8)
+    write_png(str(tmp_path / "in8.png"), inp8, 8)
+    _run("--name=local_laplacian", f"input={tmp_path / 'in8.png'}", "levels=8", "alpha=0.14285714285714285", "beta=1",
+         f"output={tmp_path / 'out8.png'}", "--output_extents=[160,90,3]")
+    want8 = oracle.local_laplacian(inp8.astype(np.uint16) * 257, 8, np.float32(0.14285714285714285), 1.0)
+    assert np.array_equal(read_png(str(tmp_path / "out8.png")), want8)
