@@ -463,6 +463,17 @@ def membench_sweep(nbytes: int = 1 << 30, iters: int = 10) -> dict:
     return json.loads(buf.value.decode())
 
 
+def membench_widths(nbytes: int = 1 << 30, iters: int = 4) -> dict:
+    """Read-only kernels that fetch `nbytes` exactly once with 4 / 8 / 16-byte aligned, 8-byte misaligned and overlapping
+    8-byte loads: the known-bytes calibration runs for rocprofv3's FETCH_SIZE (csrc/membench.hip)."""
+    fn = lib.hlmi_membench_widths
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+    out = (C.c_double * 5)()
+    _check(fn(int(nbytes), int(iters), out))
+    return dict(zip(("ld4_gbs", "ld8_gbs", "ld16_gbs", "ld8u_gbs", "ld8o_gbs"), (round(v, 1) for v in out)))
+
+
 def membench(nbytes: int = 1 << 30, iters: int = 10, blocks: int = 0) -> dict:
     """Measurement hook: the practical HBM ceiling the pipelines' roofline fractions can be read against — the BEST copy /
     read-only / write-only rate over the sweep of streaming-kernel variants, beside the naive kernel's and hipMemcpyDtoD's."""

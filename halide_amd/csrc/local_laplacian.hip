@@ -35,6 +35,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
+#include <vector>
 
 using namespace hlmi;
 
@@ -1589,6 +1590,50 @@ std::mutex g_lut_mu;
 LutImage g_lut[8];
 uint64_t g_lut_clock = 0;
 
+// ---- HIP graphs.  One frame is a chain of 8 dependent launches whose arguments are a pure function of (buffers, shape,
+// parameters, workspace, switches); callers that process a stream of equally shaped frames into the same buffers (bench.py,
+// apps/local_laplacian/process.cpp:38's benchmark loop, a video pipeline with a ring of frames) repeat the same chain.  The
+// SECOND call with a given key captures the chain on the call's stream (hipStreamBeginCapture, thread-local mode) and
+// instantiates it; that call and every later one replay it with one hipGraphLaunch instead of 8 launches' worth of host
+// work.  Keys that differ in any pointer, extent, stride, parameter, switch or in the workspace address never match, so a
+// graph can only replay launches that the eager path would have issued with identical arguments.  HLMI_LL_GRAPH=0 disables.
+struct GraphKey {
+    int device;
+    hipStream_t stream;
+    const void *in, *out, *ws, *lut;
+    int32_t idim[3][3], odim[3][3];   // min, extent, stride
+    int32_t levels;
+    uint32_t alpha_bits, beta_bits;
+    uint64_t env_sig;
+    bool operator==(const GraphKey &o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
+};
+struct GraphEntry {
+    GraphKey key;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool failed = false;       // capture or instantiation was refused once: stay eager for this key
+    bool out1_pending = false; // debug bookkeeping of the captured call (hlmi_debug_local_laplacian_outg)
+    uint64_t used = 0;
+};
+std::mutex g_graph_mu;
+std::vector<GraphEntry> g_graphs;   // small (<= 64): linear search
+uint64_t g_graph_clock = 0;
+
+uint64_t ll_env_signature() {
+    static const char *const names[] = {"HLMI_LL_NO_LUT_CACHE", "HLMI_LL_UNITS0", "HLMI_LL_NO_VEC", "HLMI_LL_D0F", "HLMI_LL_FUSE_D2",
+                                        "HLMI_LL_D01_EXCH", "HLMI_LL_FUSE_FROM", "HLMI_LL_UNITSB", "HLMI_LL_UPCHAIN_FROM",
+                                        "HLMI_LL_UP0_OLD", "HLMI_LL_FUSE_UP1", "HLMI_LL_RU"};
+    uint64_t h = 1469598103934665603ull;
+    for (const char *n : names) {
+        const char *e = getenv(n);
+        for (const char *c = e ? e : ""; ; c++) {
+            h = (h ^ (uint8_t)*c) * 1099511628211ull;
+            if (!*c) break;
+        }
+    }
+    return h;
+}
+
 }  // namespace
 
 extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alpha, float beta, halide_buffer_t *output) {
@@ -1730,6 +1775,8 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     } else {
         HLMI_LAUNCH(uc, "ll_remap_lut", st, ll_remap_lut, dim3((nlut + 255) / 256), dim3(256), 0, lut, gm.half, alpha);
     }
+    bool fuse1_out = false;
+    auto enqueue = [&]() -> int {   // the launch chain of one frame (everything below depends only on what GraphKey holds)
     bool fuse_d2 = false;
     {
         const Level &d = lv[1];
@@ -1953,8 +2000,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         HLMI_LAUNCH(uc, nm, st, ll_up, dim3((rw + 255) / 256, rh), dim3(256), 0, a.g, a.ws, a.ps, a.lox, a.loy, c.g,
                     c.out, c.ws, c.ps, c.lox, c.loy, a.rx0, a.ry0, rw, rh, levels, gm.Km1, a.out);
     }
-    t_dbg_out1_pending = fuse1;
-    t_dbg_K = levels, t_dbg_Km1 = gm.Km1;
+    fuse1_out = fuse1;
     {
         const Level &c = lv[1];
         dim3 grid((ow + 255) / 256, (oh + 2 * p.RU - 1) / (2 * p.RU)), block(256);
@@ -1987,6 +2033,117 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             else HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0<false, false>), grid, block, lut_sh, p, gm);
         }
     }
+    return 0;
+    };  // enqueue
+
+    t_dbg_K = levels, t_dbg_Km1 = gm.Km1;
+    // ---- replay / capture / eager
+    GraphEntry *ge = nullptr;
+    const bool graphs = env_int("HLMI_LL_GRAPH", 1) && !stream_is_special(st) && !timing_enabled() && !env_int("HLMI_LL_NO_LUT_CACHE", 0);
+    bool capture = false;
+    GraphKey key;
+    memset(&key, 0, sizeof key);   // padding bytes too: keys are compared with memcmp
+    if (graphs) {
+        key.device = ctx.device, key.stream = st, key.in = din, key.out = dout, key.ws = ws, key.lut = lut;
+        for (int d = 0; d < 3; d++) {
+            key.idim[d][0] = input->dim[d].min, key.idim[d][1] = input->dim[d].extent, key.idim[d][2] = input->dim[d].stride;
+            key.odim[d][0] = output->dim[d].min, key.odim[d][1] = output->dim[d].extent, key.odim[d][2] = output->dim[d].stride;
+        }
+        key.levels = levels;
+        memcpy(&key.alpha_bits, &alpha, 4);
+        memcpy(&key.beta_bits, &beta, 4);
+        key.env_sig = ll_env_signature();
+        std::lock_guard<std::mutex> lock(g_graph_mu);
+        for (auto &e : g_graphs) {
+            if (e.key == key) {
+                ge = &e;
+                break;
+            }
+        }
+        if (ge && ge->exec) {
+            ge->used = ++g_graph_clock;
+            t_dbg_out1_pending = ge->out1_pending;
+            HLMI_HIP(uc, hipGraphLaunch(ge->exec, st));   // under the lock: an entry cannot be evicted while it is launched
+            mark_output_written(output);
+            return 0;
+        }
+        if (!ge) {   // first sight of this key: remember it, run eagerly
+            if (g_graphs.size() >= 64) {
+                size_t victim = 0;
+                for (size_t i = 1; i < g_graphs.size(); i++) if (g_graphs[i].used < g_graphs[victim].used) victim = i;
+                GraphEntry &v = g_graphs[victim];
+                if (v.exec) {   // may still be executing on its stream
+                    (void)hipStreamSynchronize(v.key.stream);
+                    (void)hipGraphExecDestroy(v.exec);
+                    (void)hipGraphDestroy(v.graph);
+                    (void)hipGetLastError();
+                }
+                g_graphs.erase(g_graphs.begin() + victim);
+            }
+            GraphEntry e;
+            e.key = key, e.used = ++g_graph_clock;
+            g_graphs.push_back(e);
+        } else if (!ge->failed) {
+            capture = true;   // second sight
+        }
+    }
+    if (capture) {
+        // the entry may move when another thread pushes (`ge` is not used beyond this point): capture into locals, publish
+        // under the lock by key
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        int er = 0;
+        if (ok) {
+            er = enqueue();
+            ok = hipStreamEndCapture(st, &graph) == hipSuccess && graph != nullptr && er == 0;
+        }
+        if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            if (exec) (void)hipGraphExecDestroy(exec);
+            if (graph) (void)hipGraphDestroy(graph);
+            exec = nullptr, graph = nullptr;
+        }
+        {
+            std::lock_guard<std::mutex> lock(g_graph_mu);
+            for (auto &e : g_graphs) {
+                if (e.key == key) {
+                    if (ok && !e.exec) {
+                        e.graph = graph, e.exec = exec, e.out1_pending = fuse1_out, e.used = ++g_graph_clock;
+                        graph = nullptr, exec = nullptr;
+                    } else if (!ok) {
+                        e.failed = true;
+                    }
+                    break;
+                }
+            }
+        }
+        if (exec) {   // another thread published the same key meanwhile (or the entry was evicted): use ours once, drop it
+            HLMI_HIP(uc, hipGraphLaunch(exec, st));
+            (void)hipStreamSynchronize(st);
+            (void)hipGraphExecDestroy(exec);
+            (void)hipGraphDestroy(graph);
+            t_dbg_out1_pending = fuse1_out;
+            mark_output_written(output);
+            return 0;
+        }
+        if (ok) {
+            std::lock_guard<std::mutex> lock(g_graph_mu);
+            for (auto &e : g_graphs) {
+                if (e.key == key && e.exec) {
+                    t_dbg_out1_pending = e.out1_pending;
+                    HLMI_HIP(uc, hipGraphLaunch(e.exec, st));
+                    mark_output_written(output);
+                    return 0;
+                }
+            }
+        }
+        if (er) return er;   // a launch error inside the capture: reported as the eager path would
+        // capture refused: fall through to the eager path
+    }
+    if ((r = enqueue())) return r;
+    t_dbg_out1_pending = fuse1_out;
     mark_output_written(output);
     return 0;
 }

@@ -63,6 +63,28 @@ __global__ __launch_bounds__(256) void mb_stream(const f32x4 *__restrict__ src, 
     if (MODE == 1 && acc.x + acc.y + acc.z + acc.w == 12345.678f) dst[0] = acc;   // never true for the zero-filled source
 }
 
+// ---- calibration of the PMC byte counters by access width (MI355X_MICROARCH.md §HBM: FETCH_SIZE is calibrated only for 16-byte
+// streaming reads).  Each kernel reads every byte of the buffer exactly once from HBM with one access shape:
+//   mb_ld4 / mb_ld8 / mb_ld16: aligned 4 / 8 / 16-byte loads, consecutive lanes consecutive addresses
+//   mb_ld8u: 8-byte loads at 4-byte misalignment (what a packed, 4-aligned float2 gather compiles to)
+//   mb_ld8o: OVERLAPPING 8-byte loads at a 4-byte lane stride — ll_up0f's plane gathers (lane i reads columns c+i, c+i+1)
+// so that rocprofv3's FETCH_SIZE (and the TCC request counters) of each can be divided by the known byte count.
+struct __attribute__((packed, aligned(4))) F2P { float x, y; };
+template<int MODE>
+__global__ __launch_bounds__(256) void mb_width(const char *__restrict__ src, float *__restrict__ sink, size_t bytes) {
+    float acc = 0.0f;
+    const size_t per_wave_iter = MODE == 0 ? 256 : MODE == 1 ? 512 : MODE == 2 ? 1024 : MODE == 3 ? 512 : 256;
+    const size_t lane = threadIdx.x & 63, wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (size_t)gridDim.x * 4;
+    for (size_t base = wave * per_wave_iter; base + per_wave_iter + 16 <= bytes; base += nwaves * per_wave_iter) {
+        if (MODE == 0) acc += *reinterpret_cast<const float *>(src + base + 4 * lane);
+        if (MODE == 1) { const float2 v = *reinterpret_cast<const float2 *>(src + base + 8 * lane); acc += v.x + v.y; }
+        if (MODE == 2) { const f32x4 v = *reinterpret_cast<const f32x4 *>(src + base + 16 * lane); acc += v.x + v.y + v.z + v.w; }
+        if (MODE == 3) { const F2P v = *reinterpret_cast<const F2P *>(src + base + 4 + 8 * lane); acc += v.x + v.y; }
+        if (MODE == 4) { const F2P v = *reinterpret_cast<const F2P *>(src + base + 4 * lane); acc += v.x + v.y; }
+    }
+    if (acc == 12345.678f) sink[0] = acc;   // never true for the zero-filled source
+}
+
 struct Timer {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipStream_t st;
@@ -158,6 +180,34 @@ extern "C" int hlmi_membench(size_t bytes, int iters, int blocks, double *out_gb
     }
     (void)hipFree(a);
     (void)hipFree(b);
+    return hipGetLastError() == hipSuccess ? 0 : halide_error_code_device_run_failed;
+}
+
+// Launches the five width-calibration kernels (mb_width<0..4>: ld4, ld8, ld16, ld8u, ld8o) `iters` times each over a buffer of
+// `bytes`; out_gbs[5] = achieved GB/s.  Meant to be run under `rocprofv3 --pmc FETCH_SIZE` (scripts/gpu_r3_pmc.sh).
+extern "C" int hlmi_membench_widths(size_t bytes, int iters, double *out_gbs) {
+    DeviceCtx ctx;
+    int r = acquire_device(nullptr, &ctx);
+    if (r) return r;
+    if (iters < 1 || !out_gbs) return halide_error_code_bad_dimensions;
+    Buffers buf;
+    if ((r = buf.alloc(bytes, ctx.stream))) return r;
+    const size_t nbytes = buf.n16 * 16;
+    const int cus = stream_cu_count(ctx.device, nullptr);
+    Timer t(ctx.stream);
+    for (int mode = 0; mode < 5; mode++) {
+        const double ms = t.ms_per_iter(iters, [&] {
+            const dim3 grid(cus * 8), block(256);
+            switch (mode) {
+                case 0: hipLaunchKernelGGL(mb_width<0>, grid, block, 0, ctx.stream, (const char *)buf.a, (float *)buf.b, nbytes); break;
+                case 1: hipLaunchKernelGGL(mb_width<1>, grid, block, 0, ctx.stream, (const char *)buf.a, (float *)buf.b, nbytes); break;
+                case 2: hipLaunchKernelGGL(mb_width<2>, grid, block, 0, ctx.stream, (const char *)buf.a, (float *)buf.b, nbytes); break;
+                case 3: hipLaunchKernelGGL(mb_width<3>, grid, block, 0, ctx.stream, (const char *)buf.a, (float *)buf.b, nbytes); break;
+                default: hipLaunchKernelGGL(mb_width<4>, grid, block, 0, ctx.stream, (const char *)buf.a, (float *)buf.b, nbytes); break;
+            }
+        });
+        out_gbs[mode] = (double)nbytes / (ms * 1e-3) / 1e9;
+    }
     return hipGetLastError() == hipSuccess ? 0 : halide_error_code_device_run_failed;
 }
 
