@@ -84,42 +84,74 @@ __global__ void bg_histogram_blurz(const float *__restrict__ in, long in_sy, BGe
 // Same function for grids of at most 16 planes (r_sigma >= 1/14.5; the reference's 0.1 gives 12), parallel over
 // (cell, range bin): thread (c, z) walks the 64 pixels of cell c in RDom order and adds those that fall into bin z —
 // per bin exactly the additions, in exactly the order, of the serial histogram (:28-29), but a register chain of 64
-// steps instead of 64 LDS read-modify-writes, and 16x the threads.
-constexpr int HC = 16, HZ = 16;  // cells per workgroup (one grid row segment), bin slots per cell
-__global__ __launch_bounds__(HC * HZ) void bg_histogram_blurz_par(const float *__restrict__ in, long in_sy, BGeom g,
-                                                                  float2 *__restrict__ bz) {
-    __shared__ __attribute__((aligned(16))) float s_val[HC][S * S];
-    __shared__ __attribute__((aligned(16))) int s_zi[HC][S * S];
+// steps instead of 64 LDS read-modify-writes, and HZ x the threads.
+//   * HZ = bin slots per cell: 12 when the grid has at most 12 planes (r_sigma = 0.1: 11 bins, 12 planes; 21 cells per
+//     workgroup of 252 threads), else 16 — idle bin lanes are pure loss in a kernel bound by VALU issue.
+//   * the weight channel is a COUNT (sums of 1.0f up to 64 are exact in any order): an integer add-with-carry per pixel
+//     instead of a select and a float add.
+//   * LDS rows are padded to 68 words: the 16 (or 12) threads of a cell read one address (broadcast), but unpadded rows put
+//     every cell's row on the same banks (4-way conflicts on both 16-byte reads of each step; 1.1 M conflict cycles per launch
+//     in profiles/r02f_apps_pmc.txt — with four SIMDs sharing the LDS that, not the VALU, set the pace).
+constexpr int HTH = 256;         // at most this many threads per workgroup
+constexpr int HROW = S * S + 4;  // padded row of the staged cell
+template<int HZ>
+__global__ __launch_bounds__(HTH) void bg_histogram_blurz_par(const float *__restrict__ in, long in_sy, BGeom g,
+                                                              float2 *__restrict__ bz, int vec) {
+    constexpr int HC = HTH / HZ, NT = HC * HZ;   // cells per workgroup (one grid row segment), threads used
+    __shared__ __attribute__((aligned(16))) float s_val[HC][HROW];
+    __shared__ __attribute__((aligned(16))) int s_zi[HC][HROW];
     __shared__ float2 s_h[HC][HZ + 4];          // histogram, bins -2 .. HZ+1 (zero padded for the z blur)
-    const int t = threadIdx.x, c = t / HZ, z = t % HZ;
+    const int t = threadIdx.x, c = t / HZ, z = t - c * HZ;
     const int cx0 = blockIdx.x * HC, cy = blockIdx.y;
     const int gy = g.gy0 - 2 + cy;
-    for (int i = t; i < HC * S * S; i += HC * HZ) {
-        const int cc = i / (S * S), p = i % (S * S), ry = p / S, rx = p % S;
-        const int gx = g.gx0 - 2 + cx0 + cc;
-        const int py = dev::clampi(gy * S + ry - S / 2, g.iy0, g.iy1) - g.iy0;
-        const int px = dev::clampi(gx * S + rx - S / 2, g.ix0, g.ix1) - g.ix0;
-        const float val = dev::clampf(in[(long)py * in_sy + px], 0.0f, 1.0f);
-        s_val[cc][p] = val;
-        s_zi[cc][p] = (int)(val * g.inv_r + 0.5f);
+    // staging.  Interior workgroups (every staged column inside the image, rows 16-byte aligned: `vec`) move float4: a wave
+    // reads 1 KB of one image row per instruction and writes the two LDS arrays 16 bytes at a time — 6 instead of 35 VALU
+    // instructions per pixel; workgroups that touch the left / right image edge clamp every column.
+    const int xlo = (g.gx0 - 2 + cx0) * S - S / 2;   // absolute x of the first staged column
+    constexpr int RQ = HC * S / 4;                   // float4 per staged row
+    if (vec && xlo >= g.ix0 && xlo + HC * S - 1 <= g.ix1) {
+        for (int i = t; i < S * RQ; i += NT) {
+            const int ry = i / RQ, q = i - ry * RQ;
+            const int py = dev::clampi(gy * S + ry - S / 2, g.iy0, g.iy1) - g.iy0;
+            const float4 v = *reinterpret_cast<const float4 *>(in + (long)py * in_sy + (xlo - g.ix0) + 4 * q);
+            const int cc = q >> 1, o = ry * S + (q & 1) * 4;
+            float4 cv;
+            cv.x = dev::clampf(v.x, 0.0f, 1.0f), cv.y = dev::clampf(v.y, 0.0f, 1.0f);
+            cv.z = dev::clampf(v.z, 0.0f, 1.0f), cv.w = dev::clampf(v.w, 0.0f, 1.0f);
+            int4 zi;
+            zi.x = (int)(cv.x * g.inv_r + 0.5f), zi.y = (int)(cv.y * g.inv_r + 0.5f);
+            zi.z = (int)(cv.z * g.inv_r + 0.5f), zi.w = (int)(cv.w * g.inv_r + 0.5f);
+            *reinterpret_cast<float4 *>(&s_val[cc][o]) = cv;
+            *reinterpret_cast<int4 *>(&s_zi[cc][o]) = zi;
+        }
+    } else {
+        for (int i = t; i < HC * S * S; i += NT) {
+            const int ry = i / (HC * S), xx = i - ry * (HC * S), cc = xx / S, rx = xx % S;   // lanes run along the image row
+            const int py = dev::clampi(gy * S + ry - S / 2, g.iy0, g.iy1) - g.iy0;
+            const int px = dev::clampi(xlo + xx, g.ix0, g.ix1) - g.ix0;
+            const float val = dev::clampf(in[(long)py * in_sy + px], 0.0f, 1.0f);
+            s_val[cc][ry * S + rx] = val;
+            s_zi[cc][ry * S + rx] = (int)(val * g.inv_r + 0.5f);
+        }
     }
-    for (int i = t; i < HC * (HZ + 4); i += HC * HZ) s_h[i / (HZ + 4)][i % (HZ + 4)] = make_float2(0.0f, 0.0f);
+    for (int i = t; i < HC * (HZ + 4); i += NT) s_h[i / (HZ + 4)][i % (HZ + 4)] = make_float2(0.0f, 0.0f);
     __syncthreads();
     // four pixels per LDS instruction; a sum that starts at +0 and only ever adds non-negative terms is never -0, so adding
     // +0 for the pixels of other bins leaves it bit for bit what the selective add would give
-    float hv = 0.0f, hw = 0.0f;
+    float hv = 0.0f;
+    int cnt = 0;
     const float4 *v4 = reinterpret_cast<const float4 *>(s_val[c]);
     const int4 *z4 = reinterpret_cast<const int4 *>(s_zi[c]);
 #pragma unroll 4
     for (int q = 0; q < S * S / 4; q++) {
         const float4 v = v4[q];
         const int4 zz = z4[q];
-        hv = hv + (zz.x == z ? v.x : 0.0f), hw = hw + (zz.x == z ? 1.0f : 0.0f);
-        hv = hv + (zz.y == z ? v.y : 0.0f), hw = hw + (zz.y == z ? 1.0f : 0.0f);
-        hv = hv + (zz.z == z ? v.z : 0.0f), hw = hw + (zz.z == z ? 1.0f : 0.0f);
-        hv = hv + (zz.w == z ? v.w : 0.0f), hw = hw + (zz.w == z ? 1.0f : 0.0f);
+        hv = hv + (zz.x == z ? v.x : 0.0f), cnt += (zz.x == z);
+        hv = hv + (zz.y == z ? v.y : 0.0f), cnt += (zz.y == z);
+        hv = hv + (zz.z == z ? v.z : 0.0f), cnt += (zz.z == z);
+        hv = hv + (zz.w == z ? v.w : 0.0f), cnt += (zz.w == z);
     }
-    if (z < g.ZH) s_h[c][z + 2] = make_float2(hv, hw);
+    if (z < g.ZH) s_h[c][z + 2] = make_float2(hv, (float)cnt);
     __syncthreads();
     const int cx = cx0 + c;
     if (z < g.ZD && cx < g.HX) {
@@ -288,9 +320,16 @@ extern "C" int bilateral_grid(halide_buffer_t *input, float r_sigma, halide_buff
     const float *din = dev_ptr<float>(input);
     const long in_sy = input->dim[1].stride, out_sy = output->dim[1].stride;
     hipStream_t st = ctx.stream;
-    if (g.ZD <= HZ && !getenv("HLMI_BG_SERIAL")) {
-        HLMI_LAUNCH(uc, "bg_histogram_blurz", st, bg_histogram_blurz_par, dim3((g.HX + HC - 1) / HC, g.HY), dim3(HC * HZ), 0, din,
-                    in_sy, g, bz);
+    // float4 staging: rows 16-byte aligned at every staged column group (cells start at multiples of 8 minus 4)
+    const int vec = ((uintptr_t)din % 16 == 0 && in_sy % 4 == 0 && floor_div(g.ix0, 4) * 4 == g.ix0 && !getenv("HLMI_BG_NO_VEC")) ? 1 : 0;
+    if (g.ZD <= 12 && !getenv("HLMI_BG_SERIAL")) {
+        constexpr int HC = HTH / 12;
+        HLMI_LAUNCH(uc, "bg_histogram_blurz", st, bg_histogram_blurz_par<12>, dim3((g.HX + HC - 1) / HC, g.HY), dim3(HC * 12), 0, din,
+                    in_sy, g, bz, vec);
+    } else if (g.ZD <= 16 && !getenv("HLMI_BG_SERIAL")) {
+        constexpr int HC = HTH / 16;
+        HLMI_LAUNCH(uc, "bg_histogram_blurz", st, bg_histogram_blurz_par<16>, dim3((g.HX + HC - 1) / HC, g.HY), dim3(HC * 16), 0, din,
+                    in_sy, g, bz, vec);
     } else {
         int T = 64;
         while (T > 1 && (size_t)g.ZH * 2 * T * sizeof(float) > 65536) T >>= 1;

@@ -24,6 +24,7 @@
 #include "hlmi_internal.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 using namespace hlmi;
 
@@ -68,7 +69,10 @@ __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {  // {bf16(lo),
 //   FRAG = false: wB[kk][co][ci]                                  (rows of k, staged through LDS by conv3x3_bf16_mfma)
 //   FRAG = true : wB[kk][ci / 32][(ci % 32) / 16][co / 32][lane][8], lane = co % 32 + 32 ((ci % 16) / 8): every
 //                 32x16 MFMA B fragment is 1 KB contiguous in lane order (one coalesced 16-byte load per lane)
-template<bool FRAG>
+//   FRAG = 2    : wB[ci / 32][kk][(ci % 32) / 16][co / 32][lane][8]: the same 1 KB fragments in the order conv3x3_bf16_p
+//                 consumes them — tap (ci chunk, kk) is one contiguous 2 x (CO / 32) KB block, a workgroup's four
+//                 co-fragments of a k-step are 4 KB contiguous: one coalesced 16-byte load per thread and k-step
+template<int FRAG>
 __global__ void conv_filter_bf16(const float *__restrict__ filt, uint16_t *__restrict__ wb, int CI, int CO) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (kk, co, ci pair)
     const int half = CI / 2, total = 9 * CO * half;
@@ -76,9 +80,12 @@ __global__ void conv_filter_bf16(const float *__restrict__ filt, uint16_t *__res
     const int cp = e % half, co = (e / half) % CO, kk = e / (half * CO);
     const float a = filt[((size_t)(2 * cp) * 9 + kk) * CO + co], b = filt[((size_t)(2 * cp + 1) * 9 + kk) * CO + co];
     size_t o;                                             // in bf16 pairs
-    if (FRAG) {
+    if (FRAG == 1) {
         const int ci = 2 * cp, cc = ci / 32, ks = (ci % 32) / 16, kh = (ci % 16) / 8, j = ci % 8;   // 32-ci chunks (KL)
         o = ((((((size_t)kk * (CI / 32) + cc) * 2 + ks) * (CO / 32) + co / 32) * 64 + (co % 32) + 32 * kh) * 8 + j) / 2;
+    } else if (FRAG == 2) {
+        const int ci = 2 * cp, cc = ci / 32, ks = (ci % 32) / 16, kh = (ci % 16) / 8, j = ci % 8;
+        o = ((((((size_t)cc * 9 + kk) * 2 + ks) * (CO / 32) + co / 32) * 64 + (co % 32) + 32 * kh) * 8 + j) / 2;
     } else {
         o = ((size_t)kk * CO + co) * half + cp;
     }
@@ -341,6 +348,179 @@ void conv3x3_bf16_lin(const float *__restrict__ in, const uint16_t *__restrict__
         }
 }
 
+
+// ---- conv3x3_bf16_p: the same input-linear GEMM, ONE workgroup per compute unit with everything it streams staged once.
+// What conv3x3_bf16_lin left on the table at configs[4] (29.4 us): every wave pulled its own copy of the B
+// fragments through L1 (590 KB per workgroup at 64 B/clk: 5.5 us), 421 workgroups on 256 CUs ran load / MFMA / store in
+// lock-step, and a barrier per chunk drained the prefetch.  Here:
+//   * a workgroup owns TQ = 256 consecutive input-linear positions x 128 output channels (211 workgroups at configs[4]: one
+//     round, one per CU, XCD-contiguous so that neighbouring tiles find their shared halo rows in the XCD's L2); a wave owns
+//     64 positions x all 128 channels (acc[2][4] = 128 accumulator registers), so an A fragment feeds four MFMAs and a B
+//     fragment two: 6 ds_read_b128 per 8 MFMAs (37 % of the LDS pipe with four waves);
+//   * B: the fragment-ordered bf16 filter comes through LDS ONCE per workgroup — per tap 8 KB (2 k-steps x 4 fragments), one
+//     16-byte load per thread and k-step, BD = 6 taps ahead through a register ring (a wave's vmcnt is in order: loads that
+//     far ahead never make a wait drain the A window requested behind them), two LDS slots;
+//   * A: the window of a 32-ci chunk (TQ + 2 (W+2) + 2 rows) is requested when the previous chunk starts and converted into
+//     the other LDS buffer under that chunk's last tap;
+//   * ONE barrier per tap, placed after the first four of the tap's sixteen MFMAs: the fragments of the second k-step were
+//     requested before them, the next tap's B slot is written just before the barrier and its first fragments are requested
+//     right after it — the matrix pipe always has at least four MFMAs queued while a wave waits.
+// Only plain loads are in flight at a barrier (no stores before the epilogue), so __syncthreads() costs lgkmcnt(0) + s_barrier.
+constexpr int TQ = 256;        // input-linear positions per workgroup
+constexpr int BD = 6;          // B taps in flight
+constexpr int BSLOT = 4096;    // bf16 elements of one tap's B slot in LDS: [2 k-steps][4 co-fragments][64 lanes][8]
+template<int NP>
+__global__ __launch_bounds__(256) void conv3x3_bf16_p(const float *__restrict__ in, const uint16_t *__restrict__ wb,
+                                                     const float *__restrict__ bias, float *__restrict__ out, CGeom g, int AR,
+                                                     FastDiv d_img, FastDiv d_row) {
+    extern __shared__ uint16_t smem[];                       // [A window 0][A window 1][B slot 0][B slot 1]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Wp = g.W + 2, Hp = g.H + 2;
+    const uint32_t NQ = (uint32_t)g.N * Hp * Wp;
+    // XCD-contiguous tiles (blocks are dealt round-robin to the 8 XCDs; bijective for any grid size)
+    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot_in_xcd;
+    const uint32_t Q0 = (uint32_t)tile * TQ;
+    const int co0 = blockIdx.y * TC;
+    const uint32_t ncot = (uint32_t)g.CO / 32, cot0 = (uint32_t)co0 / 32;
+    const int cpk = g.CI / KL, ntap = 9 * cpk;
+    uint16_t *const sA0 = smem, *const sA1 = smem + (size_t)AR * PL, *const sB = smem + (size_t)2 * AR * PL;
+
+    floatx16 acc[2][4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const float bv = bias[co0 + 32 * b + (lane & 31)];   // C init = bias broadcast down the rows
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = bv;
+    }
+    // ---- staging roles
+    const int aq = tid & 7, ap = tid >> 3;                   // A: float4 aq of the 32-ci chunk, window rows ap + 32 i
+    float4 va[NP];
+    auto load_a = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const uint32_t q = min(Q0 + (uint32_t)(ap + 32 * i), NQ - 1);   // NQ CI < 2^31 elements
+            va[i] = *reinterpret_cast<const float4 *>(in + (q * (uint32_t)g.CI + (uint32_t)(cc * KL + 4 * aq)));
+        }
+    };
+    auto store_a = [&](uint16_t *sA) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            if (ap + 32 * i < AR) {
+                uint2 w;
+                w.x = pk_bf16(va[i].x, va[i].y), w.y = pk_bf16(va[i].z, va[i].w);
+                *reinterpret_cast<uint2 *>(sA + (ap + 32 * i) * PL + 4 * aq) = w;
+            }
+        }
+    };
+    u32x4 rb[BD][2];                                         // B taps in flight: [ring slot][k-step]
+    auto load_b = [&](int T, u32x4 (&dst)[2]) {              // T = chunk * 9 + kk; layout of conv_filter_bf16<2>
+        const uint32_t e0 = (((uint32_t)T * 2) * ncot + cot0) * 512 + (uint32_t)tid * 8;
+        dst[0] = *reinterpret_cast<const u32x4 *>(wb + e0);
+        dst[1] = *reinterpret_cast<const u32x4 *>(wb + e0 + ncot * 512);
+    };
+    auto store_b = [&](int slot, const u32x4 (&src)[2]) {
+        u32x4 *d = reinterpret_cast<u32x4 *>(sB + slot * BSLOT);
+        d[tid] = src[0];
+        d[256 + tid] = src[1];
+    };
+    // ---- fragments: two register sets, one per k-step of a tap
+    bf16x8 fa[2][2], fb[2][4];
+    const int a_lane = (64 * wave + (lane & 31)) * PL + 8 * (lane >> 5);
+    auto read_frags = [&](int fs, const uint16_t *sA, int tapoff, int ks, int slot) {
+        const uint16_t *pa = sA + a_lane + tapoff + 16 * ks;
+        fa[fs][0] = *reinterpret_cast<const bf16x8 *>(pa);
+        fa[fs][1] = *reinterpret_cast<const bf16x8 *>(pa + 32 * PL);
+        const uint16_t *pb = sB + slot * BSLOT + ks * 2048 + lane * 8;
+#pragma unroll
+        for (int b = 0; b < 4; b++) fb[fs][b] = *reinterpret_cast<const bf16x8 *>(pb + b * 512);
+    };
+    auto mfma4 = [&](int fs, int a) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[fs][a], fb[fs][b], acc[a][b], 0, 0, 0);
+    };
+    const int WpPL = Wp * PL;
+    // one tap; t = its index in the 18-tap body (two chunks), Tb = global index of the body's first tap
+    auto tap = [&](auto tt, int Tb) {
+        constexpr int t = decltype(tt)::value, kk = t % 9, half = t / 9, ky = kk / 3, kx = kk % 3;
+        constexpr int kn = (kk + 1) % 9, kyn = kn / 3, kxn = kn % 3;
+        const int T = Tb + t, cc = T / 9;                    // cc parity == half (a body starts at an even chunk)
+        uint16_t *const sAc = half ? sA1 : sA0, *const sAo = half ? sA0 : sA1;
+        // requests: B of tap T + BD into the ring slot tap T's data left when it went to LDS; next chunk's A window.
+        // UNCONDITIONAL (indices clamped at the end of the K loop, where the redundant data is simply never used): a load
+        // behind a branch makes the compiler's vmcnt bookkeeping assume nothing younger may be in flight, and every wait for
+        // a ring slot became vmcnt(0) — the whole prefetch drained once per tap.
+        load_b(min(T + BD, ntap - 1), rb[t % BD]);
+        if (kk == 0) load_a(min(cc + 1, cpk - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(1, sAc, ky * WpPL + kx * PL, 1, t & 1);   // second k-step of this tap
+        mfma4(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // the other B slot was last read by tap T - 1, whose readers all passed that tap's barrier
+        store_b((t + 1) & 1, rb[(t + 1) % BD]);
+        if (kk == 8) store_a(sAo);                           // that window was last read during chunk cc - 1
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4(0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(0, kk == 8 ? sAo : sAc, kyn * WpPL + kxn * PL, 0, (t + 1) & 1);   // first k-step of the next tap
+        mfma4(1, 0);
+        mfma4(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // ---- prologue
+    load_a(0);
+#pragma unroll
+    for (int j = 0; j < BD; j++) load_b(min(j, ntap - 1), rb[j]);
+    store_a(sA0);
+    store_b(0, rb[0]);
+    __syncthreads();
+    read_frags(0, sA0, 0, 0, 0);
+#pragma unroll 1
+    for (int Tb = 0; Tb < ntap; Tb += 18) {
+        tap(std::integral_constant<int, 0>{}, Tb);
+        tap(std::integral_constant<int, 1>{}, Tb);
+        tap(std::integral_constant<int, 2>{}, Tb);
+        tap(std::integral_constant<int, 3>{}, Tb);
+        tap(std::integral_constant<int, 4>{}, Tb);
+        tap(std::integral_constant<int, 5>{}, Tb);
+        tap(std::integral_constant<int, 6>{}, Tb);
+        tap(std::integral_constant<int, 7>{}, Tb);
+        tap(std::integral_constant<int, 8>{}, Tb);
+        tap(std::integral_constant<int, 9>{}, Tb);
+        tap(std::integral_constant<int, 10>{}, Tb);
+        tap(std::integral_constant<int, 11>{}, Tb);
+        tap(std::integral_constant<int, 12>{}, Tb);
+        tap(std::integral_constant<int, 13>{}, Tb);
+        tap(std::integral_constant<int, 14>{}, Tb);
+        tap(std::integral_constant<int, 15>{}, Tb);
+        tap(std::integral_constant<int, 16>{}, Tb);
+        tap(std::integral_constant<int, 17>{}, Tb);
+    }
+    // ---- epilogue: relu, store (co fastest); C/D map: row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), col = lane & 31
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const uint32_t q = Q0 + (uint32_t)(64 * wave + 32 * a + row);
+            if (q < NQ) {
+                const uint32_t n = fdiv(q, d_img), rem = q - n * d_img.d, y = fdiv(rem, d_row), x = rem - y * d_row.d;
+                if ((int)y < g.H && (int)x < g.W) {
+                    float *o = out + ((((size_t)n * g.H + y) * g.W + x) * g.CO + co0 + (lane & 31));
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const float v = acc[a][b][r];
+                        o[32 * b] = v > 0.0f ? v : 0.0f;
+                    }
+                }
+            }
+        }
+}
+
 const halide_type_t ty_f32 = {(decltype(halide_type_t::code))2, 32, 0};
 // estimates: BASELINE.json configs[4] (N=16, 56x56 output, 128 -> 128 channels)
 const int64_t e0 = 0, e128 = 128, e3 = 3, e58 = 58, e56 = 56, e16 = 16;
@@ -357,70 +537,140 @@ const halide_filter_argument_t conv_args[4] = {
 const halide_filter_metadata_t conv_md = {1, 4, conv_args, kTargetString, "conv_layer_bf16"};
 
 // ---- cache of re-ordered filters -------------------------------------------------------------------------------
+// One entry per (device, filter allocation, version, layout).  An entry is read by the main kernel of every call that hits
+// it, on whatever stream that call runs: the entry therefore remembers, per reader stream, an event recorded behind the last
+// main kernel enqueued there, and whoever re-fills or evicts the entry first orders its own stream behind all of them.  The
+// cache lock is held from the lookup until the caller's main kernel has been enqueued and recorded (FilterUse), so an
+// entry can never be re-filled between a hit and the launch that reads it.  Filters in memory the runtime does not own
+// (version 0: wrapped pointers, e.g. every torch tensor) are never cached: their image lives in the calling stream's own
+// scratch arena, where stream order alone protects it.
+constexpr int FI_READERS = 4;
 struct FilterImage {
     int device = -1;
     uint64_t handle = 0, version = 0;
-    bool lin = false;
+    int layout = 0;
     size_t bytes = 0;
     uint16_t *wb = nullptr;
     hipStream_t stream = nullptr;  // stream the pre-pass ran on
     hipEvent_t ready = nullptr;    // recorded behind the pre-pass
+    struct Reader {
+        hipStream_t s = nullptr;
+        hipEvent_t done = nullptr;
+        bool live = false;
+    } readers[FI_READERS];
+    bool overflow = false;         // more reader streams than slots: fall back to a device-wide wait
     uint64_t used = 0;
 };
 std::mutex g_fi_mu;
 FilterImage g_fi[8];
 uint64_t g_fi_clock = 0;
 
-// A slot being (re)filled: holds the cache lock until the pre-pass has been enqueued and its event recorded, so that
-// no other thread can match a half-described entry; if the caller bails out before done(), the entry is invalidated.
-struct FilterFill {
+// everything enqueued so far that reads `e.wb` happens before whatever `consumer` enqueues from now on
+void wait_for_readers(FilterImage &e, hipStream_t consumer) {
+    bool sync_all = e.overflow;
+    for (auto &r : e.readers) {
+        if (!r.live) continue;
+        if (r.s != consumer && wait_done(consumer, r.done) != hipSuccess) {
+            (void)hipGetLastError();
+            sync_all = true;   // e.g. the reader's stream was destroyed: nothing of it can still be pending, but be safe
+        }
+        r.live = false;
+    }
+    if (sync_all) {
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != e.device && e.device >= 0) (void)hipSetDevice(e.device);
+        (void)hipDeviceSynchronize();
+        if (cur >= 0 && cur != e.device) (void)hipSetDevice(cur);
+        (void)hipGetLastError();
+    }
+    e.overflow = false;
+}
+
+// A use of a filter image by one call: holds the cache lock (when the image is a cache entry) until done() — called after
+// the main kernel has been enqueued — has recorded this stream as a reader.  `fill` = the pre-pass has to run first.
+struct FilterUse {
     std::unique_lock<std::mutex> lock;
-    FilterImage *slot = nullptr;
-    void done(hipStream_t s) {
-        if (slot) (void)record_done(slot->ready, s);
-        slot = nullptr;
+    FilterImage *entry = nullptr;   // null: the image is in the stream's scratch arena
+    bool fill = false;
+    uint16_t *wb = nullptr;
+    void filled(hipStream_t s) {    // the pre-pass has been enqueued on s
+        if (entry) (void)record_done(entry->ready, s);
+        fill = false;
+    }
+    void done(hipStream_t s) {      // the main kernel has been enqueued on s
+        if (entry) {
+            FilterImage::Reader *slot = nullptr;
+            for (auto &r : entry->readers) {
+                if (r.live && r.s == s) slot = &r;
+            }
+            if (!slot) {
+                for (auto &r : entry->readers) {
+                    if (!r.live) { slot = &r; break; }
+                }
+            }
+            if (slot) {
+                if (!slot->done && hipEventCreateWithFlags(&slot->done, hipEventDisableTiming) != hipSuccess) slot = nullptr;
+            }
+            if (slot && record_done(slot->done, s) == hipSuccess) slot->s = s, slot->live = true;
+            else (void)hipGetLastError(), entry->overflow = true;
+        }
+        entry = nullptr;
         if (lock.owns_lock()) lock.unlock();
     }
-    ~FilterFill() {
-        if (slot) slot->version = 0, slot->handle = 0;
+    ~FilterUse() {
+        if (entry && fill) entry->version = 0, entry->handle = 0;   // bailed out before the pre-pass: never match this entry
+        if (entry) entry->overflow = true;                          // bailed out after it: an unrecorded reader may exist
     }
 };
 
-int filter_image(void *uc, const DeviceCtx &ctx, const halide_buffer_t *filter, size_t bytes, bool lin, uint16_t **wb,
-                 FilterFill *fill) {
+int filter_image(void *uc, const DeviceCtx &ctx, const halide_buffer_t *filter, size_t bytes, int layout, FilterUse *use) {
     const uint64_t version = buffer_version(filter);
-    std::unique_lock<std::mutex> lock(g_fi_mu);
-    FilterImage *slot = nullptr;
-    if (version != 0 && !getenv("HLMI_CONV_NO_FILTER_CACHE")) {
-        for (auto &e : g_fi) {
-            if (e.wb && e.device == ctx.device && e.handle == filter->device && e.version == version && e.lin == lin && e.bytes == bytes) {
-                e.used = ++g_fi_clock;
-                if (e.stream != ctx.stream && e.ready) HLMI_HIP(uc, wait_done(ctx.stream, e.ready));
-                *wb = e.wb;
-                return 0;
-            }
-        }
-        slot = &g_fi[0];
-        for (int i = 0; i < 7; i++) {
-            FilterImage &e = g_fi[i];
-            if (!e.wb) { slot = &e; break; }
-            if (e.used < slot->used) slot = &e;
-        }
-    } else {
-        slot = &g_fi[7];  // uncacheable filters share the last slot; version 0 never matches a lookup
+    if (version == 0 || getenv("HLMI_CONV_NO_FILTER_CACHE")) {
+        void *ws = nullptr;
+        int r = get_workspace(uc, ctx, bytes, &ws);
+        if (r) return r;
+        use->wb = (uint16_t *)ws, use->fill = true, use->entry = nullptr;
+        return 0;
     }
-    if (slot->wb && (slot->bytes != bytes || slot->device != ctx.device)) {
-        (void)hipFree(slot->wb);  // synchronises with every stream that may still read it
-        slot->wb = nullptr;
+    std::unique_lock<std::mutex> lock(g_fi_mu);
+    for (auto &e : g_fi) {
+        if (e.wb && e.device == ctx.device && e.handle == filter->device && e.version == version && e.layout == layout && e.bytes == bytes) {
+            e.used = ++g_fi_clock;
+            if (e.stream != ctx.stream && e.ready) HLMI_HIP(uc, wait_done(ctx.stream, e.ready));
+            use->wb = e.wb, use->fill = false, use->entry = &e, use->lock = std::move(lock);
+            return 0;
+        }
+    }
+    FilterImage *slot = &g_fi[0];
+    for (auto &e : g_fi) {
+        if (!e.wb) { slot = &e; break; }
+        if (e.used < slot->used) slot = &e;
+    }
+    if (slot->wb) {
+        // re-fill or evict: the old image may still be read on other streams (and was produced on slot->stream)
+        if (slot->device == ctx.device) {
+            wait_for_readers(*slot, ctx.stream);
+            if (slot->stream != ctx.stream && slot->ready && wait_done(ctx.stream, slot->ready) != hipSuccess) (void)hipGetLastError();
+        } else {
+            slot->overflow = true;
+            wait_for_readers(*slot, nullptr);   // another device: host-side wait for everything there
+        }
+        if (slot->bytes != bytes || slot->device != ctx.device) {
+            if (slot->device == ctx.device) HLMI_HIP(uc, hipStreamSynchronize(ctx.stream));   // the waits above have been enqueued: drain them before freeing
+            int cur = -1;
+            (void)hipGetDevice(&cur);
+            if (cur != slot->device) (void)hipSetDevice(slot->device);
+            (void)hipFree(slot->wb);
+            if (cur >= 0 && cur != slot->device) (void)hipSetDevice(cur);
+            slot->wb = nullptr;
+        }
     }
     if (!slot->wb) HLMI_HIP(uc, hipMalloc((void **)&slot->wb, bytes));
-    else if (slot->stream && slot->stream != ctx.stream) HLMI_HIP(uc, hipStreamSynchronize(slot->stream));  // old image may be in use there
     if (!slot->ready) HLMI_HIP(uc, hipEventCreateWithFlags(&slot->ready, hipEventDisableTiming));
-    slot->device = ctx.device, slot->handle = filter->device, slot->version = version, slot->lin = lin, slot->bytes = bytes;
+    slot->device = ctx.device, slot->handle = filter->device, slot->version = version, slot->layout = layout, slot->bytes = bytes;
     slot->stream = ctx.stream, slot->used = ++g_fi_clock;
-    *wb = slot->wb;
-    fill->slot = slot;
-    fill->lock = std::move(lock);
+    use->wb = slot->wb, use->fill = true, use->entry = slot, use->lock = std::move(lock);
     return 0;
 }
 
@@ -448,32 +698,52 @@ extern "C" int conv_layer_bf16(halide_buffer_t *input, halide_buffer_t *filter, 
         const size_t wb_bytes = (size_t)9 * g.CO * g.CI * sizeof(uint16_t);
         const int pairs = 9 * g.CO * (g.CI / 2);
         const int AR = TP + 2 * (g.W + 2) + 2;               // input-linear window of a 128-pixel tile
-        const size_t sh_lin = (size_t)2 * AR * (32 + 8) * sizeof(uint16_t);   // two windows of 32-ci chunks, 80-byte rows
+        const size_t sh_lin = (size_t)2 * AR * PL * sizeof(uint16_t);   // two windows of 32-ci chunks, 80-byte rows
         const long NQ = (long)g.N * (g.H + 2) * (g.W + 2);
-        const bool lin = AR <= 32 * 12 && NQ < (1L << 31) && !getenv("HLMI_CONV_IM2COL");   // W <= 125
+        const bool lin = AR <= 32 * 12 && NQ < (1L << 31) && NQ * g.CI < (1L << 31) && !getenv("HLMI_CONV_IM2COL");   // W <= 125
+        // conv3x3_bf16_p: 256-position tiles, B through LDS (see the kernel); the older kernels stay for what it does not take
+        const int ARp = TQ + 2 * (g.W + 2) + 2;
+        const size_t sh_p = ((size_t)2 * ARp * PL + 2 * BSLOT) * sizeof(uint16_t);
+        const bool pers = lin && ARp <= 32 * 16 && sh_p <= 160 * 1024 && g.CO % TC == 0 && g.CI % (2 * KL) == 0 &&
+                          !getenv("HLMI_CONV_OLD");
+        const int layout = pers ? 2 : (lin ? 1 : 0);
         // The bf16 MFMA-B image of the filter is a function of the filter's contents only: it is kept per (filter
-        // allocation, version) and the pre-pass re-runs only when the filter changed (uploaded again because the
+        // allocation, version, layout) and the pre-pass re-runs only when the filter changed (uploaded again because the
         // caller set host_dirty, written by another pipeline, re-allocated).  Weights that stay resident — the
-        // inference case — pay the re-ordering once.  Filters in memory the runtime does not own (wrapped pointers,
-        // version 0) are never cached: their owner may rewrite them behind our back.
-        uint16_t *wb = nullptr;
-        FilterFill fill;
-        if ((r = filter_image(uc, ctx, filter, wb_bytes, lin, &wb, &fill))) return r;
-        if (fill.slot) {
+        // inference case — pay the re-ordering once.
+        FilterUse use;
+        if ((r = filter_image(uc, ctx, filter, wb_bytes, layout, &use))) return r;
+        uint16_t *wb = use.wb;
+        if (use.fill) {
             timing_note_bytes(6.0 * 9 * g.CO * g.CI);
-            if (lin) {
-                HLMI_LAUNCH(uc, "conv_filter_bf16", ctx.stream, conv_filter_bf16<true>, dim3((pairs + 255) / 256), dim3(256), 0,
-                            dev_ptr<float>(filter), wb, g.CI, g.CO);
+            const dim3 fgrid((pairs + 255) / 256), fblock(256);
+            if (layout == 2) {
+                HLMI_LAUNCH(uc, "conv_filter_bf16", ctx.stream, conv_filter_bf16<2>, fgrid, fblock, 0, dev_ptr<float>(filter), wb, g.CI, g.CO);
+            } else if (layout == 1) {
+                HLMI_LAUNCH(uc, "conv_filter_bf16", ctx.stream, conv_filter_bf16<1>, fgrid, fblock, 0, dev_ptr<float>(filter), wb, g.CI, g.CO);
             } else {
-                HLMI_LAUNCH(uc, "conv_filter_bf16", ctx.stream, conv_filter_bf16<false>, dim3((pairs + 255) / 256), dim3(256), 0,
-                            dev_ptr<float>(filter), wb, g.CI, g.CO);
+                HLMI_LAUNCH(uc, "conv_filter_bf16", ctx.stream, conv_filter_bf16<0>, fgrid, fblock, 0, dev_ptr<float>(filter), wb, g.CI, g.CO);
             }
-            fill.done(ctx.stream);
+            use.filled(ctx.stream);
         }
-        if (lin) {
+        const FastDiv d_img = make_fastdiv((uint32_t)((g.H + 2) * (g.W + 2))), d_row = make_fastdiv((uint32_t)(g.W + 2));
+        if (pers) {
+            dim3 grid((unsigned)((NQ + TQ - 1) / TQ), g.CO / TC);
+            timing_note_bytes(4.0 * ((double)NQ * g.CI + (double)g.npix * g.CO) + (double)wb_bytes);
+            if (ARp <= 32 * 12) {
+                HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_p<12>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_p));
+                HLMI_LAUNCH(uc, "conv3x3_bf16_mfma", ctx.stream, conv3x3_bf16_p<12>, grid, dim3(256), sh_p, dev_ptr<float>(input), wb,
+                            dev_ptr<float>(bias), dev_ptr<float>(relu), g, ARp, d_img, d_row);
+            } else {
+                HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_p<16>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_p));
+                HLMI_LAUNCH(uc, "conv3x3_bf16_mfma", ctx.stream, conv3x3_bf16_p<16>, grid, dim3(256), sh_p, dev_ptr<float>(input), wb,
+                            dev_ptr<float>(bias), dev_ptr<float>(relu), g, ARp, d_img, d_row);
+            }
+        } else if (lin) {
             dim3 grid((unsigned)((NQ + TP - 1) / TP), g.CO / TC);
             timing_note_bytes(4.0 * ((double)NQ * g.CI + (double)g.npix * g.CO) + (double)wb_bytes);
-            const FastDiv d_img = make_fastdiv((uint32_t)((g.H + 2) * (g.W + 2))), d_row = make_fastdiv((uint32_t)(g.W + 2));
             if (AR <= 32 * 8) {
                 HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_lin<8>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_lin));
@@ -485,16 +755,16 @@ extern "C" int conv_layer_bf16(halide_buffer_t *input, halide_buffer_t *filter, 
                 HLMI_LAUNCH(uc, "conv3x3_bf16_mfma", ctx.stream, conv3x3_bf16_lin<12>, grid, dim3(256), sh_lin, dev_ptr<float>(input),
                             wb, dev_ptr<float>(bias), dev_ptr<float>(relu), g, AR, d_img, d_row);
             }
-            mark_output_written(relu);
-            return 0;
+        } else {
+            const size_t sh = (size_t)2 * (TP + TC) * PA * sizeof(uint16_t);  // 73.7 KB: above the 64 KB default window
+            HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_mfma),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+            dim3 grid((unsigned)((g.npix + TP - 1) / TP), g.CO / TC);
+            timing_note_bytes(4.0 * ((double)g.N * (g.H + 2) * (g.W + 2) * g.CI + (double)g.npix * g.CO) + (double)wb_bytes);
+            HLMI_LAUNCH(uc, "conv3x3_bf16_mfma", ctx.stream, conv3x3_bf16_mfma, grid, dim3(256), sh, dev_ptr<float>(input), wb,
+                        dev_ptr<float>(bias), dev_ptr<float>(relu), g);
         }
-        const size_t sh = (size_t)2 * (TP + TC) * PA * sizeof(uint16_t);  // 73.7 KB: above the 64 KB default window
-        HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_mfma),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        dim3 grid((unsigned)((g.npix + TP - 1) / TP), g.CO / TC);
-        timing_note_bytes(4.0 * ((double)g.N * (g.H + 2) * (g.W + 2) * g.CI + (double)g.npix * g.CO) + (double)wb_bytes);
-        HLMI_LAUNCH(uc, "conv3x3_bf16_mfma", ctx.stream, conv3x3_bf16_mfma, grid, dim3(256), sh, dev_ptr<float>(input), wb,
-                    dev_ptr<float>(bias), dev_ptr<float>(relu), g);
+        use.done(ctx.stream);
     }
     mark_output_written(relu);
     return 0;

@@ -1596,7 +1596,13 @@ uint64_t g_lut_clock = 0;
 // SECOND call with a given key captures the chain on the call's stream (hipStreamBeginCapture, thread-local mode) and
 // instantiates it; that call and every later one replay it with one hipGraphLaunch instead of 8 launches' worth of host
 // work.  Keys that differ in any pointer, extent, stride, parameter, switch or in the workspace address never match, so a
-// graph can only replay launches that the eager path would have issued with identical arguments.  HLMI_LL_GRAPH=0 disables.
+// graph can only replay launches that the eager path would have issued with identical arguments.  The capture runs on a
+// private stream of the calling thread (capturing records, it does not execute — and a capture on the caller's own stream would
+// swallow or be invalidated by whatever another host thread enqueues there meanwhile, e.g. a halide_copy_to_host); the
+// instantiated graph is then launched on the caller's stream.
+// OPT-IN (HLMI_LL_GRAPH=1): measured on MI355X it buys nothing — 84.2 vs 83.4 Gpx/s on four CU-partitioned streams (inside the
+// box-to-box noise) and 69.1 vs 72.7 Gpx/s on one stream (profiles/r03a_*): the GPU-side gap between dependent launches is the
+// same for a graph and for eager launches, and the host (44 us of enqueue per 99 us frame) is not the bottleneck.
 struct GraphKey {
     int device;
     hipStream_t stream;
@@ -2039,7 +2045,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     t_dbg_K = levels, t_dbg_Km1 = gm.Km1;
     // ---- replay / capture / eager
     GraphEntry *ge = nullptr;
-    const bool graphs = env_int("HLMI_LL_GRAPH", 1) && !stream_is_special(st) && !timing_enabled() && !env_int("HLMI_LL_NO_LUT_CACHE", 0);
+    const bool graphs = env_int("HLMI_LL_GRAPH", 0) && !stream_is_special(st) && !timing_enabled() && !env_int("HLMI_LL_NO_LUT_CACHE", 0);
     bool capture = false;
     GraphKey key;
     memset(&key, 0, sizeof key);   // padding bytes too: keys are compared with memcmp
@@ -2092,11 +2098,17 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         // under the lock by key
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
-        bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        static thread_local hipStream_t t_cap[64] = {};   // per thread and device: used for captures only, never executes
+        hipStream_t &cap = t_cap[ctx.device & 63];
+        bool ok = cap != nullptr || hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) == hipSuccess;
         int er = 0;
+        if (ok) ok = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) == hipSuccess;
         if (ok) {
+            const hipStream_t real = st;
+            st = cap;            // `enqueue` launches on `st`
             er = enqueue();
-            ok = hipStreamEndCapture(st, &graph) == hipSuccess && graph != nullptr && er == 0;
+            st = real;
+            ok = hipStreamEndCapture(cap, &graph) == hipSuccess && graph != nullptr && er == 0;
         }
         if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
         if (!ok) {
