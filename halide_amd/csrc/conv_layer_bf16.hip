@@ -353,29 +353,36 @@ void conv3x3_bf16_lin(const float *__restrict__ in, const uint16_t *__restrict__
 // What conv3x3_bf16_lin left on the table at configs[4] (29.4 us): every wave pulled its own copy of the B
 // fragments through L1 (590 KB per workgroup at 64 B/clk: 5.5 us), 421 workgroups on 256 CUs ran load / MFMA / store in
 // lock-step, and a barrier per chunk drained the prefetch.  Here:
-//   * a workgroup owns TQ = 256 consecutive input-linear positions x 128 output channels (211 workgroups at configs[4]: one
-//     round, one per CU, XCD-contiguous so that neighbouring tiles find their shared halo rows in the XCD's L2); a wave owns
-//     64 positions x all 128 channels (acc[2][4] = 128 accumulator registers), so an A fragment feeds four MFMAs and a B
-//     fragment two: 6 ds_read_b128 per 8 MFMAs (37 % of the LDS pipe with four waves);
+//   * a workgroup of EIGHT waves owns TQ = 256 consecutive input-linear positions x 128 output channels (211 workgroups at
+//     configs[4]: one round, one per CU, XCD-contiguous so that neighbouring tiles find their shared halo rows in the XCD's
+//     L2); a wave owns 64 positions x 64 channels (acc[2][2]).  Two waves per SIMD are essential: an MFMA blocks the wave
+//     that issued it, so with one wave per SIMD every ds_read, address add and wait between two MFMAs is time the matrix
+//     pipe idles (the four-wave version of this kernel, 64 x 128 per wave, measured 26.5 us: half the pipe's time);
 //   * B: the fragment-ordered bf16 filter comes through LDS ONCE per workgroup — per tap 8 KB (2 k-steps x 4 fragments), one
-//     16-byte load per thread and k-step, BD = 6 taps ahead through a register ring (a wave's vmcnt is in order: loads that
-//     far ahead never make a wait drain the A window requested behind them), two LDS slots;
+//     16-byte load per thread, BD = 6 taps ahead through a register ring (a wave's vmcnt is in order: loads that far ahead
+//     never make a wait drain the A window requested behind them), two LDS slots;
 //   * A: the window of a 32-ci chunk (TQ + 2 (W+2) + 2 rows) is requested when the previous chunk starts and converted into
 //     the other LDS buffer under that chunk's last tap;
-//   * ONE barrier per tap, placed after the first four of the tap's sixteen MFMAs: the fragments of the second k-step were
-//     requested before them, the next tap's B slot is written just before the barrier and its first fragments are requested
-//     right after it — the matrix pipe always has at least four MFMAs queued while a wave waits.
+//   * ONE barrier per tap, placed after the first half of the tap's first k-step: the fragments of the second k-step were
+//     requested before it, the next tap's B slot is written just before the barrier and its first fragments are requested
+//     right after it.
 // Only plain loads are in flight at a barrier (no stores before the epilogue), so __syncthreads() costs lgkmcnt(0) + s_barrier.
+// All requests are unconditional (indices clamped at the end of the K loop): a load behind a branch makes the compiler's
+// vmcnt bookkeeping assume nothing younger may be in flight, and every wait for a ring slot became vmcnt(0).
 constexpr int TQ = 256;        // input-linear positions per workgroup
+constexpr int PT = 512;        // threads per workgroup
 constexpr int BD = 6;          // B taps in flight
 constexpr int BSLOT = 4096;    // bf16 elements of one tap's B slot in LDS: [2 k-steps][4 co-fragments][64 lanes][8]
-template<int NP>
-__global__ __launch_bounds__(256) void conv3x3_bf16_p(const float *__restrict__ in, const uint16_t *__restrict__ wb,
-                                                     const float *__restrict__ bias, float *__restrict__ out, CGeom g, int AR,
-                                                     FastDiv d_img, FastDiv d_row) {
+// ABL: timing experiments (HLMI_CONVP_ABL=mask at run time, results wrong): 1 no output stores, 2 no K loop, 4 no B loads in
+// the loop, 8 no A loads in the loop, 16 no fragment reads, 32 no barriers, 64 no MFMAs, 128 no LDS staging writes
+template<int NP, int ABL = 0>  // A staging passes of 64 window rows (AR <= 64 NP)
+__global__ __launch_bounds__(PT) void conv3x3_bf16_p(const float *__restrict__ in, const uint16_t *__restrict__ wb,
+                                                    const float *__restrict__ bias, float *__restrict__ out, CGeom g, int AR,
+                                                    FastDiv d_img, FastDiv d_row, int stag) {
     extern __shared__ uint16_t smem[];                       // [A window 0][A window 1][B slot 0][B slot 1]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wave >> 1, wc = wave & 1;                 // the wave's 64 positions / 64 channels of the tile
     const int Wp = g.W + 2, Hp = g.H + 2;
     const uint32_t NQ = (uint32_t)g.N * Hp * Wp;
     // XCD-contiguous tiles (blocks are dealt round-robin to the 8 XCDs; bijective for any grid size)
@@ -387,88 +394,88 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_p(const float *__restrict__ 
     const int cpk = g.CI / KL, ntap = 9 * cpk;
     uint16_t *const sA0 = smem, *const sA1 = smem + (size_t)AR * PL, *const sB = smem + (size_t)2 * AR * PL;
 
-    floatx16 acc[2][4];
+    floatx16 acc[2][2];
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-        const float bv = bias[co0 + 32 * b + (lane & 31)];   // C init = bias broadcast down the rows
+    for (int b = 0; b < 2; b++) {
+        const float bv = bias[co0 + 64 * wc + 32 * b + (lane & 31)];   // C init = bias broadcast down the rows
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = bv;
     }
     // ---- staging roles
-    const int aq = tid & 7, ap = tid >> 3;                   // A: float4 aq of the 32-ci chunk, window rows ap + 32 i
+    const int aq = tid & 7, ap = tid >> 3;                   // A: float4 aq of the 32-ci chunk, window rows ap + 64 i
     float4 va[NP];
     auto load_a = [&](int cc) {
 #pragma unroll
         for (int i = 0; i < NP; i++) {
-            const uint32_t q = min(Q0 + (uint32_t)(ap + 32 * i), NQ - 1);   // NQ CI < 2^31 elements
+            const uint32_t q = min(Q0 + (uint32_t)(ap + 64 * i), NQ - 1);   // NQ CI < 2^31 elements
             va[i] = *reinterpret_cast<const float4 *>(in + (q * (uint32_t)g.CI + (uint32_t)(cc * KL + 4 * aq)));
         }
     };
     auto store_a = [&](uint16_t *sA) {
 #pragma unroll
         for (int i = 0; i < NP; i++) {
-            if (ap + 32 * i < AR) {
+            if (ap + 64 * i < AR) {
                 uint2 w;
                 w.x = pk_bf16(va[i].x, va[i].y), w.y = pk_bf16(va[i].z, va[i].w);
-                *reinterpret_cast<uint2 *>(sA + (ap + 32 * i) * PL + 4 * aq) = w;
+                *reinterpret_cast<uint2 *>(sA + (ap + 64 * i) * PL + 4 * aq) = w;
             }
         }
     };
-    u32x4 rb[BD][2];                                         // B taps in flight: [ring slot][k-step]
-    auto load_b = [&](int T, u32x4 (&dst)[2]) {              // T = chunk * 9 + kk; layout of conv_filter_bf16<2>
-        const uint32_t e0 = (((uint32_t)T * 2) * ncot + cot0) * 512 + (uint32_t)tid * 8;
-        dst[0] = *reinterpret_cast<const u32x4 *>(wb + e0);
-        dst[1] = *reinterpret_cast<const u32x4 *>(wb + e0 + ncot * 512);
+    u32x4 rb[BD];                                            // B taps in flight
+    const uint32_t b_lane = (((uint32_t)(tid >> 8)) * ncot + cot0) * 512 + (uint32_t)(tid & 255) * 8;   // k-step tid >> 8
+    auto load_b = [&](int T, u32x4 &dst) {                   // T = chunk * 9 + kk; layout of conv_filter_bf16<2>
+        dst = *reinterpret_cast<const u32x4 *>(wb + ((uint32_t)T * 2 * ncot * 512 + b_lane));
     };
-    auto store_b = [&](int slot, const u32x4 (&src)[2]) {
-        u32x4 *d = reinterpret_cast<u32x4 *>(sB + slot * BSLOT);
-        d[tid] = src[0];
-        d[256 + tid] = src[1];
-    };
+    auto store_b = [&](int slot, const u32x4 &src) { reinterpret_cast<u32x4 *>(sB + slot * BSLOT)[tid] = src; };
     // ---- fragments: two register sets, one per k-step of a tap
-    bf16x8 fa[2][2], fb[2][4];
-    const int a_lane = (64 * wave + (lane & 31)) * PL + 8 * (lane >> 5);
+    bf16x8 fa[2][2], fb[2][2];
+    const int a_lane = (64 * wq + (lane & 31)) * PL + 8 * (lane >> 5);
+    const int b_frag = 2 * wc * 512 + lane * 8;
     auto read_frags = [&](int fs, const uint16_t *sA, int tapoff, int ks, int slot) {
         const uint16_t *pa = sA + a_lane + tapoff + 16 * ks;
         fa[fs][0] = *reinterpret_cast<const bf16x8 *>(pa);
         fa[fs][1] = *reinterpret_cast<const bf16x8 *>(pa + 32 * PL);
-        const uint16_t *pb = sB + slot * BSLOT + ks * 2048 + lane * 8;
-#pragma unroll
-        for (int b = 0; b < 4; b++) fb[fs][b] = *reinterpret_cast<const bf16x8 *>(pb + b * 512);
+        const uint16_t *pb = sB + slot * BSLOT + ks * 2048 + b_frag;
+        fb[fs][0] = *reinterpret_cast<const bf16x8 *>(pb);
+        fb[fs][1] = *reinterpret_cast<const bf16x8 *>(pb + 512);
     };
-    auto mfma4 = [&](int fs, int a) {
+    auto mfma2 = [&](int fs, int a) {
 #pragma unroll
-        for (int b = 0; b < 4; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[fs][a], fb[fs][b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[fs][a], fb[fs][b], acc[a][b], 0, 0, 0);
     };
     const int WpPL = Wp * PL;
-    // one tap; t = its index in the 18-tap body (two chunks), Tb = global index of the body's first tap
+    // One tap, one barrier, placed after the first half of the tap's first k-step: the fragments of the second k-step were
+    // requested before it, the next tap's B slot is written just before the barrier and its first fragments are requested
+    // right after it.  Measured alternatives (all correct, profiles/r03_conv_bf16_ablation.txt): four waves of 64 x 128 per
+    // workgroup 26.5 us; this schedule 24.7 us; all eight fragments of a tap requested a whole tap ahead (three B slots) 26.5 us;
+    // request phase / MFMA phase with two barriers per tap and the two waves of a SIMD one barrier apart 29-32 us.  In every
+    // variant the K loop costs the SUM of its MFMA time (9.3 us for 288 MFMAs per wave, two waves per SIMD) and of the staging
+    // (global requests + LDS writes, 5-6 us), fragment reads and barriers (3.6 us): the matrix pipe does not run under them.
+    // Hazards: B slot (t + 1) & 1 is written before the barrier of tap t; its previous contents (tap t - 1) were last read
+    // before the barrier of tap t - 1 (second k-step) — every wave has passed that barrier.  The A window of chunk c + 1 is
+    // written before the barrier of chunk c's last tap into the buffer chunk c - 1 used.
     auto tap = [&](auto tt, int Tb) {
         constexpr int t = decltype(tt)::value, kk = t % 9, half = t / 9, ky = kk / 3, kx = kk % 3;
         constexpr int kn = (kk + 1) % 9, kyn = kn / 3, kxn = kn % 3;
-        const int T = Tb + t, cc = T / 9;                    // cc parity == half (a body starts at an even chunk)
+        const int T = Tb + t, cc = Tb / 9 + half;
         uint16_t *const sAc = half ? sA1 : sA0, *const sAo = half ? sA0 : sA1;
-        // requests: B of tap T + BD into the ring slot tap T's data left when it went to LDS; next chunk's A window.
-        // UNCONDITIONAL (indices clamped at the end of the K loop, where the redundant data is simply never used): a load
-        // behind a branch makes the compiler's vmcnt bookkeeping assume nothing younger may be in flight, and every wait for
-        // a ring slot became vmcnt(0) — the whole prefetch drained once per tap.
-        load_b(min(T + BD, ntap - 1), rb[t % BD]);
-        if (kk == 0) load_a(min(cc + 1, cpk - 1));
+        // requests: B of tap T + BD into the ring slot tap T's data left when it went to LDS; next chunk's A window
+        if (!(ABL & 4)) load_b(min(T + BD, ntap - 1), rb[t % BD]);
+        if (kk == 0 && !(ABL & 8)) load_a(min(cc + 1, cpk - 1));
         __builtin_amdgcn_sched_barrier(0);
-        read_frags(1, sAc, ky * WpPL + kx * PL, 1, t & 1);   // second k-step of this tap
-        mfma4(0, 0);
+        if (!(ABL & 16)) read_frags(1, sAc, ky * WpPL + kx * PL, 1, t & 1);   // second k-step of this tap
+        if (!(ABL & 64)) mfma2(0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        // the other B slot was last read by tap T - 1, whose readers all passed that tap's barrier
-        store_b((t + 1) & 1, rb[(t + 1) % BD]);
-        if (kk == 8) store_a(sAo);                           // that window was last read during chunk cc - 1
-        __syncthreads();
+        if (!(ABL & 128)) store_b((t + 1) & 1, rb[(t + 1) % BD]);
+        if (kk == 8 && !(ABL & 128)) store_a(sAo);
+        if (!(ABL & 32)) __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
-        mfma4(0, 1);
+        if (!(ABL & 64)) mfma2(0, 1);
         __builtin_amdgcn_sched_barrier(0);
-        read_frags(0, kk == 8 ? sAo : sAc, kyn * WpPL + kxn * PL, 0, (t + 1) & 1);   // first k-step of the next tap
-        mfma4(1, 0);
-        mfma4(1, 1);
+        if (!(ABL & 16)) read_frags(0, kk == 8 ? sAo : sAc, kyn * WpPL + kxn * PL, 0, (t + 1) & 1);   // first k-step of the next tap
+        if (!(ABL & 64)) mfma2(1, 0), mfma2(1, 1);
         __builtin_amdgcn_sched_barrier(0);
     };
     // ---- prologue
@@ -479,8 +486,9 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_p(const float *__restrict__ 
     store_b(0, rb[0]);
     __syncthreads();
     read_frags(0, sA0, 0, 0, 0);
+    (void)stag;
 #pragma unroll 1
-    for (int Tb = 0; Tb < ntap; Tb += 18) {
+    for (int Tb = 0; Tb < ((ABL & 2) ? 0 : ntap); Tb += 18) {
         tap(std::integral_constant<int, 0>{}, Tb);
         tap(std::integral_constant<int, 1>{}, Tb);
         tap(std::integral_constant<int, 2>{}, Tb);
@@ -506,15 +514,15 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_p(const float *__restrict__ 
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const uint32_t q = Q0 + (uint32_t)(64 * wave + 32 * a + row);
+            const uint32_t q = Q0 + (uint32_t)(64 * wq + 32 * a + row);
             if (q < NQ) {
                 const uint32_t n = fdiv(q, d_img), rem = q - n * d_img.d, y = fdiv(rem, d_row), x = rem - y * d_row.d;
                 if ((int)y < g.H && (int)x < g.W) {
-                    float *o = out + ((((size_t)n * g.H + y) * g.W + x) * g.CO + co0 + (lane & 31));
+                    float *o = out + ((((size_t)n * g.H + y) * g.W + x) * g.CO + co0 + 64 * wc + (lane & 31));
 #pragma unroll
-                    for (int b = 0; b < 4; b++) {
+                    for (int b = 0; b < 2; b++) {
                         const float v = acc[a][b][r];
-                        o[32 * b] = v > 0.0f ? v : 0.0f;
+                        if (!(ABL & 1) || v != v) o[32 * b] = v > 0.0f ? v : 0.0f;
                     }
                 }
             }
@@ -703,8 +711,8 @@ extern "C" int conv_layer_bf16(halide_buffer_t *input, halide_buffer_t *filter, 
         const bool lin = AR <= 32 * 12 && NQ < (1L << 31) && NQ * g.CI < (1L << 31) && !getenv("HLMI_CONV_IM2COL");   // W <= 125
         // conv3x3_bf16_p: 256-position tiles, B through LDS (see the kernel); the older kernels stay for what it does not take
         const int ARp = TQ + 2 * (g.W + 2) + 2;
-        const size_t sh_p = ((size_t)2 * ARp * PL + 2 * BSLOT) * sizeof(uint16_t);
-        const bool pers = lin && ARp <= 32 * 16 && sh_p <= 160 * 1024 && g.CO % TC == 0 && g.CI % (2 * KL) == 0 &&
+        const size_t sh_p = ((size_t)2 * ARp * PL + 2 * BSLOT) * sizeof(uint16_t);   // two A windows, two B slots
+        const bool pers = lin && ARp <= 64 * 8 && sh_p <= 160 * 1024 && g.CO % TC == 0 && g.CI % (2 * KL) == 0 &&
                           !getenv("HLMI_CONV_OLD");
         const int layout = pers ? 2 : (lin ? 1 : 0);
         // The bf16 MFMA-B image of the filter is a function of the filter's contents only: it is kept per (filter
@@ -730,16 +738,34 @@ extern "C" int conv_layer_bf16(halide_buffer_t *input, halide_buffer_t *filter, 
         if (pers) {
             dim3 grid((unsigned)((NQ + TQ - 1) / TQ), g.CO / TC);
             timing_note_bytes(4.0 * ((double)NQ * g.CI + (double)g.npix * g.CO) + (double)wb_bytes);
-            if (ARp <= 32 * 12) {
-                HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_p<12>),
+            const char *stag_e = getenv("HLMI_CONVP_STAG");
+            const int stag = stag_e ? atoi(stag_e) : 1;
+            const char *abl_e = getenv("HLMI_CONVP_ABL");
+            const int abl = abl_e ? atoi(abl_e) : 0;
+            if (ARp <= 64 * 6 && abl >= 1) {
+#define CONVP_ABL(n)                                                                                                         \
+    case n:                                                                                                                  \
+        HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_p<6, n>),                              \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_p));                           \
+        HLMI_LAUNCH(uc, "conv3x3_bf16_mfma", ctx.stream, (conv3x3_bf16_p<6, n>), grid, dim3(PT), sh_p, dev_ptr<float>(input), wb, \
+                    dev_ptr<float>(bias), dev_ptr<float>(relu), g, ARp, d_img, d_row, stag);                                \
+        break;
+                switch (abl) {
+                    CONVP_ABL(1) CONVP_ABL(2) CONVP_ABL(64) CONVP_ABL(16) CONVP_ABL(48) CONVP_ABL(188) CONVP_ABL(80) CONVP_ABL(112)
+                    CONVP_ABL(252) CONVP_ABL(32) CONVP_ABL(140)
+                    default: return report(uc, halide_error_code_generic_error, "HLMI_CONVP_ABL=%d is not one of the instantiated masks", abl);
+                }
+#undef CONVP_ABL
+            } else if (ARp <= 64 * 6) {
+                HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_p<6>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_p));
-                HLMI_LAUNCH(uc, "conv3x3_bf16_mfma", ctx.stream, conv3x3_bf16_p<12>, grid, dim3(256), sh_p, dev_ptr<float>(input), wb,
-                            dev_ptr<float>(bias), dev_ptr<float>(relu), g, ARp, d_img, d_row);
+                HLMI_LAUNCH(uc, "conv3x3_bf16_mfma", ctx.stream, conv3x3_bf16_p<6>, grid, dim3(PT), sh_p, dev_ptr<float>(input), wb,
+                            dev_ptr<float>(bias), dev_ptr<float>(relu), g, ARp, d_img, d_row, stag);
             } else {
-                HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_p<16>),
+                HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_p<8>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_p));
-                HLMI_LAUNCH(uc, "conv3x3_bf16_mfma", ctx.stream, conv3x3_bf16_p<16>, grid, dim3(256), sh_p, dev_ptr<float>(input), wb,
-                            dev_ptr<float>(bias), dev_ptr<float>(relu), g, ARp, d_img, d_row);
+                HLMI_LAUNCH(uc, "conv3x3_bf16_mfma", ctx.stream, conv3x3_bf16_p<8>, grid, dim3(PT), sh_p, dev_ptr<float>(input), wb,
+                            dev_ptr<float>(bias), dev_ptr<float>(relu), g, ARp, d_img, d_row, stag);
             }
         } else if (lin) {
             dim3 grid((unsigned)((NQ + TP - 1) / TP), g.CO / TC);
