@@ -116,6 +116,124 @@ __global__ __launch_bounds__(256) void ip_up(Lvl ds, Lvl up, Lvl dst) {
     dst.v[(size_t)ys * dst.w + xs] = interp_value(at(ds, x, y), up, x, y);
 }
 
+
+// ---- ip_down_multi / ip_up_multi: the middle of the pyramid (levels 3, 4, 5) in ONE launch per direction.  These levels are
+// 192 x 320 pixels and below: each took its own launch of 3 - 5 us, three quarters of it the dependent-launch gap and the
+// ramp of a nearly empty chip.  As in local_laplacian's ll_down_multi / ll_up_multi, a workgroup owns a tile of the LAST level
+// of the chain and recomputes, in LDS, whatever it needs of the levels in between; values in a tile's halo are recomputed by
+// its neighbours with identical operations (the Funcs are pure functions of their coordinates), every stored pixel is
+// written by exactly one workgroup.
+struct IBox {
+    int x0, x1, y0, y1;   // inclusive
+};
+__device__ __forceinline__ IBox ibox_of(const Lvl &L) { return IBox{L.x0, L.x0 + L.w - 1, L.y0, L.y0 + L.h - 1}; }
+__device__ __forceinline__ int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// the pixels of level box `L` (one axis: [llo, lhi]) whose `sh`-fold parent, clamped into the tile level's box [tlo, thi],
+// lies in the tile [a, b] — the tile's share of that level; tiles partition the level.  Empty when lo > hi.
+__device__ __forceinline__ void owned_range(int llo, int lhi, int sh, int tlo, int thi, int a, int b, int &lo, int &hi) {
+    lo = a <= tlo ? llo : max(llo, a * (1 << sh));                 // the first tile also takes everything left of the tile level's box
+    hi = b >= thi ? lhi : min(lhi, (b + 1) * (1 << sh) - 1);       // the last tile everything right of it
+}
+
+constexpr int DM5 = 8;                    // tile of downsampled[5]
+constexpr int DM4W = 2 * DM5 + 1 + 4;     // window of downsampled[4] a tile needs / owns (+ slack at the level's edge)
+constexpr int DM3W = 2 * DM4W + 1 + 4;    // ... of downsampled[3]
+__global__ __launch_bounds__(256) void ip_down_multi(Lvl src, Lvl d3, Lvl d4, Lvl d5, int cw, int ch, int ntx) {
+    __shared__ float4 s3[DM3W * DM3W], s4[DM4W * DM4W];
+    const int tid = threadIdx.x;
+    const int bx = blockIdx.x % ntx, by = blockIdx.x / ntx;
+    const IBox B3 = ibox_of(d3), B4 = ibox_of(d4), B5 = ibox_of(d5);
+    // the tile of level 5
+    const IBox T5 = {B5.x0 + bx * DM5, min(B5.x0 + bx * DM5 + DM5 - 1, B5.x1), B5.y0 + by * DM5, min(B5.y0 + by * DM5 + DM5 - 1, B5.y1)};
+    // level 4: what the tile reads (2x - 1 .. 2x + 1) and what it owns
+    IBox O4, O3;
+    owned_range(B4.x0, B4.x1, 1, B5.x0, B5.x1, T5.x0, T5.x1, O4.x0, O4.x1);
+    owned_range(B4.y0, B4.y1, 1, B5.y0, B5.y1, T5.y0, T5.y1, O4.y0, O4.y1);
+    const IBox W4 = {min(2 * T5.x0 - 1, O4.x0), max(2 * T5.x1 + 1, O4.x1), min(2 * T5.y0 - 1, O4.y0), max(2 * T5.y1 + 1, O4.y1)};
+    // level 3: read through the generator's coordinate clamp (:40-49), plus what the tile owns
+    owned_range(B3.x0, B3.x1, 2, B5.x0, B5.x1, T5.x0, T5.x1, O3.x0, O3.x1);
+    owned_range(B3.y0, B3.y1, 2, B5.y0, B5.y1, T5.y0, T5.y1, O3.y0, O3.y1);
+    const IBox W3 = {min(iclamp(2 * W4.x0 - 1, 0, cw), O3.x0), max(iclamp(2 * W4.x1 + 1, 0, cw), O3.x1),
+                     min(iclamp(2 * W4.y0 - 1, 0, ch), O3.y0), max(iclamp(2 * W4.y1 + 1, 0, ch), O3.y1)};
+    const int w3 = W3.x1 - W3.x0 + 1, h3 = W3.y1 - W3.y0 + 1, w4 = W4.x1 - W4.x0 + 1, h4 = W4.y1 - W4.y0 + 1;
+    const InGeom none{};
+    for (int i = tid; i < w3 * h3; i += 256) {
+        const int yy = i / w3, xx = i - yy * w3, x = W3.x0 + xx, y = W3.y0 + yy;
+        const float4 v = down_value<false>(none, src, x, y, false, cw, ch);
+        s3[yy * DM3W + xx] = v;
+        if (x >= O3.x0 && x <= O3.x1 && y >= O3.y0 && y <= O3.y1) d3.v[(size_t)(y - d3.y0) * d3.w + (x - d3.x0)] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < w4 * h4; i += 256) {
+        const int yy = i / w4, xx = i - yy * w4, x = W4.x0 + xx, y = W4.y0 + yy;
+        float4 dx[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int Y = iclamp(2 * y - 1 + j, 0, ch) - W3.y0;
+            const float4 a = s3[Y * DM3W + iclamp(2 * x - 1, 0, cw) - W3.x0], b = s3[Y * DM3W + iclamp(2 * x, 0, cw) - W3.x0],
+                         c = s3[Y * DM3W + iclamp(2 * x + 1, 0, cw) - W3.x0];
+            dx[j] = tap3(a, b, c);
+        }
+        const float4 v = tap3(dx[0], dx[1], dx[2]);
+        s4[yy * DM4W + xx] = v;
+        if (x >= O4.x0 && x <= O4.x1 && y >= O4.y0 && y <= O4.y1) d4.v[(size_t)(y - d4.y0) * d4.w + (x - d4.x0)] = v;
+    }
+    __syncthreads();
+    const int w5 = T5.x1 - T5.x0 + 1, h5 = T5.y1 - T5.y0 + 1;
+    for (int i = tid; i < w5 * h5; i += 256) {
+        const int yy = i / w5, xx = i - yy * w5, x = T5.x0 + xx, y = T5.y0 + yy;
+        float4 dx[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const float4 *row = s4 + (2 * y - 1 + j - W4.y0) * DM4W + (2 * x - 1 - W4.x0);
+            dx[j] = tap3(row[0], row[1], row[2]);
+        }
+        d5.v[(size_t)(y - d5.y0) * d5.w + (x - d5.x0)] = tap3(dx[0], dx[1], dx[2]);
+    }
+}
+
+// interpolated[3] on its box from interpolated[6] (the tail's result), downsampled[5], [4], [3]; interpolated[5] and [4]
+// exist only in LDS (their only reader is the level below)
+constexpr int UM3 = 32;                   // tile of interpolated[3]
+constexpr int UM4W = UM3 / 2 + 2, UM5W = UM4W / 2 + 2;
+__device__ __forceinline__ float4 interp_from(const float4 d, const float4 aa, const float4 ba, const float4 ab, const float4 bb) {   // (:61-72)
+    const float alpha = 1.0f - d.w;
+    auto one = [&](float d_c, float paa, float pba, float pab, float pbb) {
+        const float ua = (paa + pba) * 0.5f, ub = (pab + pbb) * 0.5f;
+        return d_c + alpha * ((ua + ub) * 0.5f);
+    };
+    return make_float4(one(d.x, aa.x, ba.x, ab.x, bb.x), one(d.y, aa.y, ba.y, ab.y, bb.y), one(d.z, aa.z, ba.z, ab.z, bb.z),
+                       one(d.w, aa.w, ba.w, ab.w, bb.w));
+}
+__global__ __launch_bounds__(256) void ip_up_multi(Lvl d3, Lvl d4, Lvl d5, Lvl up6, Lvl dst3, int ntx) {
+    __shared__ float4 s5[UM5W * UM5W], s4[UM4W * UM4W];
+    const int tid = threadIdx.x;
+    const int bx = blockIdx.x % ntx, by = blockIdx.x / ntx;
+    const IBox T3 = {dst3.x0 + bx * UM3, min(dst3.x0 + bx * UM3 + UM3 - 1, dst3.x0 + dst3.w - 1), dst3.y0 + by * UM3,
+                     min(dst3.y0 + by * UM3 + UM3 - 1, dst3.y0 + dst3.h - 1)};
+    const IBox N4 = {dev::fdiv2(T3.x0), dev::fdiv2(T3.x1 + 1), dev::fdiv2(T3.y0), dev::fdiv2(T3.y1 + 1)};
+    const IBox N5 = {dev::fdiv2(N4.x0), dev::fdiv2(N4.x1 + 1), dev::fdiv2(N4.y0), dev::fdiv2(N4.y1 + 1)};
+    const int w5 = N5.x1 - N5.x0 + 1, h5 = N5.y1 - N5.y0 + 1, w4 = N4.x1 - N4.x0 + 1, h4 = N4.y1 - N4.y0 + 1;
+    for (int i = tid; i < w5 * h5; i += 256) {
+        const int yy = i / w5, xx = i - yy * w5, x = N5.x0 + xx, y = N5.y0 + yy;
+        s5[yy * UM5W + xx] = interp_value(at(d5, x, y), up6, x, y);
+    }
+    __syncthreads();
+    for (int i = tid; i < w4 * h4; i += 256) {
+        const int yy = i / w4, xx = i - yy * w4, x = N4.x0 + xx, y = N4.y0 + yy;
+        const int xa = dev::fdiv2(x) - N5.x0, xb = dev::fdiv2(x + 1) - N5.x0, ya = dev::fdiv2(y) - N5.y0, yb = dev::fdiv2(y + 1) - N5.y0;
+        s4[yy * UM4W + xx] = interp_from(at(d4, x, y), s5[ya * UM5W + xa], s5[ya * UM5W + xb], s5[yb * UM5W + xa], s5[yb * UM5W + xb]);
+    }
+    __syncthreads();
+    const int w3 = T3.x1 - T3.x0 + 1, h3 = T3.y1 - T3.y0 + 1;
+    for (int i = tid; i < w3 * h3; i += 256) {
+        const int yy = i / w3, xx = i - yy * w3, x = T3.x0 + xx, y = T3.y0 + yy;
+        const int xa = dev::fdiv2(x) - N4.x0, xb = dev::fdiv2(x + 1) - N4.x0, ya = dev::fdiv2(y) - N4.y0, yb = dev::fdiv2(y + 1) - N4.y0;
+        dst3.v[(size_t)(y - dst3.y0) * dst3.w + (x - dst3.x0)] =
+            interp_from(at(d3, x, y), s4[ya * UM4W + xa], s4[ya * UM4W + xb], s4[yb * UM4W + xa], s4[yb * UM4W + xb]);
+    }
+}
+
 // Levels from..IL-1 in one launch of ONE workgroup: downsampled[from..9], then interpolated[8..from]; a level is
 // complete (and visible to the workgroup, which shares its CU's L1) at the barrier that follows it.
 struct TailArgs {
@@ -230,7 +348,39 @@ extern "C" int interpolate(halide_buffer_t *input, halide_buffer_t *output) {
         const char *te = getenv("HLMI_IP_TAIL_FROM");
         int T = te ? atoi(te) : 6;
         if (T < 2 || T > IL - 2) T = IL;
+        // levels 3, 4, 5 in one launch per direction (ip_down_multi / ip_up_multi) when the tail starts at 6 and every tile's
+        // windows fit the kernels' LDS arrays (they do for any image: the check guards the constants, not the input)
+        bool fused = T == 6 && !getenv("HLMI_IP_UNFUSED");
+        const int ntx5 = (ds[5].w + DM5 - 1) / DM5, nty5 = (ds[5].h + DM5 - 1) / DM5;
+        if (fused) {
+            auto owned = [](int llo, int lhi, int sh, int tlo, int thi, int a, int b, int &lo, int &hi) {
+                lo = a <= tlo ? llo : (llo > a * (1 << sh) ? llo : a * (1 << sh));
+                hi = b >= thi ? lhi : (lhi < (b + 1) * (1 << sh) - 1 ? lhi : (b + 1) * (1 << sh) - 1);
+            };
+            auto mn = [](int a, int b) { return a < b ? a : b; };
+            auto mx = [](int a, int b) { return a > b ? a : b; };
+            for (int axis = 0; axis < 2 && fused; axis++) {
+                const int b5lo = axis ? D[5].y0 : D[5].x0, b5hi = axis ? D[5].y1 : D[5].x1, b4lo = axis ? D[4].y0 : D[4].x0,
+                          b4hi = axis ? D[4].y1 : D[4].x1, b3lo = axis ? D[3].y0 : D[3].x0, b3hi = axis ? D[3].y1 : D[3].x1;
+                const int c = axis ? ch : cw;
+                for (int a = b5lo; a <= b5hi; a += DM5) {
+                    const int b = mn(a + DM5 - 1, b5hi);
+                    int o4l, o4h, o3l, o3h;
+                    owned(b4lo, b4hi, 1, b5lo, b5hi, a, b, o4l, o4h);
+                    owned(b3lo, b3hi, 2, b5lo, b5hi, a, b, o3l, o3h);
+                    const int w4l = mn(2 * a - 1, o4l), w4h = mx(2 * b + 1, o4h);
+                    const int w3l = mn(clampi(2 * w4l - 1, 0, c), o3l), w3h = mx(clampi(2 * w4h + 1, 0, c), o3h);
+                    if (w4h - w4l + 1 > DM4W || w3h - w3l + 1 > DM3W || w4l < b4lo || w4h > b4hi || w3l < b3lo || w3h > b3hi) fused = false;
+                }
+            }
+        }
         for (int l = 1; l < IL && l < T; l++) {
+            if (fused && l >= 3) {
+                if (l == 3) {
+                    HLMI_LAUNCH(uc, "ip_down_multi:3", st, ip_down_multi, dim3(ntx5 * nty5), dim3(256), 0, ds[2], ds[3], ds[4], ds[5], cw, ch, ntx5);
+                }
+                continue;
+            }
             dim3 grid((ds[l].w + 255) / 256, ds[l].h), block(256);
             snprintf(nm, sizeof nm, "ip_down:%d", l);
             if (l == 1) {
@@ -249,6 +399,13 @@ extern "C" int interpolate(halide_buffer_t *input, halide_buffer_t *output) {
             HLMI_LAUNCH(uc, nm, st, ip_tail, dim3(1), dim3(1024), 0, ta);
         }
         for (int l = (T < IL ? T - 1 : IL - 2); l >= 1; l--) {
+            if (fused && l >= 3) {
+                if (l == 3) {
+                    const int ntx3 = (ip[3].w + UM3 - 1) / UM3, nty3 = (ip[3].h + UM3 - 1) / UM3;
+                    HLMI_LAUNCH(uc, "ip_up_multi:3", st, ip_up_multi, dim3(ntx3 * nty3), dim3(256), 0, ds[3], ds[4], ds[5], ip[6], ip[3], ntx3);
+                }
+                continue;
+            }
             dim3 grid((ip[l].w + 255) / 256, ip[l].h), block(256);
             snprintf(nm, sizeof nm, "ip_up:%d", l);
             HLMI_LAUNCH(uc, nm, st, ip_up, grid, block, 0, ds[l], ip[l + 1], ip[l]);
