@@ -143,6 +143,62 @@ def test_hip_bf16_filter_image_follows_the_filter_contents(hl, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("wrapped", [False, True])
+def test_hip_bf16_filter_images_are_safe_across_threads_and_streams(hl, oracle, wrapped):
+    """the cache of re-ordered filters must not hand a thread an image that another thread, on another
+    stream, is re-filling or evicting.  Four host threads with a stream each call conv_layer_bf16 with TEN different
+    filters in random order (the cache holds eight: entries are evicted and re-filled while other streams still read
+    them); wrapped = the filters are wrapped device pointers (version 0, what every torch tensor is): never cached, their
+    image lives in the calling stream's scratch arena."""
+    import ctypes
+    import threading
+    hip = hl.hip_runtime()
+    n, h, w, ci, co = 2, 12, 20, 64, 128
+    rng = np.random.default_rng(21)
+    nf = 10
+    inputs = [rng.uniform(-1, 1, (n, h + 2, w + 2, ci)).astype(np.float32) for _ in range(4)]
+    filts = [rng.uniform(-1, 1, (ci, 3, 3, co)).astype(np.float32) for _ in range(nf)]
+    bias = rng.uniform(-1, 1, co).astype(np.float32)
+    want = [[oracle.conv_layer_bf16(inputs[t], filts[f], bias) for f in range(nf)] for t in range(4)]
+    owned = [hl.Buffer(f).copy_to_device() for f in filts]          # the filters live on the device
+    if wrapped:
+        fbufs = [hl.Buffer.wrap_device(hl.lib.halide_hip_get_device_ptr(None, b.ptr), np.float32, (co, 3, 3, ci)) for b in owned]
+    else:
+        fbufs = owned
+    bb = hl.Buffer(bias).copy_to_device()
+    errors = []
+
+    def worker(t):
+        try:
+            stream = ctypes.c_void_p()
+            assert hip.hipStreamCreateWithFlags(ctypes.byref(stream), 1) == 0
+            hl.set_stream(stream.value)
+            r = np.random.default_rng(100 + t)
+            bi = hl.Buffer(inputs[t])
+            for rep in range(40):
+                f = int(r.integers(0, nf))
+                bo = hl.Buffer(np.zeros((n, h, w, co), np.float32))
+                hl.conv_layer_bf16(bi, fbufs[f], bb, bo)
+                got = bo.numpy()
+                ref, mag = want[t][f]
+                if not (np.abs(got - ref) <= 2e-6 * mag + 1e-6).all():
+                    errors.append(f"thread {t} rep {rep} filter {f}: result is not this filter's")
+                bo.device_free()
+            hl.set_stream(None)
+            assert hip.hipStreamSynchronize(stream) == 0
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"thread {t}: {e!r}")
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
+
+
+@pytest.mark.gpu
 def test_hip_rejects_non_dense_layout(hl):
     inp, filt, bias = _data(1, 4, 4, 32, 128, 0)
     bi, bf, bb = hl.Buffer(inp), hl.Buffer(filt), hl.Buffer(bias)
