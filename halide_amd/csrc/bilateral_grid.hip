@@ -206,9 +206,11 @@ __global__ __launch_bounds__(256) void bg_slice(const float *__restrict__ in, lo
 // pixels; the blury cells they interpolate between (at most 10 x 6 x ZD), the blurx rows under those (10 x 10) and the
 // blurz cells under those (14 x 10) are produced in LDS by the same blur5 chains the separate kernels run — two launches
 // and the write + re-read of two grids less (the pipeline is launch-latency bound: 4 launches took 30 us for 16 MB).
-constexpr int FPX = 64, FPY = 32, FCX = 10, FCY = 6, FZ = 16;
+constexpr int FPX = 64, FCX = 10, FZ = 16;
+template<int FPY>   // tile height: 32 (or 16: HLMI_BG_TILE16=1, an A/B switch)
 __global__ __launch_bounds__(256) void bg_blur_slice(const float *__restrict__ in, long in_sy, BGeom g, const float2 *__restrict__ bz,
                                                     float *__restrict__ out, long out_sy, int ox0, int oy0, int ow, int oh) {
+    constexpr int FCY = FPY / S + 2;
     __shared__ float2 s_bz[FZ][FCY + 4][FCX + 4], s_bx[FZ][FCY + 4][FCX], s_by[FZ][FCY][FCX];
     const int t = threadIdx.x;
     const int x0 = blockIdx.x * FPX, y0 = blockIdx.y * FPY;
@@ -337,8 +339,13 @@ extern "C" int bilateral_grid(halide_buffer_t *input, float r_sigma, halide_buff
         HLMI_LAUNCH(uc, "bg_histogram_blurz", st, bg_histogram_blurz, dim3((g.HX + T - 1) / T, g.HY), dim3(T), sh, din, in_sy, g, bz);
     }
     if (g.ZD <= FZ && !getenv("HLMI_BG_UNFUSED")) {
-        HLMI_LAUNCH(uc, "bg_blur_slice", st, bg_blur_slice, dim3((ow + FPX - 1) / FPX, (oh + FPY - 1) / FPY), dim3(256), 0, din, in_sy, g, bz,
-                    dev_ptr<float>(output), out_sy, ox0, oy0, ow, oh);
+        if (getenv("HLMI_BG_TILE16")) {
+            HLMI_LAUNCH(uc, "bg_blur_slice", st, bg_blur_slice<16>, dim3((ow + FPX - 1) / FPX, (oh + 15) / 16), dim3(256), 0, din, in_sy, g, bz,
+                        dev_ptr<float>(output), out_sy, ox0, oy0, ow, oh);
+        } else {
+            HLMI_LAUNCH(uc, "bg_blur_slice", st, bg_blur_slice<32>, dim3((ow + FPX - 1) / FPX, (oh + 31) / 32), dim3(256), 0, din, in_sy, g, bz,
+                        dev_ptr<float>(output), out_sy, ox0, oy0, ow, oh);
+        }
     } else {
         HLMI_LAUNCH(uc, "bg_blurx", st, bg_blurx, dim3((g.GX + 63) / 64, g.HY, g.ZD), dim3(64), 0, bz, g, bx);
         HLMI_LAUNCH(uc, "bg_blury", st, bg_blury, dim3((g.GX + 63) / 64, g.GY, g.ZD), dim3(64), 0, bx, g, by);
