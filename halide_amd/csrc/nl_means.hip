@@ -187,6 +187,112 @@ __global__ __launch_bounds__(NT) void nlm_7x7(const float *__restrict__ in, long
     }
 }
 
+
+// ---- nlm_7x7w: the same computation with NO barrier inside the offset loop.  nlm_7x7 hands blur_d_y from its phase-1 threads
+// (a column, four rows) to its phase-2 threads (a row, four pixels) through LDS, one workgroup barrier per offset: all waves
+// of a workgroup read at the same time, compute at the same time and wait for each other 49 times (a third of all
+// wave-cycles, SQ_WAIT_INST_ANY).  Here a WAVE owns 64 columns x 4 rows of the tile for BOTH stages — lane = column:
+//   * stage 1 as before: d for the lane's column over the wave's 4 + 6 rows, ordered 7-term column sums -> blur_d_y of 4 rows;
+//   * stage 2 in the same lane: blur_d(x) = sum over blur_d_y(x - 3 .. x + 3) comes from the six neighbouring LANES by DPP wave
+//     shifts (three to the right, three to the left, added in the oracle's order: leftmost first), so lane L finishes output
+//     column L - 3 (lanes 3 .. 60: the tile's 58 columns; the shifted-in zeros only reach lanes whose results are not stored);
+//   * the pixel values in(x + dx, y + dy) the weighted sum needs ARE the shifted operand of stage 1 (rows 3 .. 6 of the
+//     lane's ten): no second read.
+// Per offset and lane: 30 LDS reads (the shifted operand), 6 DPP moves per output row, no LDS writes, no barrier; waves never
+// wait for each other after the window has been staged.
+__device__ __forceinline__ float nl_lane_prev(float v) {  // value held by lane-1 (0 for lane 0): DPP wave_shr:1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float nl_lane_next(float v) {  // value held by lane+1 (0 for lane 63): DPP wave_shl:1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+template<int TH, int ROWS = 4>
+__global__ __launch_bounds__(64 * TH / ROWS) void nlm_7x7w(const float *__restrict__ in, long in_sy, long in_sc, NGeom g,
+                                                    float *__restrict__ out, long out_sy, long out_sc) {
+    constexpr int NT = 64 * TH / ROWS, IH = TH + 4 * HALF;
+    extern __shared__ float lds[];
+    float *sin = lds;                       // [3][IH][IWP]
+    const int tid = threadIdx.x;
+    const int tx0 = g.ox0 + blockIdx.x * TW, ty0 = g.oy0 + blockIdx.y * TH;  // absolute coords of the tile
+    for (int i = tid; i < 3 * IH * IW; i += NT) {   // the clamped input window (repeat_edge on x, y and c, generator :27)
+        int c = i / (IH * IW), rem = i - c * (IH * IW), r = rem / IW, col = rem - r * IW;
+        int x = dev::clampi(tx0 - 2 * HALF + col, g.ix0, g.ix1) - g.ix0;
+        int y = dev::clampi(ty0 - 2 * HALF + r, g.iy0, g.iy1) - g.iy0;
+        int cc = dev::clampi(c, g.ic0, g.ic1) - g.ic0;
+        sin[(c * IH + r) * IWP + col] = in[(long)y * in_sy + x + (long)cc * in_sc];
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int col = lane + HALF;             // window column of abs x = tx0 - 3 + lane
+    const int row0 = ROWS * wave + HALF;     // window row of abs y = ty0 + ROWS * wave - 3
+    float u[ROWS + 6][3];
+#pragma unroll
+    for (int i = 0; i < ROWS + 6; i++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) u[i][c] = sin[(c * IH + row0 + i) * IWP + col];
+    }
+    float acc[ROWS][4];
+#pragma unroll
+    for (int o = 0; o < ROWS; o++) acc[o][0] = acc[o][1] = acc[o][2] = acc[o][3] = 0.0f;
+#pragma unroll 1
+    for (int dy = -HALF; dy <= HALF; dy++) {
+        const float *shifted = sin + (row0 + dy) * IWP + col;
+#pragma unroll
+        for (int dxi = 0; dxi < SA; dxi++) {
+            const int dx = dxi - HALF;
+            float sh[ROWS + 6][3];
+#pragma unroll
+            for (int i = 0; i < ROWS + 6; i++) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) sh[i][c] = shifted[(c * IH + i) * IWP + dx];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float d[ROWS + 6];
+#pragma unroll
+            for (int i = 0; i < ROWS + 6; i++) {
+                float dd;   // the oracle's sums start from 0; 0 + x is x for every x but -0, and a square is never -0
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float t = u[i][c] - sh[i][c];
+                    dd = c == 0 ? t * t : dd + t * t;
+                }
+                d[i] = dd;
+            }
+            float bdy[ROWS];
+#pragma unroll
+            for (int o = 0; o < ROWS; o++) {
+                float sum = d[o];
+#pragma unroll
+                for (int q = 1; q < 7; q++) sum = sum + d[o + q];
+                bdy[o] = sum;
+            }
+            // blur_d for output column lane - 3: blur_d_y of lanes lane - 3 .. lane + 3, leftmost first
+#pragma unroll
+            for (int o = 0; o < ROWS; o++) {
+                const float r1 = nl_lane_prev(bdy[o]), r2 = nl_lane_prev(r1), r3 = nl_lane_prev(r2);
+                const float l1 = nl_lane_next(bdy[o]), l2 = nl_lane_next(l1), l3 = nl_lane_next(l2);
+                const float sum = (((((r3 + r2) + r1) + bdy[o]) + l1) + l2) + l3;
+                const float w = dev::fast_exp(sum * g.inv);
+#pragma unroll
+                for (int c = 0; c < 3; c++) acc[o][c] = acc[o][c] + w * sh[o + HALF][c];
+                acc[o][3] = acc[o][3] + w * 1.0f;
+            }
+        }
+    }
+    // ---- normalise + store: lane L holds output column L - 3
+    const int X = tx0 + lane - HALF - g.ox0;
+    if (lane >= HALF && lane < HALF + TW && X < g.ow) {
+#pragma unroll
+        for (int o = 0; o < ROWS; o++) {
+            const int Y = ty0 + ROWS * wave + o - g.oy0;
+            if (Y < g.oh) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) out[(long)Y * out_sy + X + (long)c * out_sc] = dev::clampf(acc[o][c] / acc[o][3], 0.0f, 1.0f);
+            }
+        }
+    }
+}
+
 // generic (patch, search): one thread per pixel, everything from (L2-resident) global memory, same sum orders
 __global__ __launch_bounds__(256) void nlm_generic(const float *__restrict__ in, long in_sy, long in_sc, NGeom g, int patch,
                                                   int search, float *__restrict__ out, long out_sy, long out_sc) {
@@ -297,11 +403,31 @@ extern "C" int nl_means(halide_buffer_t *input, int32_t patch_size, int32_t sear
         HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, (nlm_7x7<TH_, NT_>), grid, dim3(NT_), lds_bytes(TH_), din, in_sy, in_sc, g, dout, \
                     out_sy, out_sc);                                                                                          \
     } while (0)
+#define NLM_LAUNCH_W(TH_)                                                                                                     \
+    do {                                                                                                                      \
+        const size_t sh_w = sizeof(float) * (size_t)3 * (TH_ + 4 * HALF) * IWP;                                               \
+        HLMI_HIP(uc, hipFuncSetAttribute((const void *)nlm_7x7w<TH_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_w)); \
+        dim3 grid((ow + TW - 1) / TW, (oh + TH_ - 1) / TH_);                                                                  \
+        HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, (nlm_7x7w<TH_>), grid, dim3(16 * TH_), sh_w, din, in_sy, in_sc, g, dout, out_sy, \
+                    out_sc);                                                                                                  \
+    } while (0)
+        const char *lk = getenv("HLMI_NLM_LDS");   // A/B: the kernel that hands blur_d_y through LDS (a barrier per offset)
+        if (getenv("HLMI_NLM_ROWS8")) {
+            const size_t sh_w = sizeof(float) * (size_t)3 * (32 + 4 * HALF) * IWP;
+            dim3 grid((ow + TW - 1) / TW, (oh + 31) / 32);
+            HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, (nlm_7x7w<32, 8>), grid, dim3(256), sh_w, din, in_sy, in_sc, g, dout, out_sy, out_sc);
+        } else
+        if (!lk || !*lk || *lk == '0') {
+            if (th == 16) NLM_LAUNCH_W(16);
+            else if (th == 64) NLM_LAUNCH_W(64);
+            else NLM_LAUNCH_W(32);
+        } else
         if (th == 80) NLM_LAUNCH(80, 1024);
         else if (th == 64) NLM_LAUNCH(64, 1024);
         else if (th == 16) NLM_LAUNCH(16, 256);
         else NLM_LAUNCH(32, 512);
 #undef NLM_LAUNCH
+#undef NLM_LAUNCH_W
     } else {
         HLMI_LAUNCH(uc, "nlm_generic", ctx.stream, nlm_generic, dim3((ow + 255) / 256, oh), dim3(256), 0, din, in_sy, in_sc, g,
                     patch_size, search_area, dout, out_sy, out_sc);
