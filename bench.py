@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--passes", type=int, default=PASSES, help="passes over the FRAMES_PER_STEP distinct frames that make one step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the bilateral_grid / nl_means / conv_layer_bf16 leg")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the live HBM copy-ceiling sweep (profiler runs)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra input variants (uniform noise, 7680x4320)")
     ap.add_argument("--partitions", type=int, default=int(os.environ.get("HLMI_BENCH_PARTITIONS", "4")),
                     help="frames of a step are spread over this many CU-partitioned streams (halide_hip_partition_stream: "
@@ -222,7 +223,7 @@ def main():
     # the practical HBM ceiling of this device, measured live: a float4 copy kernel over 1 GiB buffers (4x the MALL), HIP
     # events over 10 launches (halide_amd/csrc/membench.hip) — what "HBM-bound" can reach at best for mixed read/write traffic
     copy_ceiling, ceiling_detail = None, None
-    if rank == 0:
+    if rank == 0 and not args.no_ceiling:
         try:
             ceiling_detail = hl.membench(1 << 30, 10)
             copy_ceiling = ceiling_detail["copy_gbs"]

@@ -35,7 +35,8 @@ if ks:
             if i:
                 row[0] = short(row[0])
             w.writerow(row)
-for name in ("bench.json", "bench_1stream.json", "bench_2streams.json", "pytest_gpu.log", "rocminfo.txt", "smoke.log", "bench_apps.jsonl"):
+for name in ("bench.json", "bench_1stream.json", "bench_2streams.json", "bench_driver_flags.json", "bench_gpus2.log", "pytest_gpu.log",
+             "rocminfo.txt", "smoke.log", "bench_apps.jsonl"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f"{rnd}_{name}"))
