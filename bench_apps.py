@@ -152,12 +152,12 @@ def run(only=(), samples=5, sink=None, cpu=False):
         call = lambda: hl.stencil_chain(a, o)
         t = timed(call, o, 20)
         # Priced on the operations the kernel EXECUTES: the separable 5 + 5 form is 10 u16 multiply-adds per pixel and stage
-        # (the reference's 25-tap form would be 2.5x more), over the 128 x 96 window of a tile whose 8 fused stages leave
-        # 96 x 64 outputs (2.0x halo recomputation) = 640 executed multiply-adds per output pixel; bound: the packed 16-bit
-        # integer VALU rate (v_pk_mad_u16: 2 MACs per lane and clock = the packed-f32 figure).  Next to it the figure on the
-        # ALGORITHMIC count (32 stages x 25 taps = 1600 MACs per pixel) and the fraction of the HBM roofline SURVEY.md
-        # §8(d) assigns the pipeline (4 B/px: read + write once).
-        halo = (128.0 * 96.0) / (96.0 * 64.0)
+        # (the reference's 25-tap form would be 2.5x more), over the 128 x 128 register window of a tile whose 8 fused stages
+        # leave 96 x 96 outputs (1.78x halo recomputation; the LDS-window kernel, HLMI_SC_LDS=1: 128 x 96 -> 96 x 64, 2.0x) = 569
+        # executed multiply-adds per output pixel; bound: the packed 16-bit integer VALU rate (v_pk_mad_u16: 2 MACs per lane
+        # and clock = the packed-f32 figure).  Next to it the figure on the ALGORITHMIC count (32 stages x 25 taps = 1600 MACs
+        # per pixel) and the fraction of the HBM roofline SURVEY.md §8(d) assigns the pipeline (4 B/px: read + write once).
+        halo = (128.0 * 96.0) / (96.0 * 64.0) if os.environ.get("HLMI_SC_LDS") else (128.0 * 128.0) / (96.0 * 96.0)
         ops_exec = 2.0 * 32 * 10 * halo * W * H
         ops_alg = 2.0 * 1600 * W * H
         emit("stencil_chain", "apps/stencil_chain 32 stages 5x5, u16 1536x2560", t, W * H, "valu", ops_exec / t / 1e12,
