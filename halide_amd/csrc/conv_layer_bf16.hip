@@ -369,6 +369,9 @@ void conv3x3_bf16_lin(const float *__restrict__ in, const uint16_t *__restrict__
 // Only plain loads are in flight at a barrier (no stores before the epilogue), so __syncthreads() costs lgkmcnt(0) + s_barrier.
 // All requests are unconditional (indices clamped at the end of the K loop): a load behind a branch makes the compiler's
 // vmcnt bookkeeping assume nothing younger may be in flight, and every wait for a ring slot became vmcnt(0).
+#ifndef HLMI_CONVP_AGPR
+#define HLMI_CONVP_AGPR 0
+#endif
 constexpr int TQ = 256;        // input-linear positions per workgroup
 constexpr int PT = 512;        // threads per workgroup
 constexpr int BD = 6;          // B taps in flight
@@ -443,7 +446,15 @@ __global__ __launch_bounds__(PT) void conv3x3_bf16_p(const float *__restrict__ i
     };
     auto mfma2 = [&](int fs, int a) {
 #pragma unroll
-        for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[fs][a], fb[fs][b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 2; b++) {
+#if HLMI_CONVP_AGPR
+            // accumulators in the AGPR half of the register file (experiment: does C/D traffic in the VGPR file keep the
+            // LDS returns out?)
+            asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[a][b]) : "v"(fa[fs][a]), "v"(fb[fs][b]));
+#else
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[fs][a], fb[fs][b], acc[a][b], 0, 0, 0);
+#endif
+        }
     };
     const int WpPL = Wp * PL;
     // One tap, one barrier, placed after the first half of the tap's first k-step: the fragments of the second k-step were
