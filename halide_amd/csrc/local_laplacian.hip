@@ -640,6 +640,7 @@ struct D01Args {
     int so2, loy2, w2, h2, ws2;
     size_t ps2;
     int Pbase, S2, nsx, nsy, nunits;
+    int skip1;                 // level 1 is not stored at all: its only reader (ll_up0g) recomputes what it needs from the input
     unsigned nsy_magic;        // floor(2^32 / nsy) + 1: x / nsy == umulhi(x, magic) for x * nsy < 2^32; 0 when nsy == 1
     int rows_base, rows_rem;   // h2 / nsy, h2 % nsy
 };
@@ -888,7 +889,7 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry 
         prep_row(rc, n0);
         prep_row(rd, n1);
         __builtin_amdgcn_sched_barrier(0);
-        if (T >= Ts0 && T <= Ts1 && !(HLMI_D01_ABL & 2 && p.nunits > 0)) {
+        if (T >= Ts0 && T <= Ts1 && !p.skip1 && !(HLMI_D01_ABL & 2 && p.nunits > 0)) {
             float *drow = p.g1 + (size_t)(T - p.loy1) * p.ws1 + off1;
             if (st1_ok) {
 #pragma unroll
@@ -1240,6 +1241,7 @@ struct Up0Args {
     int lox2, loy2, ws2;
     size_t ps2;
     int rx1_1;               // right end of R_1 (the tiles of the last workgroup column stop there)
+    int rx0_1, ry0_1, ry1_1; // the rest of R_1 (ll_up0g's debug variant stores outGPyramid[1] on it)
 };
 
 template<bool VEC, bool LUT_LDS>
@@ -1386,6 +1388,9 @@ __global__ void ll_div3_check(const float *n, const float *d, int count, int *ba
 //     of by an ll_up:1 launch that writes it to memory for this kernel to gather back: one launch, the write and the
 //     re-read of the plane, and a second pass over level 1's planes less.  The tile halo costs (130 x (RU + 2)) /
 //     (128 x RU) - 1 recomputed values (16 % at RU = 16).
+#ifndef HLMI_UP0_ABL
+#define HLMI_UP0_ABL 0   // timing experiment only (csrc/Makefile VARIANT): 1 = no level-1 plane reads at all (results wrong)
+#endif
 constexpr int U0_TW = 130, U0_TS = 131;  // coarse columns of a workgroup's tile / its LDS row stride
 template<bool LUT_LDS, bool B1, bool FUSE1>
 __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
@@ -1407,7 +1412,7 @@ __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
             const int cx = cx0 + tx, cy = cy0 + ty;
             if (cx > p.rx1_1) continue;
             // outGPyramid[1] = upsample(outGPyramid[2]) + outLPyramid[1]   (:76-79), exactly as ll_up computes it
-            const float outL = outl_value(p.g1, p.ws1, p.ps1, p.lox1, p.loy1, p.g2, p.ws2, p.ps2, p.lox2, p.loy2, cx, cy, gm.K, gm.Km1);
+            const float outL = HLMI_UP0_ABL ? 0.0f : outl_value(p.g1, p.ws1, p.ps1, p.lox1, p.loy1, p.g2, p.ws2, p.ps2, p.lox2, p.loy2, cx, cy, gm.K, gm.Km1);
             s_out1[ty * U0_TS + tx] = up_at(p.out2, p.lox2, p.loy2, p.ws2, cx, cy) + outL;
         }
     }
@@ -1458,7 +1463,7 @@ __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
         // lerp(ua, ub, wy) (:280), ua from coarse row ya, ub from yb: wy = 3/4 for odd Y, 1/4 for even Y.  The row
         // whose weight is 1/4 (an exact product) is called q, the other t — a scalar choice of row pointers.
         const int yq = yodd ? ya : yb, yt = yodd ? yb : ya;
-        const float *ga = p.g1 + (size_t)yq * p.ws1, *gb = p.g1 + (size_t)yt * p.ws1;
+        const float *ga = p.g1 + (HLMI_UP0_ABL ? 0 : (size_t)yq * p.ws1), *gb = p.g1 + (HLMI_UP0_ABL ? 0 : (size_t)yt * p.ws1);
         const uint16_t ch[3][2] = {{f.c0.x, f.c0.y}, {f.c1.x, f.c1.y}, {f.c2.x, f.c2.y}};
 #pragma unroll
         for (int i = 0; i < 2; i++) {
@@ -1469,7 +1474,7 @@ __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
             const float lif = (float)li;
             const int idx = min((int)(level * 256.0f), gm.half);
             const float *lp = lut + (idx - 256 * li + gm.half);
-            const uint32_t pb = (uint32_t)li * psb + colb + 4u * i;
+            const uint32_t pb = HLMI_UP0_ABL ? (colb & 1023u) + 4u * i : (uint32_t)li * psb + colb + 4u * i;
             g.A0[i] = ld_su<F2U>(ga, pb), g.B0[i] = ld_su<F2U>(gb, pb);
             g.A1[i] = ld_su<F2U>(ga, pb + psb), g.Bp[i] = ld_su<F2U>(gb, pb + psb);
             s.lut0[i] = lp[0], s.lut1[i] = lp[-256];
@@ -1544,6 +1549,234 @@ __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// ll_up0g: outGPyramid[0] + recolouring like ll_up0f, WITHOUT reading gPyramid[1] from memory — the workgroup recomputes the
+// level-1 planes its tile needs from the input.  Why: the frame rate on CU-partitioned streams is set by bytes (409 MB per
+// frame; a timing-only build that neither stores nor reads the level-1 planes runs at 0.066 instead of 0.106 ms per frame,
+// profiles/r03b_traffic_ablation.txt), and the K + 1 level-1 planes are the largest item: 75 MB written by ll_down01f, 50-80 MB
+// read back here.  gPyramid[1](., ., k) is a pure function of the input (generator :41-47, :267-273), and a tile only ever
+// touches the planes li, li + 1 of the pixels it contains — two to four of the eight on natural images, all eight on noise.
+//   A  remap table -> LDS; the tile's level-0 window (134 x 22 pixels for 128 x 16 outputs: the 66 x 10 coarse pixels the tile
+//      reads x their 1-3-3-1 taps) -> gray and remap-table position per pixel in LDS
+//   B  inGPyramid[1] on the coarse tile (vertical 1-3-3-1, then horizontal: downsample :267-273)
+//   C  which planes does the tile need: li, li + 1 of its 128 x 16 level-0 pixels and of its coarse pixels -> a bit mask
+//   D  for every needed plane k: gPyramid[0](., ., k) pointwise from (gray, position), vertical pass -> LDS, horizontal pass ->
+//      plane k of the coarse tile in LDS — the operations of ll_down0 / ll_down01f on the same values, so bit-identical
+//   E  outGPyramid[1] on the coarse tile (the level-1 collapse, as in ll_up0f<.., .., true>, planes from LDS)
+//   F  the 128 x 16 outputs: lane = pixel pair, wave = 4 rows; ll_up0f's arithmetic with every gather served by LDS
+// 70.9 KB of LDS: two workgroups per CU.  OUT1_ONLY: stop after E and store outGPyramid[1] (hlmi_debug_local_laplacian_outg).
+constexpr int G_TW = 128, G_TH = 16, G_NT = 512;      // output tile, threads per workgroup
+constexpr int G_CW = 66, G_CH = 10, G_CP = 68;        // coarse tile and its LDS pitch
+constexpr int G_WW = 134, G_WH = 22, G_WP = 136;      // level-0 window and its LDS pitch
+constexpr int G_FLOATS(int nlut) {                    // LDS: table, gray window, position window (u16), inG1, outG1, 8 planes, mask
+    return ((nlut + 1) & ~1) + G_WH * G_WP + G_WH * G_WP / 2 + 2 * G_CH * G_CP + KCH * G_CH * G_CP + 2;
+}
+template<bool B1, bool OUT1_ONLY>
+__global__ __launch_bounds__(G_NT) void ll_up0g(Up0Args p, Geometry gm, Levels lev, int abl) {   // abl: timing experiments (HLMI_LL_G_ABL)
+    extern __shared__ float slut[];
+    const int nlut = 2 * gm.half + 1;
+    float *sgray = slut + ((nlut + 1) & ~1);
+    uint16_t *sidx = reinterpret_cast<uint16_t *>(sgray + G_WH * G_WP);      // remap-table position of every window pixel (<= (K-1) 256)
+    float *sing1 = sgray + G_WH * G_WP + G_WH * G_WP / 2;
+    float *sout1 = sing1 + G_CH * G_CP;
+    float *splane = sout1 + G_CH * G_CP;
+    unsigned *smask = reinterpret_cast<unsigned *>(splane + KCH * G_CH * G_CP);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int X0 = p.ox0 + (int)blockIdx.x * G_TW;                         // even
+    const int Yw0 = p.oy0 + (int)blockIdx.y * G_TH;
+    const int Yw1 = min(Yw0 + G_TH, p.oy0 + p.oh) - 1;
+    const int cx0 = (X0 >> 1) - 1, cy0 = dev::fdiv2(Yw0 - 1);
+    const int th = dev::fdiv2(Yw1 + 1) - cy0 + 1;                          // coarse rows the tile reads (<= G_CH)
+    const int wy0 = 2 * cy0 - 1;                                           // level-0 window origin (absolute): (2 cx0 - 1, 2 cy0 - 1) = (X0 - 3, wy0)
+    // ---- F's pixels are requested first: their latency hides under everything else.  lane = pixel pair, wave = 2 rows
+    const int x = (int)blockIdx.x * G_TW + 2 * lane;                       // output storage column of the lane's pair
+    const uint32_t inb = (uint32_t)(X0 + 2 * lane - gm.ix0) * 2u, outb = (uint32_t)x * 2u;
+    ushort2 fin[2][3];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int Y = min(Yw0 + 2 * wave + j, p.oy0 + p.oh - 1);           // rows past the end: clamped, never stored
+        const uint16_t *irow = p.in + (long)(Y - gm.iy0) * p.in_sy;
+        const uint32_t ib = x < p.ow ? inb : (uint32_t)(p.ox0 - gm.ix0) * 2u;   // columns past the end likewise
+#pragma unroll
+        for (int c = 0; c < 3; c++) fin[j][c] = ld_frame2(irow + p.gco[c], ib);
+    }
+    // ---- A
+    for (int i = tid; i < nlut; i += G_NT) slut[i] = p.lut_g[i];
+    if (tid == 0) *smask = 0u;
+    {
+        const int iw = gm.ix1 - gm.ix0, ih = gm.iy1 - gm.iy0;
+        constexpr int NIT = (G_WH * (G_WP / 2) + G_NT - 1) / G_NT;         // 3
+        uint16_t ch[NIT][3][2];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int i = min(tid + it * G_NT, G_WH * (G_WP / 2) - 1);
+            const int r = i / (G_WP / 2), q = i - r * (G_WP / 2);
+            const int a = X0 - 4 + 2 * q;                                   // absolute column of the pair's first pixel (even)
+            const uint16_t *irow = p.in + (long)dev::clampi(wy0 + r - gm.iy0, 0, ih) * p.in_sy;
+            if (abl & 8) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) ch[it][c][0] = (uint16_t)(i * 7 + c), ch[it][c][1] = (uint16_t)(i * 5 + c);
+            } else if (a >= gm.ix0 && a + 1 <= gm.ix1) {
+                const uint32_t off = (uint32_t)(a - gm.ix0) * 2u;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const ushort2 v = ld_frame2(irow + p.gco[c], off);
+                    ch[it][c][0] = v.x, ch[it][c][1] = v.y;
+                }
+            } else {
+                const int xa = dev::clampi(a - gm.ix0, 0, iw), xb = dev::clampi(a + 1 - gm.ix0, 0, iw);
+#pragma unroll
+                for (int c = 0; c < 3; c++) ch[it][c][0] = irow[p.gco[c] + xa], ch[it][c][1] = irow[p.gco[c] + xb];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int i = tid + it * G_NT;
+            if (i < G_WH * (G_WP / 2)) {
+                const int r = i / (G_WP / 2), q = i - r * (G_WP / 2);
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int wc = 2 * q - 1 + e;                            // window column
+                    if (wc >= 0 && wc < G_WW) {
+                        const float g = gray_from(ch[it][0][e], ch[it][1][e], ch[it][2][e]);
+                        sgray[r * G_WP + wc] = g;
+                        sidx[r * G_WP + wc] = (uint16_t)idx_of(g, gm.Km1, gm.half);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- B: inGPyramid[1] on the coarse tile (vertical 1-3-3-1 of the four columns, then horizontal)
+    for (int i = tid; i < G_CH * G_CW; i += G_NT) {
+        const int r = i / G_CW, c = i - r * G_CW;
+        const float *g = sgray + 2 * r * G_WP + 2 * c;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = down4_raw(g[k], g[G_WP + k], g[2 * G_WP + k], g[3 * G_WP + k]);
+        sing1[r * G_CP + c] = down4_tail(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+    // ---- C: the planes this tile reads
+    {
+        unsigned bits = 0u;
+        // level-0 pixels of the tile: pair 2 lane, rows 2 wave, 2 wave + 1; window column of X0 + x is x + 3
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int wr = Yw0 + 2 * wave + j - wy0;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const float level = sgray[wr * G_WP + 2 * lane + 3 + e] * gm.Km1;
+                bits |= 3u << min((int)level, gm.K - 2);
+            }
+        }
+        for (int i = tid; i < G_CH * G_CW; i += G_NT) {
+            const float level = sing1[(i / G_CW) * G_CP + (i % G_CW)] * gm.Km1;
+            bits |= 3u << dev::clampi((int)level, 0, gm.K - 2);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) bits |= (unsigned)__shfl_xor((int)bits, o);   // wave-wide OR, one atomic per wave
+        if (lane == 0) atomicOr(smask, bits);
+    }
+    __syncthreads();
+    const unsigned need = *smask;
+    // ---- D: the needed planes of gPyramid[1] on the coarse tile, all in one phase: item = (plane, coarse pixel), 16 pointwise
+    //      evaluations of gPyramid[0] (:44) from (gray, position), the vertical pass of the four columns, the horizontal pass
+    {
+        const int np = (abl & 1) ? 0 : __builtin_popcount(need);
+        for (int it = tid; it < np * (G_CH * G_CW); it += G_NT) {
+            const int pi = it / (G_CH * G_CW), i = it - pi * (G_CH * G_CW);
+            unsigned m = need;
+            for (int s2 = 0; s2 < pi; s2++) m &= m - 1;                      // drop the pi lowest set bits
+            const int k = __builtin_ctz(m);
+            const int r = i / G_CW, c = i - r * G_CW;
+            const float L = lev.v[k];
+            const float *lk = slut + (gm.half - 256 * k);
+            const float *g = sgray + 2 * r * G_WP + 2 * c;
+            const uint16_t *ix = sidx + 2 * r * G_WP + 2 * c;
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float a0 = g0_val<B1>(g[q], L, p.beta, lk[ix[q]]), a1 = g0_val<B1>(g[G_WP + q], L, p.beta, lk[ix[G_WP + q]]);
+                const float a2 = g0_val<B1>(g[2 * G_WP + q], L, p.beta, lk[ix[2 * G_WP + q]]);
+                const float a3 = g0_val<B1>(g[3 * G_WP + q], L, p.beta, lk[ix[3 * G_WP + q]]);
+                v[q] = down4_raw(a0, a1, a2, a3);
+            }
+            splane[k * (G_CH * G_CP) + r * G_CP + c] = down4_tail(v[0], v[1], v[2], v[3]);
+        }
+    }
+    __syncthreads();
+    // ---- E: outGPyramid[1] = upsample(outGPyramid[2]) + outLPyramid[1]   (:63-79), exactly as ll_up computes it
+    for (int e = tid; e < ((abl & 2) ? 0 : G_CW * th); e += G_NT) {
+        const int ty = e / G_CW, tx = e - ty * G_CW;
+        const int cx = cx0 + tx, cy = cy0 + ty;
+        if (cx > p.rx1_1) continue;
+        const float level = sing1[ty * G_CP + tx] * gm.Km1;
+        const int li = dev::clampi((int)level, 0, gm.K - 2);
+        const float lf = level - (float)li;
+        const float l0 = splane[li * (G_CH * G_CP) + ty * G_CP + tx] - up_at(p.g2 + (size_t)li * p.ps2, p.lox2, p.loy2, p.ws2, cx, cy);
+        const float l1 = splane[(li + 1) * (G_CH * G_CP) + ty * G_CP + tx] - up_at(p.g2 + (size_t)(li + 1) * p.ps2, p.lox2, p.loy2, p.ws2, cx, cy);
+        const float outL = (1.0f - lf) * l0 + lf * l1;
+        const float v = up_at(p.out2, p.lox2, p.loy2, p.ws2, cx, cy) + outL;
+        sout1[ty * G_CP + tx] = v;
+        if (OUT1_ONLY && cx >= p.rx0_1 && cy >= p.ry0_1 && cy <= p.ry1_1) {
+            const_cast<float *>(p.out1)[(size_t)(cy - p.loy1) * p.ws1 + (cx - p.lox1)] = v;
+        }
+    }
+    if (OUT1_ONLY) return;
+    __syncthreads();
+    // ---- F: the outputs.  lerp(zero, one, w) with w in {1/4, 3/4}: see ll_up0f
+    if (x >= p.ow || (abl & 4)) return;
+    auto hl0 = [](float rm, float r0) { return __builtin_fmaf(rm, 0.25f, r0 * 0.75f); };  // lerp(f[c], f[c-1], 1/4): X even
+    auto hl1 = [](float r0, float rp) { return __builtin_fmaf(rp, 0.25f, r0 * 0.75f); };  // lerp(f[c+1], f[c], 3/4): X odd
+    auto vl = [](float uq, float ut) { return __builtin_fmaf(uq, 0.25f, ut * 0.75f); };
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int y = (int)blockIdx.y * G_TH + 2 * wave + j;
+        if (y >= p.oh) break;
+        const int Y = p.oy0 + y;
+        const uint16_t ch[3][2] = {{fin[j][0].x, fin[j][0].y}, {fin[j][1].x, fin[j][1].y}, {fin[j][2].x, fin[j][2].y}};
+        const int ya = dev::fdiv2(Y + 1) - cy0, yb = dev::fdiv2(Y - 1) - cy0;
+        const bool yodd = dev::fmod2(Y) != 0;
+        const int yq = yodd ? ya : yb, yt = yodd ? yb : ya;                  // q: the row whose weight is 1/4
+        const float *oa = sout1 + yq * G_CP + lane, *ob = sout1 + yt * G_CP + lane;   // columns c - 1, c, c + 1 = lane, lane + 1, lane + 2
+        const float uo[2] = {vl(hl0(oa[0], oa[1]), hl0(ob[0], ob[1])), vl(hl1(oa[1], oa[2]), hl1(ob[1], ob[2]))};
+        uint16_t res[3][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const float gray = gray_from(ch[0][i], ch[1][i], ch[2][i]);
+            const float level = gray * gm.Km1;
+            const int li = min((int)level, gm.K - 2);                       // gray >= 0: the lower clamp bounds never bind
+            const float lif = (float)li;
+            const int idx = min((int)(level * 256.0f), gm.half);
+            const float *lp = slut + (idx - 256 * li + gm.half);
+            const float lut0 = lp[0], lut1 = lp[-256];
+            const float lf = level - lif;
+            const float lev0 = lif * gm.inv_Km1, lev1 = (lif + 1.0f) * gm.inv_Km1;
+            const float *Aq = splane + li * (G_CH * G_CP) + yq * G_CP + lane + i;      // columns (c - 1, c) or (c, c + 1)
+            const float *At = splane + li * (G_CH * G_CP) + yt * G_CP + lane + i;
+            const float *Aq1 = Aq + G_CH * G_CP, *At1 = At + G_CH * G_CP;             // plane li + 1
+            float u0, u1;
+            if (i == 0) u0 = vl(hl0(Aq[0], Aq[1]), hl0(At[0], At[1])), u1 = vl(hl0(Aq1[0], Aq1[1]), hl0(At1[0], At1[1]));
+            else u0 = vl(hl1(Aq[0], Aq[1]), hl1(At[0], At[1])), u1 = vl(hl1(Aq1[0], Aq1[1]), hl1(At1[0], At1[1]));
+            const float l0 = g0_val<B1>(gray, lev0, p.beta, lut0) - u0;
+            const float l1 = g0_val<B1>(gray, lev1, p.beta, lut1) - u1;
+            const float outL = (1.0f - lf) * l0 + lf * l1;
+            const float og = (uo[i] + outL) + 0.01f;
+            const float gr = gray + 0.01f;
+            const float n[3] = {(float)ch[0][i] * og, (float)ch[1][i] * og, (float)ch[2][i] * og};
+            float qv[3];
+            div3_by(n, gr, qv);
+#pragma unroll
+            for (int c = 0; c < 3; c++) res[c][i] = (uint16_t)__builtin_amdgcn_fmed3f(qv[c], 0.0f, 65535.0f);
+        }
+        uint16_t *orow = p.out + (long)y * p.out_sy;
+#pragma unroll
+        for (int c = 0; c < 3; c++) st_frame2(reinterpret_cast<char *>(orow + (long)c * p.out_sc) + outb, res[c][0], res[c][1]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 const int64_t est_zero = 0, est_w = 1536, est_h = 2560, est_c = 3;
 const int64_t *const buf_est[6] = {&est_zero, &est_w, &est_zero, &est_h, &est_zero, &est_c};
 const halide_scalar_value_t est_levels = [] { halide_scalar_value_t v{}; v.u.i32 = 8; return v; }();
@@ -1571,6 +1804,9 @@ int env_int(const char *name, int dflt) {
 thread_local Level t_dbg_lv[J];
 thread_local hipStream_t t_dbg_stream = nullptr;
 thread_local bool t_dbg_out1_pending = false;  // the last call fused level 1's collapse: outGPyramid[1] was never stored
+thread_local bool t_dbg_ondemand = false, t_dbg_b1 = false;   // ... and level 1 itself was never stored either (ll_up0g)
+thread_local Up0Args t_dbg_up0;
+thread_local Geometry t_dbg_gm;
 thread_local int t_dbg_K = 0;
 thread_local float t_dbg_Km1 = 0;
 
@@ -1781,6 +2017,57 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     } else {
         HLMI_LAUNCH(uc, "ll_remap_lut", st, ll_remap_lut, dim3((nlut + 255) / 256), dim3(256), 0, lut, gm.half, alpha);
     }
+    // levels >= S are produced / collapsed by the two multi-level kernels (S = 4: 2 launches instead of 7)
+    const int S = [&] {
+        int v = env_int("HLMI_LL_FUSE_FROM", 4);
+        return (v >= J - 4 && v <= J - 2) ? v : J;
+    }();
+    // the collapse (outGPyramid[J-1] .. outGPyramid[SU]) is ONE launch (ll_up_multi); opt-in: on the large levels its per-pixel overhead exceeds the saved launches
+    const int SU = [&] {
+        int v = env_int("HLMI_LL_UPCHAIN_FROM", 0);
+        return (v >= 1 && v <= J - 2) ? v : S;
+    }();
+    // ---- level 0 arguments first: whether the level-1 collapse is fused into ll_up0f decides if ll_up:1 is launched
+    Up0Args p;
+    bool vec, fast, fuse1;
+    {
+        const Level &c = lv[1];
+        p.in = din, p.in_sy = in_sy;
+        const int oc0 = output->dim[2].min;
+        bool same = (nc == 3);
+        for (int ch = 0; ch < 3; ch++) {
+            p.gco[ch] = gco[ch];
+            p.cco[ch] = ch < nc ? (long)(oc0 + ch - ic0) * in_sc : 0;
+            if (p.cco[ch] != p.gco[ch]) same = false;
+        }
+        p.same_ch = same ? 1 : 0;
+        p.lut_g = lut, p.g1 = c.g, p.out1 = c.out;
+        p.lox1 = c.lox, p.loy1 = c.loy, p.ws1 = c.ws, p.ps1 = c.ps;
+        p.out = dout, p.out_sy = out_sy, p.out_sc = out_sc;
+        p.ox0 = output->dim[0].min, p.oy0 = output->dim[1].min, p.ow = ow, p.oh = oh, p.nc = nc;
+        p.beta = beta;
+        p.g2 = lv[2].g, p.out2 = lv[2].out, p.lox2 = lv[2].lox, p.loy2 = lv[2].loy, p.ws2 = lv[2].ws, p.ps2 = lv[2].ps;
+        p.rx1_1 = c.rx1, p.rx0_1 = c.rx0, p.ry0_1 = c.ry0, p.ry1_1 = c.ry1;
+        vec = ((uintptr_t)din % 4 == 0) && ((uintptr_t)dout % 4 == 0) && in_sy % 2 == 0 && out_sy % 2 == 0 &&
+              out_sc % 2 == 0 && ((p.ox0 - gm.ix0) % 2 == 0) && !env_int("HLMI_LL_NO_VEC", 0);
+        for (int ch = 0; ch < 3; ch++) vec = vec && p.gco[ch] % 2 == 0 && p.cco[ch] % 2 == 0;
+        fast = vec && same && nc == 3 && (ow & 1) == 0 && (p.ox0 & 1) == 0 &&
+               (double)(levels + 1) * (4.0 * (double)c.ps) < 4.0e9 && !env_int("HLMI_LL_UP0_OLD", 0);
+        // the fused collapse needs level 2 to be a stored level of its own (SU >= 2 always holds: SU >= S >= 4 or the
+        // opt-in up-chain, which starts at >= 1 and then owns level 1 itself)
+        fuse1 = fast && SU >= 2 && env_int("HLMI_LL_FUSE_UP1", 1);
+        p.RU = max(1, env_int("HLMI_LL_RU", fuse1 ? 16 : 8));
+    }
+    // ll_up0g: level 1 is never stored — the up pass recomputes the planes each tile needs from the input (needs the fused
+    // down kernel, which can simply not store level 1, and everything ll_up0f<.., .., true> needs)
+    const bool d01_possible = levels == KCH && lut_lds && env_int("HLMI_LL_D0F", 1) && env_int("HLMI_LL_FUSE_D2", 1) &&
+                              ((uintptr_t)din % 8 == 0) && in_sy % 4 == 0 && gco[0] % 4 == 0 && gco[1] % 4 == 0 && gco[2] % 4 == 0 &&
+                              (gm.ix1 - gm.ix0 + 1) % 4 == 0 && !env_int("HLMI_LL_NO_VEC", 0);
+    // OPT-IN (HLMI_LL_ONDEMAND=1): bit-exact on the whole parity suite, and it does take 150 MB per frame off the memory system
+    // (ll_down01f 46.7 -> 37.7 us) — but ll_up0g itself takes 107 us against ll_up0f's 41 (4050 tiles at two workgroups per
+    // CU, 34 us of per-tile fixed cost, 36 us of plane recomputation), so the frame gets slower (0.128 vs 0.106 ms on four
+    // partitions); profiles/r03b_traffic_ablation.txt has the phase breakdown and what a version that pays would need.
+    const bool ondemand = d01_possible && fast && fuse1 && lut_lds && env_int("HLMI_LL_ONDEMAND", 0);
     bool fuse1_out = false;
     auto enqueue = [&]() -> int {   // the launch chain of one frame (everything below depends only on what GraphKey holds)
     bool fuse_d2 = false;
@@ -1818,6 +2105,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             const Level &e = lv[2];
             D01Args a;
             a.in = din, a.in_sy = in_sy, a.co0 = gco[0], a.co1 = gco[1], a.co2 = gco[2], a.beta = beta, a.lut_g = lut;
+            a.skip1 = ondemand ? 1 : 0;
             a.g1 = d.g, a.so1 = d.lox, a.loy1 = d.loy, a.w1 = d.w, a.h1 = d.h, a.ws1 = d.ws, a.ps1 = d.ps;
             a.g2 = e.g, a.so2 = e.lox, a.loy2 = e.loy, a.w2 = e.w, a.h2 = e.h, a.ws2 = e.ws, a.ps2 = e.ps;
             const bool odd0 = d.odd, odd1 = e.odd;   // e.odd == (d.lox & 1)
@@ -1853,7 +2141,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             a.rows_base = e.h / a.nsy, a.rows_rem = e.h % a.nsy;
             dim3 grid2((a.nunits + WPB - 1) / WPB);
             const size_t sh2 = sizeof(float) * ((nlut + 1) & ~1) + sizeof(float2) * D01_STATE * (WPB + (exch ? WPB - 1 : 0));
-            timing_note_bytes(d0_bytes + 4.0 * (levels + 1) * e.w * e.h);
+            timing_note_bytes((ondemand ? 6.0 * iw * (gm.iy1 - gm.iy0 + 1) : d0_bytes) + 4.0 * (levels + 1) * e.w * e.h);
 #define LL_D01(O0, O1, B)                                                                                              \
     do {                                                                                                               \
         if (exch) HLMI_LAUNCH(uc, "ll_down01", st, (ll_down01f<O0, O1, B, true>), grid2, block, sh2, a, gm, lev);      \
@@ -1886,11 +2174,6 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
 #undef LL_D0
         if (r) return r;
     }
-    // levels >= S are produced / collapsed by the two multi-level kernels (S = 4: 2 launches instead of 7)
-    const int S = [&] {
-        int v = env_int("HLMI_LL_FUSE_FROM", 4);
-        return (v >= J - 4 && v <= J - 2) ? v : J;
-    }();
     CoarseArgs ca;
     if (S < J) {
         for (int dl = 0; S + dl < J; dl++) {
@@ -1932,11 +2215,6 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         if (d.odd) LL_DS(true); else LL_DS(false);
 #undef LL_DS
     }
-    // the collapse (outGPyramid[J-1] .. outGPyramid[SU]) is ONE launch (ll_up_multi); opt-in: on the large levels its per-pixel overhead exceeds the saved launches
-    const int SU = [&] {
-        int v = env_int("HLMI_LL_UPCHAIN_FROM", 0);
-        return (v >= 1 && v <= J - 2) ? v : S;
-    }();
     if (SU < J) {
         CoarseArgs cu;
         for (int dl = 0; SU + dl < J; dl++) {
@@ -1965,37 +2243,6 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         HLMI_LAUNCH(uc, "ll_top", st, ll_top, dim3((rw + 63) / 64, rh), dim3(64), 0, t.g, t.ws, t.ps, t.lox, t.loy, t.rx0,
                     t.ry0, rw, rh, levels, gm.Km1, t.out);
     }
-    // ---- level 0 arguments first: whether the level-1 collapse is fused into ll_up0f decides if ll_up:1 is launched
-    Up0Args p;
-    bool vec, fast, fuse1;
-    {
-        const Level &c = lv[1];
-        p.in = din, p.in_sy = in_sy;
-        const int oc0 = output->dim[2].min;
-        bool same = (nc == 3);
-        for (int ch = 0; ch < 3; ch++) {
-            p.gco[ch] = gco[ch];
-            p.cco[ch] = ch < nc ? (long)(oc0 + ch - ic0) * in_sc : 0;
-            if (p.cco[ch] != p.gco[ch]) same = false;
-        }
-        p.same_ch = same ? 1 : 0;
-        p.lut_g = lut, p.g1 = c.g, p.out1 = c.out;
-        p.lox1 = c.lox, p.loy1 = c.loy, p.ws1 = c.ws, p.ps1 = c.ps;
-        p.out = dout, p.out_sy = out_sy, p.out_sc = out_sc;
-        p.ox0 = output->dim[0].min, p.oy0 = output->dim[1].min, p.ow = ow, p.oh = oh, p.nc = nc;
-        p.beta = beta;
-        p.g2 = lv[2].g, p.out2 = lv[2].out, p.lox2 = lv[2].lox, p.loy2 = lv[2].loy, p.ws2 = lv[2].ws, p.ps2 = lv[2].ps;
-        p.rx1_1 = c.rx1;
-        vec = ((uintptr_t)din % 4 == 0) && ((uintptr_t)dout % 4 == 0) && in_sy % 2 == 0 && out_sy % 2 == 0 &&
-              out_sc % 2 == 0 && ((p.ox0 - gm.ix0) % 2 == 0) && !env_int("HLMI_LL_NO_VEC", 0);
-        for (int ch = 0; ch < 3; ch++) vec = vec && p.gco[ch] % 2 == 0 && p.cco[ch] % 2 == 0;
-        fast = vec && same && nc == 3 && (ow & 1) == 0 && (p.ox0 & 1) == 0 &&
-               (double)(levels + 1) * (4.0 * (double)c.ps) < 4.0e9 && !env_int("HLMI_LL_UP0_OLD", 0);
-        // the fused collapse needs level 2 to be a stored level of its own (SU >= 2 always holds: SU >= S >= 4 or the
-        // opt-in up-chain, which starts at >= 1 and then owns level 1 itself)
-        fuse1 = fast && SU >= 2 && env_int("HLMI_LL_FUSE_UP1", 1);
-        p.RU = max(1, env_int("HLMI_LL_RU", fuse1 ? 16 : 8));
-    }
     for (int j = min(SU, J - 1) - 1; j >= (fuse1 ? 2 : 1); j--) {
         const Level &a = lv[j], &c = lv[j + 1];
         int rw = a.rx1 - a.rx0 + 1, rh = a.ry1 - a.ry0 + 1;
@@ -2014,6 +2261,26 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         // fused: + inG_1 and, per level-2 pixel, 2 planes of g_2 + outG_2
         const double n1 = (double)(c.rx1 - c.rx0 + 1) * (c.ry1 - c.ry0 + 1), n2 = (double)(lv[2].rx1 - lv[2].rx0 + 1) * (lv[2].ry1 - lv[2].ry0 + 1);
         const double u0_bytes = 2.0 * (3 + nc) * ow * oh + 4.0 * 3.0 * n1 + (fuse1 ? 4.0 * 3.0 * n2 : 0.0);
+        if (ondemand) {
+            // input read (through a 134 x 22 window per 128 x 16 tile) + output written + level 2 (3 planes of it)
+            timing_note_bytes(2.0 * (3 + nc) * ow * oh + 4.0 * 3.0 * n2);
+            Levels lev;
+            for (int k = 0; k < MAX_K; k++) lev.v[k] = (float)k * gm.inv_Km1;
+            const size_t shg = sizeof(float) * (size_t)G_FLOATS(nlut);
+            dim3 gridg((ow + G_TW - 1) / G_TW, (oh + G_TH - 1) / G_TH);
+            t_dbg_up0 = p, t_dbg_gm = gm, t_dbg_ondemand = true, t_dbg_b1 = (beta == 1.0f);
+            if (beta == 1.0f) {
+                static const hipError_t attr = hipFuncSetAttribute((const void *)ll_up0g<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                (void)attr;
+                HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0g<true, false>), gridg, dim3(G_NT), shg, p, gm, lev, env_int("HLMI_LL_G_ABL", 0));
+            } else {
+                static const hipError_t attr = hipFuncSetAttribute((const void *)ll_up0g<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                (void)attr;
+                HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0g<false, false>), gridg, dim3(G_NT), shg, p, gm, lev, env_int("HLMI_LL_G_ABL", 0));
+            }
+            return 0;
+        }
+        t_dbg_ondemand = false;
         timing_note_bytes(u0_bytes);
         if (fast) {
             const bool b1 = (beta == 1.0f);
@@ -2225,7 +2492,24 @@ extern "C" int hlmi_debug_local_laplacian_outg(int level, float *dst, int cap_fl
     if (rh_out) *rh_out = rh;
     if (!dst) return 0;
     if ((long)rw * rh > cap_floats) return -1;
-    if (level == 1 && t_dbg_out1_pending) {
+    if (level == 1 && t_dbg_out1_pending && t_dbg_ondemand) {
+        // ll_up0g: neither outGPyramid[1] nor gPyramid[1] was stored; its debug variant recomputes both per tile, exactly as
+        // the product launch did, and stores outGPyramid[1]
+        Levels lev;
+        for (int k = 0; k < MAX_K; k++) lev.v[k] = (float)k * t_dbg_gm.inv_Km1;
+        const int nlut = 2 * t_dbg_gm.half + 1;
+        const size_t shg = sizeof(float) * (size_t)G_FLOATS(nlut);
+        dim3 gridg((t_dbg_up0.ow + G_TW - 1) / G_TW, (t_dbg_up0.oh + G_TH - 1) / G_TH);
+        if (t_dbg_b1) {
+            (void)hipFuncSetAttribute((const void *)ll_up0g<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            hipLaunchKernelGGL((ll_up0g<true, true>), gridg, dim3(G_NT), shg, t_dbg_stream, t_dbg_up0, t_dbg_gm, lev, 0);
+        } else {
+            (void)hipFuncSetAttribute((const void *)ll_up0g<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            hipLaunchKernelGGL((ll_up0g<false, true>), gridg, dim3(G_NT), shg, t_dbg_stream, t_dbg_up0, t_dbg_gm, lev, 0);
+        }
+        if (hipGetLastError() != hipSuccess) return -1;
+        t_dbg_out1_pending = false;
+    } else if (level == 1 && t_dbg_out1_pending) {
         // the fused ll_up0f kept outGPyramid[1] in LDS: produce the plane now with the stand-alone kernel (its inputs are
         // still in the arena) so that the tests can compare every level
         const Level &a = t_dbg_lv[1], &c = t_dbg_lv[2];

@@ -430,3 +430,23 @@ def test_hip_graph_replay_on_caller_streams(hl, oracle, monkeypatch):
     for s in streams:
         hip.hipStreamSynchronize(s)
         hip.hipStreamDestroy(s)
+
+
+# ---- ll_up0g (HLMI_LL_ONDEMAND=1): level 1 never stored, the up pass recomputes the planes each tile needs from the input
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,origin,kind,beta", [(512, 208, (0, 0), "smooth", 1.0), (1024, 130, (2, 5), "uniform", 1.0),
+                                                   (260, 97, (0, -7), "smooth", 0.5), (3840, 2160, (0, 0), "smooth", 1.0)])
+def test_hip_ondemand_level1_matches_oracle(hl, oracle, monkeypatch, w, h, origin, kind, beta):
+    """The opt-in path must stay bit-exact: final result and (small cases) every outGPyramid level, including level 1 through
+    the kernel's debug variant."""
+    monkeypatch.setenv("HLMI_LL_ONDEMAND", "1")
+    inp = _rand_image(w, h, seed=w + h + 11, kind=kind)
+    a = hl.Buffer(inp).set_min(origin[0], origin[1], 0)
+    o = hl.Buffer(np.zeros_like(inp)).set_min(origin[0], origin[1], 0)
+    hl.local_laplacian(a, 8, 1.0 / 7, beta, o)
+    if w * h < 1 << 20:
+        for level in range(4, 0, -1):
+            got = hl.debug_local_laplacian_outg(level)
+            want = oracle.local_laplacian_outg(inp, 8, 1.0 / 7, beta, level, origin=origin)
+            assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"level {level}"
+    assert np.array_equal(o.numpy(), oracle.local_laplacian(inp, 8, 1.0 / 7, beta, origin=origin))
