@@ -640,6 +640,7 @@ struct D01Args {
     int so2, loy2, w2, h2, ws2;
     size_t ps2;
     int Pbase, S2, nsx, nsy, nunits;
+    int mask1;                 // store only the level-1 planes somebody reads (see the step's store batch)
     int skip1;                 // level 1 is not stored at all: its only reader (ll_up0g) recomputes what it needs from the input
     unsigned nsy_magic;        // floor(2^32 / nsy) + 1: x / nsy == umulhi(x, magic) for x * nsy < 2^32; 0 when nsy == 1
     int rows_base, rows_rem;   // h2 / nsy, h2 % nsy
@@ -802,6 +803,22 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry 
         for (int i = 0; i < 4; i++) o[i] = t[i] + d[i];
     };
 
+    // Which level-1 planes does anybody read?  The up pass reads plane k of gPyramid[1] at coarse pixel (c, r) only for k in
+    // {li, li + 1} of a level-0 pixel in [2c - 1, 2c + 1] x [2r - 1, 2r + 1] (the bilinear footprint, :276-282, with li that
+    // pixel's level, :66) or of the coarse pixel itself (outLPyramid[1], :63-72).  A wave holds exactly those pixels when it
+    // finishes level-1 row T (level-0 rows 2T - 1 .. 2T + 2 of all its lanes; the stored pairs of lanes < S2 are read from
+    // columns its own lanes hold), so it stores a plane only if some lane's set asks for it — wave-uniform, whole 512-byte row
+    // pieces: two to four of the eight planes on natural images (-45 of 75 MB written per 4K frame; the frame rate on
+    // partitioned streams is set by bytes, profiles/r03b_traffic_ablation.txt), all eight on noise.  l = 4 x table position of
+    // plane KCH - 1 (lbase = 0 for K = 8... in general idx = l / 4 - lbase), position >> 8 = the pixel's level index.
+    const int lb4 = lbase * 4;
+    auto row_bits = [&](const Row &r) {
+        unsigned bts = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; i++) bts |= 3u << min((unsigned)(r.l[i] - lb4) >> 10, (unsigned)(KCH - 2));
+        return bts;
+    };
+    unsigned pbits = 0u;       // sets of the two level-0 rows the previous step brought in
     float a[KCH + 1][4], b[KCH + 1][4], a2[KCH + 1][4], b2[KCH + 1][4];
     Raw rc, rd;
     {
@@ -821,6 +838,7 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry 
         Row r0, r1;
         prep_row(ra, r0);
         prep_row(rb, r1);
+        pbits = row_bits(r0) | row_bits(r1);
         float lv[2][8];
         lut_issue(0, r0, r1, lv[0]);
 #pragma unroll
@@ -889,11 +907,24 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry 
         prep_row(rc, n0);
         prep_row(rd, n1);
         __builtin_amdgcn_sched_barrier(0);
+        unsigned M = (1u << KCH) - 1u;                       // planes to store (wave-uniform)
+        if (p.mask1) {
+            const unsigned cb = row_bits(c0) | row_bits(c1);
+            unsigned bts = pbits | cb;
+            pbits = cb;
+            bts |= 3u << dev::clampi((int)(res[KCH].x * gm.Km1), 0, KCH - 2);
+            bts |= 3u << dev::clampi((int)(res[KCH].y * gm.Km1), 0, KCH - 2);
+            M = 0u;
+#pragma unroll
+            for (int kk = 0; kk < KCH; kk++) M |= __ballot((bts >> kk) & 1u) ? (1u << kk) : 0u;
+        }
         if (T >= Ts0 && T <= Ts1 && !p.skip1 && !(HLMI_D01_ABL & 2 && p.nunits > 0)) {
             float *drow = p.g1 + (size_t)(T - p.loy1) * p.ws1 + off1;
             if (st1_ok) {
 #pragma unroll
-                for (int kk = 0; kk <= KCH; kk++) *reinterpret_cast<float2 *>(drow + (size_t)kk * p.ps1) = res[kk];
+                for (int kk = 0; kk <= KCH; kk++) {
+                    if (kk == KCH || ((M >> kk) & 1u)) *reinterpret_cast<float2 *>(drow + (size_t)kk * p.ps1) = res[kk];
+                }
             }
         }
         if (EXCH && pub) {
@@ -2106,6 +2137,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             D01Args a;
             a.in = din, a.in_sy = in_sy, a.co0 = gco[0], a.co1 = gco[1], a.co2 = gco[2], a.beta = beta, a.lut_g = lut;
             a.skip1 = ondemand ? 1 : 0;
+            a.mask1 = env_int("HLMI_LL_PLANE_MASK", 1) ? 1 : 0;
             a.g1 = d.g, a.so1 = d.lox, a.loy1 = d.loy, a.w1 = d.w, a.h1 = d.h, a.ws1 = d.ws, a.ps1 = d.ps;
             a.g2 = e.g, a.so2 = e.lox, a.loy2 = e.loy, a.w2 = e.w, a.h2 = e.h, a.ws2 = e.ws, a.ps2 = e.ps;
             const bool odd0 = d.odd, odd1 = e.odd;   // e.odd == (d.lox & 1)
