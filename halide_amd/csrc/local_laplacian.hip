@@ -804,10 +804,11 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry 
     };
 
     // Which level-1 planes does anybody read?  The up pass reads plane k of gPyramid[1] at coarse pixel (c, r) only for k in
-    // {li, li + 1} of a level-0 pixel in [2c - 1, 2c + 1] x [2r - 1, 2r + 1] (the bilinear footprint, :276-282, with li that
-    // pixel's level, :66) or of the coarse pixel itself (outLPyramid[1], :63-72).  A wave holds exactly those pixels when it
-    // finishes level-1 row T (level-0 rows 2T - 1 .. 2T + 2 of all its lanes; the stored pairs of lanes < S2 are read from
-    // columns its own lanes hold), so it stores a plane only if some lane's set asks for it — wave-uniform, whole 512-byte row
+    // {li, li + 1} of a level-0 pixel in [2c - 1, 2c + 2] x [2r - 1, 2r + 2] (the bilinear footprint, :276-282: pixel X reads
+    // coarse columns (X + 1) / 2 and (X - 1) / 2; li = that pixel's level, :66) or of the coarse pixel itself (outLPyramid[1],
+    // :63-72).  A wave holds exactly those pixels when it finishes level-1 row T (level-0 rows 2T - 1 .. 2T + 2 of all its
+    // lanes — all four rows count: dropping row 2T + 2 from the set fails the parity suite —; the stored pairs of lanes < S2
+    // are read from columns its own lanes hold), so it stores a plane only if some lane's set asks for it — wave-uniform, whole 512-byte row
     // pieces: two to four of the eight planes on natural images (-45 of 75 MB written per 4K frame; the frame rate on
     // partitioned streams is set by bytes, profiles/r03b_traffic_ablation.txt), all eight on noise.  l = 4 x table position of
     // plane KCH - 1 (lbase = 0 for K = 8... in general idx = l / 4 - lbase), position >> 8 = the pixel's level index.
@@ -909,8 +910,8 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry 
         __builtin_amdgcn_sched_barrier(0);
         unsigned M = (1u << KCH) - 1u;                       // planes to store (wave-uniform)
         if (p.mask1) {
-            const unsigned cb = row_bits(c0) | row_bits(c1);
-            unsigned bts = pbits | cb;
+            const unsigned cb = row_bits(c0) | row_bits(c1);   // level-0 rows 2T + 1, 2T + 2
+            unsigned bts = pbits | cb;                         // ... and 2T - 1, 2T
             pbits = cb;
             bts |= 3u << dev::clampi((int)(res[KCH].x * gm.Km1), 0, KCH - 2);
             bts |= 3u << dev::clampi((int)(res[KCH].y * gm.Km1), 0, KCH - 2);
@@ -2087,7 +2088,11 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         // the fused collapse needs level 2 to be a stored level of its own (SU >= 2 always holds: SU >= S >= 4 or the
         // opt-in up-chain, which starts at >= 1 and then owns level 1 itself)
         fuse1 = fast && SU >= 2 && env_int("HLMI_LL_FUSE_UP1", 1);
-        p.RU = max(1, env_int("HLMI_LL_RU", fuse1 ? 16 : 8));
+        // rows per wave: taller tiles re-read less of level 1 (18 coarse rows per 16 output rows, 34 per 32) but keep a wave
+        // busy longer.  On a CU-partitioned stream, where several frames share the memory system and the frame rate is set by
+        // bytes, 32 rows measure 2.7 % faster (84.8 vs 82.6 Gpx/s); on a stream that owns the device 16 rows do (72.7 vs 68.2).
+        const bool partitioned = stream_cu_count(ctx.device, ctx.stream) < stream_cu_count(ctx.device, nullptr);
+        p.RU = max(1, env_int("HLMI_LL_RU", fuse1 ? (partitioned ? 32 : 16) : 8));
     }
     // ll_up0g: level 1 is never stored — the up pass recomputes the planes each tile needs from the input (needs the fused
     // down kernel, which can simply not store level 1, and everything ll_up0f<.., .., true> needs)
