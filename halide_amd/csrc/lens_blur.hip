@@ -54,17 +54,62 @@ __device__ __forceinline__ size_t at(const Box &b, int slices, int z, int c, int
     return ((size_t)(c ? slices : z) * b.h + (y - b.y0)) * b.w + (x - b.x0);
 }
 
+constexpr int LB_MAXS = 64;   // generator :14: slices <= 64
+
+// The cost stack of one pixel (:30-55).  cost(x, y, z) = sum over the channels of min(|l - r(x + 2z)|, |l - r(x + 2z + 1)|)^2
+// in float — every intermediate is an integer below 2^24, so the float operations of the generator are exact and the same
+// value comes out of integer arithmetic: packed 16-bit differences for channels 0 and 1, a dot product for the squares.  The
+// right-image pixels of a row segment sit in LDS as one 8-byte record {c0 | c1 << 16, c2} each.  cost / slices is a
+// correctly rounded division in the generator: for an integer numerator below 2^18 and a divisor 1..64 the two-FMA
+// correction of q0 = a * RN(1 / n) IS the correctly rounded quotient (checked exhaustively: tests/test_lens_blur.py,
+// tests/cpp/lb_div_check.c), which takes 3 instructions instead of the 11 of a general division.
+typedef short lb_s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short lb_u16x2 __attribute__((ext_vector_type(2)));
+struct CostRow {
+    uint32_t l01;   // c0 | c1 << 16 of the left pixel
+    int l2;
+};
+__device__ __forceinline__ uint2 lb_pack(int c0, int c1, int c2) { return make_uint2((uint32_t)c0 | (uint32_t)c1 << 16, (uint32_t)c2); }
+__device__ __forceinline__ float lb_cost1(const uint2 A, const uint2 B, const CostRow &c) {
+    const lb_s16x2 l = __builtin_bit_cast(lb_s16x2, c.l01), a = __builtin_bit_cast(lb_s16x2, A.x), b = __builtin_bit_cast(lb_s16x2, B.x);
+    const lb_s16x2 da = l - a, db = l - b, z2 = {0, 0};
+    const lb_u16x2 ma = __builtin_bit_cast(lb_u16x2, __builtin_elementwise_max(da, z2 - da)),
+                   mb = __builtin_bit_cast(lb_u16x2, __builtin_elementwise_max(db, z2 - db));
+    const lb_u16x2 m01 = __builtin_elementwise_min(ma, mb);
+    const int ea = c.l2 - (int)A.y, eb = c.l2 - (int)B.y;
+    const int m2 = min(max(ea, -ea), max(eb, -eb));
+    const uint32_t s = __builtin_amdgcn_udot2(m01, m01, (uint32_t)__mul24(m2, m2), false);
+    return (float)s;
+}
+// FULL: slices == SB (the default 32, and 64): no guards at all.  Otherwise the whole stack of SB costs is computed without
+// branches (the LDS reads stay inside the staged array; what lies beyond the row segment is never used) and the slices that
+// do not exist add 0.0f to the two sums, which leaves a non-negative sum as it is.
+template<int SB, bool FULL>
+__device__ __forceinline__ float cost_stack(const uint2 *__restrict__ sr, int tid, const CostRow &c, const LBGeom &g, float (&cz)[SB]) {
+    float sa = 0.0f, sb = 0.0f;
+    const float rn = 1.0f / g.fslices;
+#pragma unroll
+    for (int z = 0; z < SB; z++) {
+        cz[z] = lb_cost1(sr[tid + 2 * z], sr[tid + 2 * z + 1], c);
+        const bool on = FULL || z < g.slices;
+        const float sq = cz[z] * cz[z];
+        sa = sa + (on ? sq : 0.0f);
+        const float q0 = cz[z] * rn;                                   // cz / fslices, see above
+        const float q = __builtin_fmaf(__builtin_fmaf(-g.fslices, q0, cz[z]), rn, q0);
+        sb = sb + (on ? q : 0.0f);
+    }
+    return sa / g.fslices - sb * sb;   // the confidence
+}
+
 // One workgroup = 256 consecutive pixels of a row of E.  Every pixel compares itself with the 2 * slices right-image pixels
 // to its right (:33-36), so neighbours share almost all of them: the row segment [x0, x0 + 256 + 2 slices) of the (clamped)
-// right image is staged in LDS once and the left pixel sits in registers — instead of 9 clamped byte loads per (pixel, slice),
-// twice (the costs are needed again after their variance is known).
-constexpr int LB_MAXS = 64;   // generator :14: slices <= 64
+// right image is staged in LDS once and the left pixel sits in registers.
 // SB: compile-time bound of `slices` (32 or 64): the costs of a pixel stay in registers between the pass that finds their
 // variance and the pass that writes them scaled by it
-template<int SB>
+template<int SB, bool FULL>
 __global__ __launch_bounds__(256) void lb_cost(const uint8_t *__restrict__ L, const uint8_t *__restrict__ Rr, LBGeom g, Box E,
                                               float *__restrict__ push0) {
-    __shared__ uint8_t sr[3][256 + 2 * LB_MAXS];
+    __shared__ uint2 sr[256 + 2 * LB_MAXS];
     const int tid = threadIdx.x, xi = blockIdx.x * 256 + tid, yi = blockIdx.y;
     const int x = E.x0 + xi, y = E.y0 + yi;
     {
@@ -72,34 +117,18 @@ __global__ __launch_bounds__(256) void lb_cost(const uint8_t *__restrict__ L, co
         const int xb = E.x0 + blockIdx.x * 256;
         for (int i = tid; i < 256 + 2 * g.slices; i += 256) {
             const long o = ro + (dev::clampi(xb + i, g.rx0, g.rx1) - g.rx0);
-#pragma unroll
-            for (int c = 0; c < 3; c++) sr[c][i] = Rr[o + g.r_c[c]];
+            sr[i] = lb_pack(Rr[o + g.r_c[0]], Rr[o + g.r_c[1]], Rr[o + g.r_c[2]]);
         }
     }
     __syncthreads();
     if (xi >= E.w) return;
     const long lo = (long)(dev::clampi(y, g.ly0, g.ly1) - g.ly0) * g.l_sy + (dev::clampi(x, g.lx0, g.lx1) - g.lx0);
-    const int l0 = L[lo + g.l_c[0]], l1 = L[lo + g.l_c[1]], l2 = L[lo + g.l_c[2]];
-    auto cost = [&](int z) -> float {                     // cost(x, y, z) (:30-39): integer-valued float
-        const int i = tid + 2 * z;
-        const int a0 = sr[0][i], b0 = sr[0][i + 1], a1 = sr[1][i], b1 = sr[1][i + 1], a2 = sr[2][i], b2 = sr[2][i + 1];
-        const float d0 = (float)min(abs(l0 - a0), abs(l0 - b0)), d1 = (float)min(abs(l1 - a1), abs(l1 - b1)),
-                    d2 = (float)min(abs(l2 - a2), abs(l2 - b2));
-        return d0 * d0 + d1 * d1 + d2 * d2;
-    };
-    float sa = 0.0f, sb = 0.0f, cz[SB];
-#pragma unroll
-    for (int z = 0; z < SB; z++) {
-        if (z < g.slices) {
-            cz[z] = cost(z);
-            sa = sa + cz[z] * cz[z];
-            sb = sb + cz[z] / g.fslices;
-        }
-    }
-    const float conf = sa / g.fslices - sb * sb;
+    const CostRow c = {(uint32_t)L[lo + g.l_c[0]] | (uint32_t)L[lo + g.l_c[1]] << 16, (int)L[lo + g.l_c[2]]};
+    float cz[SB];
+    const float conf = cost_stack<SB, FULL>(sr, tid, c, g, cz);
 #pragma unroll
     for (int z = 0; z < SB; z++)
-        if (z < g.slices) push0[at(E, g.slices, z, 0, x, y)] = cz[z] * conf;
+        if (FULL || z < g.slices) push0[at(E, g.slices, z, 0, x, y)] = cz[z] * conf;
     push0[at(E, g.slices, 0, 1, x, y)] = conf;
 }
 
@@ -227,6 +256,162 @@ __global__ __launch_bounds__(256) void lb_depth(const float *__restrict__ push0,
     const size_t o = (size_t)yi * D.w + xi;
     const long lo = (long)(dev::clampi(y, g.ly0, g.ly1) - g.ly0) * g.l_sy + (dev::clampi(x, g.lx0, g.lx1) - g.lx0);
     rec[o] = (uint32_t)best_i | (uint32_t)L[lo + g.l_c[0]] << 8 | (uint32_t)L[lo + g.l_c[1]] << 16 | (uint32_t)L[lo + g.l_c[2]] << 24;
+    br[o] = bokeh_radius(best_i, g);
+}
+
+// ---- the fused front end: push[0] (one float per pixel of E per plane: 130 MB at 768 x 1280 x 33, written once and read
+// twice) is never stored.  lb_cost_down makes push[1] directly — a workgroup owns a strip of push[1] columns and a segment of
+// its rows and walks the source rows: every thread computes the cost stack of one source pixel (the right-image row segment
+// and the next row's bytes are staged / prefetched as in lb_cost), the row of all planes goes through LDS, the 1-3-3-1 pass
+// in x is taken there and the pass in y on rolling registers — the generator's expressions (:279-285) operand for operand.
+// lb_depth_rc recomputes the cost stack of its own pixel (the same device function, so the same bits) instead of reading it.
+constexpr int CD_RP = 260;   // floats per plane row in LDS (256 source pixels + pad)
+template<int SB, bool FULL>
+__global__ __launch_bounds__(256) void lb_cost_down(const uint8_t *__restrict__ L, const uint8_t *__restrict__ Rr, LBGeom g,
+                                                   float *__restrict__ dst, Box db, int NDX, int NDY) {
+    extern __shared__ __align__(16) float s_row[];   // [slices + 1][CD_RP]
+    __shared__ uint2 sr[2][256 + 2 * LB_MAXS];
+    constexpr int KPT = ((SB + 1) * 127 + 255) / 256;
+    const int tid = threadIdx.x, zc = g.slices + 1;
+    const int dx0 = db.x0 + blockIdx.x * NDX, dy0 = db.y0 + blockIdx.y * NDY;
+    const int ndx = min(NDX, db.x0 + db.w - dx0), ndy = min(NDY, db.y0 + db.h - dy0);
+    const int sx0 = 2 * dx0 - 1, sy0 = 2 * dy0 - 1, nsx = 2 * ndx + 2, nrows = 2 * ndy + 2, nr = nsx + 2 * g.slices;
+    const int total = zc * ndx;
+    // the (plane, column) pairs of this thread in the x pass: LDS offset of the first tap, offset in a destination row
+    int qoff[KPT], doff[KPT];
+    float p0[KPT], p1[KPT], p2[KPT];
+#pragma unroll
+    for (int k = 0; k < KPT; k++) {
+        const int idx = tid + 256 * k, p = idx < total ? idx / ndx : 0, xl = idx - p * ndx;
+        qoff[k] = p * CD_RP + 2 * xl;
+        doff[k] = idx < total ? (int)((size_t)p * db.h * db.w) + (dx0 - db.x0) + xl : -1;
+        p0[k] = p1[k] = p2[k] = 0.0f;
+    }
+    const int lxo = dev::clampi(sx0 + tid, g.lx0, g.lx1) - g.lx0;
+    const int rxo0 = dev::clampi(sx0 + tid, g.rx0, g.rx1) - g.rx0, rxo1 = dev::clampi(sx0 + tid + 256, g.rx0, g.rx1) - g.rx0;
+    uint8_t nl[3], nr0[3], nr1[3];
+    auto fetch = [&](int j) {   // the bytes of source row j of the segment: all loads unconditional, indices clamped
+        const int y = sy0 + j;
+        const long lo = (long)(dev::clampi(y, g.ly0, g.ly1) - g.ly0) * g.l_sy, ro = (long)(dev::clampi(y, g.ry0, g.ry1) - g.ry0) * g.r_sy;
+#pragma unroll
+        for (int c = 0; c < 3; c++) nl[c] = L[lo + lxo + g.l_c[c]], nr0[c] = Rr[ro + rxo0 + g.r_c[c]], nr1[c] = Rr[ro + rxo1 + g.r_c[c]];
+    };
+    auto stage = [&](int b) {
+        sr[b][tid] = lb_pack(nr0[0], nr0[1], nr0[2]);
+        if (tid + 256 < nr) sr[b][tid + 256] = lb_pack(nr1[0], nr1[1], nr1[2]);
+    };
+    fetch(0);
+    stage(0);
+    CostRow cur = {(uint32_t)nl[0] | (uint32_t)nl[1] << 16, (int)nl[2]};
+    __syncthreads();
+    for (int j = 0; j < nrows; j++) {
+        if (j + 1 < nrows) fetch(j + 1);
+        if (tid < nsx) {
+            float cz[SB];
+            const float conf = cost_stack<SB, FULL>(sr[j & 1], tid, cur, g, cz);
+#pragma unroll
+            for (int z = 0; z < SB; z++)
+                if (FULL || z < g.slices) s_row[z * CD_RP + tid] = cz[z] * conf;
+            s_row[g.slices * CD_RP + tid] = conf;
+        }
+        __syncthreads();
+        // y pass on three registers per slot, no rotation: on an even row (tap 0 of an output row, tap 2 of the one before)
+        // t = a + 3 (b + d), a = d; on an odd row (tap 3 / tap 1) the output (t + d) / 8 is complete, b = d
+        if (j & 1) {
+            const bool emit = j >= 3;
+            float *drow = dst + (size_t)(dy0 - db.y0 + ((j - 3) >> 1)) * db.w;
+#pragma unroll
+            for (int k = 0; k < KPT; k++) {   // slots past the end read LDS offset 0 and store nothing
+                const float2 qa = *(const float2 *)&s_row[qoff[k]], qb = *(const float2 *)&s_row[qoff[k] + 2];
+                const float d = (qa.x + 3.0f * (qa.y + qb.x) + qb.y) * 0.125f;
+                if (emit && doff[k] >= 0) drow[doff[k]] = (p2[k] + d) * 0.125f;
+                p1[k] = d;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < KPT; k++) {
+                const float2 qa = *(const float2 *)&s_row[qoff[k]], qb = *(const float2 *)&s_row[qoff[k] + 2];
+                const float d = (qa.x + 3.0f * (qa.y + qb.x) + qb.y) * 0.125f;
+                p2[k] = p0[k] + 3.0f * (p1[k] + d);
+                p0[k] = d;
+            }
+        }
+        if (j + 1 < nrows) {
+            stage((j + 1) & 1);
+            cur = {(uint32_t)nl[0] | (uint32_t)nl[1] << 16, (int)nl[2]};
+        }
+        __syncthreads();
+    }
+}
+
+template<int SB, bool FULL>
+__global__ __launch_bounds__(256) void lb_depth_rc(const uint8_t *__restrict__ L, const uint8_t *__restrict__ Rr, const float *__restrict__ pull1, Box P1,
+                                                  LBGeom g, Box D, uint32_t *__restrict__ rec, float *__restrict__ br) {
+    __shared__ uint2 sr[256 + 2 * LB_MAXS];
+    const int tid = threadIdx.x, xi = blockIdx.x * 256 + tid, yi = blockIdx.y;
+    const int x = D.x0 + xi, y = D.y0 + yi;
+    {
+        const long ro = (long)(dev::clampi(y, g.ry0, g.ry1) - g.ry0) * g.r_sy;
+        const int xb = D.x0 + blockIdx.x * 256;
+        for (int i = tid; i < 256 + 2 * g.slices; i += 256) {
+            const long o = ro + (dev::clampi(xb + i, g.rx0, g.rx1) - g.rx0);
+            sr[i] = lb_pack(Rr[o + g.r_c[0]], Rr[o + g.r_c[1]], Rr[o + g.r_c[2]]);
+        }
+    }
+    __syncthreads();
+    if (xi >= D.w) return;
+    const long lo = (long)(dev::clampi(y, g.ly0, g.ly1) - g.ly0) * g.l_sy + (dev::clampi(x, g.lx0, g.lx1) - g.lx0);
+    const int c0 = L[lo + g.l_c[0]], c1 = L[lo + g.l_c[1]], c2 = L[lo + g.l_c[2]];
+    const CostRow c = {(uint32_t)c0 | (uint32_t)c1 << 16, c2};
+    float cz[SB];
+    const float conf = cost_stack<SB, FULL>(sr, tid, c, g, cz);
+    int best_i = 0;
+    float best = 3.402823466e38f;
+    // upsample(pull[1]) (:288-294): the four taps are the same elements of every plane — 32-bit element offsets per lane, the
+    // plane base stays uniform
+    const int xa = (x >> 1) - 1 + 2 * (x & 1), xb = x >> 1, ya = (y >> 1) - 1 + 2 * (y & 1), yb = y >> 1;
+    // (BYTE offsets: a zero-extended 32-bit lane offset on a uniform base is one load instruction, no address arithmetic)
+    const uint32_t oaa = 4u * (uint32_t)((ya - P1.y0) * P1.w + (xa - P1.x0)), oab = 4u * (uint32_t)((ya - P1.y0) * P1.w + (xb - P1.x0)),
+                   oba = 4u * (uint32_t)((yb - P1.y0) * P1.w + (xa - P1.x0)), obb = 4u * (uint32_t)((yb - P1.y0) * P1.w + (xb - P1.x0));
+    const size_t plane = (size_t)P1.h * P1.w;
+    struct Taps {
+        float aa, ab, ba, bb;
+    };
+    auto taps = [&](int zc) -> Taps {
+        const char *__restrict__ pz = (const char *)(pull1 + (size_t)zc * plane);
+        return {*(const float *)(pz + oaa), *(const float *)(pz + oab), *(const float *)(pz + oba), *(const float *)(pz + obb)};
+    };
+    auto up = [&](const Taps &t) -> float {
+        const float ua = 0.25f * t.aa + 0.75f * t.ab;
+        const float ub = 0.25f * t.ba + 0.75f * t.bb;
+        return 0.25f * ua + 0.75f * ub;
+    };
+    const float v1 = dev::lerpf(up(taps(g.slices)), conf, 0.5f);   // the same for every z
+    constexpr int ZB = 8;   // the taps of ZB slices are in flight while the ZB before them are divided and compared
+    Taps nx[ZB];
+#pragma unroll
+    for (int i = 0; i < ZB; i++) nx[i] = taps(FULL ? i : min(i, g.slices - 1));
+#pragma unroll
+    for (int zb = 0; zb < SB; zb += ZB) {
+        Taps cur[ZB];
+#pragma unroll
+        for (int i = 0; i < ZB; i++) cur[i] = nx[i];
+        if (zb + ZB < SB) {
+#pragma unroll
+            for (int i = 0; i < ZB; i++) nx[i] = taps(FULL ? zb + ZB + i : min(zb + ZB + i, g.slices - 1));
+        }
+#pragma unroll
+        for (int i = 0; i < ZB; i++) {
+            const int z = zb + i;
+            if (FULL || z < g.slices) {
+                const float v0 = dev::lerpf(up(cur[i]), cz[z] * conf, 0.5f);
+                const float fc = v0 / v1;
+                if (fc < best) best = fc, best_i = z;
+            }
+        }
+    }
+    const size_t o = (size_t)yi * D.w + xi;
+    rec[o] = (uint32_t)best_i | (uint32_t)c0 << 8 | (uint32_t)c1 << 16 | (uint32_t)c2 << 24;
     br[o] = bokeh_radius(best_i, g);
 }
 
@@ -399,7 +584,13 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
     // ---- workspace
     auto al = [](size_t n) { return (n + 63) & ~(size_t)63; };
     size_t off_push[LV], off_pull[LV], total = 0;
-    for (int i = 0; i < LV; i++) off_push[i] = total, total += al((size_t)(slices + 1) * PB[i].w * PB[i].h);
+    // fused front end (lb_cost_down, lb_depth_rc): push[0] is never stored.  HLMI_LB_UNFUSED=1: one stage per launch (A/B)
+    bool fused = (size_t)(slices + 1) * PB[1].w * PB[1].h < ((size_t)1 << 31);
+    {
+        const char *e = getenv("HLMI_LB_UNFUSED");
+        if (e && *e && atoi(e) != 0) fused = false;
+    }
+    for (int i = 0; i < LV; i++) off_push[i] = total, total += (i == 0 && fused) ? 0 : al((size_t)(slices + 1) * PB[i].w * PB[i].h);
     for (int i = 1; i < LV; i++) off_pull[i] = total, total += al((size_t)(slices + 1) * P[i].w * P[i].h);
     const size_t off_depth = total;
     total += al((size_t)D.w * D.h);
@@ -420,8 +611,39 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
     const uint8_t *dl = dev_ptr<uint8_t>(left_im), *dr = dev_ptr<uint8_t>(right_im);
     hipStream_t st = ctx.stream;
     const unsigned zc = (unsigned)slices + 1u;   // planes: cost x confidence per slice + the confidence
-    if (slices <= 32) HLMI_LAUNCH(uc, "lb_cost", st, lb_cost<32>, dim3((E.w + 255) / 256, E.h), dim3(256), 0, dl, dr, g, E, push[0]);
-    else HLMI_LAUNCH(uc, "lb_cost", st, lb_cost<64>, dim3((E.w + 255) / 256, E.h), dim3(256), 0, dl, dr, g, E, push[0]);
+    const bool s64 = slices > 32, full = slices == 32 || slices == 64;
+#define LB_DISPATCH(K, ...)                                                             \
+    do {                                                                                \
+        if (!s64 && full) HLMI_LAUNCH(uc, #K, st, (K<32, true>), __VA_ARGS__);          \
+        else if (!s64) HLMI_LAUNCH(uc, #K, st, (K<32, false>), __VA_ARGS__);            \
+        else if (full) HLMI_LAUNCH(uc, #K, st, (K<64, true>), __VA_ARGS__);             \
+        else HLMI_LAUNCH(uc, #K, st, (K<64, false>), __VA_ARGS__);                      \
+    } while (0)
+    if (fused) {
+        const int strips = (PB[1].w + 126) / 127, ndx = (PB[1].w + strips - 1) / strips;
+        // rows of push[1] per workgroup: a workgroup walks 2 ndy + 2 source rows (the 2 are halo), and the chip holds
+        // `cap` workgroups at once (registers: two per CU at 32 slices, one at 64) — the fewest row-steps over all rounds
+        int ndy = 8;
+        {
+            const long cap = (long)stream_cu_count(ctx.device, ctx.stream) * (s64 ? 1 : 2);
+            long best_steps = -1;
+            for (int c = 2; c <= 32; c++) {
+                const long wgs = (long)strips * ((PB[1].h + c - 1) / c), steps = ((wgs + cap - 1) / cap) * (2 * c + 2);
+                if (best_steps < 0 || steps < best_steps) best_steps = steps, ndy = c;
+            }
+            const char *e = getenv("HLMI_LB_NDY");
+            if (e && *e) ndy = max(1, min(1024, atoi(e)));
+        }
+        const size_t lds = (size_t)zc * CD_RP * sizeof(float);
+        const dim3 grid(strips, (PB[1].h + ndy - 1) / ndy);
+        if (s64) {
+            HLMI_HIP(uc, hipFuncSetAttribute((const void *)lb_cost_down<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HLMI_HIP(uc, hipFuncSetAttribute((const void *)lb_cost_down<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        LB_DISPATCH(lb_cost_down, grid, dim3(256), lds, dl, dr, g, push[1], PB[1], ndx, ndy);
+    } else {
+        LB_DISPATCH(lb_cost, dim3((E.w + 255) / 256, E.h), dim3(256), 0, dl, dr, g, E, push[0]);
+    }
     // levels below `tail` (at most 128 x 128 elements per plane) go down and up in ONE launch, a workgroup per plane
     int tail = LV;
     for (int i = LV - 1; i >= 2; i--) {
@@ -432,7 +654,7 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
         const char *e = getenv("HLMI_LB_TAIL_FROM");   // A/B: 8 = no tail launch
         if (e && *e) tail = max(2, min(LV, atoi(e)));
     }
-    for (int i = 1; i < tail; i++) {
+    for (int i = fused ? 2 : 1; i < tail; i++) {
         char nm[24];
         snprintf(nm, sizeof nm, "lb_down:%d", i);
         if (i == 1) HLMI_LAUNCH(uc, nm, st, lb_down<false>, dim3((PB[i].w + DTW - 1) / DTW, (PB[i].h + DTH - 1) / DTH, zc), dim3(256), 0, push[0], PB[0], push[i], PB[i]);
@@ -452,7 +674,9 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
         if (i == LV - 1) HLMI_LAUNCH(uc, nm, st, lb_pull<true>, dim3((P[i].w + 255) / 256, P[i].h, zc), dim3(256), 0, push[i], PB[i], (const float *)nullptr, P[i], pull[i], P[i]);
         else HLMI_LAUNCH(uc, nm, st, lb_pull<false>, dim3((P[i].w + 255) / 256, P[i].h, zc), dim3(256), 0, push[i], PB[i], pull[i + 1], P[i + 1], pull[i], P[i]);
     }
-    HLMI_LAUNCH(uc, "lb_depth", st, lb_depth, dim3((D.w + 255) / 256, D.h), dim3(256), 0, push[0], E, pull[1], P[1], dl, g, D, depth, br);
+    if (!fused) HLMI_LAUNCH(uc, "lb_depth", st, lb_depth, dim3((D.w + 255) / 256, D.h), dim3(256), 0, push[0], E, pull[1], P[1], dl, g, D, depth, br);
+    else LB_DISPATCH(lb_depth_rc, dim3((D.w + 255) / 256, D.h), dim3(256), 0, dl, dr, pull[1], P[1], g, D, depth, br);
+#undef LB_DISPATCH
     HLMI_LAUNCH(uc, "lb_wcy", st, lb_wcy, dim3((D.w + 255) / 256, oh), dim3(256), 0, br, D, g.R, oy0, oh, wcy);
     HLMI_LAUNCH(uc, "lb_final", st, lb_final, dim3((ow + 255) / 256, oh), dim3(256), 0, g, depth, wcy, D, ox0, oy0, ow, nc,
                 dev_ptr<float>(final_), (long)final_->dim[1].stride, (long)final_->dim[2].stride);
