@@ -270,13 +270,16 @@ def run(only=(), samples=5, sink=None, cpu=False):
         o = hl.Buffer(np.zeros((3, H, W), np.float32))
         call = lambda: hl.lens_blur(a, b, 32, 13, 0.5, 32, o)
         t = timed(call, o, 5)
-        # traffic of the straightforward decomposition: the 33-plane level 0 of the push pyramid (32 cost planes + the one
-        # confidence plane the generator's 32 copies collapse to) written once and read twice (down, depth), 4/3 of that
-        # again for the coarser push + pull levels: ~ (3 + 4/3) * 132 B per pixel
-        bytes_px = (3.0 + 4.0 / 3.0) * 33 * 4
+        # traffic of the decomposition the library runs: level 0 of the push pyramid (33 planes: 32 costs + the one confidence
+        # plane the generator's 32 copies collapse to) is never stored; levels >= 1 of the push pyramid are written once and
+        # read twice (the next level, the pull level), the pull levels written once and read once: 5 accesses of 33 * 4 B
+        # per level-1 element, 4/3 of that for the coarser levels, + the depth record / radius / output planes at level 0.
+        # (The staged front end, HLMI_LB_UNFUSED=1, adds 3 * 132 B per pixel.)
+        bytes_px = (5.0 / 4.0) * (4.0 / 3.0) * 33 * 4 + 6 + 4 * 4 + 12
         emit("lens_blur", "apps/lens_blur 32 slices, 32 aperture samples, u8 768x1280x3 stereo pair -> f32", t, W * H, "hbm",
              bytes_px * W * H / t / 1e9, HBM_PEAK_GBS, "GB/s", {"alg_bytes": bytes_px * W * H, "kernels_ms": kernels(call, o),
-                                                              "note": "one thread per element except the LDS-tiled cost and downsample stages"})
+                                                              "note": "instruction-bound (cost stack ~800, depth ~1750, samples ~2400 VALU instructions per pixel); "
+                                                                      "level 0 of the push pyramid is never stored"})
 
     # ---- bgu at the generator's estimates (bgu_generator.cpp:674-687): 192x320 low-res pair, 1536x2560 full-res image
     if not only or "bgu" in only:

@@ -184,8 +184,8 @@ __device__ __forceinline__ float up_at(const float *__restrict__ f, const Box &b
 template<bool TOP>
 __global__ __launch_bounds__(256) void lb_pull(const float *__restrict__ push, Box pb, const float *__restrict__ coarse, Box cb,
                                               float *__restrict__ dst, Box db) {
-    const int xi = blockIdx.x * 256 + threadIdx.x, y = db.y0 + blockIdx.y, zc = blockIdx.z;
-    if (xi >= db.w) return;
+    const int xi = blockIdx.x * 64 + (threadIdx.x & 63), yi = blockIdx.y * 4 + (threadIdx.x >> 6), y = db.y0 + yi, zc = blockIdx.z;
+    if (xi >= db.w || yi >= db.h) return;
     const int x = db.x0 + xi;
     const float p = src_at<true>(push, pb, zc, x, y);
     float v = p;
@@ -226,6 +226,61 @@ __global__ __launch_bounds__(1024) void lb_tail(TailArgs a) {
             const int yi = i / db.w, xi = i - yi * db.w, x = db.x0 + xi, y = db.y0 + yi;
             const float p = src_at<true>(a.push[l], pb, zc, x, y);
             a.pull[l][(size_t)zc * db.h * db.w + i] = (l == LV - 1) ? p : dev::lerpf(up_at(a.pull[l + 1], a.P[l + 1], zc, x, y), p, 0.5f);
+        }
+        __syncthreads();
+    }
+}
+
+// lb_tail with the levels in LDS: when the planes of levels `from`..7 of both pyramids fit (TAIL_LDS floats) a workgroup keeps
+// its plane there — the only global traffic is reading push[from - 1] and writing pull[from] (what lb_pull:from-1 reads);
+// a phase then costs an LDS round trip instead of a global one.  Same expressions, same order.
+constexpr int TAIL_LDS = 15360;
+__global__ __launch_bounds__(1024) void lb_tail_lds(TailArgs a) {
+    __shared__ float s_lv[TAIL_LDS];
+    const int zc = blockIdx.x, tid = threadIdx.x;
+    int opush[LV], opull[LV], off = 0;
+    for (int l = a.from; l < LV; l++) opush[l] = off, off += a.PB[l].w * a.PB[l].h;
+    for (int l = a.from; l < LV; l++) opull[l] = off, off += a.P[l].w * a.P[l].h;
+    auto lds_at = [&](int base, const Box &b, int x, int y) -> float {   // clamped to the box, as src_at<true>
+        x = dev::clampi(x, b.x0, b.x0 + b.w - 1), y = dev::clampi(y, b.y0, b.y0 + b.h - 1);
+        return s_lv[base + (y - b.y0) * b.w + (x - b.x0)];
+    };
+    for (int l = a.from; l < LV; l++) {
+        const Box sb = a.PB[l - 1], db = a.PB[l];
+        const bool first = l == a.from;
+        const float *src = a.push[l - 1];
+        for (int i = tid; i < db.w * db.h; i += 1024) {
+            const int yi = i / db.w, xi = i - yi * db.w, x = db.x0 + xi, y = db.y0 + yi;
+            float dx[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int yy = 2 * y - 1 + k;
+                float t[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    t[j] = first ? src_at<true>(src, sb, zc, 2 * x - 1 + j, yy) : lds_at(opush[l - 1], sb, 2 * x - 1 + j, yy);
+                dx[k] = (t[0] + 3.0f * (t[1] + t[2]) + t[3]) * 0.125f;
+            }
+            s_lv[opush[l] + i] = (dx[0] + 3.0f * (dx[1] + dx[2]) + dx[3]) * 0.125f;
+        }
+        __syncthreads();
+    }
+    for (int l = LV - 1; l >= a.from; l--) {
+        const Box pb = a.PB[l], db = a.P[l];
+        for (int i = tid; i < db.w * db.h; i += 1024) {
+            const int yi = i / db.w, xi = i - yi * db.w, x = db.x0 + xi, y = db.y0 + yi;
+            const float p = lds_at(opush[l], pb, x, y);
+            float v = p;
+            if (l != LV - 1) {
+                const Box cb = a.P[l + 1];
+                const int xa = (x >> 1) - 1 + 2 * (x & 1), xb = x >> 1, ya = (y >> 1) - 1 + 2 * (y & 1), yb = y >> 1;
+                const float *ra = &s_lv[opull[l + 1] + (ya - cb.y0) * cb.w - cb.x0], *rb = &s_lv[opull[l + 1] + (yb - cb.y0) * cb.w - cb.x0];
+                const float ua = 0.25f * ra[xa] + 0.75f * ra[xb];
+                const float ub = 0.25f * rb[xa] + 0.75f * rb[xb];
+                v = dev::lerpf(0.25f * ua + 0.75f * ub, p, 0.5f);
+            }
+            s_lv[opull[l] + i] = v;
+            if (l == a.from) a.pull[l][(size_t)zc * db.h * db.w + i] = v;
         }
         __syncthreads();
     }
@@ -347,19 +402,21 @@ __global__ __launch_bounds__(256) void lb_cost_down(const uint8_t *__restrict__ 
 template<int SB, bool FULL>
 __global__ __launch_bounds__(256) void lb_depth_rc(const uint8_t *__restrict__ L, const uint8_t *__restrict__ Rr, const float *__restrict__ pull1, Box P1,
                                                   LBGeom g, Box D, uint32_t *__restrict__ rec, float *__restrict__ br) {
-    __shared__ uint2 sr[256 + 2 * LB_MAXS];
-    const int tid = threadIdx.x, xi = blockIdx.x * 256 + tid, yi = blockIdx.y;
+    // a wave per row segment of 64 pixels, four rows per workgroup: narrow segments waste few lanes at the right edge
+    __shared__ uint2 srw[4][64 + 2 * LB_MAXS];
+    const int tid = threadIdx.x & 63, wv = threadIdx.x >> 6, xi = blockIdx.x * 64 + tid, yi = min((int)blockIdx.y * 4 + wv, D.h - 1);
     const int x = D.x0 + xi, y = D.y0 + yi;
+    const uint2 *sr = srw[wv];
     {
         const long ro = (long)(dev::clampi(y, g.ry0, g.ry1) - g.ry0) * g.r_sy;
-        const int xb = D.x0 + blockIdx.x * 256;
-        for (int i = tid; i < 256 + 2 * g.slices; i += 256) {
+        const int xb = D.x0 + blockIdx.x * 64;
+        for (int i = tid; i < 64 + 2 * g.slices; i += 64) {
             const long o = ro + (dev::clampi(xb + i, g.rx0, g.rx1) - g.rx0);
-            sr[i] = lb_pack(Rr[o + g.r_c[0]], Rr[o + g.r_c[1]], Rr[o + g.r_c[2]]);
+            srw[wv][i] = lb_pack(Rr[o + g.r_c[0]], Rr[o + g.r_c[1]], Rr[o + g.r_c[2]]);
         }
     }
     __syncthreads();
-    if (xi >= D.w) return;
+    if (xi >= D.w || (int)blockIdx.y * 4 + wv >= D.h) return;
     const long lo = (long)(dev::clampi(y, g.ly0, g.ly1) - g.ly0) * g.l_sy + (dev::clampi(x, g.lx0, g.lx1) - g.lx0);
     const int c0 = L[lo + g.l_c[0]], c1 = L[lo + g.l_c[1]], c2 = L[lo + g.l_c[2]];
     const CostRow c = {(uint32_t)c0 | (uint32_t)c1 << 16, c2};
@@ -436,14 +493,26 @@ __device__ __forceinline__ float rand_float_x(uint32_t ry, int x) {
 __global__ __launch_bounds__(256) void lb_final(LBGeom g, const uint32_t *__restrict__ rec, const float *__restrict__ wcy, Box D, int ox0, int oy0,
                                                int ow, int nc, float *__restrict__ out, long out_sy, long out_sc) {
     // the hash consumes (id, tag, sample, y, x) in that order: everything up to the row is the same for the whole workgroup
-    __shared__ uint32_t s_ru[LB_MAXS], s_rv[LB_MAXS];
+    // The last step hashes t = ry + x with the quadratic rng32(t) = C1 t^2 + C2 t + C3 (mod 2^32).  With t = t0 + l (t0: the
+    // state plus the workgroup's first x, l: the lane's offset) that is rng32(t0) + l (2 C1 t0 + C2) + C1 l^2: the first two
+    // coefficients are per (sample, row) — computed once per workgroup —, the last per lane: one 32-bit multiply per hash
+    // instead of two, the same residue.
+    __shared__ uint2 s_ru[LB_MAXS], s_rv[LB_MAXS];
     const int xo = blockIdx.x * 256 + threadIdx.x, yo = blockIdx.y;
     const int x = ox0 + xo, y = oy0 + yo;
     if ((int)threadIdx.x < g.samples) {
         const uint32_t seed_u = rng32(rng32(0u) + (uint32_t)g.tag), seed_v = rng32(rng32(1u) + (uint32_t)g.tag);
-        s_ru[threadIdx.x] = rng32(rng32(seed_u + threadIdx.x) + (uint32_t)y);
-        s_rv[threadIdx.x] = rng32(rng32(seed_v + threadIdx.x) + (uint32_t)y);
+        const uint32_t xb = (uint32_t)(ox0 + (int)blockIdx.x * 256);
+        const uint32_t tu = rng32(rng32(seed_u + threadIdx.x) + (uint32_t)y) + xb, tv = rng32(rng32(seed_v + threadIdx.x) + (uint32_t)y) + xb;
+        s_ru[threadIdx.x] = make_uint2(rng32(tu), 2u * 1040796640u * tu + 1121052041u);
+        s_rv[threadIdx.x] = make_uint2(rng32(tv), 2u * 1040796640u * tv + 1121052041u);
     }
+    const uint32_t ln = threadIdx.x, kl = 1040796640u * ln * ln;
+    auto rand_lane = [&](const uint2 ab) -> float {
+        uint32_t r = ab.x + ln * ab.y + kl;
+        r = r ^ (r >> 16);
+        return dev::clampf(__uint_as_float((127u << 23) | (r >> 9)) - 1.0f, 0.0f, 1.0f);
+    };
     __syncthreads();
     if (xo >= ow) return;
     float worst = -INFINITY;
@@ -454,8 +523,8 @@ __global__ __launch_bounds__(256) void lb_final(LBGeom g, const uint32_t *__rest
     const int dxy = (int)(w0 & 255u);
     const float br0 = bokeh_radius(dxy, g), brs = br0 * br0;
     for (int s = 0; s < g.samples; s++) {
-        const float fu = ((rand_float_x(s_ru[s], x) - 0.5f) * 2.0f) * worst;
-        const float fv = ((rand_float_x(s_rv[s], x) - 0.5f) * 2.0f) * worst;
+        const float fu = ((rand_lane(s_ru[s]) - 0.5f) * 2.0f) * worst;
+        const float fv = ((rand_lane(s_rv[s]) - 0.5f) * 2.0f) * worst;
         const int u = dev::clampi((int)fu, -g.R, g.R), v = dev::clampi((int)fv, -g.R, g.R);
         const uint32_t ws = rec[(size_t)(y + v - D.y0) * D.w + (x + u - D.x0)];
         const float r2 = (float)(u * u + v * v);
@@ -666,16 +735,20 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
         ta.from = tail;
         char nm[24];
         snprintf(nm, sizeof nm, "lb_tail:%d", tail);
-        HLMI_LAUNCH(uc, nm, st, lb_tail, dim3(zc), dim3(1024), 0, ta);
+        long need = 0;
+        for (int i = tail; i < LV; i++) need += (long)PB[i].w * PB[i].h + (long)P[i].w * P[i].h;
+        const char *e = getenv("HLMI_LB_TAIL_GLOBAL");   // A/B: the levels of the tail in global memory
+        if (need <= TAIL_LDS && !(e && *e && atoi(e) != 0)) HLMI_LAUNCH(uc, nm, st, lb_tail_lds, dim3(zc), dim3(1024), 0, ta);
+        else HLMI_LAUNCH(uc, nm, st, lb_tail, dim3(zc), dim3(1024), 0, ta);
     }
     for (int i = min(LV - 1, tail - 1); i >= 1; i--) {
         char nm[24];
         snprintf(nm, sizeof nm, "lb_pull:%d", i);
-        if (i == LV - 1) HLMI_LAUNCH(uc, nm, st, lb_pull<true>, dim3((P[i].w + 255) / 256, P[i].h, zc), dim3(256), 0, push[i], PB[i], (const float *)nullptr, P[i], pull[i], P[i]);
-        else HLMI_LAUNCH(uc, nm, st, lb_pull<false>, dim3((P[i].w + 255) / 256, P[i].h, zc), dim3(256), 0, push[i], PB[i], pull[i + 1], P[i + 1], pull[i], P[i]);
+        if (i == LV - 1) HLMI_LAUNCH(uc, nm, st, lb_pull<true>, dim3((P[i].w + 63) / 64, (P[i].h + 3) / 4, zc), dim3(256), 0, push[i], PB[i], (const float *)nullptr, P[i], pull[i], P[i]);
+        else HLMI_LAUNCH(uc, nm, st, lb_pull<false>, dim3((P[i].w + 63) / 64, (P[i].h + 3) / 4, zc), dim3(256), 0, push[i], PB[i], pull[i + 1], P[i + 1], pull[i], P[i]);
     }
     if (!fused) HLMI_LAUNCH(uc, "lb_depth", st, lb_depth, dim3((D.w + 255) / 256, D.h), dim3(256), 0, push[0], E, pull[1], P[1], dl, g, D, depth, br);
-    else LB_DISPATCH(lb_depth_rc, dim3((D.w + 255) / 256, D.h), dim3(256), 0, dl, dr, pull[1], P[1], g, D, depth, br);
+    else LB_DISPATCH(lb_depth_rc, dim3((D.w + 63) / 64, (D.h + 3) / 4), dim3(256), 0, dl, dr, pull[1], P[1], g, D, depth, br);
 #undef LB_DISPATCH
     HLMI_LAUNCH(uc, "lb_wcy", st, lb_wcy, dim3((D.w + 255) / 256, oh), dim3(256), 0, br, D, g.R, oy0, oh, wcy);
     HLMI_LAUNCH(uc, "lb_final", st, lb_final, dim3((ow + 255) / 256, oh), dim3(256), 0, g, depth, wcy, D, ox0, oy0, ow, nc,

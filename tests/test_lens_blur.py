@@ -162,6 +162,18 @@ def test_oracle_depth_finds_the_disparity_of_a_shifted_pair(oracle):
     assert np.count_nonzero(inner == 5) > 0.95 * inner.size
 
 
+def test_two_fma_division_of_the_cost_stack_is_the_correctly_rounded_quotient(tmp_path):
+    """halide_amd/csrc/lens_blur.hip divides a cost by `slices` with a multiply and two FMAs; tests/cpp/lb_div_check.c
+    checks every (cost, slices) pair the generator admits against the correctly rounded division."""
+    import subprocess
+    from pathlib import Path
+    src = Path(__file__).parent / "cpp" / "lb_div_check.c"
+    exe = tmp_path / "lb_div_check"
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), str(src), "-lm"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "0", r.stdout + r.stderr
+
+
 # ---------------------------------------------------------------------------------------------------- GPU
 def _run(hl, left, right, slices, focus, scale, samples, out_shape=None):
     bl, br_ = hl.Buffer(left), hl.Buffer(right)
@@ -178,6 +190,26 @@ def test_hip_matches_oracle(hl, oracle, w, h, slices, focus, scale, samples):
     got = _run(hl, left, right, slices, focus, scale, samples)
     want = oracle.lens_blur(left, right, slices, focus, scale, samples)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"{np.count_nonzero(got != want)} of {got.size} differ"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("unfused", [False, True])
+@pytest.mark.parametrize("w,h,slices,samples", [(530, 70, 32, 8), (300, 41, 33, 5), (258, 36, 64, 4), (515, 19, 31, 3)])
+def test_hip_front_ends_agree_with_the_oracle(hl, oracle, monkeypatch, unfused, w, h, slices, samples):
+    """The fused front end (lb_cost_down + lb_depth_rc: level 0 of the push pyramid is never stored) and the staged one
+    (HLMI_LB_UNFUSED=1), on widths that need several strips of uneven width and on slice counts that are / are not the
+    compile-time bound of the cost stack (32, 64)."""
+    if unfused:
+        monkeypatch.setenv("HLMI_LB_UNFUSED", "1")
+    for ndy in ("", "3", "16"):
+        if ndy:
+            monkeypatch.setenv("HLMI_LB_NDY", ndy)
+        left, right = _pair(w, h, seed=w + h + slices, shift=5)
+        got = _run(hl, left, right, slices, min(slices, 32) // 2 + 1, 0.5, samples)
+        want = oracle.lens_blur(left, right, slices, min(slices, 32) // 2 + 1, 0.5, samples)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"ndy={ndy!r}: {np.count_nonzero(got != want)} of {got.size} differ"
+        if unfused:
+            break
 
 
 @pytest.mark.gpu
