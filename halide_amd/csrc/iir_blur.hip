@@ -31,7 +31,7 @@ namespace {
 #define HLMI_IIR_PROBE 0
 #endif
 #if HLMI_IIR_PROBE
-__device__ unsigned long long g_iprobe[16];
+__device__ unsigned long long g_iprobe[32];
 #define IP_T(v) const unsigned long long v = wall_clock64()
 #define IP_ACC(a, d) a += (d)
 #else
@@ -48,23 +48,32 @@ constexpr int TG = 260, TSZ = (TR / 4) * TG;
 __device__ __forceinline__ int at(int r, int l) { return (r >> 2) * TG + 4 * l + (r & 3); }
 constexpr int NHELP = 8, NLOAD = 4, LR = TR / NLOAD, SR = TR / (NHELP - NLOAD);   // helper waves: loaders / storers and the tile rows each moves
 constexpr int NSET = 4;                   // tiles a helper has requested and not yet put into LDS (+1 being filled)
-constexpr int SLOTS = 4;                  // LDS tile slots
+constexpr int SLOTS = 8;                  // LDS tile slots (133 KB): four in rotation + the tiles kept for the turn
+constexpr int KEEP = 7;                   // forward tiles that stay in LDS for the backward pass (see `turn`)
 
 // src: [C][Hd][Wd] (row stride s_sy, plane stride s_sc); scratch: same shape, dense; dst: [C][Wd][Hd] (d_sy, d_sc)
 __global__ __launch_bounds__(64 * (1 + NHELP)) void iir_cols_T(const float *__restrict__ src, long s_sy, long s_sc, int Wd, int Hd,
                                                                float alpha, float *__restrict__ scratch, float *__restrict__ dst,
                                                                long d_sy, long d_sc) {
-    extern __shared__ __attribute__((aligned(16))) float tiles_raw[];   // [SLOTS][TSZ]: 66.5 KB, above the static limit
+    extern __shared__ __attribute__((aligned(16))) float tiles_raw[];   // [SLOTS][TSZ]: 133 KB, above the static limit
     auto tiles = reinterpret_cast<float (*)[TSZ]>(tiles_raw);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x0 = blockIdx.x * 64, c = blockIdx.y;
     const int x = min(x0 + lane, Wd - 1);                    // lanes past the edge shadow the last column (never stored)
     const float c1 = 1.0f - alpha;
-    const float *s = src + (long)c * s_sc + x;
+    const float *sbase = src + (long)c * s_sc, *tbase = scratch + ((long)c * Hd) * Wd;   // uniform; the loaders add xoff
+    const uint32_t xoff = 4u * (uint32_t)x;
     float *t = scratch + ((long)c * Hd) * Wd + x;
     float *dcol = dst + (long)c * d_sc;
     const int NT = (Hd + TR - 1) / TR;
     float b = 0.0f;                                          // scanner: the recurrence state
+    // THE TURN.  The backward pass starts where the forward pass ends, so its first tiles are the forward pass's last ones —
+    // which are still in LDS.  Sending them through the scratch plane put a store round trip (the last tiles must be
+    // visible) and a load round trip (~3 us before tile 0 is back) between the two passes of every launch.  With `turn`
+    // (whole tiles only) the last KEEP forward tiles are not written out: the helpers reverse them in place (row r -> step
+    // 63 - r, times alpha: what a loader would have put there) between two barriers, the scanner goes straight on, and the
+    // loaders' first loads (tile KEEP) have KEEP - 2 tiles of recurrence to arrive.
+    const bool turn = (Hd % TR) == 0 && NT >= 16;
 
     // one pass over the column: tile p (processing order) holds steps 0..n-1; forward: step st = row 64p + st of `s`,
     // backward: row Hd-1 - 64p - st of the scratch plane.  The scanner and the helpers run DIFFERENT loops that meet at the
@@ -73,12 +82,38 @@ __global__ __launch_bounds__(64 * (1 + NHELP)) void iir_cols_T(const float *__re
     // this structure exists to hide.
     auto pass = [&](auto back_tag) {
         constexpr bool BACK = decltype(back_tag)::value;
+        // slot of tile p (processing order).  With the turn the backward pass walks the slots downwards from the one the
+        // forward pass ended in: backward tile p IS forward tile NT-1-p, found where the forward pass left it
+        auto sl = [&](int p) { return (BACK && turn) ? ((NT - 1 - p) & (SLOTS - 1)) : (p & (SLOTS - 1)); };
         auto rows_of = [&](int p) { return min(TR, Hd - p * TR); };
         auto row_at = [&](int p, int st) { return BACK ? Hd - 1 - p * TR - st : p * TR + st; };
+        // the turn, helpers' side: wave hw of the eight takes groups 2 hw, 2 hw + 1 (rows 8 hw .. 8 hw + 7) of each kept tile,
+        // everybody reads, barrier, everybody writes the mirrored groups: step st = 63 - r holds alpha * forward(r), the
+        // pass's very first step (tile 0, step 0) the raw value — exactly what fill() makes of the scratch rows
+        auto reverse_kept = [&](int hw) {
+            const int g0 = 2 * hw, g1 = 2 * hw + 1;
+            float4 ka[KEEP], kb[KEEP];
+#pragma unroll
+            for (int q = 0; q < KEEP; q++) {
+                const float4 *tl = reinterpret_cast<const float4 *>(tiles[sl(q)] + 4 * lane);
+                ka[q] = tl[g0 * (TG / 4)], kb[q] = tl[g1 * (TG / 4)];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < KEEP; q++) {
+                float4 *tl = reinterpret_cast<float4 *>(tiles[sl(q)] + 4 * lane);
+                float4 wa, wb;
+                wa.x = alpha * ka[q].w, wa.y = alpha * ka[q].z, wa.z = alpha * ka[q].y, wa.w = alpha * ka[q].x;
+                wb.x = (q == 0 && g1 == TR / 4 - 1) ? kb[q].w : alpha * kb[q].w;
+                wb.y = alpha * kb[q].z, wb.z = alpha * kb[q].y, wb.w = alpha * kb[q].x;
+                tl[(TR / 4 - 1 - g0) * (TG / 4)] = wa;
+                tl[(TR / 4 - 1 - g1) * (TG / 4)] = wb;
+            }
+        };
         if (wave == 0) {
             // ---- the scanner: b = c1 * b + (alpha * in), in place in the tile's LDS slot
             auto slow = [&](int p) {                         // first tile (its first row is taken as it is, :21, :26-28) and a short last tile
-                float *tl = tiles[p % SLOTS];
+                float *tl = tiles[sl(p)];
                 const int n = rows_of(p);
                 int st = 0;
                 if (p == 0) {
@@ -92,8 +127,8 @@ __global__ __launch_bounds__(64 * (1 + NHELP)) void iir_cols_T(const float *__re
             };
             // a full tile whose 64 inputs are already in registers; the NEXT tile's inputs are read meanwhile
             auto fast = [&](int p, const float4 (&ucur)[TR / 4], float4 (&unxt)[TR / 4]) {
-                float4 *tl = reinterpret_cast<float4 *>(tiles[p % SLOTS] + 4 * lane);
-                const float4 *tn = reinterpret_cast<const float4 *>(tiles[(p + 1) % SLOTS] + 4 * lane);
+                float4 *tl = reinterpret_cast<float4 *>(tiles[sl(p)] + 4 * lane);
+                const float4 *tn = reinterpret_cast<const float4 *>(tiles[sl(p + 1)] + 4 * lane);
 #pragma unroll
                 for (int gq = 0; gq < TR / 4; gq++) {
                     float4 r;
@@ -105,15 +140,52 @@ __global__ __launch_bounds__(64 * (1 + NHELP)) void iir_cols_T(const float *__re
                     unxt[gq] = tn[gq * (TG / 4)];
                 }
             };
+            // the first and the last tile of a pass, when full: all 64 inputs in registers before the chain starts (one LDS
+            // round trip), as in the steady state — the row-at-a-time loop of slow() pays that round trip per row (~45 ns
+            // against 7.4), 2 x 2.4 us per pass
+            auto first_full = [&]() {
+                float4 *tl = reinterpret_cast<float4 *>(tiles[sl(0)] + 4 * lane);
+                float4 u[TR / 4];
+#pragma unroll
+                for (int gq = 0; gq < TR / 4; gq++) u[gq] = tl[gq * (TG / 4)];
+#pragma unroll
+                for (int gq = 0; gq < TR / 4; gq++) {
+                    float4 r;
+                    if (gq == 0) b = u[0].x;                 // the pass's first row is taken as it is (:21, :26-28)
+                    else b = c1 * b + u[gq].x;
+                    r.x = b;
+                    b = c1 * b + u[gq].y, r.y = b;
+                    b = c1 * b + u[gq].z, r.z = b;
+                    b = c1 * b + u[gq].w, r.w = b;
+                    tl[gq * (TG / 4)] = r;
+                }
+            };
+            auto last_full = [&](int p, const float4 (&ucur)[TR / 4]) {
+                float4 *tl = reinterpret_cast<float4 *>(tiles[sl(p)] + 4 * lane);
+#pragma unroll
+                for (int gq = 0; gq < TR / 4; gq++) {
+                    float4 r;
+                    b = c1 * b + ucur[gq].x, r.x = b;
+                    b = c1 * b + ucur[gq].y, r.y = b;
+                    b = c1 * b + ucur[gq].z, r.z = b;
+                    b = c1 * b + ucur[gq].w, r.w = b;
+                    tl[gq * (TG / 4)] = r;
+                }
+            };
             float4 ua[TR / 4], ub[TR / 4];
+            IP_T(w0);
+            if (BACK && turn) __syncthreads();               // the helpers' reversal of the kept tiles (read | write)
             __syncthreads();
-            slow(0);
+            IP_T(w1);
+            if (rows_of(0) == TR) first_full();
+            else slow(0);
             if (NT > 2) {                                    // tile 1 is full and was filled before the barrier above
-                const float4 *tn = reinterpret_cast<const float4 *>(tiles[1] + 4 * lane);
+                const float4 *tn = reinterpret_cast<const float4 *>(tiles[sl(1)] + 4 * lane);
 #pragma unroll
                 for (int gq = 0; gq < TR / 4; gq++) ua[gq] = tn[gq * (TG / 4)];
             }
             __syncthreads();
+            IP_T(w2);
             int p = 1;
 #if HLMI_IIR_PROBE
             unsigned long long pr_chain = 0, pr_bar = 0;
@@ -137,11 +209,25 @@ __global__ __launch_bounds__(64 * (1 + NHELP)) void iir_cols_T(const float *__re
 #if HLMI_IIR_PROBE
             if (lane == 0) atomicAdd(&g_iprobe[0], pr_chain), atomicAdd(&g_iprobe[1], pr_bar), atomicAdd(&g_iprobe[2], 1ull);
 #endif
+            IP_T(w3);
             if (NT > 1) {
-                slow(NT - 1);
+                if (NT > 2 && rows_of(NT - 1) == TR) {       // its inputs were read during tile NT-2: odd tiles sit in ua
+                    if ((NT - 1) & 1) last_full(NT - 1, ua);
+                    else last_full(NT - 1, ub);
+                } else {
+                    slow(NT - 1);
+                }
                 __syncthreads();
             }
             __syncthreads();
+#if HLMI_IIR_PROBE
+            {
+                IP_T(w4);
+                const int o = BACK ? 21 : 16;
+                if (lane == 0) atomicAdd(&g_iprobe[o], w1 - w0), atomicAdd(&g_iprobe[o + 1], w2 - w1), atomicAdd(&g_iprobe[o + 2], w3 - w2),
+                               atomicAdd(&g_iprobe[o + 3], w4 - w3), atomicAdd(&g_iprobe[o + 4], 1ull);
+            }
+#endif
             return;
         }
         // ---- the helpers: waves 1..NLOAD only LOAD (global -> registers -> LDS), the others only STORE (LDS -> global).  A wave
@@ -153,16 +239,22 @@ __global__ __launch_bounds__(64 * (1 + NHELP)) void iir_cols_T(const float *__re
             float set[NSET][LR];                             // rows of NSET tiles in flight
             auto issue = [&](int p, float (&v)[LR]) {        // p past the end re-reads the last tile, rows past a short tile its last row
                 const int pc = min(p, NT - 1), last = rows_of(pc) - 1;
+                // the rows are the same for the whole wave: a uniform row pointer (scalar arithmetic) + the lane's 32-bit byte
+                // offset is ONE vector instruction per load, and the pointer ADVANCES by one row stride per load (a 64-bit
+                // product per row made an issue() 330 ns of scalar arithmetic — 2 us of every pass's start-up)
+                const long rs = BACK ? -(long)Wd : s_sy;
+                const float *rowp = BACK ? tbase + (long)row_at(pc, min(l0, last)) * Wd : sbase + (long)row_at(pc, min(l0, last)) * s_sy;
 #pragma unroll
                 for (int i = 0; i < LR; i++) {
-                    const int r = row_at(pc, min(l0 + i, last));
-                    v[i] = BACK ? t[(long)r * Wd] : s[(long)r * s_sy];
+                    v[i] = *(const float *)((const char *)rowp + xoff);
+                    rowp += (l0 + i < last) ? rs : 0;        // rows past a short tile repeat its last row
                 }
             };
             // the loaders also do the recurrence's independent product: LDS holds alpha * in (the pass's very first row stays
-            // raw).  Filling a slot for a tile past the end is harmless: that slot's tile has been written out already.
+            // raw).  Filling a slot for a tile past the end is harmless (that slot's tile has been written out already) except in a
+            // forward pass with the turn, whose last tiles stay: iter_tail guards it.
             auto fill = [&](int p, const float (&v)[LR]) {
-                float4 *tl = reinterpret_cast<float4 *>(tiles[p % SLOTS] + at(l0, lane));   // l0 is a multiple of 4
+                float4 *tl = reinterpret_cast<float4 *>(tiles[sl(p)] + at(l0, lane));   // l0 is a multiple of 4
 #pragma unroll
                 for (int gq = 0; gq < LR / 4; gq++) {
                     float4 w;
@@ -185,29 +277,55 @@ __global__ __launch_bounds__(64 * (1 + NHELP)) void iir_cols_T(const float *__re
                 IP_T(q3);
                 IP_ACC(pr_fill, q1 - q0); IP_ACC(pr_issue, q2 - q1); IP_ACC(pr_lbar, q3 - q2);
             };
-            static_assert(NSET == 4 && SLOTS == 4, "the unrolled tile loop below names the phases");
-            issue(0, set[0]);
-            issue(1, set[1]);
-            issue(2, set[2]);
-            issue(3, set[3]);
-            fill(0, set[0]);
-            issue(4, set[0]);
-            fill(1, set[1]);
-            issue(5, set[1]);
-            __syncthreads();
-            fill(2, set[2]);
-            issue(6, set[2]);
-            __syncthreads();
+            // the last iterations of a pass: a forward pass with the turn must not fill tiles past the end (the slots hold
+            // the tiles it keeps); the branch costs the loads' latency hiding, which no longer matters there
+            auto iter_tail = [&](int p, auto ph_tag) {
+                constexpr int PH = decltype(ph_tag)::value;
+                if (BACK || !turn || p + 2 < NT) fill(p + 2, set[(PH + 2) % NSET]);
+                if (p + 2 + NSET < NT) issue(p + 2 + NSET, set[(PH + 2) % NSET]);   // nothing in flight when the pass ends
+                __syncthreads();
+            };
+            static_assert(NSET == 4 && SLOTS == 8 && KEEP == 7, "the unrolled tile loop below names the phases; tile t travels in set t % 4");
             int p = 1;
-            for (; p + 3 < NT; p += 4) {
+            if (BACK && turn) {
+                // tiles 0 .. KEEP-1 are in LDS already; the first loads are tiles KEEP .. KEEP+3
+                // the reversal first — the scanner waits for it —, then the loads: they have KEEP - 2 tiles to arrive.  (Only
+                // three sets before the next barrier: the 64th load in flight would stall this wave — vmcnt counts to 63 —
+                // until the first one is back, with the scanner waiting at the barrier behind it.)
+                reverse_kept(wave - 1);
+                __syncthreads();
+                issue(KEEP, set[3]);
+                issue(KEEP + 1, set[0]);
+                issue(KEEP + 2, set[1]);
+                __syncthreads();
+                issue(KEEP + 3, set[2]);
+                for (; p < KEEP - 2; p++) __syncthreads();   // iterations whose tile p + 2 needs no fill
+            } else {
+                issue(0, set[0]);
+                issue(1, set[1]);
+                issue(2, set[2]);
+                issue(3, set[3]);
+                fill(0, set[0]);
+                fill(1, set[1]);
+                __syncthreads();                             // the scanner starts on tile 0 as early as possible
+                issue(4, set[0]);
+                issue(5, set[1]);
+                fill(2, set[2]);
+                issue(6, set[2]);
+                __syncthreads();
+            }
+            // p = 1 or KEEP - 2 = 5: p % 4 == 1 either way
+            for (; p + 5 < NT; p += 4) {
                 iter(p, std::integral_constant<int, 1>{});
                 iter(p + 1, std::integral_constant<int, 2>{});
                 iter(p + 2, std::integral_constant<int, 3>{});
                 iter(p + 3, std::integral_constant<int, 0>{});
             }
-            if (p < NT) iter(p++, std::integral_constant<int, 1>{});
-            if (p < NT) iter(p++, std::integral_constant<int, 2>{});
-            if (p < NT) iter(p++, std::integral_constant<int, 3>{});
+            if (p < NT) iter_tail(p++, std::integral_constant<int, 1>{});
+            if (p < NT) iter_tail(p++, std::integral_constant<int, 2>{});
+            if (p < NT) iter_tail(p++, std::integral_constant<int, 3>{});
+            if (p < NT) iter_tail(p++, std::integral_constant<int, 0>{});
+            if (p < NT) iter_tail(p++, std::integral_constant<int, 1>{});
             __syncthreads();                                 // the storers' last tile
 #if HLMI_IIR_PROBE
             if (lane == 0 && wave == 1) atomicAdd(&g_iprobe[4], pr_fill), atomicAdd(&g_iprobe[5], pr_issue), atomicAdd(&g_iprobe[6], pr_lbar), atomicAdd(&g_iprobe[7], 1ull);
@@ -216,7 +334,7 @@ __global__ __launch_bounds__(64 * (1 + NHELP)) void iir_cols_T(const float *__re
         }
         const int h0 = (wave - 1 - NLOAD) * SR;              // storer: first tile row (forward) / tile column (backward) it moves
         auto drain_full = [&](int p) {                       // tile p (64 rows) leaves LDS
-            const float *tl = tiles[p % SLOTS];
+            const float *tl = tiles[sl(p)];
 #pragma unroll
             for (int i = 0; i < SR; i++) {
                 if (!BACK) {
@@ -230,7 +348,7 @@ __global__ __launch_bounds__(64 * (1 + NHELP)) void iir_cols_T(const float *__re
             }
         };
         auto drain_last = [&](int p) {                       // the (possibly short) last tile
-            const float *tl = tiles[p % SLOTS];
+            const float *tl = tiles[sl(p)];
             const int n = rows_of(p);
 #pragma unroll
             for (int i = 0; i < SR; i++) {
@@ -242,6 +360,7 @@ __global__ __launch_bounds__(64 * (1 + NHELP)) void iir_cols_T(const float *__re
                 }
             }
         };
+        if (BACK && turn) reverse_kept(wave - 1);
         __syncthreads();
         __syncthreads();                                     // iteration 0: nothing to write out yet
 #if HLMI_IIR_PROBE
@@ -249,7 +368,7 @@ __global__ __launch_bounds__(64 * (1 + NHELP)) void iir_cols_T(const float *__re
 #endif
         for (int p = 1; p < NT; p++) {
             IP_T(q0);
-            drain_full(p - 1);
+            if (BACK || !turn || p - 1 < NT - KEEP) drain_full(p - 1);   // a forward pass with the turn keeps its last tiles
             IP_T(q1);
             __syncthreads();
             IP_T(q2);
@@ -258,7 +377,7 @@ __global__ __launch_bounds__(64 * (1 + NHELP)) void iir_cols_T(const float *__re
 #if HLMI_IIR_PROBE
         if (lane == 0 && wave == NLOAD + 1) atomicAdd(&g_iprobe[8], pr_drain), atomicAdd(&g_iprobe[9], pr_sbar), atomicAdd(&g_iprobe[10], 1ull);
 #endif
-        drain_last(NT - 1);
+        if (BACK || !turn) drain_last(NT - 1);
         __syncthreads();                                     // the scratch rows are visible to the whole workgroup
     };
     pass(std::false_type{});
@@ -279,11 +398,11 @@ const halide_filter_metadata_t ib_md = {1, 3, ib_args, kTargetString, "iir_blur"
 
 }  // namespace
 
-extern "C" int hlmi_debug_iir_probe(unsigned long long *out16) {
+extern "C" int hlmi_debug_iir_probe(unsigned long long *out16) {   // 32 counters
 #if HLMI_IIR_PROBE
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_iprobe), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    unsigned long long zero[16] = {};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_iprobe), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    unsigned long long zero[32] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_iprobe), zero, sizeof zero) != hipSuccess) return -1;
     return 1;
 #else

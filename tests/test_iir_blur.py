@@ -56,7 +56,8 @@ def _run(hl, inp, alpha):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,h,c,alpha", [(1536, 2560, 3, 0.1), (1, 1, 3, 0.5), (64, 64, 1, 0.5), (65, 130, 3, 0.25), (200, 77, 2, 0.9)])
+@pytest.mark.parametrize("w,h,c,alpha", [(1536, 2560, 3, 0.1), (1, 1, 3, 0.5), (64, 64, 1, 0.5), (65, 130, 3, 0.25), (200, 77, 2, 0.9),
+                                            (1024, 70, 1, 0.3), (1088, 1024, 1, 0.6), (960, 1030, 2, 0.2), (1027, 1152, 1, 0.45)])
 def test_hip_matches_oracle_bit_for_bit(hl, oracle, w, h, c, alpha):
     rng = np.random.default_rng(w + h)
     inp = rng.random((c, h, w), dtype=np.float32)
