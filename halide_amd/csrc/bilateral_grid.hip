@@ -215,10 +215,35 @@ __global__ __launch_bounds__(256) void bg_blur_slice(const float *__restrict__ i
     const int t = threadIdx.x;
     const int x0 = blockIdx.x * FPX, y0 = blockIdx.y * FPY;
     const int cxa = dev::fdiv8(ox0 + x0) - g.gx0, cya = dev::fdiv8(oy0 + y0) - g.gy0;   // first blury cell of the tile
-    for (int e = t; e < g.ZD * (FCY + 4) * (FCX + 4); e += 256) {
-        const int z = e / ((FCY + 4) * (FCX + 4)), rem = e - z * ((FCY + 4) * (FCX + 4)), j = rem / (FCX + 4), i = rem - j * (FCX + 4);
-        const int hx = min(cxa + i, g.HX - 1), hy = min(cya + j, g.HY - 1);     // cells past the grid are never interpolated
-        s_bz[z][j][i] = bz[((size_t)z * g.HY + hy) * g.HX + hx];
+    // the thread's own pixels first: their latency hides behind the three grid phases (a load cannot move above a barrier
+    // by itself); rows / columns past the output re-read its last row / column and are never stored
+    float pix[FPY / 4];
+    {
+        const int axc = ox0 + min(x0 + (t & 63), ow - 1);
+#pragma unroll
+        for (int k = 0; k < FPY / 4; k++) {
+            const int ayc = oy0 + min(y0 + (t >> 6) + 4 * k, oh - 1);
+            pix[k] = in[(long)(ayc - g.iy0) * in_sy + (axc - g.ix0)];
+        }
+    }
+    {
+        // all of the thread's cells are requested before the first one is waited for (a loop with a run-time trip count
+        // pays the round trip per iteration: 7 x ~0.7 us was most of this kernel)
+        constexpr int PLANE = (FCY + 4) * (FCX + 4), N1 = (FZ * PLANE + 255) / 256;
+        const int total = g.ZD * PLANE;
+        float2 v[N1];
+#pragma unroll
+        for (int k = 0; k < N1; k++) {
+            const int e = min(t + 256 * k, total - 1);
+            const int z = e / PLANE, rem = e - z * PLANE, j = rem / (FCX + 4), i = rem - j * (FCX + 4);
+            const int hx = min(cxa + i, g.HX - 1), hy = min(cya + j, g.HY - 1);     // cells past the grid are never interpolated
+            v[k] = bz[((size_t)z * g.HY + hy) * g.HX + hx];
+        }
+#pragma unroll
+        for (int k = 0; k < N1; k++) {
+            const int e = t + 256 * k;
+            if (e < total) (&s_bz[0][0][0])[e] = v[k];
+        }
     }
     __syncthreads();
     for (int e = t; e < g.ZD * (FCY + 4) * FCX; e += 256) {
@@ -243,7 +268,7 @@ __global__ __launch_bounds__(256) void bg_blur_slice(const float *__restrict__ i
         const int y = y0 + (t >> 6) + 4 * k;
         if (y >= oh) break;
         const int ay = oy0 + y;
-        const float val = dev::clampf(in[(long)(ay - g.iy0) * in_sy + (ax - g.ix0)], 0.0f, 1.0f);
+        const float val = dev::clampf(pix[k], 0.0f, 1.0f);
         const float zv = val * g.inv_r;
         const int zi = (int)zv;
         const float zf = zv - (float)zi;
