@@ -477,7 +477,16 @@ __global__ __launch_bounds__(256) void lb_wcy(const float *__restrict__ br, Box 
     if (xi >= D.w) return;
     const int y = oy0 + yo;
     float m = -INFINITY;
-    for (int r = -R; r <= R; r++) m = fmaxf(m, br[(size_t)(y + r - D.y0) * D.w + xi]);
+    // eight rows requested at a time (a run-time trip count one load at a time pays the round trip per row); rows past the
+    // window repeat its last row: the maximum does not change
+    const float *col = br + (size_t)(y - R - D.y0) * D.w + xi;
+    for (int r0 = 0; r0 <= 2 * R; r0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = col[(size_t)min(r0 + j, 2 * R) * D.w];
+#pragma unroll
+        for (int j = 0; j < 8; j++) m = fmaxf(m, v[j]);
+    }
     wcy[(size_t)yo * D.w + xi] = m;
 }
 
@@ -516,26 +525,50 @@ __global__ __launch_bounds__(256) void lb_final(LBGeom g, const uint32_t *__rest
     __syncthreads();
     if (xo >= ow) return;
     float worst = -INFINITY;
-    for (int r = -g.R; r <= g.R; r++) worst = fmaxf(worst, wcy[(size_t)yo * D.w + (x + r - D.x0)]);
+    {
+        const float *wrow = wcy + (size_t)yo * D.w + (x - g.R - D.x0);
+        for (int r0 = 0; r0 <= 2 * g.R; r0 += 8) {   // batched as in lb_wcy
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = wrow[min(r0 + j, 2 * g.R)];
+#pragma unroll
+            for (int j = 0; j < 8; j++) worst = fmaxf(worst, v[j]);
+        }
+    }
     const size_t o = (size_t)(y - D.y0) * D.w + (x - D.x0);
     const uint32_t w0 = rec[o];
     float acc[4] = {(float)((w0 >> 8) & 255u), (float)((w0 >> 16) & 255u), (float)(w0 >> 24), 255.0f};
     const int dxy = (int)(w0 & 255u);
     const float br0 = bokeh_radius(dxy, g), brs = br0 * br0;
-    for (int s = 0; s < g.samples; s++) {
-        const float fu = ((rand_lane(s_ru[s]) - 0.5f) * 2.0f) * worst;
-        const float fv = ((rand_lane(s_rv[s]) - 0.5f) * 2.0f) * worst;
-        const int u = dev::clampi((int)fu, -g.R, g.R), v = dev::clampi((int)fv, -g.R, g.R);
-        const uint32_t ws = rec[(size_t)(y + v - D.y0) * D.w + (x + u - D.x0)];
-        const float r2 = (float)(u * u + v * v);
-        const int ds = (int)(ws & 255u);
-        const float bs = bokeh_radius(ds, g);
-        const bool take = ((r2 < brs) || (ds < dxy)) && (r2 < bs * bs);
-        const float wgt = take ? 1.0f : 0.0f;
-        acc[0] = acc[0] + wgt * (float)((ws >> 8) & 255u);
-        acc[1] = acc[1] + wgt * (float)((ws >> 16) & 255u);
-        acc[2] = acc[2] + wgt * (float)(ws >> 24);
-        acc[3] = acc[3] + wgt * 255.0f;
+    // Samples in batches of SBATCH: the gathers of a batch are all requested before the first one is used (one at a time,
+    // every sample paid the round trip of its gather).  Samples past the count re-use the last one with weight 0: adding
+    // 0.0f leaves the non-negative sums as they are.  32-bit element offsets (the host checks D fits): the row product is
+    // one 24-bit multiply.
+    constexpr int SBATCH = 4;
+    const uint32_t *const rrow = rec + (size_t)(y - D.y0) * D.w + (x - D.x0);
+    for (int s0 = 0; s0 < g.samples; s0 += SBATCH) {
+        uint32_t ws[SBATCH];
+        float r2[SBATCH];
+#pragma unroll
+        for (int j = 0; j < SBATCH; j++) {
+            const int s = min(s0 + j, g.samples - 1);
+            const float fu = ((rand_lane(s_ru[s]) - 0.5f) * 2.0f) * worst;
+            const float fv = ((rand_lane(s_rv[s]) - 0.5f) * 2.0f) * worst;
+            const int u = dev::clampi((int)fu, -g.R, g.R), v = dev::clampi((int)fv, -g.R, g.R);
+            ws[j] = rrow[__mul24(v, D.w) + u];
+            r2[j] = (float)(__mul24(u, u) + __mul24(v, v));
+        }
+#pragma unroll
+        for (int j = 0; j < SBATCH; j++) {
+            const int ds = (int)(ws[j] & 255u);
+            const float bs = bokeh_radius(ds, g);
+            const bool take = (s0 + j < g.samples) && ((r2[j] < brs) || (ds < dxy)) && (r2[j] < bs * bs);
+            const float wgt = take ? 1.0f : 0.0f;
+            acc[0] = acc[0] + wgt * (float)((ws[j] >> 8) & 255u);
+            acc[1] = acc[1] + wgt * (float)((ws[j] >> 16) & 255u);
+            acc[2] = acc[2] + wgt * (float)(ws[j] >> 24);
+            acc[3] = acc[3] + wgt * 255.0f;
+        }
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -632,6 +665,9 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
 
     // ---- boxes (oracle/lens_blur_oracle.c); the pyramids' clamp extents come from left_im's extents (:57-61)
     Box D = {ox0 - g.R, oy0 - g.R, ow + 2 * g.R, oh + 2 * g.R};
+    if (D.w >= (1 << 23)) {   // lb_final addresses a sample's row with a 24-bit multiply
+        return report(uc, halide_error_code_buffer_extents_too_large, "Output buffer final is %d wide: at most %d columns are supported", ow, (1 << 23) - 1 - 2 * g.R);
+    }
     Box P[LV], PB[LV];
     P[0] = D;
     for (int i = 1; i < LV; i++) {
