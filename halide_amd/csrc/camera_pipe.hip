@@ -196,11 +196,24 @@ __global__ __launch_bounds__(256) void cp_demosaic_tile(const uint16_t *__restri
     const int QX0 = -1 + TQX * (int)blockIdx.x, QY0 = -1 + TQY * (int)blockIdx.y;   // quads start at fdiv(-1, 2) = -1
     s_curve[tid] = reinterpret_cast<const uint32_t *>(s->curve)[tid];
     const int rx0 = 2 * QX0 - 4, ry0 = 2 * QY0 - 4;   // raw window origin (even)
-    for (int i = tid; i < RH * RWD; i += 256) {
-        const int r = i / RWD, cdw = i - r * RWD;
-        const int x = rx0 + 2 * cdw, y = ry0 + r;
-        const bool ok = x >= -6 && x + 1 <= W + 5 && y >= -6 && y <= H + 5;
-        s_raw[r * RPD + cdw] = ok ? *reinterpret_cast<const uint32_t *>(raw + (long)y * in_sy + x) : 0u;
+    {
+        // the thread's window dwords are requested together (a loop waited for each before asking for the next); sites outside
+        // the raw image read its first dword and become 0
+        constexpr int N1 = (RH * RWD + 255) / 256;
+        uint32_t v[N1];
+        bool ok[N1];
+#pragma unroll
+        for (int k = 0; k < N1; k++) {
+            const int i = min(tid + 256 * k, RH * RWD - 1), r = i / RWD, cdw = i - r * RWD;
+            const int x = rx0 + 2 * cdw, y = ry0 + r;
+            ok[k] = x >= -6 && x + 1 <= W + 5 && y >= -6 && y <= H + 5;
+            v[k] = *reinterpret_cast<const uint32_t *>(raw + (ok[k] ? (long)y * in_sy + x : 0l));
+        }
+#pragma unroll
+        for (int k = 0; k < N1; k++) {
+            const int i = tid + 256 * k;
+            if (i < RH * RWD) s_raw[(i / RWD) * RPD + (i - (i / RWD) * RWD)] = ok[k] ? v[k] : 0u;
+        }
     }
     __syncthreads();
     // hot-pixel suppression (:240-250) on pixel pairs: clamped quad (i, j), pair cy -> raw window dword (i + 1, 2 j + cy + 2)

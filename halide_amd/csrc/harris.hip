@@ -28,11 +28,27 @@ __global__ __launch_bounds__(256) void harris_tile(const float *__restrict__ in,
     const int X0 = g.ox0 + blockIdx.x * TW, Y0 = g.oy0 + blockIdx.y * TH;
     // the last tiles poke past the output region: clamp their reads to the rows / columns the region itself needs
     const int xmax = g.ox0 + g.ow + 1, ymax = g.oy0 + g.oh + 1;
-    for (int i = tid; i < GW * GH; i += 256) {
-        const int r = i / GW, c = i - r * GW;
-        const int x = min(X0 - 2 + c, xmax) - g.ix0, y = min(Y0 - 2 + r, ymax) - g.iy0;
-        const float *p = in + (long)y * g.in_sy + x;
-        s_g[r * GP + c] = (0.299f * p[0] + 0.587f * p[g.in_sc]) + 0.114f * p[2 * g.in_sc];
+    {
+        // all of the thread's elements are requested before the first is used (as a loop, every iteration waited for its own
+        // three loads: six memory round trips in a row at the head of every workgroup)
+        constexpr int N1 = (GW * GH + 255) / 256;
+        float v[N1][3];
+#pragma unroll
+        for (int k = 0; k < N1; k++) {
+            const int i = min(tid + 256 * k, GW * GH - 1);
+            const int r = i / GW, c = i - r * GW;
+            const int x = min(X0 - 2 + c, xmax) - g.ix0, y = min(Y0 - 2 + r, ymax) - g.iy0;
+            const float *p = in + (long)y * g.in_sy + x;
+            v[k][0] = p[0], v[k][1] = p[g.in_sc], v[k][2] = p[2 * g.in_sc];
+        }
+#pragma unroll
+        for (int k = 0; k < N1; k++) {
+            const int i = tid + 256 * k;
+            if (i < GW * GH) {
+                const int r = i / GW, c = i - r * GW;
+                s_g[r * GP + c] = (0.299f * v[k][0] + 0.587f * v[k][1]) + 0.114f * v[k][2];
+            }
+        }
     }
     __syncthreads();
     const float a = -1.0f / 12, b = 1.0f / 12, c2 = -2.0f / 12, d = 2.0f / 12;

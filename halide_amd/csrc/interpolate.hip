@@ -79,9 +79,21 @@ __global__ __launch_bounds__(256) void ip_down0_tile(InGeom g, Lvl dst) {
     const int tid = threadIdx.x;
     const int tx0 = dst.x0 + blockIdx.x * I0W, ty0 = dst.y0 + blockIdx.y * I0H;
     const int ix0 = 2 * tx0 - 1, iy0 = 2 * ty0 - 1;
-    for (int i = tid; i < (2 * I0H + 1) * (2 * I0W + 1); i += 256) {
-        const int r = i / (2 * I0W + 1), c = i - r * (2 * I0W + 1);
-        s_in[r][c] = ds0(g, ix0 + c, iy0 + r);
+    {
+        // the thread's nine window pixels are all requested before the first is used (as a loop, every iteration waited for
+        // its own four channel loads: nine memory round trips in a row at the head of every workgroup)
+        constexpr int NW = (2 * I0H + 1) * (2 * I0W + 1), N1 = (NW + 255) / 256;
+        float4 v[N1];
+#pragma unroll
+        for (int k = 0; k < N1; k++) {
+            const int i = min(tid + 256 * k, NW - 1), r = i / (2 * I0W + 1), c = i - r * (2 * I0W + 1);
+            v[k] = ds0(g, ix0 + c, iy0 + r);
+        }
+#pragma unroll
+        for (int k = 0; k < N1; k++) {
+            const int i = tid + 256 * k;
+            if (i < NW) (&s_in[0][0])[i] = v[k];
+        }
     }
     __syncthreads();
     for (int i = tid; i < (2 * I0H + 1) * I0W; i += 256) {

@@ -32,11 +32,27 @@ __global__ __launch_bounds__(256) void unsharp_tile(const float *__restrict__ in
     __shared__ float s_by[TH * GP];
     const int tid = threadIdx.x;
     const int X0 = g.ox0 + blockIdx.x * TW, Y0 = g.oy0 + blockIdx.y * TH;   // absolute origin of the tile
-    for (int i = tid; i < GW * GH; i += 256) {
-        const int r = i / GW, c = i - r * GW;
-        const int x = min(max(X0 - R + c, g.ix0), g.ix0 + g.W - 1) - g.ix0, y = min(max(Y0 - R + r, g.iy0), g.iy0 + g.H - 1) - g.iy0;
-        const float *p = in + (long)y * g.in_sy + x;
-        s_gray[r * GP + c] = (0.299f * p[0] + 0.587f * p[g.in_sc]) + 0.114f * p[2 * g.in_sc];
+    {
+        // every element of the thread is requested before the first one is used: left as a loop, each of the 11 iterations
+        // waited for its own three loads — 11 memory round trips in a row at the head of every workgroup
+        constexpr int N1 = (GW * GH + 255) / 256;
+        float v[N1][3];
+#pragma unroll
+        for (int k = 0; k < N1; k++) {
+            const int i = min(tid + 256 * k, GW * GH - 1);
+            const int r = i / GW, c = i - r * GW;
+            const int x = min(max(X0 - R + c, g.ix0), g.ix0 + g.W - 1) - g.ix0, y = min(max(Y0 - R + r, g.iy0), g.iy0 + g.H - 1) - g.iy0;
+            const float *p = in + (long)y * g.in_sy + x;
+            v[k][0] = p[0], v[k][1] = p[g.in_sc], v[k][2] = p[2 * g.in_sc];
+        }
+#pragma unroll
+        for (int k = 0; k < N1; k++) {
+            const int i = tid + 256 * k;
+            if (i < GW * GH) {
+                const int r = i / GW, c = i - r * GW;
+                s_gray[r * GP + c] = (0.299f * v[k][0] + 0.587f * v[k][1]) + 0.114f * v[k][2];
+            }
+        }
     }
     __syncthreads();
     for (int i = tid; i < GW * TH; i += 256) {
@@ -45,18 +61,29 @@ __global__ __launch_bounds__(256) void unsharp_tile(const float *__restrict__ in
         s_by[r * GP + c] = ((g.k[0] * q[0] + g.k[1] * (q[-GP] + q[GP])) + g.k[2] * (q[-2 * GP] + q[2 * GP])) + g.k[3] * (q[-3 * GP] + q[3 * GP]);
     }
     __syncthreads();
-    for (int i = tid; i < TW * TH; i += 256) {
-        const int r = i / TW, c = i - r * TW;
+    static_assert((TW * TH) % 256 == 0, "whole passes");
+    constexpr int N3 = TW * TH / 256;
+    float px[N3][3];
+#pragma unroll
+    for (int k = 0; k < N3; k++) {   // the pixels themselves, all requested first (pixels past the region re-read its last one)
+        const int i = tid + 256 * k, r = i / TW, c = i - r * TW;
+        const int x = min((int)blockIdx.x * TW + c, g.ow - 1), y = min((int)blockIdx.y * TH + r, g.oh - 1);
+        const float *p = in + (long)(g.oy0 + y - g.iy0) * g.in_sy + (g.ox0 + x - g.ix0);
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) px[k][ch] = p[ch * g.in_sc];
+    }
+#pragma unroll
+    for (int k = 0; k < N3; k++) {
+        const int i = tid + 256 * k, r = i / TW, c = i - r * TW;
         const int x = blockIdx.x * TW + c, y = blockIdx.y * TH + r;
         if (x >= g.ow || y >= g.oh) continue;
         const float *q = s_by + r * GP + c + R;
         const float bx = ((g.k[0] * q[0] + g.k[1] * (q[-1] + q[1])) + g.k[2] * (q[-2] + q[2])) + g.k[3] * (q[-3] + q[3]);
         const float gr = s_gray[(r + R) * GP + c + R];
         const float ratio = (2.0f * gr - bx) / gr;
-        const float *p = in + (long)(g.oy0 + y - g.iy0) * g.in_sy + (g.ox0 + x - g.ix0);
         float *o = out + (long)y * g.out_sy + x;
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) o[ch * g.out_sc] = ratio * p[ch * g.in_sc];
+        for (int ch = 0; ch < 3; ch++) o[ch * g.out_sc] = ratio * px[k][ch];
     }
 }
 
