@@ -200,13 +200,23 @@ __global__ __launch_bounds__(NT) void nlm_7x7(const float *__restrict__ in, long
 //     lane's ten): no second read.
 // Per offset and lane: 30 LDS reads (the shifted operand), 6 DPP moves per output row, no LDS writes, no barrier; waves never
 // wait for each other after the window has been staged.
+// Round 3 — the kernel is VALU-issue bound (every instruction left is arithmetic of the algorithm: per pixel and offset 24.5
+// adds, 18.7 multiplies, 6.3 subtractions, 4 conversions at eight rows per wave; SQ_ACTIVE_INST_VALU ~ all cycles), so what
+// helps is fewer VALU instructions: XL takes the six DPP moves per value off the VALU (0.198 -> 0.177 ms), eight rows per wave
+// instead of four recompute fewer rows of d (14 / 8 instead of 10 / 4 per output row: -> 0.169 ms).  What did NOT help:
+// packed f32 arithmetic on pairs of offsets (v_pk_add_f32 / v_pk_mul_f32: 30 % fewer instructions, bit-exact, 0.212 ms — the
+// packed f32 operations do not issue at the scalar rate on this part), sixteen rows per wave (0.37 ms: registers).
 __device__ __forceinline__ float nl_lane_prev(float v) {  // value held by lane-1 (0 for lane 0): DPP wave_shr:1
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float nl_lane_next(float v) {  // value held by lane+1 (0 for lane 63): DPP wave_shl:1
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
-template<int TH, int ROWS = 4>
+// XL: the sum across columns reads the six neighbours' blur_d_y from a wave-private LDS row (the lanes of a wave run in lock
+// step and a wave's LDS operations complete in order) instead of six chained DPP moves per value: the VALU is the unit this
+// kernel saturates (79 instructions per pixel and offset, every issue cycle taken: profiles/r03_nlm_pmc.txt), the LDS pipe is not.
+constexpr int XSP = 64 + 2 * HALF;   // a wave's row: three columns of padding either side (their results are never used)
+template<int TH, int ROWS = 4, bool XL = false>
 __global__ __launch_bounds__(64 * TH / ROWS) void nlm_7x7w(const float *__restrict__ in, long in_sy, long in_sc, NGeom g,
                                                     float *__restrict__ out, long out_sy, long out_sc) {
     constexpr int NT = 64 * TH / ROWS, IH = TH + 4 * HALF;
@@ -225,6 +235,7 @@ __global__ __launch_bounds__(64 * TH / ROWS) void nlm_7x7w(const float *__restri
     const int lane = tid & 63, wave = tid >> 6;
     const int col = lane + HALF;             // window column of abs x = tx0 - 3 + lane
     const int row0 = ROWS * wave + HALF;     // window row of abs y = ty0 + ROWS * wave - 3
+    float *xs = lds + 3 * IH * IWP + wave * ROWS * XSP + HALF + lane;   // XL: this lane's column of the wave's rows
     float u[ROWS + 6][3];
 #pragma unroll
     for (int i = 0; i < ROWS + 6; i++) {
@@ -266,16 +277,35 @@ __global__ __launch_bounds__(64 * TH / ROWS) void nlm_7x7w(const float *__restri
                 for (int q = 1; q < 7; q++) sum = sum + d[o + q];
                 bdy[o] = sum;
             }
+            if (XL) {
+#pragma unroll
+                for (int o = 0; o < ROWS; o++) xs[o * XSP] = bdy[o];
+                // what the neighbours stored above is what the loads below return; the fences keep the compiler from moving
+                // one across the other
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
             // blur_d for output column lane - 3: blur_d_y of lanes lane - 3 .. lane + 3, leftmost first
 #pragma unroll
             for (int o = 0; o < ROWS; o++) {
-                const float r1 = nl_lane_prev(bdy[o]), r2 = nl_lane_prev(r1), r3 = nl_lane_prev(r2);
-                const float l1 = nl_lane_next(bdy[o]), l2 = nl_lane_next(l1), l3 = nl_lane_next(l2);
+                float r1, r2, r3, l1, l2, l3;
+                if (XL) {
+                    const float *n = xs + o * XSP;
+                    r3 = n[-3], r2 = n[-2], r1 = n[-1], l1 = n[1], l2 = n[2], l3 = n[3];
+                } else {
+                    r1 = nl_lane_prev(bdy[o]), r2 = nl_lane_prev(r1), r3 = nl_lane_prev(r2);
+                    l1 = nl_lane_next(bdy[o]), l2 = nl_lane_next(l1), l3 = nl_lane_next(l2);
+                }
                 const float sum = (((((r3 + r2) + r1) + bdy[o]) + l1) + l2) + l3;
                 const float w = dev::fast_exp(sum * g.inv);
 #pragma unroll
                 for (int c = 0; c < 3; c++) acc[o][c] = acc[o][c] + w * sh[o + HALF][c];
                 acc[o][3] = acc[o][3] + w * 1.0f;
+            }
+            if (XL) {   // the next offset's stores stay behind these loads
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
         }
     }
@@ -405,17 +435,28 @@ extern "C" int nl_means(halide_buffer_t *input, int32_t patch_size, int32_t sear
     } while (0)
 #define NLM_LAUNCH_W(TH_)                                                                                                     \
     do {                                                                                                                      \
-        const size_t sh_w = sizeof(float) * (size_t)3 * (TH_ + 4 * HALF) * IWP;                                               \
-        HLMI_HIP(uc, hipFuncSetAttribute((const void *)nlm_7x7w<TH_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_w)); \
+        const size_t sh_w = sizeof(float) * ((size_t)3 * (TH_ + 4 * HALF) * IWP + (xl ? (size_t)TH_ * XSP : 0));                 \
         dim3 grid((ow + TW - 1) / TW, (oh + TH_ - 1) / TH_);                                                                  \
-        HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, (nlm_7x7w<TH_>), grid, dim3(16 * TH_), sh_w, din, in_sy, in_sc, g, dout, out_sy, \
-                    out_sc);                                                                                                  \
+        if (xl) {                                                                                                             \
+            HLMI_HIP(uc, hipFuncSetAttribute((const void *)nlm_7x7w<TH_, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_w)); \
+            HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, (nlm_7x7w<TH_, 4, true>), grid, dim3(16 * TH_), sh_w, din, in_sy, in_sc, g, dout, out_sy, \
+                        out_sc);                                                                                              \
+        } else {                                                                                                              \
+            HLMI_HIP(uc, hipFuncSetAttribute((const void *)nlm_7x7w<TH_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_w)); \
+            HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, (nlm_7x7w<TH_>), grid, dim3(16 * TH_), sh_w, din, in_sy, in_sc, g, dout, out_sy, \
+                        out_sc);                                                                                              \
+        }                                                                                                                     \
     } while (0)
+        const char *xe = getenv("HLMI_NLM_XLDS");   // A/B: 0 = the column sum by DPP moves instead of a wave-private LDS row
+        const bool xl = !(xe && *xe == '0');
         const char *lk = getenv("HLMI_NLM_LDS");   // A/B: the kernel that hands blur_d_y through LDS (a barrier per offset)
-        if (getenv("HLMI_NLM_ROWS8")) {
-            const size_t sh_w = sizeof(float) * (size_t)3 * (32 + 4 * HALF) * IWP;
+        const char *r4 = getenv("HLMI_NLM_ROWS4");   // A/B: four rows per wave (512 threads) instead of eight (256)
+        const bool rows8 = getenv("HLMI_NLM_ROWS8") || (th == 32 && !(lk && *lk && *lk != '0') && !(r4 && *r4 && *r4 != '0'));
+        if (rows8) {
+            const size_t sh_w = sizeof(float) * ((size_t)3 * (32 + 4 * HALF) * IWP + (xl ? (size_t)32 * XSP : 0));
             dim3 grid((ow + TW - 1) / TW, (oh + 31) / 32);
-            HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, (nlm_7x7w<32, 8>), grid, dim3(256), sh_w, din, in_sy, in_sc, g, dout, out_sy, out_sc);
+            if (xl) HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, (nlm_7x7w<32, 8, true>), grid, dim3(256), sh_w, din, in_sy, in_sc, g, dout, out_sy, out_sc);
+            else HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, (nlm_7x7w<32, 8>), grid, dim3(256), sh_w, din, in_sy, in_sc, g, dout, out_sy, out_sc);
         } else
         if (!lk || !*lk || *lk == '0') {
             if (th == 16) NLM_LAUNCH_W(16);
