@@ -378,11 +378,16 @@ constexpr int BD = 6;          // B taps in flight
 constexpr int BSLOT = 4096;    // bf16 elements of one tap's B slot in LDS: [2 k-steps][4 co-fragments][64 lanes][8]
 // ABL: timing experiments (HLMI_CONVP_ABL=mask at run time, results wrong): 1 no output stores, 2 no K loop, 4 no B loads in
 // the loop, 8 no A loads in the loop, 16 no fragment reads, 32 no barriers, 64 no MFMAs, 128 no LDS staging writes
-template<int NP, int ABL = 0>  // A staging passes of 64 window rows (AR <= 64 NP)
-__global__ __launch_bounds__(PT) void conv3x3_bf16_p(const float *__restrict__ in, const uint16_t *__restrict__ wb,
+// HALF: 128-position tiles, four waves (256 threads), TWO workgroups per CU.  The 256-position kernel runs ONE round of one
+// workgroup per CU: its prologue (first A window + the B ring, ~6 us) and its epilogue (131 KB of stores, 2.4 us) are exposed,
+// 8.3 of 24.7 us with the matrix pipe idle.  Two independent half-size workgroups per CU have independent barriers: one's
+// staging, fragment reads and stores can sit under the other's MFMAs.
+template<int NP, int ABL = 0, bool HALF = false>  // A staging passes of PT / 8 window rows (AR <= PT / 8 * NP)
+__global__ __launch_bounds__(HALF ? 256 : 512) void conv3x3_bf16_p(const float *__restrict__ in, const uint16_t *__restrict__ wb,
                                                     const float *__restrict__ bias, float *__restrict__ out, CGeom g, int AR,
                                                     FastDiv d_img, FastDiv d_row, int stag) {
     extern __shared__ uint16_t smem[];                       // [A window 0][A window 1][B slot 0][B slot 1]
+    constexpr int TQ = HALF ? 128 : 256, PT = HALF ? 256 : 512, RPP = PT / 8, NBP = 512 / PT;   // shadow the file-scope pair
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wq = wave >> 1, wc = wave & 1;                 // the wave's 64 positions / 64 channels of the tile
@@ -407,31 +412,43 @@ __global__ __launch_bounds__(PT) void conv3x3_bf16_p(const float *__restrict__ i
             for (int r = 0; r < 16; r++) acc[a][b][r] = bv;
     }
     // ---- staging roles
-    const int aq = tid & 7, ap = tid >> 3;                   // A: float4 aq of the 32-ci chunk, window rows ap + 64 i
+    const int aq = tid & 7, ap = tid >> 3;                   // A: float4 aq of the 32-ci chunk, window rows ap + RPP i
     float4 va[NP];
     auto load_a = [&](int cc) {
 #pragma unroll
         for (int i = 0; i < NP; i++) {
-            const uint32_t q = min(Q0 + (uint32_t)(ap + 64 * i), NQ - 1);   // NQ CI < 2^31 elements
+            const uint32_t q = min(Q0 + (uint32_t)(ap + RPP * i), NQ - 1);   // NQ CI < 2^31 elements
             va[i] = *reinterpret_cast<const float4 *>(in + (q * (uint32_t)g.CI + (uint32_t)(cc * KL + 4 * aq)));
         }
     };
     auto store_a = [&](uint16_t *sA) {
 #pragma unroll
         for (int i = 0; i < NP; i++) {
-            if (ap + 64 * i < AR) {
+            if (ap + RPP * i < AR) {
                 uint2 w;
                 w.x = pk_bf16(va[i].x, va[i].y), w.y = pk_bf16(va[i].z, va[i].w);
-                *reinterpret_cast<uint2 *>(sA + (ap + 64 * i) * PL + 4 * aq) = w;
+                *reinterpret_cast<uint2 *>(sA + (ap + RPP * i) * PL + 4 * aq) = w;
             }
         }
     };
-    u32x4 rb[BD];                                            // B taps in flight
-    const uint32_t b_lane = (((uint32_t)(tid >> 8)) * ncot + cot0) * 512 + (uint32_t)(tid & 255) * 8;   // k-step tid >> 8
-    auto load_b = [&](int T, u32x4 &dst) {                   // T = chunk * 9 + kk; layout of conv_filter_bf16<2>
-        dst = *reinterpret_cast<const u32x4 *>(wb + ((uint32_t)T * 2 * ncot * 512 + b_lane));
+    struct BReg {
+        u32x4 v[NBP];
     };
-    auto store_b = [&](int slot, const u32x4 &src) { reinterpret_cast<u32x4 *>(sB + slot * BSLOT)[tid] = src; };
+    BReg rb[BD];                                             // B taps in flight: 512 16-byte pieces per tap, NBP per thread
+    uint32_t b_lane[NBP];
+#pragma unroll
+    for (int j = 0; j < NBP; j++) {
+        const uint32_t pc = (uint32_t)tid + (uint32_t)PT * j;   // piece: k-step pc >> 8
+        b_lane[j] = ((pc >> 8) * ncot + cot0) * 512 + (pc & 255) * 8;
+    }
+    auto load_b = [&](int T, BReg &dst) {                    // T = chunk * 9 + kk; layout of conv_filter_bf16<2>
+#pragma unroll
+        for (int j = 0; j < NBP; j++) dst.v[j] = *reinterpret_cast<const u32x4 *>(wb + ((uint32_t)T * 2 * ncot * 512 + b_lane[j]));
+    };
+    auto store_b = [&](int slot, const BReg &src) {
+#pragma unroll
+        for (int j = 0; j < NBP; j++) reinterpret_cast<u32x4 *>(sB + slot * BSLOT)[tid + PT * j] = src.v[j];
+    };
     // ---- fragments: two register sets, one per k-step of a tap
     bf16x8 fa[2][2], fb[2][2];
     const int a_lane = (64 * wq + (lane & 31)) * PL + 8 * (lane >> 5);
@@ -557,8 +574,8 @@ const halide_filter_metadata_t conv_md = {1, 4, conv_args, kTargetString, "conv_
 
 // ---- cache of re-ordered filters -------------------------------------------------------------------------------
 // One entry per (device, filter allocation, version, layout).  An entry is read by the main kernel of every call that hits
-// it, on whatever stream that call runs: the entry therefore remembers, per reader stream, an event recorded behind the last
-// main kernel enqueued there, and whoever re-fills or evicts the entry first orders its own stream behind all of them.  The
+// it, on whatever stream that call runs: the entry therefore remembers its reader streams, and whoever re-fills or evicts the
+// entry first records an event behind everything those streams hold and orders its own stream behind all of them.  The
 // cache lock is held from the lookup until the caller's main kernel has been enqueued and recorded (FilterUse), so an
 // entry can never be re-filled between a hit and the launch that reads it.  Filters in memory the runtime does not own
 // (version 0: wrapped pointers, e.g. every torch tensor) are never cached: their image lives in the calling stream's own
@@ -589,9 +606,15 @@ void wait_for_readers(FilterImage &e, hipStream_t consumer) {
     bool sync_all = e.overflow;
     for (auto &r : e.readers) {
         if (!r.live) continue;
-        if (r.s != consumer && wait_done(consumer, r.done) != hipSuccess) {
-            (void)hipGetLastError();
-            sync_all = true;   // e.g. the reader's stream was destroyed: nothing of it can still be pending, but be safe
+        if (r.s != consumer) {
+            // the reader's event is recorded NOW, behind everything its stream has been given so far (a record per call
+            // put a barrier packet between consecutive kernels of a stream: ~3 us of every 30 us call)
+            bool ok = r.done || hipEventCreateWithFlags(&r.done, hipEventDisableTiming) == hipSuccess;
+            ok = ok && record_done(r.done, r.s) == hipSuccess && wait_done(consumer, r.done) == hipSuccess;
+            if (!ok) {
+                (void)hipGetLastError();
+                sync_all = true;   // e.g. the reader's stream was destroyed: nothing of it can still be pending, but be safe
+            }
         }
         r.live = false;
     }
@@ -628,11 +651,8 @@ struct FilterUse {
                     if (!r.live) { slot = &r; break; }
                 }
             }
-            if (slot) {
-                if (!slot->done && hipEventCreateWithFlags(&slot->done, hipEventDisableTiming) != hipSuccess) slot = nullptr;
-            }
-            if (slot && record_done(slot->done, s) == hipSuccess) slot->s = s, slot->live = true;
-            else (void)hipGetLastError(), entry->overflow = true;
+            if (slot) slot->s = s, slot->live = true;   // the stream is remembered; wait_for_readers records behind it when needed
+            else entry->overflow = true;
         }
         entry = nullptr;
         if (lock.owns_lock()) lock.unlock();
@@ -721,7 +741,10 @@ extern "C" int conv_layer_bf16(halide_buffer_t *input, halide_buffer_t *filter, 
         const long NQ = (long)g.N * (g.H + 2) * (g.W + 2);
         const bool lin = AR <= 32 * 12 && NQ < (1L << 31) && NQ * g.CI < (1L << 31) && !getenv("HLMI_CONV_IM2COL");   // W <= 125
         // conv3x3_bf16_p: 256-position tiles, B through LDS (see the kernel); the older kernels stay for what it does not take
-        const int ARp = TQ + 2 * (g.W + 2) + 2;
+        const char *half_e = getenv("HLMI_CONVP_HALF");   // A/B: 128-position tiles, two workgroups per CU
+        const bool halfp = half_e && *half_e && *half_e != '0' && 128 + 2 * (g.W + 2) + 2 <= 32 * 8;
+        const int TQp = halfp ? 128 : TQ;
+        const int ARp = TQp + 2 * (g.W + 2) + 2;
         const size_t sh_p = ((size_t)2 * ARp * PL + 2 * BSLOT) * sizeof(uint16_t);   // two A windows, two B slots
         const bool pers = lin && ARp <= 64 * 8 && sh_p <= 160 * 1024 && g.CO % TC == 0 && g.CI % (2 * KL) == 0 &&
                           !getenv("HLMI_CONV_OLD");
@@ -747,13 +770,18 @@ extern "C" int conv_layer_bf16(halide_buffer_t *input, halide_buffer_t *filter, 
         }
         const FastDiv d_img = make_fastdiv((uint32_t)((g.H + 2) * (g.W + 2))), d_row = make_fastdiv((uint32_t)(g.W + 2));
         if (pers) {
-            dim3 grid((unsigned)((NQ + TQ - 1) / TQ), g.CO / TC);
+            dim3 grid((unsigned)((NQ + TQp - 1) / TQp), g.CO / TC);
             timing_note_bytes(4.0 * ((double)NQ * g.CI + (double)g.npix * g.CO) + (double)wb_bytes);
             const char *stag_e = getenv("HLMI_CONVP_STAG");
             const int stag = stag_e ? atoi(stag_e) : 1;
             const char *abl_e = getenv("HLMI_CONVP_ABL");
             const int abl = abl_e ? atoi(abl_e) : 0;
-            if (ARp <= 64 * 6 && abl >= 1) {
+            if (halfp) {
+                HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_p<8, 0, true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_p));
+                HLMI_LAUNCH(uc, "conv3x3_bf16_mfma", ctx.stream, (conv3x3_bf16_p<8, 0, true>), grid, dim3(256), sh_p, dev_ptr<float>(input), wb,
+                            dev_ptr<float>(bias), dev_ptr<float>(relu), g, ARp, d_img, d_row, stag);
+            } else if (ARp <= 64 * 6 && abl >= 1) {
 #define CONVP_ABL(n)                                                                                                         \
     case n:                                                                                                                  \
         HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_p<6, n>),                              \

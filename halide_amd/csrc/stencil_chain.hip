@@ -153,12 +153,14 @@ __global__ __launch_bounds__(256) void stencil_fused8w(const uint16_t *__restric
 // what the edge lanes / edge rows make of their missing neighbours is garbage that moves inwards 2 pixels per stage — the
 // shrinking valid box — and is never stored.  RW = 32: 96 x 96 outputs per workgroup (1.78x halo recomputation instead of the
 // LDS version's 2.0x), 476 workgroups at 1536 x 2560.
-template<bool CLAMP, bool PIN, bool POUT, int RW>
-__global__ __launch_bounds__(256) void stencil_fused8r(const uint16_t *__restrict__ src, long src_sy, int sx0, int sy0, int sw,
+// NW waves of RW rows: 4 x 32 and 8 x 16 make the same 128-row window; eight thinner waves double the waves per SIMD (the
+// workgroup count is fixed by the tile, 476 at 1536 x 2560: 1.9 waves per SIMD with four) at twice the exchanges.
+template<bool CLAMP, bool PIN, bool POUT, int RW, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void stencil_fused8r(const uint16_t *__restrict__ src, long src_sy, int sx0, int sy0, int sw,
                                                        int sh, uint16_t *__restrict__ dst, long dst_sy, int dx0, int dy0,
                                                        int dw, int dh) {
-    constexpr int WR = 4 * RW, OR = WR - 4 * FUSE;                       // window rows, output rows
-    __shared__ uint32_t xch[2][4][4][64];                                // [stage parity][wave][top0, top1, bot0, bot1][lane]
+    constexpr int WR = NW * RW, OR = WR - 4 * FUSE;                      // window rows, output rows
+    __shared__ uint32_t xch[2][NW][4][64];                                // [stage parity][wave][top0, top1, bot0, bot1][lane]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ox = dx0 + blockIdx.x * WTW, oy = dy0 + blockIdx.y * OR;   // absolute coords of the output tile
@@ -211,10 +213,10 @@ __global__ __launch_bounds__(256) void stencil_fused8r(const uint16_t *__restric
         __syncthreads();
         // rows -2, -1 (the wave above's bottom rows) and RW, RW + 1 (the wave below's top rows); the first / last wave of the
         // window has no such neighbour: zeros, i.e. garbage in rows that are outside the valid box anyway
-        const int wu = max(wave - 1, 0), wd = min(wave + 1, 3);
+        const int wu = max(wave - 1, 0), wd = min(wave + 1, NW - 1);
         uint32_t p2 = x[wu][2][lane], p1 = x[wu][3][lane], b0 = x[wd][0][lane], b1 = x[wd][1][lane];
         if (wave == 0) p2 = 0u, p1 = 0u;
-        if (wave == 3) b0 = 0u, b1 = 0u;
+        if (wave == NW - 1) b0 = 0u, b1 = 0u;
 #pragma unroll
         for (int r = 0; r < RW; r++) {
             const uint32_t cur = R[r];
@@ -324,8 +326,13 @@ extern "C" int stencil_chain(halide_buffer_t *input, halide_buffer_t *output) {
 HLMI_LAUNCH(uc, "stencil_fused8", ctx.stream, (stencil_fused8w<C, I, O>), gridw, dim3(256), 0, src, src_sy, sx0, sy0, sw, sh, dst, \
             dst_sy, dx0, dy0, dw, dh)
 #define SC_R(C, I, O)                                                                                                          \
-HLMI_LAUNCH(uc, "stencil_fused8", ctx.stream, (stencil_fused8r<C, I, O, RW>), gridr, dim3(256), 0, src, src_sy, sx0, sy0, sw, sh, dst, \
-            dst_sy, dx0, dy0, dw, dh)
+do {                                                                                                                           \
+    if (thin) HLMI_LAUNCH(uc, "stencil_fused8", ctx.stream, (stencil_fused8r<C, I, O, 16, 8>), gridr, dim3(512), 0, src, src_sy, sx0, sy0, sw, \
+                          sh, dst, dst_sy, dx0, dy0, dw, dh);                                                                   \
+    else HLMI_LAUNCH(uc, "stencil_fused8", ctx.stream, (stencil_fused8r<C, I, O, RW>), gridr, dim3(256), 0, src, src_sy, sx0, sy0, sw, sh, dst, \
+                     dst_sy, dx0, dy0, dw, dh);                                                                                \
+} while (0)
+        const bool thin = getenv("HLMI_SC_THIN") != nullptr;   // A/B: eight waves of 16 rows instead of four of 32
         if (regs) {
             if (L == 0) {
                 if (pin) { if (pout) SC_R(true, true, true); else SC_R(true, true, false); }
