@@ -399,6 +399,85 @@ __global__ __launch_bounds__(256) void lb_cost_down(const uint8_t *__restrict__ 
     }
 }
 
+// lb_cost_down2: the same walk, TWO source rows per step by 512 threads (threads 0..255 the even row, 256..511 the odd one).
+// lb_cost_down holds a pixel's cost stack AND the y-pass state of 17 (plane, column) slots per thread: 192 registers, two
+// waves per SIMD, and the VALU idles a third of the time behind LDS round trips.  With twice the threads a thread keeps 9
+// slots, a step makes one even and one odd row (exactly one `t = a + 3 (b + d)` and one output per slot), and a CU holds
+// sixteen waves.
+template<int SB, bool FULL>
+__global__ __launch_bounds__(512) void lb_cost_down2(const uint8_t *__restrict__ L, const uint8_t *__restrict__ Rr, LBGeom g,
+                                                    float *__restrict__ dst, Box db, int NDX, int NDY) {
+    extern __shared__ __align__(16) float s_row[];   // [2 rows][slices + 1][CD_RP]
+    __shared__ uint2 sr[2][2][256 + 2 * SB];         // [buffer][row of the pair][pixel] (sized by SB: two workgroups per CU at 32)
+    constexpr int KPT = ((SB + 1) * 127 + 511) / 512;
+    const int tid = threadIdx.x, t = tid & 255, half = tid >> 8, zc = g.slices + 1;
+    const int dx0 = db.x0 + blockIdx.x * NDX, dy0 = db.y0 + blockIdx.y * NDY;
+    const int ndx = min(NDX, db.x0 + db.w - dx0), ndy = min(NDY, db.y0 + db.h - dy0);
+    const int sx0 = 2 * dx0 - 1, sy0 = 2 * dy0 - 1, nsx = 2 * ndx + 2, nsteps = ndy + 1, nr = nsx + 2 * g.slices;
+    const int total = zc * ndx, rowsz = zc * CD_RP;
+    int qoff[KPT], doff[KPT];
+    float p0[KPT], p1[KPT], p2[KPT];
+#pragma unroll
+    for (int k = 0; k < KPT; k++) {
+        const int idx = tid + 512 * k, p = idx < total ? idx / ndx : 0, xl = idx < total ? idx - p * ndx : 0;
+        qoff[k] = p * CD_RP + 2 * xl;
+        doff[k] = idx < total ? (int)((size_t)p * db.h * db.w) + (dx0 - db.x0) + xl : -1;
+        p0[k] = p1[k] = p2[k] = 0.0f;
+    }
+    const int lxo = dev::clampi(sx0 + t, g.lx0, g.lx1) - g.lx0;
+    const int rxo0 = dev::clampi(sx0 + t, g.rx0, g.rx1) - g.rx0, rxo1 = dev::clampi(sx0 + t + 256, g.rx0, g.rx1) - g.rx0;
+    uint8_t nl[3], nr0[3], nr1[3];
+    auto fetch = [&](int step) {   // this thread's row of the pair: source row 2 step + half of the segment
+        const int y = sy0 + 2 * step + half;
+        const long lo = (long)(dev::clampi(y, g.ly0, g.ly1) - g.ly0) * g.l_sy, ro = (long)(dev::clampi(y, g.ry0, g.ry1) - g.ry0) * g.r_sy;
+#pragma unroll
+        for (int c = 0; c < 3; c++) nl[c] = L[lo + lxo + g.l_c[c]], nr0[c] = Rr[ro + rxo0 + g.r_c[c]], nr1[c] = Rr[ro + rxo1 + g.r_c[c]];
+    };
+    auto stage = [&](int b) {
+        sr[b][half][t] = lb_pack(nr0[0], nr0[1], nr0[2]);
+        if (t + 256 < nr) sr[b][half][t + 256] = lb_pack(nr1[0], nr1[1], nr1[2]);
+    };
+    fetch(0);
+    stage(0);
+    CostRow cur = {(uint32_t)nl[0] | (uint32_t)nl[1] << 16, (int)nl[2]};
+    __syncthreads();
+    for (int st = 0; st < nsteps; st++) {
+        if (st + 1 < nsteps) fetch(st + 1);
+        if (t < nsx) {
+            float cz[SB];
+            const float conf = cost_stack<SB, FULL>(sr[st & 1][half], t, cur, g, cz);
+            float *row = s_row + half * rowsz;
+#pragma unroll
+            for (int z = 0; z < SB; z++)
+                if (FULL || z < g.slices) row[z * CD_RP + t] = cz[z] * conf;
+            row[g.slices * CD_RP + t] = conf;
+        }
+        __syncthreads();
+        {
+            // the even row (tap 0 of an output row, tap 2 of the one before): t = a + 3 (b + d), a = d; then the odd row
+            // (tap 3 / tap 1): the output (t + d) / 8 is complete, b = d
+            const bool emit = st >= 1;
+            float *drow = dst + (size_t)(dy0 - db.y0 + st - 1) * db.w;
+#pragma unroll
+            for (int k = 0; k < KPT; k++) {   // slots past the end read LDS offset 0 and store nothing
+                const float2 ea = *(const float2 *)&s_row[qoff[k]], eb = *(const float2 *)&s_row[qoff[k] + 2];
+                const float2 oa = *(const float2 *)&s_row[rowsz + qoff[k]], ob = *(const float2 *)&s_row[rowsz + qoff[k] + 2];
+                const float de = (ea.x + 3.0f * (ea.y + eb.x) + eb.y) * 0.125f;
+                const float dd = (oa.x + 3.0f * (oa.y + ob.x) + ob.y) * 0.125f;
+                p2[k] = p0[k] + 3.0f * (p1[k] + de);
+                p0[k] = de;
+                if (emit && doff[k] >= 0) drow[doff[k]] = (p2[k] + dd) * 0.125f;
+                p1[k] = dd;
+            }
+        }
+        if (st + 1 < nsteps) {
+            stage((st + 1) & 1);
+            cur = {(uint32_t)nl[0] | (uint32_t)nl[1] << 16, (int)nl[2]};
+        }
+        __syncthreads();
+    }
+}
+
 template<int SB, bool FULL>
 __global__ __launch_bounds__(256) void lb_depth_rc(const uint8_t *__restrict__ L, const uint8_t *__restrict__ Rr, const float *__restrict__ pull1, Box P1,
                                                   LBGeom g, Box D, uint32_t *__restrict__ rec, float *__restrict__ br) {
@@ -745,7 +824,20 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
             HLMI_HIP(uc, hipFuncSetAttribute((const void *)lb_cost_down<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HLMI_HIP(uc, hipFuncSetAttribute((const void *)lb_cost_down<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
-        LB_DISPATCH(lb_cost_down, grid, dim3(256), lds, dl, dr, g, push[1], PB[1], ndx, ndy);
+        const char *two = getenv("HLMI_LB_ROWS2");   // two source rows per step, 512 threads (default up to 32 slices; 0 / 1: A/B)
+        if (two && *two ? *two != '0' : !s64) {
+            const size_t lds2 = 2 * lds;
+            if (s64) {
+                HLMI_HIP(uc, hipFuncSetAttribute((const void *)lb_cost_down2<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+                HLMI_HIP(uc, hipFuncSetAttribute((const void *)lb_cost_down2<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            } else {
+                HLMI_HIP(uc, hipFuncSetAttribute((const void *)lb_cost_down2<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+                HLMI_HIP(uc, hipFuncSetAttribute((const void *)lb_cost_down2<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            }
+            LB_DISPATCH(lb_cost_down2, grid, dim3(512), lds2, dl, dr, g, push[1], PB[1], ndx, ndy);
+        } else {
+            LB_DISPATCH(lb_cost_down, grid, dim3(256), lds, dl, dr, g, push[1], PB[1], ndx, ndy);
+        }
     } else {
         LB_DISPATCH(lb_cost, dim3((E.w + 255) / 256, E.h), dim3(256), 0, dl, dr, g, E, push[0]);
     }

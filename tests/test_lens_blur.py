@@ -201,6 +201,8 @@ def test_hip_front_ends_agree_with_the_oracle(hl, oracle, monkeypatch, unfused, 
     compile-time bound of the cost stack (32, 64)."""
     if unfused:
         monkeypatch.setenv("HLMI_LB_UNFUSED", "1")
+    elif (w + h) % 2:
+        monkeypatch.setenv("HLMI_LB_ROWS2", "0" if slices <= 32 else "1")   # the other front-end kernel than the default
     for ndy in ("", "3", "16"):
         if ndy:
             monkeypatch.setenv("HLMI_LB_NDY", ndy)
