@@ -41,6 +41,19 @@ for name in ("bench.json", "bench_1stream.json", "bench_2streams.json", "bench_d
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f"{rnd}_{name}"))
 
+for name in ("apps_pmc.txt", "membench.log", "pmc_widths.txt", "pmc_ll_tcc.txt", "membench_sweep_1024MB.json"):   # scripts/gpu_r3_evidence.sh
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, f"{rnd}_{name}"))
+ka = glob.glob(os.path.join(src, "kt_apps", "*kernel_stats.csv"))
+if ka:
+    with open(ka[0]) as f, open(os.path.join(dst, f"{rnd}_apps_kernel_stats.csv"), "w") as g:
+        w = csv.writer(g)
+        for i, row in enumerate(csv.reader(f)):
+            if i:
+                row[0] = short(row[0])
+            w.writerow(row)
+
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     for p in glob.glob(os.path.join(src, f"pmc_{ctr}", "*counter_collection.csv")):
