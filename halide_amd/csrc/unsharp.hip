@@ -17,7 +17,7 @@ using namespace hlmi;
 
 namespace {
 
-constexpr int TW = 64, TH = 32, R = 3;
+constexpr int TW = 128, TH = 32, R = 3;
 constexpr int GW = TW + 2 * R, GH = TH + 2 * R, GP = GW + 1;   // gray window and its LDS pitch
 
 struct UGeom {
