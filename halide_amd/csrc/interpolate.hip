@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void ip_down(InGeom g, Lvl src, Lvl dst, int c
 // downsampled[1] from the input, tiled: a workgroup makes 32 x 16 cells; their 65 x 33 window of downsampled[0] (the input,
 // premultiplied by alpha, edge-clamped) goes through LDS once — every input pixel is a tap of up to four cells and a planar
 // load of four channels — then the (1 2 1) pass in x and in y, as down_value does them.
-constexpr int I0W = 32, I0H = 16;
+constexpr int I0W = 64, I0H = 8;
 __global__ __launch_bounds__(256) void ip_down0_tile(InGeom g, Lvl dst) {
     __shared__ float4 s_in[2 * I0H + 1][2 * I0W + 1];
     __shared__ float4 s_dx[2 * I0H + 1][I0W];
