@@ -55,21 +55,41 @@ def synth_frame(seed, w=W, h=H, kind="smooth"):
 
 
 def cpu_baseline(frame):
-    """The CPU oracle (kind "port": restated algorithm, OpenMP, untuned schedule — NOT Halide's tuned CPU
-    schedule, which cannot be built here) timed on the host cores on a bounded sample of the same workload."""
+    """The tuned CPU evaluation of the oracle's algorithm (oracle/local_laplacian_fast_oracle.c: the oracle's operations
+    in the oracle's order — tests/test_local_laplacian.py pins the two bit for bit — with level 0 of the processed pyramid
+    computed at its consumer, the colour stage fused, buffers kept between calls; OpenMP over all host threads) timed on
+    a bounded sample of the same workload.  kind "port": NOT Halide's own x86 schedule, which cannot be built here (the
+    generator quotes 184 Mpx/s on 16 cores for it, local_laplacian_generator.cpp:139-140)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib  # cpu_baseline leg only
-    cores = os.cpu_count() or 1
-    oracle_lib.local_laplacian(frame, LEVELS, ALPHA, BETA)  # warm
+    ncpu = os.cpu_count() or 1
+    oracle_lib.local_laplacian_fast(frame, LEVELS, ALPHA, BETA)  # warm (first touch of the arena)
+    # the thread count that runs fastest on this host (the pyramid's small levels do not feed 256 threads)
+    best_t, best_dt = ncpu, None
+    for t in sorted({t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu}):
+        oracle_lib.set_threads(t)
+        oracle_lib.local_laplacian_fast(frame, LEVELS, ALPHA, BETA)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            oracle_lib.local_laplacian_fast(frame, LEVELS, ALPHA, BETA)
+        d = (time.perf_counter() - t0) / 3
+        if best_dt is None or d < best_dt:
+            best_t, best_dt = t, d
+    oracle_lib.set_threads(best_t)
     n, t0 = 0, time.perf_counter()
     while True:
-        oracle_lib.local_laplacian(frame, LEVELS, ALPHA, BETA)
+        oracle_lib.local_laplacian_fast(frame, LEVELS, ALPHA, BETA)
         n += 1
         dt = time.perf_counter() - t0
-        if dt > 12.0 or n >= 12:
+        if dt > 10.0 or n >= 256:
             break
-    return {"value": round(n * W * H / dt / 1e6, 3), "unit": "Mpx/s", "cores": cores, "kind": "port",
-            "sample": f"{n} frames of {W}x{H} u16 RGB in {dt:.2f} s (OpenMP, all host threads)"}
+    oracle_lib.set_threads(0)
+    plain0 = time.perf_counter()
+    oracle_lib.local_laplacian(frame, LEVELS, ALPHA, BETA)
+    plain = time.perf_counter() - plain0
+    return {"value": round(n * W * H / dt / 1e6, 3), "unit": "Mpx/s", "cores": best_t, "kind": "port",
+            "sample": f"{n} frames of {W}x{H} u16 RGB in {dt:.2f} s (tuned CPU evaluation, OpenMP; {best_t} threads = the fastest of "
+                      f"8..{ncpu} on this host; the plain oracle on all {ncpu}: {W * H / plain / 1e6:.1f} Mpx/s)"}
 
 
 def stub_main(args, rank, local_rank, world):

@@ -44,6 +44,11 @@ _lib.oracle_ll_remap_lut.argtypes = [C.c_int, C.c_float, _f32p]
 _lib.oracle_local_laplacian.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_float, C.c_float, _u16p, C.c_int, C.c_int, C.c_int, C.c_void_p]
 _lib.oracle_local_laplacian.restype = C.c_int
+_lib.oracle_local_laplacian_fast.argtypes = [_u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_float, C.c_float, _u16p, C.c_int, C.c_int]
+_lib.oracle_local_laplacian_fast.restype = C.c_int
+_lib.oracle_set_threads.argtypes = [C.c_int]
+_lib.oracle_set_threads.restype = None
 
 
 def halide_exp(x: float) -> float:
@@ -102,6 +107,23 @@ def local_laplacian(inp: np.ndarray, levels: int, alpha: float, beta: float, J: 
     assert r == 0
     return out
 
+
+
+def set_threads(n: int) -> None:
+    """OpenMP threads of the oracle library from now on (n <= 0: the default, every processor)."""
+    _lib.oracle_set_threads(int(n))
+
+
+def local_laplacian_fast(inp: np.ndarray, levels: int, alpha: float, beta: float, J: int = 8, origin=(0, 0)) -> np.ndarray:
+    """The tuned CPU evaluation (oracle/local_laplacian_fast_oracle.c): same operations, CPU-friendly schedule; the
+    cpu_baseline leg of bench.py times this one, tests/test_local_laplacian.py pins it to the oracle bit for bit."""
+    inp = np.ascontiguousarray(inp, np.uint16)
+    c, h, w = inp.shape
+    assert c == 3
+    out = np.zeros_like(inp)
+    r = _lib.oracle_local_laplacian_fast(inp, w, h, w, w * h, int(origin[0]), int(origin[1]), J, levels, alpha, beta, out, w, w * h)
+    assert r == 0
+    return out
 
 
 def local_laplacian_outg(inp: np.ndarray, levels: int, alpha: float, beta: float, level: int, J: int = 8,

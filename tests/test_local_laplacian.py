@@ -127,6 +127,21 @@ def test_oracle_matches_naive_pure_function_evaluator(oracle, w, h, levels):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("w,h,levels,J,origin,beta", [(64, 48, 8, 8, (0, 0), 1.0), (333, 201, 8, 8, (-5, 7), 1.0), (1, 1, 2, 8, (0, 0), 1.0),
+                                                       (130, 67, 9, 5, (3, -2), 0.75), (257, 129, 3, 2, (0, 0), 1.5), (77, 300, 20, 8, (11, 13), 1.0)])
+def test_tuned_cpu_evaluation_equals_the_oracle(oracle, w, h, levels, J, origin, beta):
+    """oracle/local_laplacian_fast_oracle.c (what bench.py's cpu_baseline times) computes the oracle's operations in the
+    oracle's order under a CPU-friendly schedule: bit for bit the same image, also when called again with another size
+    (its arena is kept between calls)."""
+    rng = np.random.default_rng(w * 7 + h + levels)
+    inp = rng.integers(0, 65536, (3, h, w), dtype=np.uint16)
+    alpha = np.float32(1.0 / (levels - 1))
+    want = oracle.local_laplacian(inp, levels, alpha, np.float32(beta), J=J, origin=origin)
+    for _ in range(2):
+        got = oracle.local_laplacian_fast(inp, levels, alpha, np.float32(beta), J=J, origin=origin)
+        assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} of {got.size} differ"
+
+
 def test_oracle_alpha0_beta1_is_identity_within_one_lsb(oracle):
     # remap == 0 and beta == 1 make every processed pyramid equal to the input pyramid, so the collapse
     # reconstructs gray and the recolouring returns the input (up to float rounding -> <= 1 LSB)
