@@ -125,7 +125,9 @@ HLMI_DECLARE_AUX(iir_blur)
  * stereo (cost volume of `slices` disparities, confidence-weighted 8-level push-pull), depth-dependent bokeh from
  * `aperture_samples` pseudo-random samples per pixel.  Adjacent app, same boundary.  The sample
  * positions are Halide's random_float(): a fixed hash whose "definition tag" is a counter of the reference's COMPILER that
- * cannot be observed without it — see hlmi_lens_blur_set_random_tag below and oracle/lens_blur_oracle.c. */
+ * cannot be observed without it — see hlmi_lens_blur_set_random_tag below and oracle/lens_blur_oracle.c.
+ * Limit of this implementation: the output plus its blur radius on either side must be narrower than 2^23 columns
+ * (halide_error_code_buffer_extents_too_large otherwise). */
 int lens_blur(struct halide_buffer_t *left_im, struct halide_buffer_t *right_im, int32_t slices, int32_t focus_depth,
               float blur_radius_scale, int32_t aperture_samples, struct halide_buffer_t *final);
 HLMI_DECLARE_AUX(lens_blur)
