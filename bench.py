@@ -134,6 +134,8 @@ def main():
                          "disjoint quarters of the chip by default), one frame per partition at a time: frames are "
                          "independent units, so the latency-bound coarse pyramid levels of one frame run beside the large "
                          "kernels of the others instead of competing with them; 0 = plain streams (--streams)")
+    ap.add_argument("--streams-per-partition", type=int, default=int(os.environ.get("HLMI_BENCH_SPP", "1")),
+                    help="streams on each CU partition: with 2, one frame's short launch chain runs under the other's large kernels")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("HLMI_BENCH_STREAMS", "2")),
                     help="with --partitions 0: plain HIP streams the frames of a step are spread over")
     args = ap.parse_args()
@@ -193,8 +195,9 @@ def main():
 
     streams, keep, mode = [], [], "1 stream"
     if args.partitions > 1:
-        streams = [hl.partition_stream(p, args.partitions) for p in range(args.partitions)]
-        mode = f"{args.partitions} CU-partitioned streams"
+        spp = max(1, args.streams_per_partition)
+        streams = [hl.partition_stream(p, args.partitions, r) for r in range(spp) for p in range(args.partitions)]
+        mode = f"{args.partitions} CU-partitioned streams" + (f" x {spp}" if spp > 1 else "")
         if not all(streams):
             streams = []            # the device refused a CU mask: plain streams instead
     if not streams and args.streams > 1:

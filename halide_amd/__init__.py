@@ -234,11 +234,12 @@ def set_stream(stream_ptr: int | None) -> None:
     lib.halide_hip_set_stream(C.c_void_p(stream_ptr or 0))
 
 
-def partition_stream(part: int, nparts: int) -> int | None:
-    """hipStream_t of partition `part` of `nparts` disjoint CU partitions (include/hlmi_runtime.h), or None."""
-    lib.halide_hip_partition_stream.restype = C.c_void_p
-    lib.halide_hip_partition_stream.argtypes = [C.c_int, C.c_int]
-    return lib.halide_hip_partition_stream(int(part), int(nparts))
+def partition_stream(part: int, nparts: int, replica: int = 0) -> int | None:
+    """hipStream_t of partition `part` of `nparts` disjoint CU partitions (include/hlmi_runtime.h), or None; `replica` > 0:
+    a further stream on the same compute units."""
+    lib.halide_hip_partition_stream_replica.restype = C.c_void_p
+    lib.halide_hip_partition_stream_replica.argtypes = [C.c_int, C.c_int, C.c_int]
+    return lib.halide_hip_partition_stream_replica(int(part), int(nparts), int(replica))
 
 
 def kernel_timing(enable: bool) -> None:

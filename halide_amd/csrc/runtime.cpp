@@ -439,7 +439,7 @@ static int note_use(void *uc, const DeviceCtx &ctx, uint64_t handle, const char 
     return 0;
 }
 
-static std::map<std::tuple<int, int, int>, hipStream_t> g_part_streams;   // (device, part, nparts) -> stream (under g_mu)
+static std::map<std::tuple<int, int, int, int>, hipStream_t> g_part_streams;   // (device, part, nparts, replica) -> stream (under g_mu)
 static std::unordered_map<hipStream_t, int> g_part_cus;                    // partition stream -> its number of CUs
 
 // compute units a launch on `stream` can use: the partition's share for a library-owned partition stream, else the device's
@@ -1326,12 +1326,16 @@ void halide_hip_set_stream(void *stream) { t_stream_override = (hipStream_t)stre
 // long kernels of the others instead of being starved by them (measured on MI355X, local_laplacian 4K: 4 partitions
 // 114-118 us per frame against 120-147 us on two unmasked streams; single-XCD partitions (8) are slower).
 // Streams are created once per (device, part, nparts) and owned by the library.  Returns NULL on failure.
-void *halide_hip_partition_stream(int part, int nparts) {
+void *halide_hip_partition_stream(int part, int nparts) { return halide_hip_partition_stream_replica(part, nparts, 0); }
+
+// Several streams on the SAME compute units (replica 0, 1, ..): two frames in flight on a partition keep its CUs busy with
+// one frame's large kernels while the other's short launch chain (six latency-bound kernels of a few microseconds) runs.
+void *halide_hip_partition_stream_replica(int part, int nparts, int replica) {
     DeviceCtx ctx;
-    if (nparts < 1 || part < 0 || part >= nparts || acquire_device(nullptr, &ctx, false)) return nullptr;
+    if (nparts < 1 || part < 0 || part >= nparts || replica < 0 || replica > 15 || acquire_device(nullptr, &ctx, false)) return nullptr;
     std::lock_guard<std::mutex> lock(g_mu);
     auto &streams = g_part_streams;
-    auto key = std::make_tuple(ctx.device, part, nparts);
+    auto key = std::make_tuple(ctx.device, part, nparts, replica);
     auto it = streams.find(key);
     if (it != streams.end()) return (void *)it->second;
     int ncu = 0;

@@ -112,6 +112,8 @@ void *halide_hip_get_stream(void *user_context);
  * (every nparts-th bit of the CU mask; hipExtStreamCreateWithCUMask).  For batches of independent frames: one frame per
  * partition at a time keeps the frames from slowing each other down.  NULL if the device refuses.  No reference counterpart. */
 void *halide_hip_partition_stream(int part, int nparts);
+/* another stream on the same compute units as partition `part` (replica 0 is halide_hip_partition_stream's) */
+void *halide_hip_partition_stream_replica(int part, int nparts, int replica);
 
 /* ---- in-process frame sharder (no reference counterpart: the reference has no multi-device layer,
  * its building block is the per-thread halide_set_gpu_device above) ------------------------------------------
