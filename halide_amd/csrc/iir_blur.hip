@@ -398,15 +398,15 @@ const halide_filter_metadata_t ib_md = {1, 3, ib_args, kTargetString, "iir_blur"
 
 }  // namespace
 
-extern "C" int hlmi_debug_iir_probe(unsigned long long *out16) {   // 32 counters
+extern "C" int hlmi_debug_iir_probe(unsigned long long *out32) {   // 32 counters (probe builds only)
 #if HLMI_IIR_PROBE
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_iprobe), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_iprobe), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
     unsigned long long zero[32] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_iprobe), zero, sizeof zero) != hipSuccess) return -1;
     return 1;
 #else
-    (void)out16;
+    (void)out32;
     return 0;
 #endif
 }
