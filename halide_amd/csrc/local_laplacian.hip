@@ -808,9 +808,11 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry 
     // coarse columns (X + 1) / 2 and (X - 1) / 2; li = that pixel's level, :66) or of the coarse pixel itself (outLPyramid[1],
     // :63-72).  A wave holds exactly those pixels when it finishes level-1 row T (level-0 rows 2T - 1 .. 2T + 2 of all its
     // lanes — all four rows count: dropping row 2T + 2 from the set fails the parity suite —; the stored pairs of lanes < S2
-    // are read from columns its own lanes hold), so it stores a plane only if some lane's set asks for it — wave-uniform, whole 512-byte row
-    // pieces: two to four of the eight planes on natural images (-45 of 75 MB written per 4K frame; the frame rate on
-    // partitioned streams is set by bytes, profiles/r03b_traffic_ablation.txt), all eight on noise.  l = 4 x table position of
+    // are read from columns its own lanes hold), so it stores a plane only if some lane's set asks for it — per 16-lane row of the
+    // wave (mask1 = 2: the sets of the row's lanes and of the lane either side of it, OR-ed by four DPP row rotations; one
+    // 128-byte line per plane and row; +3-5 % frames/s over the wave-uniform mask1 = 1, whole 512-byte row pieces): two to four of
+    // the eight planes on natural images (-45 of 75 MB written per 4K frame with the wave-uniform mask already; the frame rate
+    // on partitioned streams is set by bytes, profiles/r03b_traffic_ablation.txt), all eight on noise.  l = 4 x table position of
     // plane KCH - 1 (lbase = 0 for K = 8... in general idx = l / 4 - lbase), position >> 8 = the pixel's level index.
     const int lb4 = lbase * 4;
     auto row_bits = [&](const Row &r) {
@@ -908,16 +910,30 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry 
         prep_row(rc, n0);
         prep_row(rd, n1);
         __builtin_amdgcn_sched_barrier(0);
-        unsigned M = (1u << KCH) - 1u;                       // planes to store (wave-uniform)
+        unsigned M = (1u << KCH) - 1u;                       // planes to store (wave-uniform, or per 16-lane row)
         if (p.mask1) {
             const unsigned cb = row_bits(c0) | row_bits(c1);   // level-0 rows 2T + 1, 2T + 2
             unsigned bts = pbits | cb;                         // ... and 2T - 1, 2T
             pbits = cb;
             bts |= 3u << dev::clampi((int)(res[KCH].x * gm.Km1), 0, KCH - 2);
             bts |= 3u << dev::clampi((int)(res[KCH].y * gm.Km1), 0, KCH - 2);
-            M = 0u;
+            if (p.mask1 == 2) {
+                // per 16-lane row (62 level-1 columns, one 128-byte line per plane and row): the sets of the row's lanes and of
+                // the lane either side of it (a pair's footprint reaches one level-0 pixel into the neighbour lanes)
+                auto dppu = [](unsigned v, auto ctrl) {
+                    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, 0xf, 0xf, true);
+                };
+                unsigned e = bts | dppu(bts, std::integral_constant<int, 0x138>{}) | dppu(bts, std::integral_constant<int, 0x130>{});
+                e |= dppu(e, std::integral_constant<int, 0x121>{});   // row_ror:1, 2, 4, 8: every lane of a row ends with the row's OR
+                e |= dppu(e, std::integral_constant<int, 0x122>{});
+                e |= dppu(e, std::integral_constant<int, 0x124>{});
+                e |= dppu(e, std::integral_constant<int, 0x128>{});
+                M = e & ((1u << KCH) - 1u);
+            } else {
+                M = 0u;
 #pragma unroll
-            for (int kk = 0; kk < KCH; kk++) M |= __ballot((bts >> kk) & 1u) ? (1u << kk) : 0u;
+                for (int kk = 0; kk < KCH; kk++) M |= __ballot((bts >> kk) & 1u) ? (1u << kk) : 0u;
+            }
         }
         if (T >= Ts0 && T <= Ts1 && !p.skip1 && !(HLMI_D01_ABL & 2 && p.nunits > 0)) {
             float *drow = p.g1 + (size_t)(T - p.loy1) * p.ws1 + off1;
@@ -2142,7 +2158,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             D01Args a;
             a.in = din, a.in_sy = in_sy, a.co0 = gco[0], a.co1 = gco[1], a.co2 = gco[2], a.beta = beta, a.lut_g = lut;
             a.skip1 = ondemand ? 1 : 0;
-            a.mask1 = env_int("HLMI_LL_PLANE_MASK", 1) ? 1 : 0;
+            a.mask1 = max(0, min(2, env_int("HLMI_LL_PLANE_MASK", 2)));   // 0 every plane, 1 per wave, 2 per 16-lane row (default)
             a.g1 = d.g, a.so1 = d.lox, a.loy1 = d.loy, a.w1 = d.w, a.h1 = d.h, a.ws1 = d.ws, a.ps1 = d.ps;
             a.g2 = e.g, a.so2 = e.lox, a.loy2 = e.loy, a.w2 = e.w, a.h2 = e.h, a.ws2 = e.ws, a.ps2 = e.ps;
             const bool odd0 = d.odd, odd1 = e.odd;   // e.odd == (d.lox & 1)
