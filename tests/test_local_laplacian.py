@@ -465,3 +465,21 @@ def test_hip_ondemand_level1_matches_oracle(hl, oracle, monkeypatch, w, h, origi
             want = oracle.local_laplacian_outg(inp, 8, 1.0 / 7, beta, level, origin=origin)
             assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"level {level}"
     assert np.array_equal(o.numpy(), oracle.local_laplacian(inp, 8, 1.0 / 7, beta, origin=origin))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+@pytest.mark.parametrize("w,h,origin,kind", [(1500, 333, (0, 0), "smooth"), (777, 250, (-3, 5), "uniform"), (3840, 2160, (0, 0), "smooth")])
+def test_hip_plane_mask_modes_match_oracle(hl, oracle, monkeypatch, mode, w, h, origin, kind):
+    """ll_down01f stores a level-1 plane only where the up pass reads it (HLMI_LL_PLANE_MASK: 0 every plane, 1 decided per
+    wave, 2 per 16-lane row — the default).  A plane that is read but was not stored holds whatever an earlier frame left
+    there, so every frame is preceded by a DIFFERENT frame of the same size through the same workspace: a missing store shows
+    up as the other frame's values."""
+    monkeypatch.setenv("HLMI_LL_PLANE_MASK", mode)
+    other = _rand_image(w, h, seed=w + 3 * h + 1, kind="uniform" if kind == "smooth" else "smooth")
+    inp = _rand_image(w, h, seed=w + h + 29, kind=kind)
+    for img in (other, inp):
+        a = hl.Buffer(img).set_min(origin[0], origin[1], 0)
+        o = hl.Buffer(np.zeros_like(img)).set_min(origin[0], origin[1], 0)
+        hl.local_laplacian(a, 8, 1.0 / 7, 1.0, o)
+    assert np.array_equal(o.numpy(), oracle.local_laplacian(inp, 8, 1.0 / 7, 1.0, origin=origin))
