@@ -1000,6 +1000,358 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// ll_down01e: ll_down01f re-cut so that the (K + 1)-plane level-1 pyramid never leaves the chip (round 4).
+//
+// outLPyramid[0](x, y) (:63-72) — ONE value per pixel — is a pure function of gray(x, y), of gPyramid[0](x, y, li / li + 1)
+// (pointwise from gray and the remap table) and of gPyramid[1] at the 2 x 2 coarse pixels of the bilinear footprint (:276-282),
+// planes li and li + 1.  A wave holds all of that at the moment it finishes level-1 row T: the gray values and table positions
+// of level-0 rows 2T - 1 and 2T (the previous step's row pair, still in registers) and level-1 rows T - 1 and T of every plane
+// (the raw rows of its level-1 -> 2 window state in LDS; the data-dependent plane index is an LDS address, the left
+// neighbour's pair is the float2 before the lane's own).  So the wave emits outLPyramid[0] rows 2T - 1, 2T (4 bytes per
+// pixel) and, of level 1, only what the collapse of level 1 reads at the coarse pixel itself (:63-72): inGPyramid[1] and
+// gPyramid[1](., ., li1), gPyramid[1](., ., li1 + 1) for li1 of that coarse pixel — three planes instead of K + 1, and no
+// data-dependent plane gathers from memory in the up pass: uniform noise costs what a smooth frame costs.
+// The up pass becomes outGPyramid[0] = upsample(outGPyramid[1]) + outLPyramid[0] + recolouring (ll_up0h).  Every Func is
+// still evaluated by the same operations on the same values: bit-identical to ll_down01f + ll_up0f.
+//   * Level-1 -> 2 window state: the two LDS slots per (plane, lane) now hold RAW level-1 rows only (slot T & 1... see the
+//     step); the partial sum pc = a + 3 (b + c) between an odd step and the even step that completes a level-2 row stays in
+//     registers (18; the kernel is launch-bound to two waves per SIMD = 256 VGPRs).  Same LDS footprint as ll_down01f.
+//   * Who emits what: the steps T in [2A, 2B + 1] of a unit owning level-2 rows [A, B] emit level-0 rows [4A - 1, 4B + 2]; a
+//     wave that takes rows 2B + 1, 2B + 2 from the wave below (EXCH) emits the last pair after its walk, from its own row 2B and
+//     the published row 2B + 1.  Lanes 1 .. S2 emit (lane 0 has no left neighbour; strips advance by S2 lanes).
+struct D01EArgs {
+    D01Args d;
+    float *outl0;              // outLPyramid[0] on [ix0, ix1] x [oy0, oy0 + oh - 1], row stride = input width (a multiple of 4)
+    int oy0, oh;
+};
+#ifndef HLMI_D01E_ABL
+#define HLMI_D01E_ABL 0   // timing experiments only (csrc/Makefile VARIANT): 1 no emission at all, 2 no outL0 stores, 4 no sel-plane stores
+#endif
+template<bool ODD0, bool ODD1, bool B1, bool EXCH>
+__global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometry gm, Levels lev) {
+    const D01Args &p = pe.d;
+    extern __shared__ float slut[];
+    for (int i = threadIdx.x; i <= 2 * gm.half; i += D0_THREADS) slut[i] = p.lut_g[i];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int sx, A, B;              // strip; level-2 rows [A, B] owned
+    bool self_halo = true;     // the walk itself continues over the two rows below the unit
+    bool publish = false;      // first two rows go to LDS for the wave above
+    if (EXCH) {
+        const int wg = xcd_block();
+        sx = p.nsy_magic ? (int)__umulhi((unsigned)wg, p.nsy_magic) : wg;
+        const int gy = wg - sx * p.nsy;
+        const int GA = p.loy2 + gy * p.rows_base + min(gy, p.rows_rem);
+        const int GB = GA + p.rows_base + (gy < p.rows_rem ? 1 : 0) - 1;
+        const int n = (GB - GA + 1 + 1 + 3) >> 2;
+        A = GA + wave * n, B = min(A + n - 1, GB);
+        if (A > GB) {          // no rows left for this wave: it only keeps the barrier count
+            __syncthreads();
+            return;
+        }
+        self_halo = !(wave < 3 && A + n <= GB);
+        publish = wave > 0;
+    } else {
+        const int unit = xcd_block() * (D0_THREADS / 64) + wave;
+        if (unit >= p.nunits) return;
+        sx = p.nsy_magic ? (int)__umulhi((unsigned)unit, p.nsy_magic) : unit;
+        const int sy = unit - sx * p.nsy;
+        A = p.loy2 + sy * p.rows_base + min(sy, p.rows_rem);
+        B = A + p.rows_base + (sy < p.rows_rem ? 1 : 0) - 1;
+    }
+    const int P = p.Pbase + 2 * p.S2 * sx + 2 * lane;   // absolute level-1 column of the lane's pair
+    const int q0 = ODD0 ? 2 * P - 1 : 2 * P - 2;
+    const int iw = gm.ix1 - gm.ix0 + 1, ih = gm.iy1 - gm.iy0;
+    const QuadSel qs = quad_sel(q0 - gm.ix0, iw);
+    int xo[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) xo[i] = qs.oq + qs.sel[i];
+    const bool edge_wave = __any(!qs.plain);
+    // level-1 rows [T0, T1] computed, [Ts0, Ts1] stored (their three planes), steps [2A, 2B + 1] emit outLPyramid[0]
+    const int T0 = 2 * A - 1, T1 = self_halo ? 2 * B + 2 : 2 * B;
+    const int Ts0 = max(EXCH ? 2 * A - 1 : 2 * A, p.loy1), Ts1 = min(EXCH ? 2 * B : 2 * B + 1, p.loy1 + p.h1 - 1);
+    const int off1 = P - p.so1;
+    const bool st1_ok = lane < p.S2 && off1 >= 0 && off1 < p.w1;
+    const int X2 = ODD1 ? (P + 1) >> 1 : P >> 1;
+    const int off2 = X2 - p.so2;
+    const bool st2_ok = (ODD1 ? lane < p.S2 : (lane >= 1 && lane <= p.S2)) && off2 >= 0 && off2 < p.w2;
+    // the lane's four level-0 columns are one aligned quad of the input's box: inside it entirely or not at all
+    const bool em_ok = lane >= 1 && lane <= p.S2 && q0 >= gm.ix0 && q0 + 3 <= gm.ix1;
+    float *const em_col = pe.outl0 + (q0 - gm.ix0);
+    // LDS: [plane][slot][64 lanes] float2 per wave, then the published rows of waves 1..3 as [plane][row][64 lanes]
+    float2 *st2 = reinterpret_cast<float2 *>(slut + ((2 * gm.half + 2) & ~1)) + wave * D01_STATE + lane;
+    float2 *pub_all = reinterpret_cast<float2 *>(slut + ((2 * gm.half + 2) & ~1)) + (D0_THREADS / 64) * D01_STATE + lane;
+    float2 *pub_mine = pub_all + (wave - 1) * D01_STATE, *pub_next = pub_all + wave * D01_STATE;
+    const int lbase = gm.half - 256 * (KCH - 1);
+    float level[KCH];
+#pragma unroll
+    for (int kk = 0; kk < KCH; kk++) {
+        level[kk] = lev.v[kk];
+        asm volatile("" : "+v"(level[kk]));
+    }
+    auto walk = [&](auto edge_tag) {
+    constexpr bool EDGE = decltype(edge_tag)::value;
+    auto load_row = [&](Raw &r, int y_abs) {
+        const uint16_t *rp = p.in + (long)(dev::clampi(y_abs - gm.iy0, 0, ih)) * p.in_sy;
+        load_raw<true>(r, rp, p.co0, p.co1, p.co2, qs.oq, xo);
+    };
+    auto u16s = [&](const ushort4 &c, uint16_t (&o)[4]) {
+        const uint2 w = __builtin_bit_cast(uint2, c);
+        o[0] = (uint16_t)(w.x & 0xffffu), o[1] = (uint16_t)(w.x >> 16);
+        o[2] = (uint16_t)(w.y & 0xffffu), o[3] = (uint16_t)(w.y >> 16);
+    };
+    struct Row {
+        float g[4];
+        int l[4];
+    };
+    auto prep_row = [&](const Raw &r, Row &o) {
+        uint16_t rr[4], gg[4], bb[4];
+        u16s(r.c0, rr), u16s(r.c1, gg), u16s(r.c2, bb);
+#pragma unroll
+        for (int i = 0; i < 4; i++) o.g[i] = gray_from(rr[i], gg[i], bb[i]);
+        if (EDGE) {
+            const float g0 = o.g[0], g1v = o.g[1], g2v = o.g[2], g3 = o.g[3];
+#pragma unroll
+            for (int i = 0; i < 4; i++) o.g[i] = pick4(g0, g1v, g2v, g3, qs.sel[i]);
+        }
+        // l = LDS byte offset of the table entry of plane KCH-1 (see ll_down01f)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            o.l[i] = (min((int)((o.g[i] * gm.Km1) * 256.0f), gm.half) + lbase) * 4;
+            asm volatile("" : "+v"(o.l[i]));
+        }
+    };
+    auto lut_issue = [&](int kk, const Row &r0, const Row &r1, float (&dst)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            dst[i] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(slut) + r0.l[i] + 1024 * (KCH - 1 - kk));
+            dst[4 + i] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(slut) + r1.l[i] + 1024 * (KCH - 1 - kk));
+        }
+    };
+    auto plane_vals = [&](int kk, const Row &r0, const Row &r1, const float (&lv)[8], float (&v0)[4], float (&v1)[4]) {
+        if (kk < KCH) {
+            const float L = level[kk < KCH ? kk : 0];
+            float t[8];
+#pragma unroll
+            for (int i = 0; i < 4; i++) t[i] = r0.g[i] - L, t[4 + i] = r1.g[i] - L;
+            if (!B1) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) t[i] = p.beta * t[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) t[i] = t[i] + L;
+#pragma unroll
+            for (int i = 0; i < 4; i++) v0[i] = t[i] + lv[i], v1[i] = t[4 + i] + lv[4 + i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) v0[i] = r0.g[i], v1[i] = r1.g[i];
+        }
+    };
+    auto vpass = [&](const float (&ia)[4], const float (&ib)[4], const float (&c)[4], const float (&d)[4], float (&o)[4]) {
+        float t[4];   // down4_raw, column-parallel
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[i] = ib[i] + c[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[i] = 3.0f * t[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[i] = ia[i] + t[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = t[i] + d[i];
+    };
+    // ---- outLPyramid[0] of one level-0 row (the lane's quad): rq / rt = the lane's float2 of plane 0 in the level-1 row whose
+    // vertical weight is 1/4 / 3/4 (plane stride 128 float2 in both the window slots and the published rows).  The arithmetic is
+    // ll_up0f's stage 2 (hl0 / hl1 / vl: lerps with the exact quarter product folded into an fma, :276-282 with the parities known).
+    auto emit_row = [&](const Row &n, int y, const float2 *rq, const float2 *rt) {
+        constexpr int COL[4] = {ODD0 ? -1 : -2, -1, ODD0 ? 0 : -1, 0};   // first float of the coarse column pair, relative to the lane's own .x
+        const float *fq = reinterpret_cast<const float *>(rq), *ft = reinterpret_cast<const float *>(rt);
+        float lut0[4], lut1[4], lf[4], lev0[4], lev1[4];
+        float q0a[4], q0b[4], t0a[4], t0b[4], q1a[4], q1b[4], t1a[4], t1b[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int pos = n.l[i] - lbase * 4;                        // 4 x table index of the pixel
+            const int li = min(pos >> 10, KCH - 2);                    // (int)(gray * (K-1)), clamped (:66); gray >= 0
+            const char *lp = reinterpret_cast<const char *>(slut) + (n.l[i] + 1024 * (KCH - 1)) - (li << 10);
+            lut0[i] = *reinterpret_cast<const float *>(lp), lut1[i] = *reinterpret_cast<const float *>(lp - 1024);
+            const float *aq = fq + (li << 8) + COL[i], *at = ft + (li << 8) + COL[i];
+            q0a[i] = aq[0], q0b[i] = aq[1], q1a[i] = aq[256], q1b[i] = aq[257];
+            t0a[i] = at[0], t0b[i] = at[1], t1a[i] = at[256], t1b[i] = at[257];
+            const float lif = (float)li;
+            lf[i] = n.g[i] * gm.Km1 - lif;
+            lev0[i] = lif * gm.inv_Km1, lev1[i] = (lif + 1.0f) * gm.inv_Km1;
+        }
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool xodd = ODD0 ? (i & 1) == 0 : (i & 1) == 1;
+            // even x: lerp(f[c], f[c-1], 1/4) = f[c-1]/4 + 3 f[c]/4; odd x: lerp(f[c+1], f[c], 3/4) = f[c+1]/4 + 3 f[c]/4
+            auto hl = [&](float fa, float fb) { return xodd ? __builtin_fmaf(fb, 0.25f, fa * 0.75f) : __builtin_fmaf(fa, 0.25f, fb * 0.75f); };
+            auto vl = [](float uq, float ut) { return __builtin_fmaf(uq, 0.25f, ut * 0.75f); };
+            const float u0 = vl(hl(q0a[i], q0b[i]), hl(t0a[i], t0b[i]));
+            const float u1 = vl(hl(q1a[i], q1b[i]), hl(t1a[i], t1b[i]));
+            const float l0 = g0_val<B1>(n.g[i], lev0[i], p.beta, lut0[i]) - u0;
+            const float l1 = g0_val<B1>(n.g[i], lev1[i], p.beta, lut1[i]) - u1;
+            o[i] = (1.0f - lf[i]) * l0 + lf[i] * l1;
+        }
+        if (em_ok && y >= pe.oy0 && y < pe.oy0 + pe.oh && !(HLMI_D01E_ABL & 2 && p.nunits > 0)) {
+            *reinterpret_cast<float4 *>(em_col + (size_t)(y - pe.oy0) * iw) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    };
+    float a[KCH + 1][4], b[KCH + 1][4], a2[KCH + 1][4], b2[KCH + 1][4];
+    float2 pcr[KCH + 1];       // a + 3 (b + c) of the level-2 window between its third and fourth row
+    Raw rc, rd;
+    {
+        Raw ra, rb;
+        load_row(ra, 2 * T0 - 1);
+        load_row(rb, 2 * T0);
+        load_row(rc, 2 * T0 + 1);
+        load_row(rd, 2 * T0 + 2);
+        Row r0, r1;
+        prep_row(ra, r0);
+        prep_row(rb, r1);
+        float lv[2][8];
+        lut_issue(0, r0, r1, lv[0]);
+#pragma unroll
+        for (int kk = 0; kk <= KCH; kk++) {
+            if (kk + 1 < KCH) lut_issue(kk + 1, r0, r1, lv[(kk + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            plane_vals(kk, r0, r1, lv[kk & 1], a[kk], b[kk]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // One level-1 row T.  PH = 0: the third row of a level-2 window (slot 0 takes it), PH = 1: the fourth (slot 1) — the step
+    // that completes level-2 row (T - 2) / 2.  c0 / c1: level-0 rows 2T + 1, 2T + 2; n0 / n1 still hold rows 2T - 1, 2T (the
+    // previous step's pair) until this step's end, when they take the rows after c0 / c1.
+    auto step = [&](auto ph_tag, int T, const Row &c0, const Row &c1, Row &n0, Row &n1, float (&ia)[KCH + 1][4],
+                    float (&ib)[KCH + 1][4], float (&oa)[KCH + 1][4], float (&ob)[KCH + 1][4], float2 *pub) {
+        constexpr int PH = decltype(ph_tag)::value;
+        float lv[2][8], dy[2][4];
+        float2 res[KCH + 1];
+        float2 sa, sb;
+        const bool out2 = PH == 1 && T >= 2 * A + 2;   // wave-uniform
+        float *d2 = p.g2 + (size_t)(((T - 2) >> 1) - p.loy2) * p.ws2 + off2;
+        auto level2 = [&](int k) {
+            const float2 c = res[k];
+            if (PH == 0) {
+                pcr[k].x = sa.x + 3.0f * (sb.x + c.x);
+                pcr[k].y = sa.y + 3.0f * (sb.y + c.y);
+                st2[(2 * k) * 64] = c;
+            } else {
+                const float rx = pcr[k].x + c.x, ry = pcr[k].y + c.y;   // down4_raw of the lane's two level-1 columns
+                float o;
+                if (ODD1) {
+                    const float nx = lane_next(rx), ny = lane_next(ry);
+                    o = down4_tail(rx, ry, nx, ny);
+                } else {
+                    const float py = lane_prev(ry), nx = lane_next(rx);
+                    o = down4_tail(py, rx, ry, nx);
+                }
+                if (out2 && st2_ok) d2[(size_t)k * p.ps2] = o;
+                st2[(2 * k + 1) * 64] = c;
+            }
+        };
+        auto state_issue = [&](int k) {
+            if (PH == 0) sa = st2[(2 * k) * 64], sb = st2[(2 * k + 1) * 64];
+        };
+        lut_issue(0, c0, c1, lv[0]);
+#pragma unroll
+        for (int kk = 0; kk <= KCH; kk++) {
+            if (kk > 0) state_issue(kk - 1);   // before the gathers: LDS returns in order, the state must not wait for them
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 1 < KCH) lut_issue(kk + 1, c0, c1, lv[(kk + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            plane_vals(kk, c0, c1, lv[kk & 1], oa[kk], ob[kk]);
+            vpass(ia[kk], ib[kk], oa[kk], ob[kk], dy[kk & 1]);
+            if (kk > 0) {
+                res[kk - 1] = hpair<ODD0>(dy[(kk - 1) & 1]);
+                level2(kk - 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        state_issue(KCH);
+        res[KCH] = hpair<ODD0>(dy[KCH & 1]);
+        level2(KCH);
+        if (EXCH && pub) {
+#pragma unroll
+            for (int kk = 0; kk <= KCH; kk++) pub[(2 * kk) * 64] = res[kk];
+        }
+        // level-1 rows T - 1 and T of every plane are in the two slots now; other lanes' entries are read below: the wave runs
+        // its LDS instructions in order, the compiler must not move the reads above the writes
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        float2 *const rowT = st2 + (PH == 0 ? 0 : 64), *const rowP = st2 + (PH == 0 ? 64 : 0);   // rows T and T - 1
+        if (T >= Ts0 && T <= Ts1) {
+            // of level 1 the up pass reads inGPyramid[1] and gPyramid[1](., ., li1 / li1 + 1) at the coarse pixel itself (:63-72)
+            const int lx = dev::clampi((int)(res[KCH].x * gm.Km1), 0, KCH - 2), ly = dev::clampi((int)(res[KCH].y * gm.Km1), 0, KCH - 2);
+            const float *fx = reinterpret_cast<const float *>(rowT) + (lx << 8), *fy = reinterpret_cast<const float *>(rowT) + (ly << 8) + 1;
+            const float2 s0 = make_float2(fx[0], fy[0]), s1 = make_float2(fx[256], fy[256]);
+            float *drow = p.g1 + (size_t)(T - p.loy1) * p.ws1 + off1;
+            if (st1_ok && !(HLMI_D01E_ABL & 4 && p.nunits > 0)) {
+                *reinterpret_cast<float2 *>(drow) = s0;
+                *reinterpret_cast<float2 *>(drow + p.ps1) = s1;
+                *reinterpret_cast<float2 *>(drow + (size_t)KCH * p.ps1) = res[KCH];
+            }
+        }
+        if (T >= 2 * A && T <= 2 * B + 1 && !(HLMI_D01E_ABL & 1 && p.nunits > 0)) {   // wave-uniform
+            emit_row(n0, 2 * T - 1, rowT, rowP);   // odd row: coarse row T weighs 1/4
+            __builtin_amdgcn_sched_barrier(0);
+            emit_row(n1, 2 * T, rowP, rowT);
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // unconditional: after the last row rc / rd still hold the previous (valid) rows and the result is unused
+        prep_row(rc, n0);
+        prep_row(rd, n1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (T + 1 < T1) {
+            load_row(rc, 2 * T + 5);
+            load_row(rd, 2 * T + 6);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    Row p0, p1, p2, p3;
+    prep_row(rc, p0);
+    prep_row(rd, p1);
+    load_row(rc, 2 * T0 + 3);   // T0 < T1 always: a unit walks at least 2 rows
+    load_row(rd, 2 * T0 + 4);
+    for (int T = T0; T <= T1; T += 2) {
+        const bool first = EXCH && T == T0;
+        step(std::integral_constant<int, 0>{}, T, p0, p1, p2, p3, a, b, a2, b2, first && publish ? pub_mine : nullptr);
+        step(std::integral_constant<int, 1>{}, T + 1, p2, p3, p0, p1, a2, b2, a, b, first && publish ? pub_mine + 64 : nullptr);
+        if (first) __syncthreads();   // every wave of the workgroup that has rows passes here exactly once
+    }
+    if (EXCH && !self_halo) {
+        // level-2 row B: rows "c" (2B+1) and "d" (2B+2) are the first two rows of the wave below
+        float *d2 = p.g2 + (size_t)(B - p.loy2) * p.ws2 + off2;
+#pragma unroll
+        for (int k = 0; k <= KCH; k++) {
+            const float2 sa = st2[(2 * k) * 64], sb = st2[(2 * k + 1) * 64];
+            const float2 c = pub_next[(2 * k) * 64], d = pub_next[(2 * k + 1) * 64];
+            const float rx = (sa.x + 3.0f * (sb.x + c.x)) + d.x, ry = (sa.y + 3.0f * (sb.y + c.y)) + d.y;
+            float o;
+            if (ODD1) {
+                const float nx = lane_next(rx), ny = lane_next(ry);
+                o = down4_tail(rx, ry, nx, ny);
+            } else {
+                const float py = lane_prev(ry), nx = lane_next(rx);
+                o = down4_tail(py, rx, ry, nx);
+            }
+            if (st2_ok) d2[(size_t)k * p.ps2] = o;
+        }
+        // outLPyramid[0] rows 4B + 1, 4B + 2 (the pair the last step brought in: p2 / p3) from level-1 rows 2B (slot 1) and 2B + 1
+        // (published)
+        if (!(HLMI_D01E_ABL & 1 && p.nunits > 0)) {
+            emit_row(p2, 4 * B + 1, pub_next, st2 + 64);
+            emit_row(p3, 4 * B + 2, st2 + 64, pub_next);
+        }
+    }
+    };  // walk
+    if (edge_wave) walk(std::true_type{});
+    else walk(std::false_type{});
+}
+
+// ---------------------------------------------------------------------------------------------------
 // level j -> j+1 (j >= 1): one wave = (strip of 126 destination columns, TY rows, one plane)
 template<bool ODD>
 __global__ __launch_bounds__(256) void ll_down_strip(const float *__restrict__ src, int slox, int sloy, int sw, int sh,
@@ -1062,6 +1414,9 @@ __device__ __forceinline__ float top_value(const float *__restrict__ g, size_t p
     return (1.0f - lf) * g[(size_t)li * ps + o] + lf * g[(size_t)(li + 1) * ps + o];
 }
 // outLPyramid[j](X,Y), 0 < j < J-1 (:50-54, :63-72): g = level j (origin lox/loy), gc = level j+1
+// SEL: level j was stored by ll_down01e — plane 0 = gPyramid[j](., ., li), plane 1 = gPyramid[j](., ., li + 1) for the pixel's own
+// li (the only two values of level j this function reads), plane K = inGPyramid[j]
+template<bool SEL = false>
 __device__ __forceinline__ float outl_value(const float *__restrict__ g, int ws, size_t ps, int lox, int loy,
                                             const float *__restrict__ gc, int cws, size_t cps, int clox, int cloy,
                                             int X, int Y, int K, float Km1) {
@@ -1069,8 +1424,8 @@ __device__ __forceinline__ float outl_value(const float *__restrict__ g, int ws,
     float level = g[(size_t)K * ps + o] * Km1;
     int li = dev::clampi((int)level, 0, K - 2);
     float lf = level - (float)li;
-    float l0 = g[(size_t)li * ps + o] - up_at(gc + (size_t)li * cps, clox, cloy, cws, X, Y);
-    float l1 = g[(size_t)(li + 1) * ps + o] - up_at(gc + (size_t)(li + 1) * cps, clox, cloy, cws, X, Y);
+    float l0 = g[(SEL ? 0 : (size_t)li * ps) + o] - up_at(gc + (size_t)li * cps, clox, cloy, cws, X, Y);
+    float l1 = g[(SEL ? ps : (size_t)(li + 1) * ps) + o] - up_at(gc + (size_t)(li + 1) * cps, clox, cloy, cws, X, Y);
     return (1.0f - lf) * l0 + lf * l1;
 }
 
@@ -1083,6 +1438,7 @@ __global__ void ll_top(const float *__restrict__ g, int ws, size_t ps, int lox, 
 }
 
 // outGPyramid[j] = upsample(outGPyramid[j+1]) + outLPyramid[j], 1 <= j <= J-2 (:50-54, :63-79)
+template<bool SEL = false>
 __global__ __launch_bounds__(256) void ll_up(const float *__restrict__ g, int ws, size_t ps, int lox, int loy,
                                              const float *__restrict__ gc, const float *__restrict__ outc, int cws,
                                              size_t cps, int clox, int cloy, int rx0, int ry0, int rw, int rh, int K,
@@ -1091,7 +1447,7 @@ __global__ __launch_bounds__(256) void ll_up(const float *__restrict__ g, int ws
     if (x >= rw || y >= rh) return;
     int X = rx0 + x, Y = ry0 + y;
     size_t o = (size_t)(Y - loy) * ws + (X - lox);
-    float outL = outl_value(g, ws, ps, lox, loy, gc, cws, cps, clox, cloy, X, Y, K, Km1);
+    float outL = outl_value<SEL>(g, ws, ps, lox, loy, gc, cws, cps, clox, cloy, X, Y, K, Km1);
     out[o] = up_at(outc, clox, cloy, cws, X, Y) + outL;
 }
 
@@ -1597,6 +1953,97 @@ __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// ll_up0h: the up pass of the re-cut dataflow (ll_down01e): outGPyramid[0] = upsample(outGPyramid[1]) + outLPyramid[0]
+// (:76-79) + recolouring (:82-87), with outLPyramid[0] read as ONE stored plane and outGPyramid[1] collapsed per workgroup tile
+// in LDS from the three level-1 planes ll_down01e stored (phase 1 of ll_up0f<.., .., true>, the two data-dependent plane
+// reads of level 1 replaced by planes 0 and 1).  No remap table, no plane gathers: per pixel pair and row three u16 pairs, one
+// float2 and six LDS reads.  Arithmetic: ll_up0f's (hl0 / hl1 / vl, div3_by).
+struct Up0HArgs {
+    Up0Args u;
+    const float *outl0;        // outLPyramid[0] on [ix0, ix1] x [oy0, oy0 + oh - 1]
+    int l0_ws;                 // its row stride in floats (= input width)
+};
+constexpr int U0H_PF = 4;      // rows in flight per wave
+__global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
+    const Up0Args &p = ph.u;
+    extern __shared__ float s_out1[];
+    const int X0 = p.ox0 + (int)blockIdx.x * 256;                       // even
+    const int Yw0 = p.oy0 + (int)blockIdx.y * (2 * p.RU);
+    const int Yw1 = min(Yw0 + 2 * p.RU, p.oy0 + p.oh) - 1;
+    const int cx0 = (X0 >> 1) - 1, cy0 = dev::fdiv2(Yw0 - 1);
+    const int th = dev::fdiv2(Yw1 + 1) - cy0 + 1;
+    for (int e = threadIdx.x; e < U0_TW * th; e += 256) {
+        const int ty = e / U0_TW, tx = e - ty * U0_TW;
+        const int cx = cx0 + tx, cy = cy0 + ty;
+        if (cx > p.rx1_1) continue;
+        // outGPyramid[1] = upsample(outGPyramid[2]) + outLPyramid[1]   (:76-79), exactly as ll_up computes it
+        const float outL = outl_value<true>(p.g1, p.ws1, p.ps1, p.lox1, p.loy1, p.g2, p.ws2, p.ps2, p.lox2, p.loy2, cx, cy, gm.K, gm.Km1);
+        s_out1[ty * U0_TS + tx] = up_at(p.out2, p.lox2, p.loy2, p.ws2, cx, cy) + outL;
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 256 + (wave & 1) * 128 + 2 * lane;  // output storage column of the lane's pair
+    const int y0 = blockIdx.y * (2 * p.RU) + (wave >> 1) * p.RU;
+    if (y0 >= p.oh || x >= p.ow) return;
+    const int y1 = min(y0 + p.RU, p.oh);
+    const int X = p.ox0 + x;                                              // even
+    const uint32_t inb = (uint32_t)(X - gm.ix0) * 2u, outb = (uint32_t)x * 2u, l0b = (uint32_t)(X - gm.ix0) * 4u;
+    auto hl0 = [](float rm, float r0) { return __builtin_fmaf(rm, 0.25f, r0 * 0.75f); };  // lerp(f[c], f[c-1], 1/4): X even
+    auto hl1 = [](float r0, float rp) { return __builtin_fmaf(rp, 0.25f, r0 * 0.75f); };  // lerp(f[c+1], f[c], 3/4): X odd
+    auto vl = [](float uq, float ut) { return __builtin_fmaf(uq, 0.25f, ut * 0.75f); };
+    struct Frame {
+        ushort2 c0, c1, c2;
+        float2 l0;
+    };
+    auto load_frame = [&](int y, Frame &f) {
+        const int yc = min(y, y1 - 1);
+        const uint16_t *irow = p.in + (long)(p.oy0 + yc - gm.iy0) * p.in_sy;
+        f.c0 = ld_frame2(irow + p.gco[0], inb), f.c1 = ld_frame2(irow + p.gco[1], inb), f.c2 = ld_frame2(irow + p.gco[2], inb);
+        f.l0 = ld_su<float2>(ph.outl0 + (size_t)yc * ph.l0_ws, l0b);
+    };
+    auto finish = [&](int y, const Frame &f) {
+        const int Y = p.oy0 + min(y, y1 - 1);
+        const int ya = dev::fdiv2(Y + 1), yb = dev::fdiv2(Y - 1);
+        const bool yodd = dev::fmod2(Y) != 0;  // wave-uniform
+        const int yq = yodd ? ya : yb, yt = yodd ? yb : ya;   // q: the coarse row whose weight is 1/4 (see ll_up0f)
+        const float *oa = s_out1 + (yq - cy0) * U0_TS + (wave & 1) * 64 + lane;
+        const float *ob = s_out1 + (yt - cy0) * U0_TS + (wave & 1) * 64 + lane;
+        const float ax = oa[0], ay = oa[1], az = oa[2], bx = ob[0], by = ob[1], bz = ob[2];
+        const float uo[2] = {vl(hl0(ax, ay), hl0(bx, by)), vl(hl1(ay, az), hl1(by, bz))};
+        const float outL[2] = {f.l0.x, f.l0.y};
+        const uint16_t ch[3][2] = {{f.c0.x, f.c0.y}, {f.c1.x, f.c1.y}, {f.c2.x, f.c2.y}};
+        uint16_t res[3][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const float gray = gray_from(ch[0][i], ch[1][i], ch[2][i]);
+            const float og = (uo[i] + outL[i]) + 0.01f;
+            const float gr = gray + 0.01f;
+            const float n[3] = {(float)ch[0][i] * og, (float)ch[1][i] * og, (float)ch[2][i] * og};
+            float q[3];
+            div3_by(n, gr, q);
+#pragma unroll
+            for (int c = 0; c < 3; c++) res[c][i] = (uint16_t)__builtin_amdgcn_fmed3f(q[c], 0.0f, 65535.0f);  // q is never NaN
+        }
+        if (y < y1) {
+            uint16_t *orow = p.out + (long)y * p.out_sy;
+#pragma unroll
+            for (int c = 0; c < 3; c++) st_frame2(reinterpret_cast<char *>(orow + (long)c * p.out_sc) + outb, res[c][0], res[c][1]);
+        }
+    };
+    Frame f[U0H_PF];
+#pragma unroll
+    for (int i = 0; i < U0H_PF; i++) load_frame(y0 + i, f[i]);
+    for (int y = y0; y < y1; y += U0H_PF) {
+#pragma unroll
+        for (int i = 0; i < U0H_PF; i++) {
+            const Frame cur = f[i];
+            load_frame(y + U0H_PF + i, f[i]);
+            finish(y + i, cur);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // ll_up0g: outGPyramid[0] + recolouring like ll_up0f, WITHOUT reading gPyramid[1] from memory — the workgroup recomputes the
 // level-1 planes its tile needs from the input.  Why: the frame rate on CU-partitioned streams is set by bytes (409 MB per
 // frame; a timing-only build that neither stores nor reads the level-1 planes runs at 0.066 instead of 0.106 ms per frame,
@@ -1852,7 +2299,7 @@ int env_int(const char *name, int dflt) {
 thread_local Level t_dbg_lv[J];
 thread_local hipStream_t t_dbg_stream = nullptr;
 thread_local bool t_dbg_out1_pending = false;  // the last call fused level 1's collapse: outGPyramid[1] was never stored
-thread_local bool t_dbg_ondemand = false, t_dbg_b1 = false;   // ... and level 1 itself was never stored either (ll_up0g)
+thread_local bool t_dbg_ondemand = false, t_dbg_b1 = false, t_dbg_emit = false;   // ... and level 1 itself was never stored either (ll_up0g)
 thread_local Up0Args t_dbg_up0;
 thread_local Geometry t_dbg_gm;
 thread_local int t_dbg_K = 0;
@@ -1912,7 +2359,8 @@ uint64_t g_graph_clock = 0;
 uint64_t ll_env_signature() {
     static const char *const names[] = {"HLMI_LL_NO_LUT_CACHE", "HLMI_LL_UNITS0", "HLMI_LL_NO_VEC", "HLMI_LL_D0F", "HLMI_LL_FUSE_D2",
                                         "HLMI_LL_D01_EXCH", "HLMI_LL_FUSE_FROM", "HLMI_LL_UNITSB", "HLMI_LL_UPCHAIN_FROM",
-                                        "HLMI_LL_UP0_OLD", "HLMI_LL_FUSE_UP1", "HLMI_LL_RU"};
+                                        "HLMI_LL_UP0_OLD", "HLMI_LL_FUSE_UP1", "HLMI_LL_RU", "HLMI_LL_PLANE_MASK", "HLMI_LL_ONDEMAND",
+                                        "HLMI_LL_G_ABL", "HLMI_LL_EMIT"};
     uint64_t h = 1469598103934665603ull;
     for (const char *n : names) {
         const char *e = getenv(n);
@@ -2010,10 +2458,14 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         rx0 = floor_div(rx0 - 1, 2), rx1 = floor_div(rx1 + 1, 2);
         ry0 = floor_div(ry0 - 1, 2), ry1 = floor_div(ry1 + 1, 2);
     }
+    // outLPyramid[0] of the re-cut dataflow (ll_down01e -> ll_up0h): input width x output rows
+    const size_t off_l0 = ws_floats;
+    ws_floats += ((size_t)(gm.ix1 - gm.ix0 + 1) * (size_t)oh + 63) & ~(size_t)63;
     void *ws = nullptr;
     if ((r = get_workspace(uc, ctx, ws_floats * sizeof(float), &ws))) return r;
     float *wsf = (float *)ws;
     float *lut = wsf;
+    float *outl0 = wsf + off_l0;
     for (int j = 1; j < J; j++) lv[j].g = wsf + off_g[j], lv[j].out = wsf + off_out[j];
     lv[0].g = lv[0].out = nullptr;
     for (int j = 0; j < J; j++) t_dbg_lv[j] = lv[j];
@@ -2120,6 +2572,9 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     // CU, 34 us of per-tile fixed cost, 36 us of plane recomputation), so the frame gets slower (0.128 vs 0.106 ms on four
     // partitions); profiles/r03b_traffic_ablation.txt has the phase breakdown and what a version that pays would need.
     const bool ondemand = d01_possible && fast && fuse1 && lut_lds && env_int("HLMI_LL_ONDEMAND", 0);
+    // The default for the common geometry: ll_down01e emits outLPyramid[0] and three planes of level 1, ll_up0h collapses
+    // (HLMI_LL_EMIT=0: the round-3 pair ll_down01f / ll_up0f with the materialised K + 1 level-1 planes)
+    const bool emit = d01_possible && fast && fuse1 && !ondemand && env_int("HLMI_LL_EMIT", 1);
     bool fuse1_out = false;
     auto enqueue = [&]() -> int {   // the launch chain of one frame (everything below depends only on what GraphKey holds)
     bool fuse_d2 = false;
@@ -2194,6 +2649,28 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             a.rows_base = e.h / a.nsy, a.rows_rem = e.h % a.nsy;
             dim3 grid2((a.nunits + WPB - 1) / WPB);
             const size_t sh2 = sizeof(float) * ((nlut + 1) & ~1) + sizeof(float2) * D01_STATE * (WPB + (exch ? WPB - 1 : 0));
+            if (emit) {
+                // input read once; outLPyramid[0] (4 B per output pixel), three level-1 planes and K + 1 level-2 planes written
+                timing_note_bytes(6.0 * iw * (gm.iy1 - gm.iy0 + 1) + 4.0 * iw * oh + 4.0 * 3.0 * d.w * d.h + 4.0 * (levels + 1) * e.w * e.h);
+                D01EArgs ae;
+                ae.d = a, ae.outl0 = outl0, ae.oy0 = output->dim[1].min, ae.oh = oh;
+#define LL_D01E(O0, O1, B)                                                                                             \
+    do {                                                                                                               \
+        if (exch) HLMI_LAUNCH(uc, "ll_down01", st, (ll_down01e<O0, O1, B, true>), grid2, block, sh2, ae, gm, lev);     \
+        else HLMI_LAUNCH(uc, "ll_down01", st, (ll_down01e<O0, O1, B, false>), grid2, block, sh2, ae, gm, lev);         \
+    } while (0)
+                switch ((odd0 ? 4 : 0) | (odd1 ? 2 : 0) | (b1 ? 1 : 0)) {
+                    case 0: LL_D01E(false, false, false); break;
+                    case 1: LL_D01E(false, false, true); break;
+                    case 2: LL_D01E(false, true, false); break;
+                    case 3: LL_D01E(false, true, true); break;
+                    case 4: LL_D01E(true, false, false); break;
+                    case 5: LL_D01E(true, false, true); break;
+                    case 6: LL_D01E(true, true, false); break;
+                    default: LL_D01E(true, true, true); break;
+                }
+#undef LL_D01E
+            } else {
             timing_note_bytes((ondemand ? 6.0 * iw * (gm.iy1 - gm.iy0 + 1) : d0_bytes) + 4.0 * (levels + 1) * e.w * e.h);
 #define LL_D01(O0, O1, B)                                                                                              \
     do {                                                                                                               \
@@ -2211,6 +2688,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
                 default: LL_D01(true, true, true); break;
             }
 #undef LL_D01
+            }
         } else if (levels == KCH && vec && lut_lds && env_int("HLMI_LL_D0F", 1)) {
             if (d.odd) r = b1 ? launch_d0(&ll_down0f<true, true>) : launch_d0(&ll_down0f<true, false>);
             else r = b1 ? launch_d0(&ll_down0f<false, true>) : launch_d0(&ll_down0f<false, false>);
@@ -2303,7 +2781,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         snprintf(nm, sizeof nm, "ll_up:%d", j);
         // per output: 2 planes of g_j + inG_j read, outG_j written; per coarse pixel: 2 planes of g_{j+1} + outG_{j+1}
         timing_note_bytes(4.0 * (4.0 * rw * rh + 3.0 * (c.rx1 - c.rx0 + 1) * (c.ry1 - c.ry0 + 1)));
-        HLMI_LAUNCH(uc, nm, st, ll_up, dim3((rw + 255) / 256, rh), dim3(256), 0, a.g, a.ws, a.ps, a.lox, a.loy, c.g,
+        HLMI_LAUNCH(uc, nm, st, ll_up<false>, dim3((rw + 255) / 256, rh), dim3(256), 0, a.g, a.ws, a.ps, a.lox, a.loy, c.g,
                     c.out, c.ws, c.ps, c.lox, c.loy, a.rx0, a.ry0, rw, rh, levels, gm.Km1, a.out);
     }
     fuse1_out = fuse1;
@@ -2334,6 +2812,16 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             return 0;
         }
         t_dbg_ondemand = false;
+        t_dbg_emit = emit;
+        if (emit) {
+            // input read + output written (u16 x 3 channels), outLPyramid[0] read, three planes of level 1, per level-2 pixel two
+            // planes of g_2 + outG_2
+            timing_note_bytes(2.0 * (3 + nc) * ow * oh + 4.0 * ow * oh + 4.0 * 3.0 * n1 + 4.0 * 3.0 * n2);
+            Up0HArgs ph;
+            ph.u = p, ph.outl0 = outl0, ph.l0_ws = gm.ix1 - gm.ix0 + 1;
+            HLMI_LAUNCH(uc, "ll_up0", st, ll_up0h, grid, block, sizeof(float) * U0_TS * (p.RU + 2), ph, gm);
+            return 0;
+        }
         timing_note_bytes(u0_bytes);
         if (fast) {
             const bool b1 = (beta == 1.0f);
@@ -2566,8 +3054,13 @@ extern "C" int hlmi_debug_local_laplacian_outg(int level, float *dst, int cap_fl
         // the fused ll_up0f kept outGPyramid[1] in LDS: produce the plane now with the stand-alone kernel (its inputs are
         // still in the arena) so that the tests can compare every level
         const Level &a = t_dbg_lv[1], &c = t_dbg_lv[2];
-        hipLaunchKernelGGL(ll_up, dim3((rw + 255) / 256, rh), dim3(256), 0, t_dbg_stream, a.g, a.ws, a.ps, a.lox, a.loy, c.g, c.out,
-                           c.ws, c.ps, c.lox, c.loy, a.rx0, a.ry0, rw, rh, t_dbg_K, t_dbg_Km1, a.out);
+        if (t_dbg_emit) {   // level 1 holds its three planes only (ll_down01e)
+            hipLaunchKernelGGL(ll_up<true>, dim3((rw + 255) / 256, rh), dim3(256), 0, t_dbg_stream, a.g, a.ws, a.ps, a.lox, a.loy, c.g, c.out,
+                               c.ws, c.ps, c.lox, c.loy, a.rx0, a.ry0, rw, rh, t_dbg_K, t_dbg_Km1, a.out);
+        } else {
+            hipLaunchKernelGGL(ll_up<false>, dim3((rw + 255) / 256, rh), dim3(256), 0, t_dbg_stream, a.g, a.ws, a.ps, a.lox, a.loy, c.g, c.out,
+                               c.ws, c.ps, c.lox, c.loy, a.rx0, a.ry0, rw, rh, t_dbg_K, t_dbg_Km1, a.out);
+        }
         if (hipGetLastError() != hipSuccess) return -1;
         t_dbg_out1_pending = false;
     }
