@@ -1025,8 +1025,18 @@ struct D01EArgs {
     int oy0, oh;
 };
 #ifndef HLMI_D01E_ABL
-#define HLMI_D01E_ABL 0   // timing experiments only (csrc/Makefile VARIANT): 1 no emission at all, 2 no outL0 stores, 4 no sel-plane stores
+#define HLMI_D01E_ABL 0   // timing experiments only (csrc/Makefile VARIANT): 1 no emission at all, 2 no outL0 stores, 4 no sel-plane stores, 8 emission without its LDS reads, 16 no table gathers in the plane loop
 #endif
+// Packed arithmetic: at two waves per SIMD this kernel is bound by how often ONE wave can issue (a wave issues an
+// independent VALU instruction every ~2.1 ns whatever it is, scripts/ubench/valu_pk.hip: v_pk_add / mul / fma_f32 2.4 ns for
+// two results against 2.1 ns for one), so every pointwise pass runs on column PAIRS held as <2 x float>: pair A = the
+// lane's columns (0, 2), pair B = columns (1, 3) — pixels of equal x parity, which is what the horizontal lerps of the
+// emission want.  (The same substitution made ll_up0f slower in round 2: at five waves per SIMD the VALU is throughput-bound
+// and a packed instruction costs two issue slots.)  IEEE per component: bit-identical.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 f2s(float v) { return f2{v, v}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 template<bool ODD0, bool ODD1, bool B1, bool EXCH>
 __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometry gm, Levels lev) {
     const D01Args &p = pe.d;
@@ -1080,9 +1090,9 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
     const bool em_ok = lane >= 1 && lane <= p.S2 && q0 >= gm.ix0 && q0 + 3 <= gm.ix1;
     float *const em_col = pe.outl0 + (q0 - gm.ix0);
     // LDS: [plane][slot][64 lanes] float2 per wave, then the published rows of waves 1..3 as [plane][row][64 lanes]
-    float2 *st2 = reinterpret_cast<float2 *>(slut + ((2 * gm.half + 2) & ~1)) + wave * D01_STATE + lane;
-    float2 *pub_all = reinterpret_cast<float2 *>(slut + ((2 * gm.half + 2) & ~1)) + (D0_THREADS / 64) * D01_STATE + lane;
-    float2 *pub_mine = pub_all + (wave - 1) * D01_STATE, *pub_next = pub_all + wave * D01_STATE;
+    f2 *st2 = reinterpret_cast<f2 *>(slut + ((2 * gm.half + 2) & ~1)) + wave * D01_STATE + lane;
+    f2 *pub_all = reinterpret_cast<f2 *>(slut + ((2 * gm.half + 2) & ~1)) + (D0_THREADS / 64) * D01_STATE + lane;
+    f2 *pub_mine = pub_all + (wave - 1) * D01_STATE, *pub_next = pub_all + wave * D01_STATE;
     const int lbase = gm.half - 256 * (KCH - 1);
     float level[KCH];
 #pragma unroll
@@ -1102,103 +1112,127 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         o[2] = (uint16_t)(w.y & 0xffffu), o[3] = (uint16_t)(w.y >> 16);
     };
     struct Row {
-        float g[4];
-        int l[4];
+        f2 g[2];     // gray: g[0] = columns (0, 2), g[1] = columns (1, 3)
+        int l[4];    // LDS byte offset of the table entry of plane KCH-1, per column (see ll_down01f)
     };
     auto prep_row = [&](const Raw &r, Row &o) {
         uint16_t rr[4], gg[4], bb[4];
         u16s(r.c0, rr), u16s(r.c1, gg), u16s(r.c2, bb);
+        constexpr float s = (float)(1.0 / 65535.0);
+        constexpr float C0 = (float)((double)s * (double)0.299f), C1 = (float)((double)s * (double)0.587f),
+                        C2 = (float)((double)s * (double)0.114f);   // gray_from's constants
 #pragma unroll
-        for (int i = 0; i < 4; i++) o.g[i] = gray_from(rr[i], gg[i], bb[i]);
+        for (int h = 0; h < 2; h++) {
+            const f2 fr = {(float)rr[h], (float)rr[h + 2]}, fg = {(float)gg[h], (float)gg[h + 2]}, fb = {(float)bb[h], (float)bb[h + 2]};
+            o.g[h] = (fr * C0 + fg * C1) + fb * C2;
+        }
         if (EDGE) {
-            const float g0 = o.g[0], g1v = o.g[1], g2v = o.g[2], g3 = o.g[3];
-#pragma unroll
-            for (int i = 0; i < 4; i++) o.g[i] = pick4(g0, g1v, g2v, g3, qs.sel[i]);
+            const float g0 = o.g[0].x, g1v = o.g[1].x, g2v = o.g[0].y, g3 = o.g[1].y;
+            o.g[0].x = pick4(g0, g1v, g2v, g3, qs.sel[0]), o.g[1].x = pick4(g0, g1v, g2v, g3, qs.sel[1]);
+            o.g[0].y = pick4(g0, g1v, g2v, g3, qs.sel[2]), o.g[1].y = pick4(g0, g1v, g2v, g3, qs.sel[3]);
         }
-        // l = LDS byte offset of the table entry of plane KCH-1 (see ll_down01f)
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            o.l[i] = (min((int)((o.g[i] * gm.Km1) * 256.0f), gm.half) + lbase) * 4;
-            asm volatile("" : "+v"(o.l[i]));
+        for (int h = 0; h < 2; h++) {
+            const f2 t = (o.g[h] * gm.Km1) * 256.0f;
+            o.l[h] = (min((int)t.x, gm.half) + lbase) * 4;
+            o.l[h + 2] = (min((int)t.y, gm.half) + lbase) * 4;
         }
+#pragma unroll
+        for (int i = 0; i < 4; i++) asm volatile("" : "+v"(o.l[i]));
     };
-    auto lut_issue = [&](int kk, const Row &r0, const Row &r1, float (&dst)[8]) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            dst[i] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(slut) + r0.l[i] + 1024 * (KCH - 1 - kk));
-            dst[4 + i] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(slut) + r1.l[i] + 1024 * (KCH - 1 - kk));
-        }
+    // table values of plane kk for two rows: dst[0], dst[1] = row r0 pairs A, B; dst[2], dst[3] = row r1
+    auto lut_issue = [&](int kk, const Row &r0, const Row &r1, f2 (&dst)[4]) {
+        auto rd = [&](int l) {
+#if HLMI_D01E_ABL & 16
+            return __builtin_bit_cast(float, l + kk);
+#else
+            return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(slut) + l + 1024 * (KCH - 1 - kk));
+#endif
+        };
+        dst[0].x = rd(r0.l[0]), dst[1].x = rd(r0.l[1]), dst[0].y = rd(r0.l[2]), dst[1].y = rd(r0.l[3]);
+        dst[2].x = rd(r1.l[0]), dst[3].x = rd(r1.l[1]), dst[2].y = rd(r1.l[2]), dst[3].y = rd(r1.l[3]);
     };
-    auto plane_vals = [&](int kk, const Row &r0, const Row &r1, const float (&lv)[8], float (&v0)[4], float (&v1)[4]) {
+    auto plane_vals = [&](int kk, const Row &r0, const Row &r1, const f2 (&lv)[4], f2 (&v0)[2], f2 (&v1)[2]) {
         if (kk < KCH) {
-            const float L = level[kk < KCH ? kk : 0];
-            float t[8];
-#pragma unroll
-            for (int i = 0; i < 4; i++) t[i] = r0.g[i] - L, t[4 + i] = r1.g[i] - L;
+            const f2 L = f2s(level[kk < KCH ? kk : 0]);
+            f2 t[4] = {r0.g[0] - L, r0.g[1] - L, r1.g[0] - L, r1.g[1] - L};
             if (!B1) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) t[i] = p.beta * t[i];
+                for (int i = 0; i < 4; i++) t[i] = p.beta * t[i];
             }
 #pragma unroll
-            for (int i = 0; i < 8; i++) t[i] = t[i] + L;
-#pragma unroll
-            for (int i = 0; i < 4; i++) v0[i] = t[i] + lv[i], v1[i] = t[4 + i] + lv[4 + i];
+            for (int i = 0; i < 4; i++) t[i] = t[i] + L;
+            v0[0] = t[0] + lv[0], v0[1] = t[1] + lv[1], v1[0] = t[2] + lv[2], v1[1] = t[3] + lv[3];
         } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) v0[i] = r0.g[i], v1[i] = r1.g[i];
+            v0[0] = r0.g[0], v0[1] = r0.g[1], v1[0] = r1.g[0], v1[1] = r1.g[1];
         }
     };
-    auto vpass = [&](const float (&ia)[4], const float (&ib)[4], const float (&c)[4], const float (&d)[4], float (&o)[4]) {
-        float t[4];   // down4_raw, column-parallel
-#pragma unroll
-        for (int i = 0; i < 4; i++) t[i] = ib[i] + c[i];
-#pragma unroll
-        for (int i = 0; i < 4; i++) t[i] = 3.0f * t[i];
-#pragma unroll
-        for (int i = 0; i < 4; i++) t[i] = ia[i] + t[i];
-#pragma unroll
-        for (int i = 0; i < 4; i++) o[i] = t[i] + d[i];
+    auto vpass = [&](const f2 (&ia)[2], const f2 (&ib)[2], const f2 (&c)[2], const f2 (&d)[2], f2 (&o)[2]) {
+        f2 t[2] = {ib[0] + c[0], ib[1] + c[1]};   // down4_raw, column-parallel
+        t[0] = 3.0f * t[0], t[1] = 3.0f * t[1];
+        t[0] = ia[0] + t[0], t[1] = ia[1] + t[1];
+        o[0] = t[0] + d[0], o[1] = t[1] + d[1];
+    };
+    // horizontal 1-3-3-1 (hpair<ODD0>) on the paired layout: dy[0] = columns (0, 2), dy[1] = columns (1, 3)
+    auto hpair2 = [&](const f2 (&dy)[2]) {
+        const float d4[4] = {dy[0].x, dy[1].x, dy[0].y, dy[1].y};
+        const float2 r = hpair<ODD0>(d4);
+        return f2{r.x, r.y};
     };
     // ---- outLPyramid[0] of one level-0 row (the lane's quad): rq / rt = the lane's float2 of plane 0 in the level-1 row whose
     // vertical weight is 1/4 / 3/4 (plane stride 128 float2 in both the window slots and the published rows).  The arithmetic is
-    // ll_up0f's stage 2 (hl0 / hl1 / vl: lerps with the exact quarter product folded into an fma, :276-282 with the parities known).
-    auto emit_row = [&](const Row &n, int y, const float2 *rq, const float2 *rt) {
+    // ll_up0f's stage 2 (hl0 / hl1 / vl: lerps with the exact quarter product folded into an fma, :276-282 with the parities
+    // known), on the pixel pairs (0, 2) and (1, 3).
+    auto emit_row = [&](const Row &n, const f2 *rq, const f2 *rt, f2 (&o)[2]) {
         constexpr int COL[4] = {ODD0 ? -1 : -2, -1, ODD0 ? 0 : -1, 0};   // first float of the coarse column pair, relative to the lane's own .x
         const float *fq = reinterpret_cast<const float *>(rq), *ft = reinterpret_cast<const float *>(rt);
-        float lut0[4], lut1[4], lf[4], lev0[4], lev1[4];
-        float q0a[4], q0b[4], t0a[4], t0b[4], q1a[4], q1b[4], t1a[4], t1b[4];
+        f2 lut0[2], lut1[2], lif[2];
+        f2 q0a[2], q0b[2], t0a[2], t0b[2], q1a[2], q1b[2], t1a[2], t1b[2];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
+            const int h = i & 1, e = i >> 1;                           // pair, element of the pair
             const int pos = n.l[i] - lbase * 4;                        // 4 x table index of the pixel
             const int li = min(pos >> 10, KCH - 2);                    // (int)(gray * (K-1)), clamped (:66); gray >= 0
             const char *lp = reinterpret_cast<const char *>(slut) + (n.l[i] + 1024 * (KCH - 1)) - (li << 10);
-            lut0[i] = *reinterpret_cast<const float *>(lp), lut1[i] = *reinterpret_cast<const float *>(lp - 1024);
             const float *aq = fq + (li << 8) + COL[i], *at = ft + (li << 8) + COL[i];
-            q0a[i] = aq[0], q0b[i] = aq[1], q1a[i] = aq[256], q1b[i] = aq[257];
-            t0a[i] = at[0], t0b[i] = at[1], t1a[i] = at[256], t1b[i] = at[257];
-            const float lif = (float)li;
-            lf[i] = n.g[i] * gm.Km1 - lif;
-            lev0[i] = lif * gm.inv_Km1, lev1[i] = (lif + 1.0f) * gm.inv_Km1;
+#if HLMI_D01E_ABL & 8
+            lut0[h][e] = __builtin_bit_cast(float, (int)(size_t)lp), lut1[h][e] = n.g[h][e];
+            q0a[h][e] = __builtin_bit_cast(float, (int)(size_t)aq), q0b[h][e] = n.g[h][e], q1a[h][e] = lut0[h][e], q1b[h][e] = q0a[h][e];
+            t0a[h][e] = __builtin_bit_cast(float, (int)(size_t)at), t0b[h][e] = n.g[h][e], t1a[h][e] = lut0[h][e], t1b[h][e] = t0a[h][e];
+#else
+            lut0[h][e] = *reinterpret_cast<const float *>(lp), lut1[h][e] = *reinterpret_cast<const float *>(lp - 1024);
+            q0a[h][e] = aq[0], q0b[h][e] = aq[1], q1a[h][e] = aq[256], q1b[h][e] = aq[257];
+            t0a[h][e] = at[0], t0b[h][e] = at[1], t1a[h][e] = at[256], t1b[h][e] = at[257];
+#endif
+            lif[h][e] = (float)li;
         }
-        float o[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const bool xodd = ODD0 ? (i & 1) == 0 : (i & 1) == 1;
+        for (int h = 0; h < 2; h++) {
+            const bool xodd = ODD0 ? h == 0 : h == 1;
             // even x: lerp(f[c], f[c-1], 1/4) = f[c-1]/4 + 3 f[c]/4; odd x: lerp(f[c+1], f[c], 3/4) = f[c+1]/4 + 3 f[c]/4
-            auto hl = [&](float fa, float fb) { return xodd ? __builtin_fmaf(fb, 0.25f, fa * 0.75f) : __builtin_fmaf(fa, 0.25f, fb * 0.75f); };
-            auto vl = [](float uq, float ut) { return __builtin_fmaf(uq, 0.25f, ut * 0.75f); };
-            const float u0 = vl(hl(q0a[i], q0b[i]), hl(t0a[i], t0b[i]));
-            const float u1 = vl(hl(q1a[i], q1b[i]), hl(t1a[i], t1b[i]));
-            const float l0 = g0_val<B1>(n.g[i], lev0[i], p.beta, lut0[i]) - u0;
-            const float l1 = g0_val<B1>(n.g[i], lev1[i], p.beta, lut1[i]) - u1;
-            o[i] = (1.0f - lf[i]) * l0 + lf[i] * l1;
-        }
-        if (em_ok && y >= pe.oy0 && y < pe.oy0 + pe.oh && !(HLMI_D01E_ABL & 2 && p.nunits > 0)) {
-            *reinterpret_cast<float4 *>(em_col + (size_t)(y - pe.oy0) * iw) = make_float4(o[0], o[1], o[2], o[3]);
+            auto hl = [&](f2 fa, f2 fb) { return xodd ? fma2(fb, f2s(0.25f), fa * 0.75f) : fma2(fa, f2s(0.25f), fb * 0.75f); };
+            auto vl = [](f2 uq, f2 ut) { return fma2(uq, f2s(0.25f), ut * 0.75f); };
+            const f2 g = n.g[h];
+            const f2 lf = g * gm.Km1 - lif[h];
+            const f2 lev0 = lif[h] * gm.inv_Km1, lev1 = (lif[h] + 1.0f) * gm.inv_Km1;
+            const f2 u0 = vl(hl(q0a[h], q0b[h]), hl(t0a[h], t0b[h]));
+            const f2 u1 = vl(hl(q1a[h], q1b[h]), hl(t1a[h], t1b[h]));
+            const f2 l0 = (B1 ? ((g - lev0) + lev0) + lut0[h] : (p.beta * (g - lev0) + lev0) + lut0[h]) - u0;   // g0_val
+            const f2 l1 = (B1 ? ((g - lev1) + lev1) + lut1[h] : (p.beta * (g - lev1) + lev1) + lut1[h]) - u1;
+            o[h] = (1.0f - lf) * l0 + lf * l1;
         }
     };
-    float a[KCH + 1][4], b[KCH + 1][4], a2[KCH + 1][4], b2[KCH + 1][4];
-    float2 pcr[KCH + 1];       // a + 3 (b + c) of the level-2 window between its third and fourth row
+    auto emit_store = [&](int y, const f2 (&o)[2]) {
+        if (em_ok && y >= pe.oy0 && y < pe.oy0 + pe.oh && !(HLMI_D01E_ABL & 2 && p.nunits > 0)) {
+            *reinterpret_cast<float4 *>(em_col + (size_t)(y - pe.oy0) * iw) = make_float4(o[0].x, o[1].x, o[0].y, o[1].y);
+        }
+    };
+#if HLMI_LL_PROBE
+    unsigned long long pr_planes = 0, pr_emit = 0, pr_prep = 0, pr_steps = 0;
+    LL_PROBE_T(pe0);
+#endif
+    f2 a[KCH + 1][2], b[KCH + 1][2], a2[KCH + 1][2], b2[KCH + 1][2];
+    f2 pcr[KCH + 1];           // a + 3 (b + c) of the level-2 window between its third and fourth row
     Raw rc, rd;
     {
         Raw ra, rb;
@@ -1209,7 +1243,7 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         Row r0, r1;
         prep_row(ra, r0);
         prep_row(rb, r1);
-        float lv[2][8];
+        f2 lv[2][4];
         lut_issue(0, r0, r1, lv[0]);
 #pragma unroll
         for (int kk = 0; kk <= KCH; kk++) {
@@ -1222,29 +1256,29 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
     // One level-1 row T.  PH = 0: the third row of a level-2 window (slot 0 takes it), PH = 1: the fourth (slot 1) — the step
     // that completes level-2 row (T - 2) / 2.  c0 / c1: level-0 rows 2T + 1, 2T + 2; n0 / n1 still hold rows 2T - 1, 2T (the
     // previous step's pair) until this step's end, when they take the rows after c0 / c1.
-    auto step = [&](auto ph_tag, int T, const Row &c0, const Row &c1, Row &n0, Row &n1, float (&ia)[KCH + 1][4],
-                    float (&ib)[KCH + 1][4], float (&oa)[KCH + 1][4], float (&ob)[KCH + 1][4], float2 *pub) {
+    auto step = [&](auto ph_tag, int T, const Row &c0, const Row &c1, Row &n0, Row &n1, f2 (&ia)[KCH + 1][2],
+                    f2 (&ib)[KCH + 1][2], f2 (&oa)[KCH + 1][2], f2 (&ob)[KCH + 1][2], f2 *pub) {
         constexpr int PH = decltype(ph_tag)::value;
-        float lv[2][8], dy[2][4];
-        float2 res[KCH + 1];
-        float2 sa, sb;
+        f2 lv[2][4], dy[2][2];
+        f2 res[KCH + 1];
+        f2 sa, sb;
         const bool out2 = PH == 1 && T >= 2 * A + 2;   // wave-uniform
         float *d2 = p.g2 + (size_t)(((T - 2) >> 1) - p.loy2) * p.ws2 + off2;
+        LL_PROBE_T(ps0);
         auto level2 = [&](int k) {
-            const float2 c = res[k];
+            const f2 c = res[k];
             if (PH == 0) {
-                pcr[k].x = sa.x + 3.0f * (sb.x + c.x);
-                pcr[k].y = sa.y + 3.0f * (sb.y + c.y);
+                pcr[k] = sa + 3.0f * (sb + c);
                 st2[(2 * k) * 64] = c;
             } else {
-                const float rx = pcr[k].x + c.x, ry = pcr[k].y + c.y;   // down4_raw of the lane's two level-1 columns
+                const f2 r = pcr[k] + c;   // down4_raw of the lane's two level-1 columns
                 float o;
                 if (ODD1) {
-                    const float nx = lane_next(rx), ny = lane_next(ry);
-                    o = down4_tail(rx, ry, nx, ny);
+                    const float nx = lane_next(r.x), ny = lane_next(r.y);
+                    o = down4_tail(r.x, r.y, nx, ny);
                 } else {
-                    const float py = lane_prev(ry), nx = lane_next(rx);
-                    o = down4_tail(py, rx, ry, nx);
+                    const float py = lane_prev(r.y), nx = lane_next(r.x);
+                    o = down4_tail(py, r.x, r.y, nx);
                 }
                 if (out2 && st2_ok) d2[(size_t)k * p.ps2] = o;
                 st2[(2 * k + 1) * 64] = c;
@@ -1263,13 +1297,13 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
             plane_vals(kk, c0, c1, lv[kk & 1], oa[kk], ob[kk]);
             vpass(ia[kk], ib[kk], oa[kk], ob[kk], dy[kk & 1]);
             if (kk > 0) {
-                res[kk - 1] = hpair<ODD0>(dy[(kk - 1) & 1]);
+                res[kk - 1] = hpair2(dy[(kk - 1) & 1]);
                 level2(kk - 1);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         state_issue(KCH);
-        res[KCH] = hpair<ODD0>(dy[KCH & 1]);
+        res[KCH] = hpair2(dy[KCH & 1]);
         level2(KCH);
         if (EXCH && pub) {
 #pragma unroll
@@ -1280,35 +1314,54 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        float2 *const rowT = st2 + (PH == 0 ? 0 : 64), *const rowP = st2 + (PH == 0 ? 64 : 0);   // rows T and T - 1
-        if (T >= Ts0 && T <= Ts1) {
+        LL_PROBE_T(ps1);
+        f2 *const rowT = st2 + (PH == 0 ? 0 : 64), *const rowP = st2 + (PH == 0 ? 64 : 0);   // rows T and T - 1
+        // Everything that is stored is computed first and stored AFTER prep_row: prep_row waits for the input rows requested at
+        // the end of the previous step, and vmcnt counts in order — with this step's (conditional) stores issued before it, the
+        // only wait that covers the loads is vmcnt(0), i.e. a round trip of the stores to memory in every step.
+        const bool st1_row = T >= Ts0 && T <= Ts1;                                                  // wave-uniform
+        const bool em_rows = T >= 2 * A && T <= 2 * B + 1 && !(HLMI_D01E_ABL & 1 && p.nunits > 0);   // wave-uniform
+        float2 s0 = make_float2(0.0f, 0.0f), s1 = s0;
+        const f2 sK = res[KCH];
+        if (st1_row) {
             // of level 1 the up pass reads inGPyramid[1] and gPyramid[1](., ., li1 / li1 + 1) at the coarse pixel itself (:63-72)
-            const int lx = dev::clampi((int)(res[KCH].x * gm.Km1), 0, KCH - 2), ly = dev::clampi((int)(res[KCH].y * gm.Km1), 0, KCH - 2);
+            const int lx = dev::clampi((int)(sK.x * gm.Km1), 0, KCH - 2), ly = dev::clampi((int)(sK.y * gm.Km1), 0, KCH - 2);
             const float *fx = reinterpret_cast<const float *>(rowT) + (lx << 8), *fy = reinterpret_cast<const float *>(rowT) + (ly << 8) + 1;
-            const float2 s0 = make_float2(fx[0], fy[0]), s1 = make_float2(fx[256], fy[256]);
-            float *drow = p.g1 + (size_t)(T - p.loy1) * p.ws1 + off1;
-            if (st1_ok && !(HLMI_D01E_ABL & 4 && p.nunits > 0)) {
-                *reinterpret_cast<float2 *>(drow) = s0;
-                *reinterpret_cast<float2 *>(drow + p.ps1) = s1;
-                *reinterpret_cast<float2 *>(drow + (size_t)KCH * p.ps1) = res[KCH];
-            }
+            s0 = make_float2(fx[0], fy[0]), s1 = make_float2(fx[256], fy[256]);
         }
-        if (T >= 2 * A && T <= 2 * B + 1 && !(HLMI_D01E_ABL & 1 && p.nunits > 0)) {   // wave-uniform
-            emit_row(n0, 2 * T - 1, rowT, rowP);   // odd row: coarse row T weighs 1/4
+        f2 eo[2] = {f2s(0.0f), f2s(0.0f)}, ee[2] = {f2s(0.0f), f2s(0.0f)};
+        if (em_rows) {
+            emit_row(n0, rowT, rowP, eo);   // odd row 2T - 1: coarse row T weighs 1/4
             __builtin_amdgcn_sched_barrier(0);
-            emit_row(n1, 2 * T, rowP, rowT);
+            emit_row(n1, rowP, rowT, ee);   // even row 2T
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        LL_PROBE_T(ps2);
         // unconditional: after the last row rc / rd still hold the previous (valid) rows and the result is unused
         prep_row(rc, n0);
         prep_row(rd, n1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st1_row && st1_ok && !(HLMI_D01E_ABL & 4 && p.nunits > 0)) {
+            float *drow = p.g1 + (size_t)(T - p.loy1) * p.ws1 + off1;
+            *reinterpret_cast<float2 *>(drow) = s0;
+            *reinterpret_cast<float2 *>(drow + p.ps1) = s1;
+            *reinterpret_cast<f2 *>(drow + (size_t)KCH * p.ps1) = sK;
+        }
+        if (em_rows) {
+            emit_store(2 * T - 1, eo);
+            emit_store(2 * T, ee);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (T + 1 < T1) {
             load_row(rc, 2 * T + 5);
             load_row(rd, 2 * T + 6);
         }
         __builtin_amdgcn_sched_barrier(0);
+#if HLMI_LL_PROBE
+        LL_PROBE_T(ps3);
+        pr_planes += ps1 - ps0, pr_emit += ps2 - ps1, pr_prep += ps3 - ps2, pr_steps += 1;
+#endif
     };
     Row p0, p1, p2, p3;
     prep_row(rc, p0);
@@ -1321,31 +1374,42 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         step(std::integral_constant<int, 1>{}, T + 1, p2, p3, p0, p1, a2, b2, a, b, first && publish ? pub_mine + 64 : nullptr);
         if (first) __syncthreads();   // every wave of the workgroup that has rows passes here exactly once
     }
+#if HLMI_LL_PROBE
+    LL_PROBE_T(pe1);
+#endif
     if (EXCH && !self_halo) {
         // level-2 row B: rows "c" (2B+1) and "d" (2B+2) are the first two rows of the wave below
         float *d2 = p.g2 + (size_t)(B - p.loy2) * p.ws2 + off2;
 #pragma unroll
         for (int k = 0; k <= KCH; k++) {
-            const float2 sa = st2[(2 * k) * 64], sb = st2[(2 * k + 1) * 64];
-            const float2 c = pub_next[(2 * k) * 64], d = pub_next[(2 * k + 1) * 64];
-            const float rx = (sa.x + 3.0f * (sb.x + c.x)) + d.x, ry = (sa.y + 3.0f * (sb.y + c.y)) + d.y;
+            const f2 sa = st2[(2 * k) * 64], sb = st2[(2 * k + 1) * 64];
+            const f2 c = pub_next[(2 * k) * 64], d = pub_next[(2 * k + 1) * 64];
+            const f2 r = (sa + 3.0f * (sb + c)) + d;
             float o;
             if (ODD1) {
-                const float nx = lane_next(rx), ny = lane_next(ry);
-                o = down4_tail(rx, ry, nx, ny);
+                const float nx = lane_next(r.x), ny = lane_next(r.y);
+                o = down4_tail(r.x, r.y, nx, ny);
             } else {
-                const float py = lane_prev(ry), nx = lane_next(rx);
-                o = down4_tail(py, rx, ry, nx);
+                const float py = lane_prev(r.y), nx = lane_next(r.x);
+                o = down4_tail(py, r.x, r.y, nx);
             }
             if (st2_ok) d2[(size_t)k * p.ps2] = o;
         }
         // outLPyramid[0] rows 4B + 1, 4B + 2 (the pair the last step brought in: p2 / p3) from level-1 rows 2B (slot 1) and 2B + 1
         // (published)
         if (!(HLMI_D01E_ABL & 1 && p.nunits > 0)) {
-            emit_row(p2, 4 * B + 1, pub_next, st2 + 64);
-            emit_row(p3, 4 * B + 2, st2 + 64, pub_next);
+            f2 eo[2], ee[2];
+            emit_row(p2, pub_next, st2 + 64, eo);
+            emit_row(p3, st2 + 64, pub_next, ee);
+            emit_store(4 * B + 1, eo);
+            emit_store(4 * B + 2, ee);
         }
     }
+#if HLMI_LL_PROBE
+    LL_PROBE_T(pe2);
+    LL_PROBE_ADD(20, pr_planes); LL_PROBE_ADD(21, pr_emit); LL_PROBE_ADD(22, pr_prep); LL_PROBE_ADD(23, pr_steps);
+    LL_PROBE_ADD(24, 1); LL_PROBE_ADD(25, pe1 - pe0); LL_PROBE_ADD(26, pe2 - pe1);
+#endif
     };  // walk
     if (edge_wave) walk(std::true_type{});
     else walk(std::false_type{});

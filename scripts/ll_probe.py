@@ -24,7 +24,15 @@ v = [int(x) for x in buf]
 # s_memtime ticks at a constant 100 MHz on gfx9 (10 ns)
 tick = 10.0  # wall_clock64
 nw = v[1] / N
-print(f"down01: waves {nw:.0f}; per wave [ns]: lut fill {v[0] / v[1] * tick:.0f}, prologue {v[2] / v[1] * tick:.0f}, first pair+barrier {v[3] / max(1, v[1]) * tick:.0f}, "
+if v[1]:
+  print(f"down01: waves {nw:.0f}; per wave [ns]: lut fill {v[0] / v[1] * tick:.0f}, prologue {v[2] / v[1] * tick:.0f}, first pair+barrier {v[3] / max(1, v[1]) * tick:.0f}, "
       f"loop {v[4] / v[1] * tick:.0f} for {v[5] / v[1]:.1f} rows, total {v[6] / v[1] * tick:.0f}")
-print(f"down01 prologue: setup before loads {v[17] / v[1] * tick:.0f}, first four rows' loads outstanding {v[16] / v[1] * tick:.0f}")
-print(f"up0: waves {v[10] / N:.0f}; per wave [ns]: tile phase {v[8] / v[10] * tick:.0f}, barrier wait {v[9] / v[10] * tick:.0f}, rows {v[11] / v[10] * tick:.0f}, total {v[12] / v[10] * tick:.0f}")
+if v[1]:
+  print(f"down01 prologue: setup before loads {v[17] / v[1] * tick:.0f}, first four rows' loads outstanding {v[16] / v[1] * tick:.0f}")
+if v[10]:
+  print(f"up0: waves {v[10] / N:.0f}; per wave [ns]: tile phase {v[8] / v[10] * tick:.0f}, barrier wait {v[9] / v[10] * tick:.0f}, rows {v[11] / v[10] * tick:.0f}, total {v[12] / v[10] * tick:.0f}")
+if v[24]:
+    w = v[24]
+    print(f"down01e: waves {w / N:.0f}; per wave [ns]: steps {v[23] / w:.1f}; plane loop {v[20] / w * tick:.0f}, sel + emission {v[21] / w * tick:.0f}, "
+          f"prep + loads {v[22] / w * tick:.0f}; prologue + walk {v[25] / w * tick:.0f}, tail {v[26] / w * tick:.0f}")
+    print(f"  per step [ns]: planes {v[20] / v[23] * tick:.0f}, sel + emission {v[21] / v[23] * tick:.0f}, prep + loads {v[22] / v[23] * tick:.0f}")
