@@ -1180,51 +1180,62 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         return f2{r.x, r.y};
     };
     // ---- outLPyramid[0] of one level-0 row (the lane's quad): rq / rt = the lane's float2 of plane 0 in the level-1 row whose
-    // vertical weight is 1/4 / 3/4 (plane stride 128 float2 in both the window slots and the published rows).  The arithmetic is
-    // ll_up0f's stage 2 (hl0 / hl1 / vl: lerps with the exact quarter product folded into an fma, :276-282 with the parities
-    // known), on the pixel pairs (0, 2) and (1, 3).
-    auto emit_row = [&](const Row &n, const f2 *rq, const f2 *rt, f2 (&o)[2]) {
+    // vertical weight is 1/4 / 3/4 (plane stride 128 float2 = 4 x 64 dwords in both the window slots and the published rows).
+    // The arithmetic is ll_up0f's stage 2 (hl0 / hl1 / vl: lerps with the exact quarter product folded into an fma, :276-282
+    // with the parities known).  Per pixel the pair is (plane li, plane li + 1): one ds_read2st64_b32 fetches both planes of a
+    // coarse value (or both table entries), and every pass up to the final blend runs on the two planes at once.  The gathers
+    // are issued by hand (the compiler pairs adjacent dwords instead, and then shuffles them into plane pairs with v_mov's):
+    // all 20 of a row first, one s_waitcnt that every result is routed through, then the arithmetic.
+    auto emit_row = [&](const Row &n, const f2 *rq, const f2 *rt, float (&r)[4]) {
         constexpr int COL[4] = {ODD0 ? -1 : -2, -1, ODD0 ? 0 : -1, 0};   // first float of the coarse column pair, relative to the lane's own .x
-        const float *fq = reinterpret_cast<const float *>(rq), *ft = reinterpret_cast<const float *>(rt);
-        f2 lut0[2], lut1[2], lif[2];
-        f2 q0a[2], q0b[2], t0a[2], t0b[2], q1a[2], q1b[2], t1a[2], t1b[2];
+        const uint32_t aq0 = (uint32_t)(size_t)rq, at0 = (uint32_t)(size_t)rt, alut = (uint32_t)(size_t)slut + 1024u * (KCH - 2);
+        f2 lut[4], qa[4], qb[4], ta[4], tb[4];
+        float lif[4];
+        auto rd2 = [](uint32_t addr, auto swap_tag) {   // (dword at addr, dword at addr + 1024 bytes), or swapped
+            f2 v;
+#if HLMI_D01E_ABL & 8
+            v = f2{__builtin_bit_cast(float, addr), 1.0f};
+#else
+            if (decltype(swap_tag)::value) asm volatile("ds_read2st64_b32 %0, %1 offset0:4" : "=v"(v) : "v"(addr) : "memory");
+            else asm volatile("ds_read2st64_b32 %0, %1 offset1:4" : "=v"(v) : "v"(addr) : "memory");
+#endif
+            return v;
+        };
+        constexpr std::false_type asc{};
+        constexpr std::true_type desc{};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int h = i & 1, e = i >> 1;                           // pair, element of the pair
             const int pos = n.l[i] - lbase * 4;                        // 4 x table index of the pixel
             const int li = min(pos >> 10, KCH - 2);                    // (int)(gray * (K-1)), clamped (:66); gray >= 0
-            const char *lp = reinterpret_cast<const char *>(slut) + (n.l[i] + 1024 * (KCH - 1)) - (li << 10);
-            const float *aq = fq + (li << 8) + COL[i], *at = ft + (li << 8) + COL[i];
-#if HLMI_D01E_ABL & 8
-            lut0[h][e] = __builtin_bit_cast(float, (int)(size_t)lp), lut1[h][e] = n.g[h][e];
-            q0a[h][e] = __builtin_bit_cast(float, (int)(size_t)aq), q0b[h][e] = n.g[h][e], q1a[h][e] = lut0[h][e], q1b[h][e] = q0a[h][e];
-            t0a[h][e] = __builtin_bit_cast(float, (int)(size_t)at), t0b[h][e] = n.g[h][e], t1a[h][e] = lut0[h][e], t1b[h][e] = t0a[h][e];
-#else
-            lut0[h][e] = *reinterpret_cast<const float *>(lp), lut1[h][e] = *reinterpret_cast<const float *>(lp - 1024);
-            q0a[h][e] = aq[0], q0b[h][e] = aq[1], q1a[h][e] = aq[256], q1b[h][e] = aq[257];
-            t0a[h][e] = at[0], t0b[h][e] = at[1], t1a[h][e] = at[256], t1b[h][e] = at[257];
-#endif
-            lif[h][e] = (float)li;
+            const uint32_t po = (uint32_t)(li << 10) + (uint32_t)(COL[i] * 4);
+            lut[i] = rd2(alut + (uint32_t)n.l[i] - (uint32_t)(li << 10), desc);   // plane li + 1's entry is the lower address
+            qa[i] = rd2(aq0 + po, asc), qb[i] = rd2(aq0 + po + 4u, asc);
+            ta[i] = rd2(at0 + po, asc), tb[i] = rd2(at0 + po + 4u, asc);
+            lif[i] = (float)li;
         }
+#if !(HLMI_D01E_ABL & 8)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lut[0]), "+v"(qa[0]), "+v"(qb[0]), "+v"(ta[0]), "+v"(tb[0]), "+v"(lut[1]), "+v"(qa[1]), "+v"(qb[1]), "+v"(ta[1]), "+v"(tb[1]));
+        asm volatile("" : "+v"(lut[2]), "+v"(qa[2]), "+v"(qb[2]), "+v"(ta[2]), "+v"(tb[2]), "+v"(lut[3]), "+v"(qa[3]), "+v"(qb[3]), "+v"(ta[3]), "+v"(tb[3]));
+#endif
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const bool xodd = ODD0 ? h == 0 : h == 1;
+        for (int i = 0; i < 4; i++) {
+            const bool xodd = ODD0 ? (i & 1) == 0 : (i & 1) == 1;
             // even x: lerp(f[c], f[c-1], 1/4) = f[c-1]/4 + 3 f[c]/4; odd x: lerp(f[c+1], f[c], 3/4) = f[c+1]/4 + 3 f[c]/4
             auto hl = [&](f2 fa, f2 fb) { return xodd ? fma2(fb, f2s(0.25f), fa * 0.75f) : fma2(fa, f2s(0.25f), fb * 0.75f); };
             auto vl = [](f2 uq, f2 ut) { return fma2(uq, f2s(0.25f), ut * 0.75f); };
-            const f2 g = n.g[h];
-            const f2 lf = g * gm.Km1 - lif[h];
-            const f2 lev0 = lif[h] * gm.inv_Km1, lev1 = (lif[h] + 1.0f) * gm.inv_Km1;
-            const f2 u0 = vl(hl(q0a[h], q0b[h]), hl(t0a[h], t0b[h]));
-            const f2 u1 = vl(hl(q1a[h], q1b[h]), hl(t1a[h], t1b[h]));
-            const f2 l0 = (B1 ? ((g - lev0) + lev0) + lut0[h] : (p.beta * (g - lev0) + lev0) + lut0[h]) - u0;   // g0_val
-            const f2 l1 = (B1 ? ((g - lev1) + lev1) + lut1[h] : (p.beta * (g - lev1) + lev1) + lut1[h]) - u1;
-            o[h] = (1.0f - lf) * l0 + lf * l1;
+            const float g = n.g[i & 1][i >> 1];
+            const float lf = g * gm.Km1 - lif[i];
+            const f2 lev = f2{lif[i], lif[i] + 1.0f} * gm.inv_Km1;
+            const f2 u = vl(hl(qa[i], qb[i]), hl(ta[i], tb[i]));
+            const f2 g2 = f2s(g);
+            const f2 l = (B1 ? ((g2 - lev) + lev) + lut[i] : (p.beta * (g2 - lev) + lev) + lut[i]) - u;   // g0_val of planes li, li + 1
+            const f2 m = f2{1.0f - lf, lf} * l;
+            r[i] = m.x + m.y;
         }
     };
-    auto emit_store = [&](int y, const f2 (&o)[2]) {
+    auto emit_store = [&](int y, const float (&r)[4]) {
         if (em_ok && y >= pe.oy0 && y < pe.oy0 + pe.oh && !(HLMI_D01E_ABL & 2 && p.nunits > 0)) {
-            *reinterpret_cast<float4 *>(em_col + (size_t)(y - pe.oy0) * iw) = make_float4(o[0].x, o[1].x, o[0].y, o[1].y);
+            *reinterpret_cast<float4 *>(em_col + (size_t)(y - pe.oy0) * iw) = make_float4(r[0], r[1], r[2], r[3]);
         }
     };
 #if HLMI_LL_PROBE
@@ -1329,7 +1340,7 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
             const float *fx = reinterpret_cast<const float *>(rowT) + (lx << 8), *fy = reinterpret_cast<const float *>(rowT) + (ly << 8) + 1;
             s0 = make_float2(fx[0], fy[0]), s1 = make_float2(fx[256], fy[256]);
         }
-        f2 eo[2] = {f2s(0.0f), f2s(0.0f)}, ee[2] = {f2s(0.0f), f2s(0.0f)};
+        float eo[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ee[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (em_rows) {
             emit_row(n0, rowT, rowP, eo);   // odd row 2T - 1: coarse row T weighs 1/4
             __builtin_amdgcn_sched_barrier(0);
@@ -1398,7 +1409,7 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         // outLPyramid[0] rows 4B + 1, 4B + 2 (the pair the last step brought in: p2 / p3) from level-1 rows 2B (slot 1) and 2B + 1
         // (published)
         if (!(HLMI_D01E_ABL & 1 && p.nunits > 0)) {
-            f2 eo[2], ee[2];
+            float eo[4], ee[4];
             emit_row(p2, pub_next, st2 + 64, eo);
             emit_row(p3, st2 + 64, pub_next, ee);
             emit_store(4 * B + 1, eo);
