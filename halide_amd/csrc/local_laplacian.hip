@@ -1023,6 +1023,11 @@ struct D01EArgs {
     D01Args d;
     float *outl0;              // outLPyramid[0] on [ix0, ix1] x [oy0, oy0 + oh - 1], row stride = input width (a multiple of 4)
     int oy0, oh;
+    // EXCH: workgroups numbered strip-fastest (wg = gy * nsx + sx) so that the contiguous range xcd_block() hands an XCD holds
+    // horizontal AND vertical neighbours: a strip's 512-byte row pieces start 16 bytes before a 128-byte line, which its left
+    // neighbour reads too — from the same L2 then (0: row-fastest as in ll_down01f)
+    int xmajor;
+    unsigned nsx_magic;        // floor(2^32 / nsx) + 1, 0 when nsx == 1
 };
 #ifndef HLMI_D01E_ABL
 #define HLMI_D01E_ABL 0   // timing experiments only (csrc/Makefile VARIANT): 1 no emission at all, 2 no outL0 stores, 4 no sel-plane stores, 8 emission without its LDS reads, 16 no table gathers in the plane loop
@@ -1050,8 +1055,14 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
     bool publish = false;      // first two rows go to LDS for the wave above
     if (EXCH) {
         const int wg = xcd_block();
-        sx = p.nsy_magic ? (int)__umulhi((unsigned)wg, p.nsy_magic) : wg;
-        const int gy = wg - sx * p.nsy;
+        int gy;
+        if (pe.xmajor) {
+            gy = pe.nsx_magic ? (int)__umulhi((unsigned)wg, pe.nsx_magic) : 0;
+            sx = wg - gy * p.nsx;
+        } else {
+            sx = p.nsy_magic ? (int)__umulhi((unsigned)wg, p.nsy_magic) : wg;
+            gy = wg - sx * p.nsy;
+        }
         const int GA = p.loy2 + gy * p.rows_base + min(gy, p.rows_rem);
         const int GB = GA + p.rows_base + (gy < p.rows_rem ? 1 : 0) - 1;
         const int n = (GB - GA + 1 + 1 + 3) >> 2;
@@ -2037,13 +2048,23 @@ struct Up0HArgs {
     Up0Args u;
     const float *outl0;        // outLPyramid[0] on [ix0, ix1] x [oy0, oy0 + oh - 1]
     int l0_ws;                 // its row stride in floats (= input width)
+    int xcd_tiles;
 };
 constexpr int U0H_PF = 4;      // rows in flight per wave
 __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
     const Up0Args &p = ph.u;
     extern __shared__ float s_out1[];
-    const int X0 = p.ox0 + (int)blockIdx.x * 256;                       // even
-    const int Yw0 = p.oy0 + (int)blockIdx.y * (2 * p.RU);
+    // tiles in row-major order, a contiguous run of them per XCD (blocks are dealt round-robin over the 8 XCDs): a tile's
+    // 130 x (RU + 2) coarse window overlaps its neighbours' by two columns / rows, and its 130-float rows start one float before a
+    // 512-byte boundary — 6 lines for 4 of payload, the outer two shared with the neighbour tile: same L2 now
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (ph.xcd_tiles) {
+        const int b = by * (int)gridDim.x + bx, nb8 = (int)(gridDim.x * gridDim.y) >> 3;
+        const int lb = b < (nb8 << 3) ? (b & 7) * nb8 + (b >> 3) : b;
+        by = lb / (int)gridDim.x, bx = lb - by * (int)gridDim.x;
+    }
+    const int X0 = p.ox0 + bx * 256;                       // even
+    const int Yw0 = p.oy0 + by * (2 * p.RU);
     const int Yw1 = min(Yw0 + 2 * p.RU, p.oy0 + p.oh) - 1;
     const int cx0 = (X0 >> 1) - 1, cy0 = dev::fdiv2(Yw0 - 1);
     const int th = dev::fdiv2(Yw1 + 1) - cy0 + 1;
@@ -2057,8 +2078,8 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
     }
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int x = blockIdx.x * 256 + (wave & 1) * 128 + 2 * lane;  // output storage column of the lane's pair
-    const int y0 = blockIdx.y * (2 * p.RU) + (wave >> 1) * p.RU;
+    const int x = bx * 256 + (wave & 1) * 128 + 2 * lane;  // output storage column of the lane's pair
+    const int y0 = by * (2 * p.RU) + (wave >> 1) * p.RU;
     if (y0 >= p.oh || x >= p.ow) return;
     const int y1 = min(y0 + p.RU, p.oh);
     const int X = p.ox0 + x;                                              // even
@@ -2435,7 +2456,7 @@ uint64_t ll_env_signature() {
     static const char *const names[] = {"HLMI_LL_NO_LUT_CACHE", "HLMI_LL_UNITS0", "HLMI_LL_NO_VEC", "HLMI_LL_D0F", "HLMI_LL_FUSE_D2",
                                         "HLMI_LL_D01_EXCH", "HLMI_LL_FUSE_FROM", "HLMI_LL_UNITSB", "HLMI_LL_UPCHAIN_FROM",
                                         "HLMI_LL_UP0_OLD", "HLMI_LL_FUSE_UP1", "HLMI_LL_RU", "HLMI_LL_PLANE_MASK", "HLMI_LL_ONDEMAND",
-                                        "HLMI_LL_G_ABL", "HLMI_LL_EMIT"};
+                                        "HLMI_LL_G_ABL", "HLMI_LL_EMIT", "HLMI_LL_XMAJOR", "HLMI_LL_XCD_TILES"};
     uint64_t h = 1469598103934665603ull;
     for (const char *n : names) {
         const char *e = getenv(n);
@@ -2605,6 +2626,8 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     // ---- level 0 arguments first: whether the level-1 collapse is fused into ll_up0f decides if ll_up:1 is launched
     Up0Args p;
     bool vec, fast, fuse1;
+    const int stream_cus = stream_cu_count(ctx.device, ctx.stream);
+    const bool partitioned = stream_cus < stream_cu_count(ctx.device, nullptr);
     {
         const Level &c = lv[1];
         p.in = din, p.in_sy = in_sy;
@@ -2634,7 +2657,6 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         // rows per wave: taller tiles re-read less of level 1 (18 coarse rows per 16 output rows, 34 per 32) but keep a wave
         // busy longer.  On a CU-partitioned stream, where several frames share the memory system and the frame rate is set by
         // bytes, 32 rows measure 2.7 % faster (84.8 vs 82.6 Gpx/s); on a stream that owns the device 16 rows do (72.7 vs 68.2).
-        const bool partitioned = stream_cu_count(ctx.device, ctx.stream) < stream_cu_count(ctx.device, nullptr);
         p.RU = max(1, env_int("HLMI_LL_RU", fuse1 ? (partitioned ? 32 : 16) : 8));
     }
     // ll_up0g: level 1 is never stored — the up pass recomputes the planes each tile needs from the input (needs the fused
@@ -2650,6 +2672,9 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     // The default for the common geometry: ll_down01e emits outLPyramid[0] and three planes of level 1, ll_up0h collapses
     // (HLMI_LL_EMIT=0: the round-3 pair ll_down01f / ll_up0f with the materialised K + 1 level-1 planes)
     const bool emit = d01_possible && fast && fuse1 && !ondemand && env_int("HLMI_LL_EMIT", 1);
+    // ll_up0h has no data-dependent gathers to amortise over a tall tile: short tiles (more, smaller workgroups) are faster on a
+    // stream that owns the device (31.7 us at 8 rows per wave against 33.5 / 38.4 at 16 / 32); on CU partitions 8..32 measure the same
+    if (emit) p.RU = max(1, env_int("HLMI_LL_RU", partitioned ? 16 : 8));
     bool fuse1_out = false;
     auto enqueue = [&]() -> int {   // the launch chain of one frame (everything below depends only on what GraphKey holds)
     bool fuse_d2 = false;
@@ -2700,7 +2725,10 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             a.nsx = max((hi2 - x2_first + a.S2) / a.S2, (hi1 - a.Pbase + 2 * a.S2) / (2 * a.S2));
             // sized for the whole device even on a CU-partitioned stream: units sized for the partition's 64 CUs (one round
             // of 18-row units) measured 2-3 % slower than 3.6 rounds of 5-row units (101.5 vs 98.9 us per frame)
-            const int target2 = env_int("HLMI_LL_UNITS0", 8 * stream_cu_count(ctx.device, nullptr));
+            // (ll_down01f).  ll_down01e on a partition: two rounds of taller units — a quarter fewer seam rows walked twice — measure
+            // 5-7 % more frames per second than 3.6 rounds of 5-row units (83.4 vs 88-89 us per frame on four partitions), while on
+            // a stream that owns the device one round of resident waves is what counts (52.7 us against 57.1)
+            const int target2 = env_int("HLMI_LL_UNITS0", emit && partitioned ? 16 * stream_cus : 8 * stream_cu_count(ctx.device, nullptr));
             // EXCH: a workgroup = 4 vertically adjacent units exchanging their seam rows through LDS.  With n level-2 rows
             // per wave a workgroup owns R = 4 n - 1 rows (the bottom wave walks the two seam rows of the next workgroup
             // itself and owns one row less); n = the smallest that keeps the launch within `target2` resident waves.
@@ -2729,6 +2757,8 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
                 timing_note_bytes(6.0 * iw * (gm.iy1 - gm.iy0 + 1) + 4.0 * iw * oh + 4.0 * 3.0 * d.w * d.h + 4.0 * (levels + 1) * e.w * e.h);
                 D01EArgs ae;
                 ae.d = a, ae.outl0 = outl0, ae.oy0 = output->dim[1].min, ae.oh = oh;
+                ae.xmajor = env_int("HLMI_LL_XMAJOR", 1) ? 1 : 0;
+                ae.nsx_magic = a.nsx == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)a.nsx + 1ull);
 #define LL_D01E(O0, O1, B)                                                                                             \
     do {                                                                                                               \
         if (exch) HLMI_LAUNCH(uc, "ll_down01", st, (ll_down01e<O0, O1, B, true>), grid2, block, sh2, ae, gm, lev);     \
@@ -2894,6 +2924,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             timing_note_bytes(2.0 * (3 + nc) * ow * oh + 4.0 * ow * oh + 4.0 * 3.0 * n1 + 4.0 * 3.0 * n2);
             Up0HArgs ph;
             ph.u = p, ph.outl0 = outl0, ph.l0_ws = gm.ix1 - gm.ix0 + 1;
+            ph.xcd_tiles = env_int("HLMI_LL_XCD_TILES", 1) ? 1 : 0;
             HLMI_LAUNCH(uc, "ll_up0", st, ll_up0h, grid, block, sizeof(float) * U0_TS * (p.RU + 2), ph, gm);
             return 0;
         }

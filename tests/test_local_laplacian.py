@@ -483,3 +483,47 @@ def test_hip_plane_mask_modes_match_oracle(hl, oracle, monkeypatch, mode, w, h, 
         o = hl.Buffer(np.zeros_like(img)).set_min(origin[0], origin[1], 0)
         hl.local_laplacian(a, 8, 1.0 / 7, 1.0, o)
     assert np.array_equal(o.numpy(), oracle.local_laplacian(inp, 8, 1.0 / 7, 1.0, origin=origin))
+
+
+# ---- round 4: the re-cut dataflow (ll_down01e emits outLPyramid[0] + three level-1 planes, ll_up0h collapses) against the
+# materialised-pyramid pair (ll_down01f / ll_up0f, HLMI_LL_EMIT=0)
+@pytest.mark.gpu
+@pytest.mark.parametrize("emit", ["1", "0"])
+@pytest.mark.parametrize("w,h,origin,kind,beta", [(1500, 334, (0, 0), "smooth", 1.0), (776, 250, (-4, 5), "uniform", 1.0), (1024, 131, (2, -3), "uniform", 0.7),
+                                                   (260, 97, (6, 1), "smooth", 1.0), (3840, 2160, (0, 0), "uniform", 1.0)])
+def test_hip_emit_and_materialised_dataflows_match_oracle(hl, oracle, monkeypatch, emit, w, h, origin, kind, beta):
+    """Both dataflows are the same pure functions: bit-identical results, and (small cases) every outGPyramid level.  The frame
+    is preceded by a DIFFERENT frame through the same workspace: outLPyramid[0] rows or level-1 planes that a unit fails to
+    emit would hold the other frame's values."""
+    monkeypatch.setenv("HLMI_LL_EMIT", emit)
+    other = _rand_image(w, h, seed=w + 3 * h + 2, kind="uniform" if kind == "smooth" else "smooth")
+    inp = _rand_image(w, h, seed=w + h + 31, kind=kind)
+    for img in (other, inp):
+        a = hl.Buffer(img).set_min(origin[0], origin[1], 0)
+        o = hl.Buffer(np.zeros_like(img)).set_min(origin[0], origin[1], 0)
+        hl.local_laplacian(a, 8, 1.0 / 7, beta, o)
+    if w * h < 1 << 20:
+        for level in range(4, 0, -1):
+            got = hl.debug_local_laplacian_outg(level)
+            want = oracle.local_laplacian_outg(inp, 8, 1.0 / 7, beta, level, origin=origin)
+            assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"level {level}"
+    assert np.array_equal(o.numpy(), oracle.local_laplacian(inp, 8, 1.0 / 7, beta, origin=origin))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("xmajor,xcd_tiles,units,ru", [("0", "0", 0, 0), ("1", "1", 1024, 8), ("1", "0", 300, 32), ("0", "1", 4096, 3)])
+def test_hip_emit_launch_geometries_match_oracle(hl, oracle, monkeypatch, xmajor, xcd_tiles, units, ru):
+    """Workgroup numbering (strip-fastest / row-fastest, XCD-contiguous tiles), unit heights and tile heights only change who
+    computes what."""
+    monkeypatch.setenv("HLMI_LL_XMAJOR", xmajor)
+    monkeypatch.setenv("HLMI_LL_XCD_TILES", xcd_tiles)
+    if units:
+        monkeypatch.setenv("HLMI_LL_UNITS0", str(units))
+    if ru:
+        monkeypatch.setenv("HLMI_LL_RU", str(ru))
+    for (w, h, origin) in [(2048, 700, (0, 0)), (520, 333, (-2, 7))]:
+        inp = _rand_image(w, h, seed=w + h + units, kind="uniform")
+        a = hl.Buffer(inp).set_min(origin[0], origin[1], 0)
+        o = hl.Buffer(np.zeros_like(inp)).set_min(origin[0], origin[1], 0)
+        hl.local_laplacian(a, 8, 1.0 / 7, 1.0, o)
+        assert np.array_equal(o.numpy(), oracle.local_laplacian(inp, 8, 1.0 / 7, 1.0, origin=origin))
