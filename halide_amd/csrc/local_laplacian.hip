@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         const int wg = xcd_block();
         int gy;
         if (pe.xmajor) {
-            gy = pe.nsx_magic ? (int)__umulhi((unsigned)wg, pe.nsx_magic) : 0;
+            gy = pe.nsx_magic ? (int)__umulhi((unsigned)wg, pe.nsx_magic) : wg;   // one strip: wg / 1
             sx = wg - gy * p.nsx;
         } else {
             sx = p.nsy_magic ? (int)__umulhi((unsigned)wg, p.nsy_magic) : wg;
