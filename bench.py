@@ -42,11 +42,21 @@ ALG_BYTES_PER_PX = 12         # SURVEY.md §8(d) primary figure: 6 B read + 6 B 
 
 def synth_frame(seed, w=W, h=H, kind="smooth"):
     """SURVEY.md §8d input variants: (ii) smooth natural-like frame + noise — the headline input; the data-dependent
-    level selection is cache sensitive — and (i) uniform full-range noise, the worst case for the plane gathers."""
+    level selection is cache sensitive —, (i) uniform full-range noise (what the reference's RunGen feeds a benchmark run,
+    tools/RunGen.h:482-505; the worst case for data-dependent plane gathers) and (iii) the one natural image of the reference
+    checkout (apps/images/rgb_small.png, 192x320 8-bit RGB: tests/golden/rgb_small_u8.npz, made by scripts/make_golden.py),
+    widened to 16 bits the way the reference's image loader does (x * 257) and tiled to the frame size, shifted per frame."""
     import numpy as np
     rng = np.random.default_rng(seed)
     if kind == "noise":
         return rng.integers(0, 65536, (C, h, w), dtype=np.uint16)
+    if kind == "natural":
+        small = np.load(os.path.join(ROOT, "tests", "golden", "rgb_small_u8.npz"))["rgb"]   # (3, 320, 192) u8
+        tile = small.astype(np.uint16) * 257
+        reps = (1, -(-h // tile.shape[1]) + 1, -(-w // tile.shape[2]) + 1)
+        big = np.tile(tile, reps)
+        oy, ox = (37 * seed) % tile.shape[1], (53 * seed) % tile.shape[2]
+        return np.ascontiguousarray(big[:, oy:oy + h, ox:ox + w])
     yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
     base = (np.sin(xx / 311.0 + seed) + np.cos(yy / 173.0) + np.sin((xx + yy) / 97.0) + 3.3) / 6.6
     img = np.stack([base * 65535.0, np.roll(base, 64, 1) * 52000.0, base[::-1] * 46000.0])
@@ -257,6 +267,7 @@ def main():
     variants = None
     if rank == 0 and world == 1 and not args.no_variants:
         variants = {"unit": "Mpx/s", "uniform_noise_3840x2160": run_variant(W, H, "noise", 8, 100),
+                    "natural_tiled_3840x2160": run_variant(W, H, "natural", 8, 100),
                     "smooth_7680x4320": run_variant(2 * W, 2 * H, "smooth", 4, 40),
                     "uniform_noise_7680x4320": run_variant(2 * W, 2 * H, "noise", 4, 40)}
         variants["frame_ms"] = {k: round((4 if "7680" in k else 1) * W * H / v / 1e3, 4) for k, v in variants.items() if k != "unit"}
@@ -288,18 +299,34 @@ def main():
         # MI355X_MICROARCH.md prescribes for wide coalesced reads + WRITE_SIZE), committed under profiles/
         traffic = None
         frame_traffic = None   # all launches of one frame: what the whole pipeline moves through HBM / MALL
+        traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
+            import hashlib
             with open(tpath) as f:
-                per_launch = json.load(f).get("bytes_per_launch", {})
-            traffic = per_launch.get(dom)
-            if all(k in per_launch for k in per_frame):
-                frame_traffic = int(sum(per_launch[k] for k in per_frame))
+                tj = json.load(f)
+            per_launch = tj.get("bytes_per_launch", {})
+            with open(os.path.join(ROOT, "halide_amd", "csrc", "local_laplacian.hip"), "rb") as f:
+                sha_now = hashlib.sha256(f.read()).hexdigest()
+            # NOT measured in this run: counters of a separate rocprofv3 PMC run (committed under profiles/).  Printed only while the
+            # kernel source is byte for byte the one that run profiled — a later edit of the kernels makes them stale
+            if tj.get("kernel_source_sha256") == sha_now:
+                traffic = per_launch.get(dom)
+                if all(k in per_launch for k in per_frame):
+                    frame_traffic = int(sum(per_launch[k] for k in per_frame))
+                traffic_source = {"file": tj.get("source"), "git_head_when_collected": tj.get("git_head_when_collected"),
+                                  "measured_in_this_run": False}
+            else:
+                traffic_source = {"file": tj.get("source"), "stale": "local_laplacian.hip changed since these counters were collected; traffic withheld"}
         result = {
             "metric": "megapixels/sec local_laplacian 8-level fp32 4K",
             "value": round(value, 2), "unit": "Mpx/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # the same call on the two other input classes of SURVEY.md §8d (details under config.variants): uniform noise is what
+            # the reference's own benchmark protocol feeds (RunGen), `natural` the reference checkout's one natural image, tiled
+            "value_uniform_noise": None if not variants else variants.get("uniform_noise_3840x2160"),
+            "value_natural_tiled": None if not variants else variants.get("natural_tiled_3840x2160"),
             "config": {"workload": "apps/local_laplacian J=8 levels=8 alpha=1/7 beta=1, u16 RGB planar 3840x2160",
                        "frames_per_step_per_gpu": frames_per_step, "distinct_frames_per_gpu": FRAMES_PER_STEP,
                        "passes_per_step": args.passes, "frame_ms": round(frame_ms, 4),
@@ -315,6 +342,9 @@ def main():
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": traffic_source,
+                         # the same fraction on the bytes the kernel actually moved (PMC) instead of its algorithmic bytes
+                         "frac_moved": None if traffic is None else round(traffic / (dom_rec["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "alg_bytes_per_launch": int(alg_bytes),
                          "kernel_avg_ms": round(dom_rec["avg_ms"], 5),
                          "pipeline_alg_bytes_per_frame": ALG_BYTES_PER_PX * W * H,

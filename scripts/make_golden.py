@@ -53,7 +53,62 @@ def digests():
     return {k: hashlib.sha256(np.ascontiguousarray(f()).tobytes()).hexdigest() for k, f in cases().items()}
 
 
+def decode_png_rgb8(path):
+    """8-bit RGB, non-interlaced PNG -> (3, H, W) uint8 (zlib + the five PNG row filters; nothing else is needed here)."""
+    import struct
+    import zlib
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w = 8, b"", None
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        if typ == b"IHDR":
+            w, h, depth, ctype, _, _, interlace = struct.unpack(">IIBBBBB", body)
+            assert (depth, ctype, interlace) == (8, 2, 0)
+        elif typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 3 * w)
+    out = np.zeros((h, 3 * w), np.int32)
+    for y in range(h):
+        ft, line = int(raw[y, 0]), raw[y, 1:].astype(np.int32)
+        up = out[y - 1] if y else np.zeros(3 * w, np.int32)
+        cur = out[y]
+        for x in range(3 * w):
+            a = cur[x - 3] if x >= 3 else 0
+            b, c = up[x], (up[x - 3] if x >= 3 else 0)
+            if ft == 0:
+                pr = 0
+            elif ft == 1:
+                pr = a
+            elif ft == 2:
+                pr = b
+            elif ft == 3:
+                pr = (a + b) >> 1
+            else:
+                pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            cur[x] = (line[x] + pr) & 255
+    return np.ascontiguousarray(out.astype(np.uint8).reshape(h, w, 3).transpose(2, 0, 1))
+
+
+def natural_image():
+    """tests/golden/rgb_small_u8.npz: the pixels of the reference checkout's one natural RGB test image
+    (/root/reference/apps/images/rgb_small.png, 192 x 320, 8 bit) as a planar array — INPUT DATA for bench.py's `natural` variant
+    (SURVEY.md §8d (iii)), not source code; the GPU box has no /root/reference."""
+    src = "/root/reference/apps/images/rgb_small.png"
+    if not os.path.exists(src):
+        return False
+    rgb = decode_png_rgb8(src)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "rgb_small_u8.npz"), rgb=rgb)
+    return True
+
+
 if __name__ == "__main__":
+    if "--natural" in sys.argv:
+        print("natural image fixture:", natural_image())
+        sys.exit(0)
     d = {"_comment": "Regression digests of the canonical CPU oracle (sha256 of the output bytes on fixed seeded inputs, "
                      "scripts/make_golden.py). NOT reference-derived: the reference ships no golden outputs for these pipelines."}
     d.update(digests())

@@ -76,7 +76,7 @@ if rows:
     # level 1 -> 2 comes out of ll_down01f when that kernel ran (then the strips start at level 2); the level-1 collapse
     # is part of ll_up0f when only two ll_up launches ran (levels 3 and 2)
     strips = sorted([r for r in rows if r[0].startswith("ll_down_strip")], key=lambda r: -r[5])
-    first_strip = 2 if any(r[0].startswith("ll_down01f") for r in rows) else 1
+    first_strip = 2 if any(r[0].startswith("ll_down01") for r in rows) else 1
     for i, r in enumerate(strips):
         per[f"ll_down_strip:{i + first_strip}"] = r[5]
     ups = sorted([r for r in rows if r[0] == "ll_up"], key=lambda r: -r[5])
@@ -84,7 +84,7 @@ if rows:
     for i, r in enumerate(ups):
         per[f"ll_up:{i + first_up}"] = r[5]
     for r in rows:
-        for base, name in (("ll_down01f", "ll_down01"), ("ll_down0f", "ll_down0"), ("ll_down0<", "ll_down0"), ("ll_up0", "ll_up0"),
+        for base, name in (("ll_down01f", "ll_down01"), ("ll_down01e", "ll_down01"), ("ll_down0f", "ll_down0"), ("ll_down0<", "ll_down0"), ("ll_up0", "ll_up0"),
                            ("ll_top", "ll_top"), ("ll_remap_lut", "ll_remap_lut")):
             if r[0].startswith(base):
                 per[name] = r[5]
@@ -92,6 +92,16 @@ if rows:
         for base, depth_to_s in (("ll_down_multi", lambda d: 7 - d), ("ll_up_multi", lambda d: 7 - d)):
             if r[0].startswith(base + "<"):
                 per[f"{base}:{depth_to_s(int(r[0].split('<')[1].split('>')[0]))}"] = r[5]
+    import hashlib
+    import subprocess
+    ksrc = os.path.join(ROOT, "halide_amd", "csrc", "local_laplacian.hip")
+    try:
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        head = ""
+    # bench.py prints `traffic` only while the kernel source is the one these counters were collected with
     json.dump({"source": f"profiles/{rnd}_pmc_traffic.csv", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per dispatch",
+               "kernel_source": "halide_amd/csrc/local_laplacian.hip", "kernel_source_sha256": hashlib.sha256(open(ksrc, "rb").read()).hexdigest(),
+               "git_head_when_collected": head, "input": "smooth 3840x2160 frames of bench.py (the re-cut dataflow moves the same bytes for every input)",
                "bytes_per_launch": per}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print("wrote", sorted(os.listdir(dst)))

@@ -95,3 +95,46 @@ def test_result_produced_on_another_stream_is_complete_when_read_back(hl, oracle
         hl.local_laplacian(a, 8, 1.0 / 7.0, 1.0, o)
         hl.set_stream(None)
         assert np.array_equal(o.numpy(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_frames_in_flight_on_partition_streams_match_single_calls(hl, oracle):
+    """bench_apps.py's throughput mode: distinct frames of bilateral_grid / nl_means / conv_layer_bf16 in flight on four
+    CU-partitioned streams (two frames per stream, back to back, no host synchronisation in between).  Every output must be
+    what the same call produces alone on the default stream — and, for the bit-exact pipelines, the oracle's."""
+    streams = [hl.partition_stream(p, 4) for p in range(4)]
+    assert all(streams)
+    rng = np.random.default_rng(11)
+    nf = 8
+    gray = [rng.random((270, 480), dtype=np.float32) for _ in range(nf)]
+    rgb = [rng.random((3, 96, 160), dtype=np.float32) for _ in range(nf)]
+    cin = [rng.uniform(-1, 1, (2, 18, 18, 128)).astype(np.float32) for _ in range(nf)]
+    cf = rng.uniform(-1, 1, (128, 3, 3, 128)).astype(np.float32)
+    cb = rng.uniform(-1, 1, 128).astype(np.float32)
+    filt, bias = hl.Buffer(cf), hl.Buffer(cb)
+
+    def run_all(use_streams):
+        outs = []
+        for i in range(nf):
+            if use_streams:
+                hl.set_stream(streams[i % 4])
+            bg_o = hl.Buffer(np.zeros_like(gray[i]))
+            hl.bilateral_grid(hl.Buffer(gray[i]), 0.1, bg_o)
+            nl_o = hl.Buffer(np.zeros_like(rgb[i]))
+            hl.nl_means(hl.Buffer(rgb[i]), 7, 7, 0.12, nl_o)
+            cv_o = hl.Buffer(np.zeros((2, 16, 16, 128), np.float32))
+            hl.conv_layer_bf16(hl.Buffer(cin[i]), filt, bias, cv_o)
+            outs.append((bg_o, nl_o, cv_o))
+        hl.set_stream(None)
+        return [tuple(b.numpy().copy() for b in t) for t in outs]
+
+    single = run_all(False)
+    for rep in range(2):
+        batched = run_all(True)
+        for i in range(nf):
+            for k, name in enumerate(("bilateral_grid", "nl_means", "conv_layer_bf16")):
+                assert np.array_equal(batched[i][k].view(np.uint32), single[i][k].view(np.uint32)), f"rep {rep} frame {i}: {name} differs"
+    for i in (0, nf - 1):
+        assert np.array_equal(single[i][0].view(np.uint32), oracle.bilateral_grid(gray[i], 0.1).view(np.uint32))
+        assert np.array_equal(single[i][1].view(np.uint32), oracle.nl_means(rgb[i], 7, 7, 0.12).view(np.uint32))
