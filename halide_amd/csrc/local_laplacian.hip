@@ -445,171 +445,8 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down0(const uint16_t *__rest
     }
 }
 
-// ---- ll_down0f: ll_down0 for the common case (levels == KCH, vectorisable input, LUT in LDS), written for
-// instruction count — the kernel is bound by instruction issue, not by HBM or the LDS:
-//   * the results of a step wait for their store batch in registers (levels == KCH: no per-plane guards, so there is room)
-//   * gray AND the LUT positions of the next row pair are carried in registers instead of being recomputed
-//   * gray >= 0, so the lower bound of clamp(cast<int>(idx), 0, (levels-1)*256) (:43) can never bind: one v_min
-//   * the horizontal pass of plane k-1 is issued after the vertical pass of plane k, so that the DPP lane
-//     exchanges never read a register written by the previous instruction (no s_nop hazard padding)
-//   * only waves that touch the left / right image edge run the per-column clamp selects (a second instance of
-//     the strip walk behind ONE wave-uniform branch); their extra work must stay small, because every wave is
-//     resident at once and the launch lasts as long as its slowest wave
-template<bool ODD, bool B1>
-__global__ __launch_bounds__(D0_THREADS, 2) void ll_down0f(const uint16_t *__restrict__ in, long in_sy, long co0, long co1,
-                                                    long co2, Geometry gm, Levels lev, float beta,
-                                                    const float *__restrict__ lut_g, float *__restrict__ g1, int Xs,
-                                                    int loy1, int w1, int h1, int ws1, size_t ps1, int nsx, int nsy,
-                                                    int nunits) {
-    extern __shared__ float slut[];
-    for (int i = threadIdx.x; i <= 2 * gm.half; i += D0_THREADS) slut[i] = lut_g[i];
-    __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int unit = xcd_block() * (D0_THREADS / 64) + wave;
-    if (unit >= nunits) return;
-    const int lane = threadIdx.x & 63;
-    const int sy = unit % nsy, sx = unit / nsy;
-    const int off = STRIP * sx + 2 * lane;
-    const int P = Xs + off;
-    const int q0 = ODD ? 2 * P - 1 : 2 * P - 2;
-    const int iw = gm.ix1 - gm.ix0 + 1, ih = gm.iy1 - gm.iy0;
-    const QuadSel qs = quad_sel(q0 - gm.ix0, iw);
-    int xo[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) xo[i] = qs.oq + qs.sel[i];
-    const bool edge_wave = __any(!qs.plain);
-    const bool store_ok = (lane < 63) && (off < w1);
-    const int t0 = (int)((long)sy * h1 / nsy), t1 = (int)((long)(sy + 1) * h1 / nsy) - 1;
-    const int lbase = gm.half - 256 * (KCH - 1);
-    float level[KCH];
-#pragma unroll
-    for (int kk = 0; kk < KCH; kk++) {
-        level[kk] = lev.v[kk];
-        asm volatile("" : "+s"(level[kk]));
-    }
-    // the whole strip walk is instantiated twice and selected by ONE wave-uniform branch: a branch around the
-    // loads inside the row loop would make the compiler wait for all outstanding VMEM traffic at every join
-    auto walk = [&](auto edge_tag) {
-    constexpr bool EDGE = decltype(edge_tag)::value;
-    auto load_row = [&](Raw &r, int y_abs) {
-        const uint16_t *rp = in + (long)(dev::clampi(y_abs - gm.iy0, 0, ih)) * in_sy;
-        load_raw<true>(r, rp, co0, co1, co2, qs.oq, xo);
-    };
-    auto u16s = [&](const ushort4 &c, uint16_t (&o)[4]) {
-        // two dwords, explicit halves: the conversions become SDWA word selects
-        const uint2 w = __builtin_bit_cast(uint2, c);
-        o[0] = (uint16_t)(w.x & 0xffffu), o[1] = (uint16_t)(w.x >> 16);
-        o[2] = (uint16_t)(w.y & 0xffffu), o[3] = (uint16_t)(w.y >> 16);
-    };
-    struct Row {
-        float g[4];  // gray
-        int l[4];    // LUT position of plane KCH-1 (plane k reads l + 256 (KCH-1-k))
-    };
-    auto prep_row = [&](const Raw &r, Row &o) {
-        uint16_t rr[4], gg[4], bb[4];
-        u16s(r.c0, rr), u16s(r.c1, gg), u16s(r.c2, bb);
-#pragma unroll
-        for (int i = 0; i < 4; i++) o.g[i] = gray_from(rr[i], gg[i], bb[i]);
-        if (EDGE) {  // the aligned quad was loaded; column i takes its (clamped) element sel[i]
-            const float g0 = o.g[0], g1v = o.g[1], g2 = o.g[2], g3 = o.g[3];
-#pragma unroll
-            for (int i = 0; i < 4; i++) o.g[i] = pick4(g0, g1v, g2, g3, qs.sel[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) o.l[i] = min((int)((o.g[i] * gm.Km1) * 256.0f), gm.half) + lbase;
-    };
-    auto lut_issue = [&](int kk, const Row &r0, const Row &r1, float (&dst)[8]) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            dst[i] = slut[r0.l[i] + 256 * (KCH - 1 - kk)];
-            dst[4 + i] = slut[r1.l[i] + 256 * (KCH - 1 - kk)];
-        }
-    };
-    // gPyramid[0] (slot kk < KCH) or gray (slot KCH) of the lane's 4 columns in the two rows r0, r1
-    auto plane_vals = [&](int kk, const Row &r0, const Row &r1, const float (&lv)[8], float (&v0)[4], float (&v1)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            v0[i] = kk < KCH ? g0_val<B1>(r0.g[i], level[kk < KCH ? kk : 0], beta, lv[i]) : r0.g[i];
-            v1[i] = kk < KCH ? g0_val<B1>(r1.g[i], level[kk < KCH ? kk : 0], beta, lv[4 + i]) : r1.g[i];
-        }
-    };
-
-    float a[KCH + 1][4], b[KCH + 1][4], a2[KCH + 1][4], b2[KCH + 1][4];
-    const int T0 = loy1 + t0;
-    {   // the two rows above the first output row: window state only
-        Raw ra, rb;
-        load_row(ra, 2 * T0 - 1);
-        load_row(rb, 2 * T0);
-        Row r0, r1;
-        prep_row(ra, r0);
-        prep_row(rb, r1);
-        float lv[2][8];
-        lut_issue(0, r0, r1, lv[0]);
-#pragma unroll
-        for (int kk = 0; kk <= KCH; kk++) {
-            if (kk + 1 < KCH) lut_issue(kk + 1, r0, r1, lv[(kk + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            plane_vals(kk, r0, r1, lv[kk & 1], a[kk], b[kk]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    Raw rc, rd;
-    // One output row; order of VMEM traffic as in ll_down0 (arithmetic, next rows' gray, store batch, loads).
-    auto step = [&](int t, const Row &c0, const Row &c1, Row &n0, Row &n1, float (&ia)[KCH + 1][4],
-                    float (&ib)[KCH + 1][4], float (&oa)[KCH + 1][4], float (&ob)[KCH + 1][4]) {
-        const int T = loy1 + t;
-        float lv[2][8], dy[2][4];
-        float2 res[KCH + 1];
-        lut_issue(0, c0, c1, lv[0]);
-#pragma unroll
-        for (int kk = 0; kk <= KCH; kk++) {
-            if (kk + 1 < KCH) lut_issue(kk + 1, c0, c1, lv[(kk + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            plane_vals(kk, c0, c1, lv[kk & 1], oa[kk], ob[kk]);
-#pragma unroll
-            for (int i = 0; i < 4; i++) dy[kk & 1][i] = down4_raw(ia[kk][i], ib[kk][i], oa[kk][i], ob[kk][i]);
-            if (kk > 0) res[kk - 1] = hpair<ODD>(dy[(kk - 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        res[KCH] = hpair<ODD>(dy[KCH & 1]);
-        if (t < t1) {
-            prep_row(rc, n0);
-            prep_row(rd, n1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        float *drow = g1 + (size_t)t * ws1 + off;
-        if (store_ok) {
-#pragma unroll
-            for (int kk = 0; kk <= KCH; kk++) *reinterpret_cast<float2 *>(drow + (size_t)kk * ps1) = res[kk];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < t1) {
-            load_row(rc, 2 * T + 5);
-            load_row(rd, 2 * T + 6);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    Row p0, p1, p2, p3;
-    load_row(rc, 2 * T0 + 1);
-    load_row(rd, 2 * T0 + 2);
-    prep_row(rc, p0);
-    prep_row(rd, p1);
-    if (t0 < t1) {
-        load_row(rc, 2 * T0 + 3);
-        load_row(rd, 2 * T0 + 4);
-    }
-    for (int t = t0; t <= t1;) {
-        step(t, p0, p1, p2, p3, a, b, a2, b2);
-        if (++t > t1) break;
-        step(t, p2, p3, p0, p1, a2, b2, a, b);
-        ++t;
-    }
-    };  // walk
-    if (edge_wave) walk(std::true_type{});
-    else walk(std::false_type{});
-}
-
-// ---- ll_down01f: ll_down0f that ALSO produces level 2 (all K+1 planes) in the same walk — the ll_down_strip:1 launch, its
+// ---- ll_down01f: levels 1 AND 2 (all K+1 planes of both) from the input in one walk, for levels == KCH, a vectorisable input and
+// the remap table in LDS — the ll_down_strip:1 launch, its
 // read of the level-1 planes (75 MB at 4K) and its launch latency disappear.
 //   * A unit owns n level-2 rows [A, B] and the level-1 rows [2A, 2B+1] under them.  gPyramid[2] row Y needs level-1 rows
 //     2Y-1 .. 2Y+2, so the walk computes level-1 rows 2A-1 .. 2B+2 — one more above and below than it stores (its
@@ -640,19 +477,11 @@ struct D01Args {
     int so2, loy2, w2, h2, ws2;
     size_t ps2;
     int Pbase, S2, nsx, nsy, nunits;
-    int mask1;                 // store only the level-1 planes somebody reads (see the step's store batch)
-    int skip1;                 // level 1 is not stored at all: its only reader (ll_up0g) recomputes what it needs from the input
     unsigned nsy_magic;        // floor(2^32 / nsy) + 1: x / nsy == umulhi(x, magic) for x * nsy < 2^32; 0 when nsy == 1
     int rows_base, rows_rem;   // h2 / nsy, h2 % nsy
 };
 constexpr int D01_STATE = 2 * (KCH + 1) * 64;  // float2 slots of one wave's level-1 -> 2 window state (and of the two rows it publishes)
 
-#ifndef HLMI_D01_ABL
-#define HLMI_D01_ABL 0   // timing experiments only (csrc/Makefile VARIANT): 1 no LUT gathers, 2 no level-1 stores, 4 no level-2 stores, 8 no input loads
-#endif
-#ifndef HLMI_D01_LSGPR
-#define HLMI_D01_LSGPR 0
-#endif
 template<bool ODD0, bool ODD1, bool B1, bool EXCH>
 __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry gm, Levels lev) {
     extern __shared__ float slut[];
@@ -716,11 +545,7 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry 
 #pragma unroll
     for (int kk = 0; kk < KCH; kk++) {
         level[kk] = lev.v[kk];
-#if HLMI_D01_LSGPR
-        asm volatile("" : "+s"(level[kk]));
-#else
         asm volatile("" : "+v"(level[kk]));
-#endif
     }
     auto walk = [&](auto edge_tag) {
     constexpr bool EDGE = decltype(edge_tag)::value;
@@ -761,13 +586,8 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry 
     auto lut_issue = [&](int kk, const Row &r0, const Row &r1, float (&dst)[8]) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-#if HLMI_D01_ABL & 1
-            dst[i] = __builtin_bit_cast(float, r0.l[i] + kk);
-            dst[4 + i] = __builtin_bit_cast(float, r1.l[i] + kk);
-#else
             dst[i] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(slut) + r0.l[i] + 1024 * (KCH - 1 - kk));
             dst[4 + i] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(slut) + r1.l[i] + 1024 * (KCH - 1 - kk));
-#endif
         }
     };
     // In passes over the 8 pixels (not pixel by pixel): a wave issues dependent VALU instructions only every ~3.7 ns but
@@ -803,25 +623,6 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry 
         for (int i = 0; i < 4; i++) o[i] = t[i] + d[i];
     };
 
-    // Which level-1 planes does anybody read?  The up pass reads plane k of gPyramid[1] at coarse pixel (c, r) only for k in
-    // {li, li + 1} of a level-0 pixel in [2c - 1, 2c + 2] x [2r - 1, 2r + 2] (the bilinear footprint, :276-282: pixel X reads
-    // coarse columns (X + 1) / 2 and (X - 1) / 2; li = that pixel's level, :66) or of the coarse pixel itself (outLPyramid[1],
-    // :63-72).  A wave holds exactly those pixels when it finishes level-1 row T (level-0 rows 2T - 1 .. 2T + 2 of all its
-    // lanes — all four rows count: dropping row 2T + 2 from the set fails the parity suite —; the stored pairs of lanes < S2
-    // are read from columns its own lanes hold), so it stores a plane only if some lane's set asks for it — per 16-lane row of the
-    // wave (mask1 = 2: the sets of the row's lanes and of the lane either side of it, OR-ed by four DPP row rotations; one
-    // 128-byte line per plane and row; +3-5 % frames/s over the wave-uniform mask1 = 1, whole 512-byte row pieces): two to four of
-    // the eight planes on natural images (-45 of 75 MB written per 4K frame with the wave-uniform mask already; the frame rate
-    // on partitioned streams is set by bytes, profiles/r03b_traffic_ablation.txt), all eight on noise.  l = 4 x table position of
-    // plane KCH - 1 (lbase = 0 for K = 8... in general idx = l / 4 - lbase), position >> 8 = the pixel's level index.
-    const int lb4 = lbase * 4;
-    auto row_bits = [&](const Row &r) {
-        unsigned bts = 0u;
-#pragma unroll
-        for (int i = 0; i < 4; i++) bts |= 3u << min((unsigned)(r.l[i] - lb4) >> 10, (unsigned)(KCH - 2));
-        return bts;
-    };
-    unsigned pbits = 0u;       // sets of the two level-0 rows the previous step brought in
     float a[KCH + 1][4], b[KCH + 1][4], a2[KCH + 1][4], b2[KCH + 1][4];
     Raw rc, rd;
     {
@@ -841,7 +642,6 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry 
         Row r0, r1;
         prep_row(ra, r0);
         prep_row(rb, r1);
-        pbits = row_bits(r0) | row_bits(r1);
         float lv[2][8];
         lut_issue(0, r0, r1, lv[0]);
 #pragma unroll
@@ -880,7 +680,7 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry 
                     const float py = lane_prev(ry), nx = lane_next(rx);
                     o = down4_tail(py, rx, ry, nx);
                 }
-                if (out2 && st2_ok && !(HLMI_D01_ABL & 4 && p.nunits > 0)) d2[(size_t)k * p.ps2] = o;
+                if (out2 && st2_ok) d2[(size_t)k * p.ps2] = o;
                 st2[(2 * k + 1) * 64] = c;
             }
         };
@@ -910,38 +710,11 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry 
         prep_row(rc, n0);
         prep_row(rd, n1);
         __builtin_amdgcn_sched_barrier(0);
-        unsigned M = (1u << KCH) - 1u;                       // planes to store (wave-uniform, or per 16-lane row)
-        if (p.mask1) {
-            const unsigned cb = row_bits(c0) | row_bits(c1);   // level-0 rows 2T + 1, 2T + 2
-            unsigned bts = pbits | cb;                         // ... and 2T - 1, 2T
-            pbits = cb;
-            bts |= 3u << dev::clampi((int)(res[KCH].x * gm.Km1), 0, KCH - 2);
-            bts |= 3u << dev::clampi((int)(res[KCH].y * gm.Km1), 0, KCH - 2);
-            if (p.mask1 == 2) {
-                // per 16-lane row (62 level-1 columns, one 128-byte line per plane and row): the sets of the row's lanes and of
-                // the lane either side of it (a pair's footprint reaches one level-0 pixel into the neighbour lanes)
-                auto dppu = [](unsigned v, auto ctrl) {
-                    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, 0xf, 0xf, true);
-                };
-                unsigned e = bts | dppu(bts, std::integral_constant<int, 0x138>{}) | dppu(bts, std::integral_constant<int, 0x130>{});
-                e |= dppu(e, std::integral_constant<int, 0x121>{});   // row_ror:1, 2, 4, 8: every lane of a row ends with the row's OR
-                e |= dppu(e, std::integral_constant<int, 0x122>{});
-                e |= dppu(e, std::integral_constant<int, 0x124>{});
-                e |= dppu(e, std::integral_constant<int, 0x128>{});
-                M = e & ((1u << KCH) - 1u);
-            } else {
-                M = 0u;
-#pragma unroll
-                for (int kk = 0; kk < KCH; kk++) M |= __ballot((bts >> kk) & 1u) ? (1u << kk) : 0u;
-            }
-        }
-        if (T >= Ts0 && T <= Ts1 && !p.skip1 && !(HLMI_D01_ABL & 2 && p.nunits > 0)) {
+        if (T >= Ts0 && T <= Ts1) {
             float *drow = p.g1 + (size_t)(T - p.loy1) * p.ws1 + off1;
             if (st1_ok) {
 #pragma unroll
-                for (int kk = 0; kk <= KCH; kk++) {
-                    if (kk == KCH || ((M >> kk) & 1u)) *reinterpret_cast<float2 *>(drow + (size_t)kk * p.ps1) = res[kk];
-                }
+                for (int kk = 0; kk <= KCH; kk++) *reinterpret_cast<float2 *>(drow + (size_t)kk * p.ps1) = res[kk];
             }
         }
         if (EXCH && pub) {
@@ -949,7 +722,7 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry 
             for (int kk = 0; kk <= KCH; kk++) pub[kk * 64] = res[kk];
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (T + 1 < T1 && !(HLMI_D01_ABL & 8 && p.nunits > 0)) {
+        if (T + 1 < T1) {
             load_row(rc, 2 * T + 5);
             load_row(rd, 2 * T + 6);
         }
@@ -1023,10 +796,9 @@ struct D01EArgs {
     D01Args d;
     float *outl0;              // outLPyramid[0] on [ix0, ix1] x [oy0, oy0 + oh - 1], row stride = input width (a multiple of 4)
     int oy0, oh;
-    // EXCH: workgroups numbered strip-fastest (wg = gy * nsx + sx) so that the contiguous range xcd_block() hands an XCD holds
-    // horizontal AND vertical neighbours: a strip's 512-byte row pieces start 16 bytes before a 128-byte line, which its left
-    // neighbour reads too — from the same L2 then (0: row-fastest as in ll_down01f)
-    int xmajor;
+    // EXCH: workgroups are numbered strip-fastest (wg = gy * nsx + sx; ll_down01f: row-fastest) so that the contiguous range
+    // xcd_block() hands an XCD holds horizontal AND vertical neighbours: a strip's 512-byte row pieces start 16 bytes before a
+    // 128-byte line, which its left neighbour reads too — from the same L2 then (68.8 -> 58.8 MB fetched per 4K frame)
     unsigned nsx_magic;        // floor(2^32 / nsx) + 1, 0 when nsx == 1
 };
 #ifndef HLMI_D01E_ABL
@@ -1055,14 +827,8 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
     bool publish = false;      // first two rows go to LDS for the wave above
     if (EXCH) {
         const int wg = xcd_block();
-        int gy;
-        if (pe.xmajor) {
-            gy = pe.nsx_magic ? (int)__umulhi((unsigned)wg, pe.nsx_magic) : wg;   // one strip: wg / 1
-            sx = wg - gy * p.nsx;
-        } else {
-            sx = p.nsy_magic ? (int)__umulhi((unsigned)wg, p.nsy_magic) : wg;
-            gy = wg - sx * p.nsy;
-        }
+        const int gy = pe.nsx_magic ? (int)__umulhi((unsigned)wg, pe.nsx_magic) : wg;   // one strip: wg / 1
+        sx = wg - gy * p.nsx;
         const int GA = p.loy2 + gy * p.rows_base + min(gy, p.rows_rem);
         const int GB = GA + p.rows_base + (gy < p.rows_rem ? 1 : 0) - 1;
         const int n = (GB - GA + 1 + 1 + 3) >> 2;
@@ -1731,7 +1497,7 @@ struct Up0Args {
     int lox2, loy2, ws2;
     size_t ps2;
     int rx1_1;               // right end of R_1 (the tiles of the last workgroup column stop there)
-    int rx0_1, ry0_1, ry1_1; // the rest of R_1 (ll_up0g's debug variant stores outGPyramid[1] on it)
+    int rx0_1, ry0_1, ry1_1; // the rest of R_1
 };
 
 template<bool VEC, bool LUT_LDS>
@@ -1878,9 +1644,6 @@ __global__ void ll_div3_check(const float *n, const float *d, int count, int *ba
 //     of by an ll_up:1 launch that writes it to memory for this kernel to gather back: one launch, the write and the
 //     re-read of the plane, and a second pass over level 1's planes less.  The tile halo costs (130 x (RU + 2)) /
 //     (128 x RU) - 1 recomputed values (16 % at RU = 16).
-#ifndef HLMI_UP0_ABL
-#define HLMI_UP0_ABL 0   // timing experiment only (csrc/Makefile VARIANT): 1 = no level-1 plane reads at all (results wrong)
-#endif
 constexpr int U0_TW = 130, U0_TS = 131;  // coarse columns of a workgroup's tile / its LDS row stride
 template<bool LUT_LDS, bool B1, bool FUSE1>
 __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
@@ -1902,7 +1665,7 @@ __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
             const int cx = cx0 + tx, cy = cy0 + ty;
             if (cx > p.rx1_1) continue;
             // outGPyramid[1] = upsample(outGPyramid[2]) + outLPyramid[1]   (:76-79), exactly as ll_up computes it
-            const float outL = HLMI_UP0_ABL ? 0.0f : outl_value(p.g1, p.ws1, p.ps1, p.lox1, p.loy1, p.g2, p.ws2, p.ps2, p.lox2, p.loy2, cx, cy, gm.K, gm.Km1);
+            const float outL = outl_value(p.g1, p.ws1, p.ps1, p.lox1, p.loy1, p.g2, p.ws2, p.ps2, p.lox2, p.loy2, cx, cy, gm.K, gm.Km1);
             s_out1[ty * U0_TS + tx] = up_at(p.out2, p.lox2, p.loy2, p.ws2, cx, cy) + outL;
         }
     }
@@ -1953,7 +1716,7 @@ __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
         // lerp(ua, ub, wy) (:280), ua from coarse row ya, ub from yb: wy = 3/4 for odd Y, 1/4 for even Y.  The row
         // whose weight is 1/4 (an exact product) is called q, the other t — a scalar choice of row pointers.
         const int yq = yodd ? ya : yb, yt = yodd ? yb : ya;
-        const float *ga = p.g1 + (HLMI_UP0_ABL ? 0 : (size_t)yq * p.ws1), *gb = p.g1 + (HLMI_UP0_ABL ? 0 : (size_t)yt * p.ws1);
+        const float *ga = p.g1 + (size_t)yq * p.ws1, *gb = p.g1 + (size_t)yt * p.ws1;
         const uint16_t ch[3][2] = {{f.c0.x, f.c0.y}, {f.c1.x, f.c1.y}, {f.c2.x, f.c2.y}};
 #pragma unroll
         for (int i = 0; i < 2; i++) {
@@ -1964,7 +1727,7 @@ __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
             const float lif = (float)li;
             const int idx = min((int)(level * 256.0f), gm.half);
             const float *lp = lut + (idx - 256 * li + gm.half);
-            const uint32_t pb = HLMI_UP0_ABL ? (colb & 1023u) + 4u * i : (uint32_t)li * psb + colb + 4u * i;
+            const uint32_t pb = (uint32_t)li * psb + colb + 4u * i;
             g.A0[i] = ld_su<F2U>(ga, pb), g.B0[i] = ld_su<F2U>(gb, pb);
             g.A1[i] = ld_su<F2U>(ga, pb + psb), g.Bp[i] = ld_su<F2U>(gb, pb + psb);
             s.lut0[i] = lp[0], s.lut1[i] = lp[-256];
@@ -2048,7 +1811,6 @@ struct Up0HArgs {
     Up0Args u;
     const float *outl0;        // outLPyramid[0] on [ix0, ix1] x [oy0, oy0 + oh - 1]
     int l0_ws;                 // its row stride in floats (= input width)
-    int xcd_tiles;
 };
 constexpr int U0H_PF = 4;      // rows in flight per wave
 __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
@@ -2056,10 +1818,11 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
     extern __shared__ float s_out1[];
     // tiles in row-major order, a contiguous run of them per XCD (blocks are dealt round-robin over the 8 XCDs): a tile's
     // 130 x (RU + 2) coarse window overlaps its neighbours' by two columns / rows, and its 130-float rows start one float before a
-    // 512-byte boundary — 6 lines for 4 of payload, the outer two shared with the neighbour tile: same L2 now
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (ph.xcd_tiles) {
-        const int b = by * (int)gridDim.x + bx, nb8 = (int)(gridDim.x * gridDim.y) >> 3;
+    // 512-byte boundary — 6 lines for 4 of payload, the outer two shared with the neighbour tile: same L2 now (131.5 -> 118.1 MB
+    // fetched per 4K frame)
+    int bx, by;
+    {
+        const int b = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, nb8 = (int)(gridDim.x * gridDim.y) >> 3;
         const int lb = b < (nb8 << 3) ? (b & 7) * nb8 + (b >> 3) : b;
         by = lb / (int)gridDim.x, bx = lb - by * (int)gridDim.x;
     }
@@ -2140,234 +1903,6 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// ll_up0g: outGPyramid[0] + recolouring like ll_up0f, WITHOUT reading gPyramid[1] from memory — the workgroup recomputes the
-// level-1 planes its tile needs from the input.  Why: the frame rate on CU-partitioned streams is set by bytes (409 MB per
-// frame; a timing-only build that neither stores nor reads the level-1 planes runs at 0.066 instead of 0.106 ms per frame,
-// profiles/r03b_traffic_ablation.txt), and the K + 1 level-1 planes are the largest item: 75 MB written by ll_down01f, 50-80 MB
-// read back here.  gPyramid[1](., ., k) is a pure function of the input (generator :41-47, :267-273), and a tile only ever
-// touches the planes li, li + 1 of the pixels it contains — two to four of the eight on natural images, all eight on noise.
-//   A  remap table -> LDS; the tile's level-0 window (134 x 22 pixels for 128 x 16 outputs: the 66 x 10 coarse pixels the tile
-//      reads x their 1-3-3-1 taps) -> gray and remap-table position per pixel in LDS
-//   B  inGPyramid[1] on the coarse tile (vertical 1-3-3-1, then horizontal: downsample :267-273)
-//   C  which planes does the tile need: li, li + 1 of its 128 x 16 level-0 pixels and of its coarse pixels -> a bit mask
-//   D  for every needed plane k: gPyramid[0](., ., k) pointwise from (gray, position), vertical pass -> LDS, horizontal pass ->
-//      plane k of the coarse tile in LDS — the operations of ll_down0 / ll_down01f on the same values, so bit-identical
-//   E  outGPyramid[1] on the coarse tile (the level-1 collapse, as in ll_up0f<.., .., true>, planes from LDS)
-//   F  the 128 x 16 outputs: lane = pixel pair, wave = 4 rows; ll_up0f's arithmetic with every gather served by LDS
-// 70.9 KB of LDS: two workgroups per CU.  OUT1_ONLY: stop after E and store outGPyramid[1] (hlmi_debug_local_laplacian_outg).
-constexpr int G_TW = 128, G_TH = 16, G_NT = 512;      // output tile, threads per workgroup
-constexpr int G_CW = 66, G_CH = 10, G_CP = 68;        // coarse tile and its LDS pitch
-constexpr int G_WW = 134, G_WH = 22, G_WP = 136;      // level-0 window and its LDS pitch
-constexpr int G_FLOATS(int nlut) {                    // LDS: table, gray window, position window (u16), inG1, outG1, 8 planes, mask
-    return ((nlut + 1) & ~1) + G_WH * G_WP + G_WH * G_WP / 2 + 2 * G_CH * G_CP + KCH * G_CH * G_CP + 2;
-}
-template<bool B1, bool OUT1_ONLY>
-__global__ __launch_bounds__(G_NT) void ll_up0g(Up0Args p, Geometry gm, Levels lev, int abl) {   // abl: timing experiments (HLMI_LL_G_ABL)
-    extern __shared__ float slut[];
-    const int nlut = 2 * gm.half + 1;
-    float *sgray = slut + ((nlut + 1) & ~1);
-    uint16_t *sidx = reinterpret_cast<uint16_t *>(sgray + G_WH * G_WP);      // remap-table position of every window pixel (<= (K-1) 256)
-    float *sing1 = sgray + G_WH * G_WP + G_WH * G_WP / 2;
-    float *sout1 = sing1 + G_CH * G_CP;
-    float *splane = sout1 + G_CH * G_CP;
-    unsigned *smask = reinterpret_cast<unsigned *>(splane + KCH * G_CH * G_CP);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int X0 = p.ox0 + (int)blockIdx.x * G_TW;                         // even
-    const int Yw0 = p.oy0 + (int)blockIdx.y * G_TH;
-    const int Yw1 = min(Yw0 + G_TH, p.oy0 + p.oh) - 1;
-    const int cx0 = (X0 >> 1) - 1, cy0 = dev::fdiv2(Yw0 - 1);
-    const int th = dev::fdiv2(Yw1 + 1) - cy0 + 1;                          // coarse rows the tile reads (<= G_CH)
-    const int wy0 = 2 * cy0 - 1;                                           // level-0 window origin (absolute): (2 cx0 - 1, 2 cy0 - 1) = (X0 - 3, wy0)
-    // ---- F's pixels are requested first: their latency hides under everything else.  lane = pixel pair, wave = 2 rows
-    const int x = (int)blockIdx.x * G_TW + 2 * lane;                       // output storage column of the lane's pair
-    const uint32_t inb = (uint32_t)(X0 + 2 * lane - gm.ix0) * 2u, outb = (uint32_t)x * 2u;
-    ushort2 fin[2][3];
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int Y = min(Yw0 + 2 * wave + j, p.oy0 + p.oh - 1);           // rows past the end: clamped, never stored
-        const uint16_t *irow = p.in + (long)(Y - gm.iy0) * p.in_sy;
-        const uint32_t ib = x < p.ow ? inb : (uint32_t)(p.ox0 - gm.ix0) * 2u;   // columns past the end likewise
-#pragma unroll
-        for (int c = 0; c < 3; c++) fin[j][c] = ld_frame2(irow + p.gco[c], ib);
-    }
-    // ---- A
-    for (int i = tid; i < nlut; i += G_NT) slut[i] = p.lut_g[i];
-    if (tid == 0) *smask = 0u;
-    {
-        const int iw = gm.ix1 - gm.ix0, ih = gm.iy1 - gm.iy0;
-        constexpr int NIT = (G_WH * (G_WP / 2) + G_NT - 1) / G_NT;         // 3
-        uint16_t ch[NIT][3][2];
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int i = min(tid + it * G_NT, G_WH * (G_WP / 2) - 1);
-            const int r = i / (G_WP / 2), q = i - r * (G_WP / 2);
-            const int a = X0 - 4 + 2 * q;                                   // absolute column of the pair's first pixel (even)
-            const uint16_t *irow = p.in + (long)dev::clampi(wy0 + r - gm.iy0, 0, ih) * p.in_sy;
-            if (abl & 8) {
-#pragma unroll
-                for (int c = 0; c < 3; c++) ch[it][c][0] = (uint16_t)(i * 7 + c), ch[it][c][1] = (uint16_t)(i * 5 + c);
-            } else if (a >= gm.ix0 && a + 1 <= gm.ix1) {
-                const uint32_t off = (uint32_t)(a - gm.ix0) * 2u;
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    const ushort2 v = ld_frame2(irow + p.gco[c], off);
-                    ch[it][c][0] = v.x, ch[it][c][1] = v.y;
-                }
-            } else {
-                const int xa = dev::clampi(a - gm.ix0, 0, iw), xb = dev::clampi(a + 1 - gm.ix0, 0, iw);
-#pragma unroll
-                for (int c = 0; c < 3; c++) ch[it][c][0] = irow[p.gco[c] + xa], ch[it][c][1] = irow[p.gco[c] + xb];
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int i = tid + it * G_NT;
-            if (i < G_WH * (G_WP / 2)) {
-                const int r = i / (G_WP / 2), q = i - r * (G_WP / 2);
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const int wc = 2 * q - 1 + e;                            // window column
-                    if (wc >= 0 && wc < G_WW) {
-                        const float g = gray_from(ch[it][0][e], ch[it][1][e], ch[it][2][e]);
-                        sgray[r * G_WP + wc] = g;
-                        sidx[r * G_WP + wc] = (uint16_t)idx_of(g, gm.Km1, gm.half);
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // ---- B: inGPyramid[1] on the coarse tile (vertical 1-3-3-1 of the four columns, then horizontal)
-    for (int i = tid; i < G_CH * G_CW; i += G_NT) {
-        const int r = i / G_CW, c = i - r * G_CW;
-        const float *g = sgray + 2 * r * G_WP + 2 * c;
-        float v[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = down4_raw(g[k], g[G_WP + k], g[2 * G_WP + k], g[3 * G_WP + k]);
-        sing1[r * G_CP + c] = down4_tail(v[0], v[1], v[2], v[3]);
-    }
-    __syncthreads();
-    // ---- C: the planes this tile reads
-    {
-        unsigned bits = 0u;
-        // level-0 pixels of the tile: pair 2 lane, rows 2 wave, 2 wave + 1; window column of X0 + x is x + 3
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int wr = Yw0 + 2 * wave + j - wy0;
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                const float level = sgray[wr * G_WP + 2 * lane + 3 + e] * gm.Km1;
-                bits |= 3u << min((int)level, gm.K - 2);
-            }
-        }
-        for (int i = tid; i < G_CH * G_CW; i += G_NT) {
-            const float level = sing1[(i / G_CW) * G_CP + (i % G_CW)] * gm.Km1;
-            bits |= 3u << dev::clampi((int)level, 0, gm.K - 2);
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) bits |= (unsigned)__shfl_xor((int)bits, o);   // wave-wide OR, one atomic per wave
-        if (lane == 0) atomicOr(smask, bits);
-    }
-    __syncthreads();
-    const unsigned need = *smask;
-    // ---- D: the needed planes of gPyramid[1] on the coarse tile, all in one phase: item = (plane, coarse pixel), 16 pointwise
-    //      evaluations of gPyramid[0] (:44) from (gray, position), the vertical pass of the four columns, the horizontal pass
-    {
-        const int np = (abl & 1) ? 0 : __builtin_popcount(need);
-        for (int it = tid; it < np * (G_CH * G_CW); it += G_NT) {
-            const int pi = it / (G_CH * G_CW), i = it - pi * (G_CH * G_CW);
-            unsigned m = need;
-            for (int s2 = 0; s2 < pi; s2++) m &= m - 1;                      // drop the pi lowest set bits
-            const int k = __builtin_ctz(m);
-            const int r = i / G_CW, c = i - r * G_CW;
-            const float L = lev.v[k];
-            const float *lk = slut + (gm.half - 256 * k);
-            const float *g = sgray + 2 * r * G_WP + 2 * c;
-            const uint16_t *ix = sidx + 2 * r * G_WP + 2 * c;
-            float v[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float a0 = g0_val<B1>(g[q], L, p.beta, lk[ix[q]]), a1 = g0_val<B1>(g[G_WP + q], L, p.beta, lk[ix[G_WP + q]]);
-                const float a2 = g0_val<B1>(g[2 * G_WP + q], L, p.beta, lk[ix[2 * G_WP + q]]);
-                const float a3 = g0_val<B1>(g[3 * G_WP + q], L, p.beta, lk[ix[3 * G_WP + q]]);
-                v[q] = down4_raw(a0, a1, a2, a3);
-            }
-            splane[k * (G_CH * G_CP) + r * G_CP + c] = down4_tail(v[0], v[1], v[2], v[3]);
-        }
-    }
-    __syncthreads();
-    // ---- E: outGPyramid[1] = upsample(outGPyramid[2]) + outLPyramid[1]   (:63-79), exactly as ll_up computes it
-    for (int e = tid; e < ((abl & 2) ? 0 : G_CW * th); e += G_NT) {
-        const int ty = e / G_CW, tx = e - ty * G_CW;
-        const int cx = cx0 + tx, cy = cy0 + ty;
-        if (cx > p.rx1_1) continue;
-        const float level = sing1[ty * G_CP + tx] * gm.Km1;
-        const int li = dev::clampi((int)level, 0, gm.K - 2);
-        const float lf = level - (float)li;
-        const float l0 = splane[li * (G_CH * G_CP) + ty * G_CP + tx] - up_at(p.g2 + (size_t)li * p.ps2, p.lox2, p.loy2, p.ws2, cx, cy);
-        const float l1 = splane[(li + 1) * (G_CH * G_CP) + ty * G_CP + tx] - up_at(p.g2 + (size_t)(li + 1) * p.ps2, p.lox2, p.loy2, p.ws2, cx, cy);
-        const float outL = (1.0f - lf) * l0 + lf * l1;
-        const float v = up_at(p.out2, p.lox2, p.loy2, p.ws2, cx, cy) + outL;
-        sout1[ty * G_CP + tx] = v;
-        if (OUT1_ONLY && cx >= p.rx0_1 && cy >= p.ry0_1 && cy <= p.ry1_1) {
-            const_cast<float *>(p.out1)[(size_t)(cy - p.loy1) * p.ws1 + (cx - p.lox1)] = v;
-        }
-    }
-    if (OUT1_ONLY) return;
-    __syncthreads();
-    // ---- F: the outputs.  lerp(zero, one, w) with w in {1/4, 3/4}: see ll_up0f
-    if (x >= p.ow || (abl & 4)) return;
-    auto hl0 = [](float rm, float r0) { return __builtin_fmaf(rm, 0.25f, r0 * 0.75f); };  // lerp(f[c], f[c-1], 1/4): X even
-    auto hl1 = [](float r0, float rp) { return __builtin_fmaf(rp, 0.25f, r0 * 0.75f); };  // lerp(f[c+1], f[c], 3/4): X odd
-    auto vl = [](float uq, float ut) { return __builtin_fmaf(uq, 0.25f, ut * 0.75f); };
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int y = (int)blockIdx.y * G_TH + 2 * wave + j;
-        if (y >= p.oh) break;
-        const int Y = p.oy0 + y;
-        const uint16_t ch[3][2] = {{fin[j][0].x, fin[j][0].y}, {fin[j][1].x, fin[j][1].y}, {fin[j][2].x, fin[j][2].y}};
-        const int ya = dev::fdiv2(Y + 1) - cy0, yb = dev::fdiv2(Y - 1) - cy0;
-        const bool yodd = dev::fmod2(Y) != 0;
-        const int yq = yodd ? ya : yb, yt = yodd ? yb : ya;                  // q: the row whose weight is 1/4
-        const float *oa = sout1 + yq * G_CP + lane, *ob = sout1 + yt * G_CP + lane;   // columns c - 1, c, c + 1 = lane, lane + 1, lane + 2
-        const float uo[2] = {vl(hl0(oa[0], oa[1]), hl0(ob[0], ob[1])), vl(hl1(oa[1], oa[2]), hl1(ob[1], ob[2]))};
-        uint16_t res[3][2];
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const float gray = gray_from(ch[0][i], ch[1][i], ch[2][i]);
-            const float level = gray * gm.Km1;
-            const int li = min((int)level, gm.K - 2);                       // gray >= 0: the lower clamp bounds never bind
-            const float lif = (float)li;
-            const int idx = min((int)(level * 256.0f), gm.half);
-            const float *lp = slut + (idx - 256 * li + gm.half);
-            const float lut0 = lp[0], lut1 = lp[-256];
-            const float lf = level - lif;
-            const float lev0 = lif * gm.inv_Km1, lev1 = (lif + 1.0f) * gm.inv_Km1;
-            const float *Aq = splane + li * (G_CH * G_CP) + yq * G_CP + lane + i;      // columns (c - 1, c) or (c, c + 1)
-            const float *At = splane + li * (G_CH * G_CP) + yt * G_CP + lane + i;
-            const float *Aq1 = Aq + G_CH * G_CP, *At1 = At + G_CH * G_CP;             // plane li + 1
-            float u0, u1;
-            if (i == 0) u0 = vl(hl0(Aq[0], Aq[1]), hl0(At[0], At[1])), u1 = vl(hl0(Aq1[0], Aq1[1]), hl0(At1[0], At1[1]));
-            else u0 = vl(hl1(Aq[0], Aq[1]), hl1(At[0], At[1])), u1 = vl(hl1(Aq1[0], Aq1[1]), hl1(At1[0], At1[1]));
-            const float l0 = g0_val<B1>(gray, lev0, p.beta, lut0) - u0;
-            const float l1 = g0_val<B1>(gray, lev1, p.beta, lut1) - u1;
-            const float outL = (1.0f - lf) * l0 + lf * l1;
-            const float og = (uo[i] + outL) + 0.01f;
-            const float gr = gray + 0.01f;
-            const float n[3] = {(float)ch[0][i] * og, (float)ch[1][i] * og, (float)ch[2][i] * og};
-            float qv[3];
-            div3_by(n, gr, qv);
-#pragma unroll
-            for (int c = 0; c < 3; c++) res[c][i] = (uint16_t)__builtin_amdgcn_fmed3f(qv[c], 0.0f, 65535.0f);
-        }
-        uint16_t *orow = p.out + (long)y * p.out_sy;
-#pragma unroll
-        for (int c = 0; c < 3; c++) st_frame2(reinterpret_cast<char *>(orow + (long)c * p.out_sc) + outb, res[c][0], res[c][1]);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
 const int64_t est_zero = 0, est_w = 1536, est_h = 2560, est_c = 3;
 const int64_t *const buf_est[6] = {&est_zero, &est_w, &est_zero, &est_h, &est_zero, &est_c};
 const halide_scalar_value_t est_levels = [] { halide_scalar_value_t v{}; v.u.i32 = 8; return v; }();
@@ -2395,9 +1930,7 @@ int env_int(const char *name, int dflt) {
 thread_local Level t_dbg_lv[J];
 thread_local hipStream_t t_dbg_stream = nullptr;
 thread_local bool t_dbg_out1_pending = false;  // the last call fused level 1's collapse: outGPyramid[1] was never stored
-thread_local bool t_dbg_ondemand = false, t_dbg_b1 = false, t_dbg_emit = false;   // ... and level 1 itself was never stored either (ll_up0g)
-thread_local Up0Args t_dbg_up0;
-thread_local Geometry t_dbg_gm;
+thread_local bool t_dbg_emit = false;         // ... by ll_up0h: level 1 holds its three planes only (ll_down01e)
 thread_local int t_dbg_K = 0;
 thread_local float t_dbg_Km1 = 0;
 
@@ -2453,10 +1986,9 @@ std::vector<GraphEntry> g_graphs;   // small (<= 64): linear search
 uint64_t g_graph_clock = 0;
 
 uint64_t ll_env_signature() {
-    static const char *const names[] = {"HLMI_LL_NO_LUT_CACHE", "HLMI_LL_UNITS0", "HLMI_LL_NO_VEC", "HLMI_LL_D0F", "HLMI_LL_FUSE_D2",
+    static const char *const names[] = {"HLMI_LL_NO_LUT_CACHE", "HLMI_LL_UNITS0", "HLMI_LL_NO_VEC",
                                         "HLMI_LL_D01_EXCH", "HLMI_LL_FUSE_FROM", "HLMI_LL_UNITSB", "HLMI_LL_UPCHAIN_FROM",
-                                        "HLMI_LL_UP0_OLD", "HLMI_LL_FUSE_UP1", "HLMI_LL_RU", "HLMI_LL_PLANE_MASK", "HLMI_LL_ONDEMAND",
-                                        "HLMI_LL_G_ABL", "HLMI_LL_EMIT", "HLMI_LL_XMAJOR", "HLMI_LL_XCD_TILES"};
+                                        "HLMI_LL_UP0_OLD", "HLMI_LL_FUSE_UP1", "HLMI_LL_RU", "HLMI_LL_EMIT"};
     uint64_t h = 1469598103934665603ull;
     for (const char *n : names) {
         const char *e = getenv(n);
@@ -2659,19 +2191,13 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         // bytes, 32 rows measure 2.7 % faster (84.8 vs 82.6 Gpx/s); on a stream that owns the device 16 rows do (72.7 vs 68.2).
         p.RU = max(1, env_int("HLMI_LL_RU", fuse1 ? (partitioned ? 32 : 16) : 8));
     }
-    // ll_up0g: level 1 is never stored — the up pass recomputes the planes each tile needs from the input (needs the fused
-    // down kernel, which can simply not store level 1, and everything ll_up0f<.., .., true> needs)
-    const bool d01_possible = levels == KCH && lut_lds && env_int("HLMI_LL_D0F", 1) && env_int("HLMI_LL_FUSE_D2", 1) &&
+    // ll_down01f / ll_down01e: levels 1 and 2 from the input in one walk (levels == KCH planes in registers, 8-byte input loads)
+    const bool d01_possible = levels == KCH && lut_lds &&
                               ((uintptr_t)din % 8 == 0) && in_sy % 4 == 0 && gco[0] % 4 == 0 && gco[1] % 4 == 0 && gco[2] % 4 == 0 &&
                               (gm.ix1 - gm.ix0 + 1) % 4 == 0 && !env_int("HLMI_LL_NO_VEC", 0);
-    // OPT-IN (HLMI_LL_ONDEMAND=1): bit-exact on the whole parity suite, and it does take 150 MB per frame off the memory system
-    // (ll_down01f 46.7 -> 37.7 us) — but ll_up0g itself takes 107 us against ll_up0f's 41 (4050 tiles at two workgroups per
-    // CU, 34 us of per-tile fixed cost, 36 us of plane recomputation), so the frame gets slower (0.128 vs 0.106 ms on four
-    // partitions); profiles/r03b_traffic_ablation.txt has the phase breakdown and what a version that pays would need.
-    const bool ondemand = d01_possible && fast && fuse1 && lut_lds && env_int("HLMI_LL_ONDEMAND", 0);
     // The default for the common geometry: ll_down01e emits outLPyramid[0] and three planes of level 1, ll_up0h collapses
     // (HLMI_LL_EMIT=0: the round-3 pair ll_down01f / ll_up0f with the materialised K + 1 level-1 planes)
-    const bool emit = d01_possible && fast && fuse1 && !ondemand && env_int("HLMI_LL_EMIT", 1);
+    const bool emit = d01_possible && fast && fuse1 && env_int("HLMI_LL_EMIT", 1);
     // ll_up0h has no data-dependent gathers to amortise over a tall tile: short tiles (more, smaller workgroups) are faster on a
     // stream that owns the device (31.7 us at 8 rows per wave against 33.5 / 38.4 at 16 / 32); on CU partitions 8..32 measure the same
     if (emit) p.RU = max(1, env_int("HLMI_LL_RU", partitioned ? 16 : 8));
@@ -2706,14 +2232,12 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     case ((O ? 8 : 0) | (V ? 4 : 0) | (L ? 2 : 0) | (B ? 1 : 0)):      \
         r = launch_d0(&ll_down0<O, V, L, B>);                         \
         break;
-        fuse_d2 = levels == KCH && vec && lut_lds && env_int("HLMI_LL_D0F", 1) && env_int("HLMI_LL_FUSE_D2", 1);
+        fuse_d2 = levels == KCH && vec && lut_lds;
         if (fuse_d2) {
             // ---- levels 1 AND 2 from the input in one walk (ll_down01f); the ll_down_strip:1 launch below is skipped
             const Level &e = lv[2];
             D01Args a;
             a.in = din, a.in_sy = in_sy, a.co0 = gco[0], a.co1 = gco[1], a.co2 = gco[2], a.beta = beta, a.lut_g = lut;
-            a.skip1 = ondemand ? 1 : 0;
-            a.mask1 = max(0, min(2, env_int("HLMI_LL_PLANE_MASK", 2)));   // 0 every plane, 1 per wave, 2 per 16-lane row (default)
             a.g1 = d.g, a.so1 = d.lox, a.loy1 = d.loy, a.w1 = d.w, a.h1 = d.h, a.ws1 = d.ws, a.ps1 = d.ps;
             a.g2 = e.g, a.so2 = e.lox, a.loy2 = e.loy, a.w2 = e.w, a.h2 = e.h, a.ws2 = e.ws, a.ps2 = e.ps;
             const bool odd0 = d.odd, odd1 = e.odd;   // e.odd == (d.lox & 1)
@@ -2757,7 +2281,6 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
                 timing_note_bytes(6.0 * iw * (gm.iy1 - gm.iy0 + 1) + 4.0 * iw * oh + 4.0 * 3.0 * d.w * d.h + 4.0 * (levels + 1) * e.w * e.h);
                 D01EArgs ae;
                 ae.d = a, ae.outl0 = outl0, ae.oy0 = output->dim[1].min, ae.oh = oh;
-                ae.xmajor = env_int("HLMI_LL_XMAJOR", 1) ? 1 : 0;
                 ae.nsx_magic = a.nsx == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)a.nsx + 1ull);
 #define LL_D01E(O0, O1, B)                                                                                             \
     do {                                                                                                               \
@@ -2776,7 +2299,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
                 }
 #undef LL_D01E
             } else {
-            timing_note_bytes((ondemand ? 6.0 * iw * (gm.iy1 - gm.iy0 + 1) : d0_bytes) + 4.0 * (levels + 1) * e.w * e.h);
+            timing_note_bytes(d0_bytes + 4.0 * (levels + 1) * e.w * e.h);
 #define LL_D01(O0, O1, B)                                                                                              \
     do {                                                                                                               \
         if (exch) HLMI_LAUNCH(uc, "ll_down01", st, (ll_down01f<O0, O1, B, true>), grid2, block, sh2, a, gm, lev);      \
@@ -2794,9 +2317,6 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             }
 #undef LL_D01
             }
-        } else if (levels == KCH && vec && lut_lds && env_int("HLMI_LL_D0F", 1)) {
-            if (d.odd) r = b1 ? launch_d0(&ll_down0f<true, true>) : launch_d0(&ll_down0f<true, false>);
-            else r = b1 ? launch_d0(&ll_down0f<false, true>) : launch_d0(&ll_down0f<false, false>);
         } else {
             switch (variant) {
                 LL_D0(false, false, false, false) LL_D0(false, false, false, true) LL_D0(false, false, true, false)
@@ -2897,26 +2417,6 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         // fused: + inG_1 and, per level-2 pixel, 2 planes of g_2 + outG_2
         const double n1 = (double)(c.rx1 - c.rx0 + 1) * (c.ry1 - c.ry0 + 1), n2 = (double)(lv[2].rx1 - lv[2].rx0 + 1) * (lv[2].ry1 - lv[2].ry0 + 1);
         const double u0_bytes = 2.0 * (3 + nc) * ow * oh + 4.0 * 3.0 * n1 + (fuse1 ? 4.0 * 3.0 * n2 : 0.0);
-        if (ondemand) {
-            // input read (through a 134 x 22 window per 128 x 16 tile) + output written + level 2 (3 planes of it)
-            timing_note_bytes(2.0 * (3 + nc) * ow * oh + 4.0 * 3.0 * n2);
-            Levels lev;
-            for (int k = 0; k < MAX_K; k++) lev.v[k] = (float)k * gm.inv_Km1;
-            const size_t shg = sizeof(float) * (size_t)G_FLOATS(nlut);
-            dim3 gridg((ow + G_TW - 1) / G_TW, (oh + G_TH - 1) / G_TH);
-            t_dbg_up0 = p, t_dbg_gm = gm, t_dbg_ondemand = true, t_dbg_b1 = (beta == 1.0f);
-            if (beta == 1.0f) {
-                static const hipError_t attr = hipFuncSetAttribute((const void *)ll_up0g<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                (void)attr;
-                HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0g<true, false>), gridg, dim3(G_NT), shg, p, gm, lev, env_int("HLMI_LL_G_ABL", 0));
-            } else {
-                static const hipError_t attr = hipFuncSetAttribute((const void *)ll_up0g<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                (void)attr;
-                HLMI_LAUNCH(uc, "ll_up0", st, (ll_up0g<false, false>), gridg, dim3(G_NT), shg, p, gm, lev, env_int("HLMI_LL_G_ABL", 0));
-            }
-            return 0;
-        }
-        t_dbg_ondemand = false;
         t_dbg_emit = emit;
         if (emit) {
             // input read + output written (u16 x 3 channels), outLPyramid[0] read, three planes of level 1, per level-2 pixel two
@@ -2924,7 +2424,6 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             timing_note_bytes(2.0 * (3 + nc) * ow * oh + 4.0 * ow * oh + 4.0 * 3.0 * n1 + 4.0 * 3.0 * n2);
             Up0HArgs ph;
             ph.u = p, ph.outl0 = outl0, ph.l0_ws = gm.ix1 - gm.ix0 + 1;
-            ph.xcd_tiles = env_int("HLMI_LL_XCD_TILES", 1) ? 1 : 0;
             HLMI_LAUNCH(uc, "ll_up0", st, ll_up0h, grid, block, sizeof(float) * U0_TS * (p.RU + 2), ph, gm);
             return 0;
         }
@@ -3139,25 +2638,8 @@ extern "C" int hlmi_debug_local_laplacian_outg(int level, float *dst, int cap_fl
     if (rh_out) *rh_out = rh;
     if (!dst) return 0;
     if ((long)rw * rh > cap_floats) return -1;
-    if (level == 1 && t_dbg_out1_pending && t_dbg_ondemand) {
-        // ll_up0g: neither outGPyramid[1] nor gPyramid[1] was stored; its debug variant recomputes both per tile, exactly as
-        // the product launch did, and stores outGPyramid[1]
-        Levels lev;
-        for (int k = 0; k < MAX_K; k++) lev.v[k] = (float)k * t_dbg_gm.inv_Km1;
-        const int nlut = 2 * t_dbg_gm.half + 1;
-        const size_t shg = sizeof(float) * (size_t)G_FLOATS(nlut);
-        dim3 gridg((t_dbg_up0.ow + G_TW - 1) / G_TW, (t_dbg_up0.oh + G_TH - 1) / G_TH);
-        if (t_dbg_b1) {
-            (void)hipFuncSetAttribute((const void *)ll_up0g<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            hipLaunchKernelGGL((ll_up0g<true, true>), gridg, dim3(G_NT), shg, t_dbg_stream, t_dbg_up0, t_dbg_gm, lev, 0);
-        } else {
-            (void)hipFuncSetAttribute((const void *)ll_up0g<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            hipLaunchKernelGGL((ll_up0g<false, true>), gridg, dim3(G_NT), shg, t_dbg_stream, t_dbg_up0, t_dbg_gm, lev, 0);
-        }
-        if (hipGetLastError() != hipSuccess) return -1;
-        t_dbg_out1_pending = false;
-    } else if (level == 1 && t_dbg_out1_pending) {
-        // the fused ll_up0f kept outGPyramid[1] in LDS: produce the plane now with the stand-alone kernel (its inputs are
+    if (level == 1 && t_dbg_out1_pending) {
+        // the fused ll_up0f / ll_up0h kept outGPyramid[1] in LDS: produce the plane now with the stand-alone kernel (its inputs are
         // still in the arena) so that the tests can compare every level
         const Level &a = t_dbg_lv[1], &c = t_dbg_lv[2];
         if (t_dbg_emit) {   // level 1 holds its three planes only (ll_down01e)
