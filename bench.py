@@ -119,12 +119,18 @@ def stub_main(args, rank, local_rank, world):
         time.sleep(1e-4 * len(mine))
     barrier()
     elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dist, device)
+    # who is where: (rank, local rank = the HIP device the real run binds, OMP threads of the CPU legs) of every rank, on rank 0
+    me = [rank, local_rank, int(os.environ.get("OMP_NUM_THREADS", "0"))]
+    table = [me]
+    if dist is not None:
+        table = [None] * world
+        dist.all_gather_object(table, me)
     if rank == 0:
         print(json.dumps({"metric": "launcher self-test (no pipeline ran)", "value": 0.0, "unit": "Mpx/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 4),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "stub",
                           "config": {"workload": "stub", "rccl_ranks": ranks_seen, "backend": launcher.backend(),
-                                     "frames_of_rank0": mine}}), flush=True)
+                                     "frames_of_rank0": mine, "rank_table": table}}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -62,3 +62,18 @@ def test_refuses_more_gpus_than_visible():
                        text=True, timeout=300)
     assert p.returncode != 0
     assert "HIP device(s) are visible" in p.stderr
+
+
+def test_self_launch_eight_ranks_the_target_world_size():
+    """The node this is built for has 8 GPUs: the whole launch path at world size 8 (gloo stub), every rank bound to its own
+    local rank (= HIP device index in the real run) and the host threads of the CPU legs divided between the ranks."""
+    p = _run("bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1", timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    d = _json_line(p.stdout)
+    assert d["n_gpus"] == 8 and d["config"]["rccl_ranks"] == 8
+    table = sorted(d["config"]["rank_table"])
+    assert [t[0] for t in table] == list(range(8)) and [t[1] for t in table] == list(range(8))   # rank r -> device r, no sharing
+    want_threads = max(1, (os.cpu_count() or 1) // 8)
+    assert all(t[2] == want_threads for t in table), table
+    # weak scaling: 8 ranks x FRAMES_PER_STEP frames, rank 0 owns every 8th
+    assert d["config"]["frames_of_rank0"] == list(range(0, 64, 8))

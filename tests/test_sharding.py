@@ -122,3 +122,44 @@ def test_scatter_process_gather_single_process():
     from halide_amd import sharding
     out = sharding.scatter_process_gather([torch.full((2, 2), float(i)) for i in range(3)], lambda t: t + 1)
     assert [float(o[0, 0]) for o in out] == [1.0, 2.0, 3.0]
+
+
+def test_scatter_process_gather_32_frames_over_8_ranks():
+    """BASELINE.json configs[3] at its real shape: a batch of 32 frames on rank 0, 8 ranks, every rank computes its 4."""
+    import torch.multiprocessing as mp
+    n_frames, world = 32, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sg_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {r: (calls, res) for r, calls, res in (q.get(timeout=600) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert results[r][0] == list(range(r, n_frames, world))      # who computed what: round robin, 4 frames each
+    assert results[0][1] == [2.0 * i + 1 for i in range(n_frames)]   # the batch, in order, back on rank 0 only
+    assert all(results[r][1] is None for r in range(1, world))
+
+
+def test_eight_ranks_over_gloo_match_single_process():
+    import torch.multiprocessing as mp
+    import oracle_lib
+    from halide_amd import sharding
+    n_frames, world = 19, 8          # not a multiple of the world size: ranks 0..2 take three frames, the others two
+    want = [sharding.digest64(oracle_lib.blur(f)) for f in _frames(n_frames)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, digests, slowest in results:
+        assert digests == want
+        assert slowest == 0.25 * world
