@@ -85,6 +85,10 @@ def _preload_torch_hip_runtime() -> str | None:
         needed = [n for n in _elf_dynamic_strings(LIB_PATH, 1) if n.startswith("libamdhip64")]
         soname = _elf_dynamic_strings(path, 14)
         if not needed or not soname or soname[0] != needed[0]:
+            import warnings
+            warnings.warn(f"halide_amd: torch bundles {soname[0] if soname else 'an unidentified HIP runtime'} but libhlmi.so needs "
+                          f"{needed[0] if needed else 'libamdhip64'}: keeping the system HIP runtime — import torch BEFORE halide_amd "
+                          "in a process that uses both (INTEGRATION.md), or set HLMI_TORCH_HIP=1", RuntimeWarning, stacklevel=2)
             return None
     try:
         C.CDLL(path, mode=C.RTLD_GLOBAL)

@@ -595,6 +595,7 @@ struct FilterImage {
         bool live = false;
     } readers[FI_READERS];
     bool overflow = false;         // more reader streams than slots: fall back to a device-wide wait
+    int pins = 0;                  // calls between their cache hit and the enqueue of their main kernel: not evictable meanwhile
     uint64_t used = 0;
 };
 std::mutex g_fi_mu;
@@ -603,10 +604,12 @@ uint64_t g_fi_clock = 0;
 
 // everything enqueued so far that reads `e.wb` happens before whatever `consumer` enqueues from now on
 void wait_for_readers(FilterImage &e, hipStream_t consumer) {
-    bool sync_all = e.overflow;
+    // consumer == nullptr: the entry lives on ANOTHER device than the calling thread's current one — no events are created
+    // or recorded from here (they would belong to the wrong device and poison the slot); one device-wide wait over there
+    bool sync_all = e.overflow || consumer == nullptr;
     for (auto &r : e.readers) {
         if (!r.live) continue;
-        if (r.s != consumer) {
+        if (consumer != nullptr && r.s != consumer) {
             // the reader's event is recorded NOW, behind everything its stream has been given so far (a record per call
             // put a barrier packet between consecutive kernels of a stream: ~3 us of every 30 us call)
             bool ok = r.done || hipEventCreateWithFlags(&r.done, hipEventDisableTiming) == hipSuccess;
@@ -629,12 +632,15 @@ void wait_for_readers(FilterImage &e, hipStream_t consumer) {
     e.overflow = false;
 }
 
-// A use of a filter image by one call: holds the cache lock (when the image is a cache entry) until done() — called after
-// the main kernel has been enqueued — has recorded this stream as a reader.  `fill` = the pre-pass has to run first.
+// A use of a filter image by one call.  A cache HIT pins its entry (not evictable, not re-fillable) and lets go of the cache
+// lock at once — concurrent callers (the per-device workers of hlmi_run_batch, multi-stream hosts) enqueue their launches side
+// by side; done() — called after the main kernel has been enqueued — takes the lock again for a moment, records this stream
+// as a reader and unpins.  A MISS keeps the lock from the choice of the slot until done(): the entry is being (re)filled.
+// `fill` = the pre-pass has to run first.
 struct FilterUse {
     std::unique_lock<std::mutex> lock;
     FilterImage *entry = nullptr;   // null: the image is in the stream's scratch arena
-    bool fill = false;
+    bool fill = false, pinned = false;
     uint16_t *wb = nullptr;
     void filled(hipStream_t s) {    // the pre-pass has been enqueued on s
         if (entry) (void)record_done(entry->ready, s);
@@ -642,6 +648,8 @@ struct FilterUse {
     }
     void done(hipStream_t s) {      // the main kernel has been enqueued on s
         if (entry) {
+            if (!lock.owns_lock()) lock = std::unique_lock<std::mutex>(g_fi_mu);
+            if (pinned) entry->pins--, pinned = false;
             FilterImage::Reader *slot = nullptr;
             for (auto &r : entry->readers) {
                 if (r.live && r.s == s) slot = &r;
@@ -658,8 +666,11 @@ struct FilterUse {
         if (lock.owns_lock()) lock.unlock();
     }
     ~FilterUse() {
-        if (entry && fill) entry->version = 0, entry->handle = 0;   // bailed out before the pre-pass: never match this entry
-        if (entry) entry->overflow = true;                          // bailed out after it: an unrecorded reader may exist
+        if (!entry) return;
+        if (!lock.owns_lock()) lock = std::unique_lock<std::mutex>(g_fi_mu);
+        if (pinned) entry->pins--;
+        if (fill) entry->version = 0, entry->handle = 0;   // bailed out before the pre-pass: never match this entry
+        entry->overflow = true;                            // bailed out after it: an unrecorded reader may exist
     }
 };
 
@@ -677,14 +688,24 @@ int filter_image(void *uc, const DeviceCtx &ctx, const halide_buffer_t *filter, 
         if (e.wb && e.device == ctx.device && e.handle == filter->device && e.version == version && e.layout == layout && e.bytes == bytes) {
             e.used = ++g_fi_clock;
             if (e.stream != ctx.stream && e.ready) HLMI_HIP(uc, wait_done(ctx.stream, e.ready));
-            use->wb = e.wb, use->fill = false, use->entry = &e, use->lock = std::move(lock);
-            return 0;
+            e.pins++;
+            use->wb = e.wb, use->fill = false, use->entry = &e, use->pinned = true;
+            return 0;   // the lock is released here: the pin keeps the entry
         }
     }
-    FilterImage *slot = &g_fi[0];
+    FilterImage *slot = nullptr;
     for (auto &e : g_fi) {
+        if (e.pins > 0) continue;   // in use by a call that has not enqueued its kernel yet
         if (!e.wb) { slot = &e; break; }
-        if (e.used < slot->used) slot = &e;
+        if (!slot || e.used < slot->used) slot = &e;
+    }
+    if (!slot) {   // every entry is pinned by a concurrent call: this call re-orders its filter into the stream's arena
+        lock.unlock();
+        void *ws = nullptr;
+        int r = get_workspace(uc, ctx, bytes, &ws);
+        if (r) return r;
+        use->wb = (uint16_t *)ws, use->fill = true, use->entry = nullptr;
+        return 0;
     }
     if (slot->wb) {
         // re-fill or evict: the old image may still be read on other streams (and was produced on slot->stream)

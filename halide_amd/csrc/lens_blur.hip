@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void lb_cost_down(const uint8_t *__restrict__ 
     float p0[KPT], p1[KPT], p2[KPT];
 #pragma unroll
     for (int k = 0; k < KPT; k++) {
-        const int idx = tid + 256 * k, p = idx < total ? idx / ndx : 0, xl = idx - p * ndx;
+        const int idx = tid + 256 * k, p = idx < total ? idx / ndx : 0, xl = idx < total ? idx - p * ndx : 0;   // slots past `total` read LDS offset 0
         qoff[k] = p * CD_RP + 2 * xl;
         doff[k] = idx < total ? (int)((size_t)p * db.h * db.w) + (dx0 - db.x0) + xl : -1;
         p0[k] = p1[k] = p2[k] = 0.0f;

@@ -51,7 +51,17 @@ inline std::string read(const std::string &path, Image &im) {
     while (!done) {
         if (fread(head, 1, 8, f) != 8) return path + ": truncated (no IEND chunk)";
         const uint32_t len = be32(head);
+        // nothing is allocated on a length field's word alone: a chunk cannot be longer than what is left of the file, and
+        // only IDAT chunks may be large at all
         if (len > (1u << 31)) return path + ": chunk length out of range";
+        {
+            const long here = ftell(f);
+            if (here < 0 || fseek(f, 0, SEEK_END) != 0) return path + ": cannot seek";
+            const long end = ftell(f);
+            if (fseek(f, here, SEEK_SET) != 0) return path + ": cannot seek";
+            if ((long)len + 4 > end - here) return path + ": truncated chunk";
+        }
+        if (memcmp(head + 4, "IDAT", 4) && len > (1u << 20)) return path + ": oversized ancillary chunk";
         std::vector<uint8_t> body(len);
         uint8_t crc[4];
         if ((len && fread(body.data(), 1, len, f) != len) || fread(crc, 1, 4, f) != 4) return path + ": truncated chunk";
@@ -68,6 +78,8 @@ inline std::string read(const std::string &path, Image &im) {
             if (body[10] || body[11]) return path + ": unknown compression / filter method";
             if (body[12]) return path + ": interlaced PNG files are not supported";
             if (!im.width || !im.height) return path + ": empty image";
+            // (size_t)height * (rowbytes + 1) below must not wrap, and the callers keep extents in int
+            if (im.width > (1u << 20) || im.height > (1u << 20)) return path + ": dimensions beyond 2^20 are not supported";
             have_ihdr = true;
         } else if (!memcmp(head + 4, "IDAT", 4)) {
             z.insert(z.end(), body.begin(), body.end());

@@ -11,8 +11,9 @@
 // (HalideRuntime.h:1851-1853: buffers with host == device == 0) and `buf->device_interface` for sync / copy_to_host.
 //
 // Image files: PNG (8 / 16 bit, gray / gray+alpha / RGB / RGBA, non-interlaced — the formats tools/halide_image_io.h:856-1040
-// reads and writes; own codec over zlib in hlmi_png.h, this image has no libpng), binary PGM / PPM and NumPy .npy.  JPG needs
-// libjpeg, which this build does not link (printed by --help).
+// reads and writes; own codec over zlib in hlmi_png.h, this image has no libpng), binary PGM / PPM, and the reference's three raw
+// array formats: .npy, .mat (MATLAB level 5) and .tmp (ImageStack).  JPG and TIFF are not read (libjpeg is not linked; the
+// apps' drivers feed neither) — printed by --help.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -161,7 +162,7 @@ void fill_random(Arg &a, uint64_t seed) {
     }
 }
 
-// ---- image files: binary PGM / PPM (maxval 255 or 65535, big-endian samples) and .npy (C order, little endian)
+// ---- image files: binary PGM / PPM (maxval 255 or 65535, big-endian samples) and .npy (the reference's layout, little endian)
 bool ends_with(const std::string &s, const std::string &e) { return s.size() >= e.size() && s.compare(s.size() - e.size(), e.size(), e) == 0; }
 
 // conversion rule of the reference's image I/O when the file's sample type differs from the buffer's
@@ -270,9 +271,13 @@ std::string npy_descr(halide_type_t t) {
     return std::string(t.bits == 8 ? "|" : "<") + k + std::to_string(t.bits / 8);
 }
 
-void save_npy(const std::string &path, const Arg &a) {  // numpy axes = halide dimensions reversed (C order)
+// The reference's convention (tools/halide_image_io.h:1313-1385 load_npy, :1414-1470 save_npy): the header's shape tuple lists the
+// HALIDE extents, dimension 0 (x) first, 'fortran_order': False, and the payload is the dense buffer with x innermost — so
+// numpy reads a W x H x C image as an array of shape (W, H, C) whose memory is really [c][y][x].  Kept bit for bit: files
+// move between this runner and the reference's RunGen unchanged (tests/test_reference_consumers.py).
+void save_npy(const std::string &path, const Arg &a) {
     std::string shape = "(";
-    for (int d = (int)a.dims.size() - 1; d >= 0; d--) shape += std::to_string(a.dims[d].extent) + ",";
+    for (int d = 0; d < (int)a.dims.size(); d++) shape += std::to_string(a.dims[d].extent) + ",";
     shape += ")";
     std::string hdr = "{'descr': '" + npy_descr(a.md->type) + "', 'fortran_order': False, 'shape': " + shape + ", }";
     while ((10 + hdr.size() + 1) % 64) hdr += ' ';
@@ -301,10 +306,175 @@ void load_npy(const std::string &path, Arg &a) {
     for (const auto &t : split(hdr.substr(p0 + 1, p1 - p0 - 1), ','))
         if (t.find_first_of("0123456789") != std::string::npos) np.push_back(atoi(t.c_str()));
     if ((int)np.size() != a.md->dimensions) fail(path + ": expected " + std::to_string(a.md->dimensions) + " dimensions");
-    std::reverse(np.begin(), np.end());
-    a.dims = dense_shape({}, np);
+    a.dims = dense_shape({}, np);   // dimension 0 first, as the reference writes them
     allocate(a);
     f.read((char *)a.storage.data(), count(a) * elem_bytes(a.md->type));
+}
+
+// ---- .tmp (ImageStack) and .mat (MATLAB level 5, one uncompressed numeric array): the two binary array formats of the
+// reference's image I/O besides .npy (tools/halide_image_io.h:1632-1722 and :1760-2100; apps/interpolate and apps/camera_pipe feed
+// .mat matrices).  Both hold a dense array with dimension 0 innermost; samples of another type than the argument's convert like
+// every other file (convert_sample), extents of 1 are added or dropped to reach the argument's dimensionality.
+struct RawArray {
+    halide_type_t type;
+    std::vector<int> extents;
+    std::vector<uint8_t> bytes;
+};
+const halide_type_t kTmpTypes[10] = {{halide_type_float, 32, 1}, {halide_type_float, 64, 1}, {halide_type_uint, 8, 1}, {halide_type_int, 8, 1},
+                                     {halide_type_uint, 16, 1}, {halide_type_int, 16, 1}, {halide_type_uint, 32, 1}, {halide_type_int, 32, 1},
+                                     {halide_type_uint, 64, 1}, {halide_type_int, 64, 1}};
+// MAT-file data type codes (miINT8 ...) <-> element types; class codes (mxDOUBLE_CLASS ...) for the array flags
+struct MatType { uint32_t mi, mx; halide_type_t t; };
+const MatType kMatTypes[10] = {{1, 8, {halide_type_int, 8, 1}},   {2, 9, {halide_type_uint, 8, 1}},   {3, 10, {halide_type_int, 16, 1}}, {4, 11, {halide_type_uint, 16, 1}},
+                               {5, 12, {halide_type_int, 32, 1}}, {6, 13, {halide_type_uint, 32, 1}}, {7, 7, {halide_type_float, 32, 1}}, {9, 6, {halide_type_float, 64, 1}},
+                               {12, 14, {halide_type_int, 64, 1}}, {13, 15, {halide_type_uint, 64, 1}}};
+bool same_type(halide_type_t a, halide_type_t b) { return a.code == b.code && a.bits == b.bits; }
+
+double raw_value(const RawArray &r, size_t i) {
+    const uint8_t *p = r.bytes.data() + i * (r.type.bits / 8);
+    const halide_type_t t = r.type;
+    if (t.code == halide_type_float && t.bits == 32) { float x; memcpy(&x, p, 4); return x; }
+    if (t.code == halide_type_float && t.bits == 64) { double x; memcpy(&x, p, 8); return x; }
+    if (t.bits == 8) return t.code == halide_type_int ? (double)*(const int8_t *)p : (double)*p;
+    if (t.bits == 16) { uint16_t x; memcpy(&x, p, 2); return t.code == halide_type_int ? (double)(int16_t)x : (double)x; }
+    if (t.bits == 32) { uint32_t x; memcpy(&x, p, 4); return t.code == halide_type_int ? (double)(int32_t)x : (double)x; }
+    uint64_t x; memcpy(&x, p, 8);
+    return t.code == halide_type_int ? (double)(int64_t)x : (double)x;
+}
+
+void assign_raw(const std::string &path, Arg &a, const RawArray &r) {
+    std::vector<int> ext = r.extents;
+    while ((int)ext.size() > a.md->dimensions && ext.back() == 1) ext.pop_back();
+    while ((int)ext.size() < a.md->dimensions) ext.push_back(1);
+    if ((int)ext.size() != a.md->dimensions) fail(path + ": the file has more non-trivial dimensions than the argument (" + std::to_string(a.md->dimensions) + ")");
+    a.dims = dense_shape({}, ext);
+    allocate(a);
+    const size_t n = count(a);
+    if (same_type(r.type, a.md->type)) {
+        memcpy(a.storage.data(), r.bytes.data(), n * elem_bytes(a.md->type));
+        return;
+    }
+    const bool file_float = r.type.code == halide_type_float;
+    const double file_max = file_float ? 1.0 : std::ldexp(1.0, r.type.bits) - 1;
+    for (size_t i = 0; i < n; i++) {
+        double v = raw_value(r, i);
+        if (file_float && a.md->type.code != halide_type_float) {   // [0, 1] -> the integer range, rounded (the reference's rule)
+            v = std::floor(std::min(1.0, std::max(0.0, v)) * (std::ldexp(1.0, a.md->type.bits) - 1) + 0.5);
+            store_value(a, i, v);
+        } else if (file_float) {
+            store_value(a, i, v);
+        } else {
+            store_value(a, i, convert_sample(v, file_max, a.md->type));
+        }
+    }
+}
+
+void read_exact(std::ifstream &f, void *dst, size_t n, const std::string &path) {
+    f.read((char *)dst, (std::streamsize)n);
+    if ((size_t)f.gcount() != n) fail(path + ": file is truncated");
+}
+
+void load_tmp(const std::string &path, Arg &a) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) fail("cannot open " + path);
+    int32_t h[5];
+    read_exact(f, h, sizeof h, path);
+    if (h[0] <= 0 || h[1] <= 0 || h[2] <= 0 || h[3] <= 0 || h[4] < 0 || h[4] >= 10) fail(path + ": bad .tmp header");
+    if ((double)h[0] * h[1] * h[2] * h[3] > 1e10) fail(path + ": .tmp extents are implausible");
+    RawArray r;
+    r.type = kTmpTypes[h[4]];
+    r.extents = {h[0], h[1], h[2], h[3]};
+    r.bytes.resize((size_t)h[0] * h[1] * h[2] * h[3] * (r.type.bits / 8));
+    read_exact(f, r.bytes.data(), r.bytes.size(), path);
+    assign_raw(path, a, r);
+}
+
+void save_tmp(const std::string &path, const Arg &a) {
+    if (a.dims.size() > 4) fail(path + ": .tmp holds at most 4 dimensions");
+    int32_t h[5] = {1, 1, 1, 1, -1};
+    for (size_t d = 0; d < a.dims.size(); d++) h[d] = a.dims[d].extent;
+    for (int i = 0; i < 10; i++) if (same_type(kTmpTypes[i], a.md->type)) h[4] = i;
+    if (h[4] < 0) fail(path + ": element type " + type_name(a.md->type) + " cannot be stored in a .tmp file");
+    std::ofstream f(path, std::ios::binary);
+    f.write((const char *)h, sizeof h);
+    f.write((const char *)a.storage.data(), (std::streamsize)(count(a) * elem_bytes(a.md->type)));
+}
+
+void load_mat(const std::string &path, Arg &a) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) fail("cannot open " + path);
+    uint8_t text[128];
+    uint32_t w[4];
+    read_exact(f, text, sizeof text, path);
+    read_exact(f, w, 8, path);                    // data element: type, byte count
+    if (w[0] != 14) fail(path + ": the first data element is not a numeric array (compressed .mat files are not supported)");
+    read_exact(f, w, 16, path);                   // array flags sub-element
+    if (w[0] != 6 || w[1] != 8) fail(path + ": bad array-flags element");
+    read_exact(f, w, 8, path);                    // dimensions sub-element
+    if (w[0] != 5 || w[1] % 4 != 0 || w[1] / 4 < 1 || w[1] / 4 > 16) fail(path + ": bad dimensions element");
+    const int nd = (int)(w[1] / 4);
+    RawArray r;
+    r.extents.resize(nd);
+    read_exact(f, r.extents.data(), 4 * (size_t)nd, path);
+    if (nd & 1) read_exact(f, w, 4, path);        // sub-elements are padded to 8 bytes
+    double total = 1;
+    for (int e : r.extents) {
+        if (e <= 0) fail(path + ": bad extent");
+        total *= e;
+    }
+    if (total > 1e10) fail(path + ": extents are implausible");
+    read_exact(f, w, 8, path);                    // array name: either packed into these 8 bytes (small element) or a sub-element
+    if ((w[0] >> 16) == 0) {
+        if (w[0] != 1) fail(path + ": bad array-name element");
+        std::vector<uint8_t> name(((size_t)w[1] + 7) / 8 * 8);
+        if (name.size() > (1u << 20)) fail(path + ": bad array-name length");
+        read_exact(f, name.data(), name.size(), path);
+    }
+    read_exact(f, w, 8, path);                    // the real part
+    bool known = false;
+    for (const MatType &m : kMatTypes) if (m.mi == w[0]) r.type = m.t, known = true;
+    if (!known) fail(path + ": unsupported sample type " + std::to_string(w[0]));
+    r.bytes.resize((size_t)total * (r.type.bits / 8));
+    read_exact(f, r.bytes.data(), r.bytes.size(), path);
+    assign_raw(path, a, r);
+}
+
+void save_mat(const std::string &path, const Arg &a) {
+    const MatType *mt = nullptr;
+    for (const MatType &m : kMatTypes) if (same_type(m.t, a.md->type)) mt = &m;
+    if (!mt) fail(path + ": element type " + type_name(a.md->type) + " cannot be stored in a .mat file");
+    // variable name = the file's stem, made a C identifier
+    std::string name = path.substr(0, path.rfind('.'));
+    if (name.rfind('/') != std::string::npos) name = name.substr(name.rfind('/') + 1);
+    if (name.empty() || !isalpha((unsigned char)name[0])) name = "v" + name;
+    for (char &c : name) if (!isalnum((unsigned char)c)) c = '_';
+    const uint32_t name_len = (uint32_t)name.size();
+    while (name.size() & 7) name += '\0';
+    const uint64_t payload = (uint64_t)count(a) * elem_bytes(a.md->type);
+    if (payload >> 32) fail(path + ": too large for a .mat file");
+    const uint32_t pad = (uint32_t)(7 - ((payload - 1) & 7));
+    const int nd_file = std::max(2, (int)a.dims.size()), nd_padded = nd_file + (nd_file & 1);
+    char text[128];
+    memset(text, ' ', sizeof text);
+    const char *banner = "MATLAB 5.0 MAT-file, produced by hlmi_rungen";
+    memcpy(text, banner, strlen(banner));
+    text[124] = 0, text[125] = 1, text[126] = 'I', text[127] = 'M';   // version 0x0100, little endian
+    std::ofstream f(path, std::ios::binary);
+    f.write(text, sizeof text);
+    const uint32_t head[2] = {14, 40u + 4u * (uint32_t)nd_padded + (uint32_t)name.size() + (uint32_t)payload + pad};
+    const uint32_t flags[4] = {6, 8, mt->mx, 1};
+    const uint32_t shape_h[2] = {5, 4u * (uint32_t)a.dims.size()};   // as the reference writes it: the argument's own dimension count
+    std::vector<int32_t> ext;
+    for (auto &d : a.dims) ext.push_back(d.extent);
+    while ((int)ext.size() < nd_file) ext.push_back(1);
+    while ((int)ext.size() < nd_padded) ext.push_back(0);
+    const uint32_t name_h[2] = {1, name_len}, data_h[2] = {mt->mi, (uint32_t)payload};
+    f.write((const char *)head, 8), f.write((const char *)flags, 16), f.write((const char *)shape_h, 8);
+    f.write((const char *)ext.data(), (std::streamsize)(4 * ext.size()));
+    f.write((const char *)name_h, 8), f.write(name.data(), (std::streamsize)name.size()), f.write((const char *)data_h, 8);
+    f.write((const char *)a.storage.data(), (std::streamsize)payload);
+    const uint64_t zero = 0;
+    f.write((const char *)&zero, pad);
 }
 
 // ---- benchmark: protocol of tools/halide_benchmark.h:165-241 (>= 3 samples, iterations per sample grown until a
@@ -352,7 +522,7 @@ void usage() {
         "Usage: hlmi_rungen --name=PIPELINE argument=value [argument=value ...] [flags]\n"
         "   or: PIPELINE.rungen argument=value ... (pipeline = basename of argv[0] up to the first '.')\n\n"
         "Arguments follow the reference's RunGen (tools/RunGenMain.cpp): scalars as literals or `default` / `estimate`;\n"
-        "buffers as a file (.png .pgm .ppm .npy) or a pseudo-file: zero:[e0,e1,..]  constant:V:[..]  identity:[..]\n"
+        "buffers as a file (.png .pgm .ppm .npy .mat .tmp) or a pseudo-file: zero:[e0,e1,..]  constant:V:[..]  identity:[..]\n"
         "random:SEED:[..]; `auto` or `estimate` may stand for the extents.\n\n"
         "Flags: --help --describe --output_extents=[..]|estimate --benchmarks=all --benchmark_min_time=SEC\n"
         "       --parsable_output --estimate_all --default_input_buffers[=V] --default_input_scalars[=V]\n"
@@ -509,8 +679,14 @@ int main(int argc, char **argv) {
         } else if (ends_with(spec, ".npy")) {
             load_npy(spec, a);
             a.spec.clear();
+        } else if (ends_with(spec, ".mat")) {
+            load_mat(spec, a);
+            a.spec.clear();
+        } else if (ends_with(spec, ".tmp")) {
+            load_tmp(spec, a);
+            a.spec.clear();
         } else {
-            fail("cannot read '" + spec + "': supported are .png .pgm .ppm .npy and the pseudo-files of --help");
+            fail("cannot read '" + spec + "': supported are .png .pgm .ppm .npy .mat .tmp and the pseudo-files of --help");
         }
     }
     // ---- outputs: shape from --output_extents, the estimates, or a bounds query constrained by the inputs
@@ -609,7 +785,9 @@ int main(int argc, char **argv) {
         if (ends_with(a.out_path, ".npy")) save_npy(a.out_path, a);
         else if (ends_with(a.out_path, ".png")) save_png(a.out_path, a);
         else if (ends_with(a.out_path, ".pgm") || ends_with(a.out_path, ".ppm")) save_pnm(a.out_path, a);
-        else fail("cannot write '" + a.out_path + "': supported are .png .pgm .ppm .npy");
+        else if (ends_with(a.out_path, ".mat")) save_mat(a.out_path, a);
+        else if (ends_with(a.out_path, ".tmp")) save_tmp(a.out_path, a);
+        else fail("cannot write '" + a.out_path + "': supported are .png .pgm .ppm .npy .mat .tmp");
     }
     for (auto &a : args)
         if (a.md->kind != halide_argument_kind_input_scalar && a.buf.device_interface) a.buf.device_interface->device_free(nullptr, &a.buf);

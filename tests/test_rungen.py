@@ -52,10 +52,14 @@ def test_estimate_all_benchmark_parsable_output():
 def test_npy_round_trip_matches_the_direct_call(hl, oracle, tmp_path):
     rng = np.random.default_rng(3)
     inp = rng.integers(0, 65536, (3, 120, 200), dtype=np.uint16)
-    np.save(tmp_path / "in.npy", inp)
+    # the reference's .npy convention (tools/halide_image_io.h:1414-1470): the shape tuple lists the HALIDE extents, x first, over
+    # a payload with x innermost — the bytes of the (c, y, x) array under the header (W, H, C)
+    np.save(tmp_path / "in.npy", inp.reshape(200, 120, 3))
     _run("--name=local_laplacian", f"input={tmp_path / 'in.npy'}", "levels=8", "alpha=0.14285714285714285", "beta=1",
          f"output={tmp_path / 'out.npy'}", "--output_extents=[200,120,3]")
     got = np.load(tmp_path / "out.npy")
+    assert got.shape == (200, 120, 3)
+    got = got.reshape(3, 120, 200)
     want = oracle.local_laplacian(inp, 8, np.float32(0.14285714285714285), 1.0)
     assert got.shape == want.shape and np.array_equal(got, want)
 
@@ -127,3 +131,66 @@ def test_png_in_png_out_matches_the_oracle(oracle, tmp_path):
          f"output={tmp_path / 'out8.png'}", "--output_extents=[160,90,3]")
     want8 = oracle.local_laplacian(inp8.astype(np.uint16) * 257, 8, np.float32(0.14285714285714285), 1.0)
     assert np.array_equal(read_png(str(tmp_path / "out8.png")), want8)
+
+
+def _write_mat_like_the_reference(path, arr, name="m"):
+    """A level-5 .mat file laid out the way tools/halide_image_io.h:1916-2100 writes one: 128-byte text header, one miMATRIX
+    element = array flags, dimensions (dimension 0 first), name, real part; `arr` is given in numpy order (slowest first)."""
+    import struct
+    mi, mx = {np.dtype("float32"): (7, 7), np.dtype("uint16"): (4, 11), np.dtype("uint8"): (2, 9), np.dtype("float64"): (9, 6)}[arr.dtype]
+    ext = list(arr.shape[::-1])
+    nd = max(2, len(ext))
+    ext_file = ext + [1] * (nd - len(ext))
+    ext_file += [0] * (len(ext_file) & 1)
+    nm = name.encode() + b"\0" * (-len(name) % 8)
+    payload = arr.tobytes()
+    pad = 7 - ((len(payload) - 1) & 7)
+    text = b"MATLAB 5.0 MAT-file, produced by a test".ljust(124) + struct.pack("<H", 0x0100) + b"IM"
+    body = struct.pack("<4I", 6, 8, mx, 1) + struct.pack("<2I", 5, 4 * len(ext)) + struct.pack(f"<{len(ext_file)}i", *ext_file)
+    body += struct.pack("<2I", 1, len(name)) + nm + struct.pack("<2I", mi, len(payload)) + payload + b"\0" * pad
+    with open(path, "wb") as f:
+        f.write(text + struct.pack("<2I", 14, len(body)) + body)
+
+
+@pytest.mark.gpu
+def test_mat_and_tmp_files_round_trip(hl, oracle, tmp_path):
+    """The reference's two other raw array formats (tools/halide_image_io.h:1632-1722 .tmp, :1760-2100 .mat): a .mat written in the
+    reference's layout comes in, results go out as .mat and .tmp, come back in as inputs, and every path equals the direct call."""
+    import struct
+    rng = np.random.default_rng(5)
+    inp = rng.integers(0, 65536, (3, 96, 160), dtype=np.uint16)
+    want = oracle.local_laplacian(inp, 8, np.float32(0.14285714285714285), 1.0)
+    _write_mat_like_the_reference(tmp_path / "in.mat", inp)
+    args = ["--name=local_laplacian", "levels=8", "alpha=0.14285714285714285", "beta=1", "--output_extents=[160,96,3]"]
+    _run(*args, f"input={tmp_path / 'in.mat'}", f"output={tmp_path / 'out.tmp'}")
+    raw = open(tmp_path / "out.tmp", "rb").read()
+    assert struct.unpack("<5i", raw[:20]) == (160, 96, 3, 1, 4)            # extents padded to four, type code 4 = uint16
+    got = np.frombuffer(raw[20:], np.uint16).reshape(3, 96, 160)
+    assert np.array_equal(got, want)
+    # the .tmp just written as the input, .mat as the output
+    with open(tmp_path / "in.tmp", "wb") as f:
+        f.write(struct.pack("<5i", 160, 96, 3, 1, 4) + inp.tobytes())
+    _run(*args, f"input={tmp_path / 'in.tmp'}", f"output={tmp_path / 'out.mat'}")
+    raw = open(tmp_path / "out.mat", "rb").read()
+    assert raw[:10] == b"MATLAB 5.0" and raw[126:128] == b"IM"
+    assert struct.unpack("<2I", raw[128:136])[0] == 14 and struct.unpack("<4I", raw[136:152]) == (6, 8, 11, 1)
+    assert struct.unpack("<2I", raw[152:160]) == (5, 12) and struct.unpack("<4i", raw[160:176]) == (160, 96, 3, 0)
+    assert struct.unpack("<2I", raw[176:184]) == (1, 3) and raw[184:187] == b"out"
+    assert struct.unpack("<2I", raw[192:200]) == (4, inp.nbytes)
+    assert np.array_equal(np.frombuffer(raw[200:200 + inp.nbytes], np.uint16).reshape(3, 96, 160), want)
+    # samples of another type convert like every other image file: a float .mat in [0, 1] feeds the u16 input
+    _write_mat_like_the_reference(tmp_path / "inf.mat", (inp.astype(np.float64) / 65535.0).astype(np.float32))
+    _run(*args, f"input={tmp_path / 'inf.mat'}", f"output={tmp_path / 'outf.npy'}")
+    back = np.floor(np.clip((inp.astype(np.float64) / 65535.0).astype(np.float32).astype(np.float64), 0, 1) * 65535.0 + 0.5).astype(np.uint16)
+    assert np.array_equal(np.load(tmp_path / "outf.npy").reshape(3, 96, 160), oracle.local_laplacian(back, 8, np.float32(0.14285714285714285), 1.0))
+
+
+def test_damaged_mat_and_tmp_files_are_rejected(tmp_path):
+    import struct
+    (tmp_path / "short.tmp").write_bytes(struct.pack("<5i", 16, 16, 3, 1, 4) + b"\0" * 100)
+    (tmp_path / "code.tmp").write_bytes(struct.pack("<5i", 4, 4, 1, 1, 12) + b"\0" * 64)
+    (tmp_path / "huge.tmp").write_bytes(struct.pack("<5i", 1 << 30, 1 << 30, 4, 4, 2))
+    (tmp_path / "junk.mat").write_bytes(b"MATLAB 5.0".ljust(128) + struct.pack("<2I", 15, 64) + b"\0" * 64)   # a compressed element
+    for name in ("short.tmp", "code.tmp", "huge.tmp", "junk.mat"):
+        p = _run("--name=stencil_chain", f"input={tmp_path / name}", "output=/dev/null", check=False)
+        assert p.returncode != 0, name
