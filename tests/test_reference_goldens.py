@@ -1,0 +1,101 @@
+"""Oracle vs. a REAL Halide build, for whoever has one (SURVEY.md §8 row c; scripts/pin_against_halide.md).
+
+tests/golden/halide/<case>.npy are outputs of the reference's own `<app>.rungen` on the seeded inputs of
+scripts/pin_against_halide.py.  This container cannot produce them (Halide needs LLVM), so on a fresh checkout every case is an
+expected failure WITH the reason — not a silent skip: the float pipelines' parity stays "unpinned" until the files exist.  When
+they do, the oracle must reproduce them: bit for bit where the pipeline is integer in / integer out (north_star), within 1 ulp
+for float32 outputs; the difference histogram is printed either way, and for local_laplacian against every canonicalisation
+variant the oracle carries (tests/test_oracle_variants.py) so that a mismatch names the contraction Halide's LLVM applied."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import pin_against_halide as pin  # noqa: E402
+
+CASES = pin.cases()
+
+
+def _ulp_diff(a, b):
+    """distance in float32 representable values"""
+    ia, ib = a.view(np.int32).astype(np.int64), b.view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7FFFFFFF), ia)
+    ib = np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+    return np.abs(ia - ib)
+
+
+def _histogram(d):
+    edges = [0, 1, 2, 3, 5, 9, 17, 65, 1025, 1 << 62]
+    h, _ = np.histogram(d, bins=edges)
+    return ", ".join(f"{lo}{'' if hi == lo + 1 else '..' + str(hi - 1) if hi < (1 << 61) else '+'}: {n}" for lo, hi, n in zip(edges[:-1], edges[1:], h) if n)
+
+
+def test_manifest_is_current():
+    """The committed manifest is what the script generates (so the commands a maintainer runs are the ones tested here)."""
+    with open(os.path.join(pin.GOLD, "manifest.json")) as f:
+        have = json.load(f)
+    assert sorted(have) == sorted(CASES)
+    for name, c in CASES.items():
+        assert have[name]["rungen"] == c["rungen"] + ".rungen"
+        assert have[name]["output_numpy_shape"] == list(c["output"][1])
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_reproduces_halide(oracle, name):
+    c = CASES[name]
+    path = os.path.join(pin.GOLD, f"{name}.npy")
+    if not os.path.exists(path):
+        pytest.xfail(f"{os.path.relpath(path, ROOT)} is absent: no Halide build in this environment (LLVM); run scripts/pin_against_halide.sh "
+                     "where one exists — parity of this pipeline is pinned by the oracle's restatement only")
+    _, shape, dtype = c["output"]
+    want = pin.load_halide_npy(path, shape)
+    assert want.dtype == np.dtype(dtype)
+    got = np.asarray(c["oracle"](oracle))
+    assert got.shape == want.shape
+    if np.dtype(dtype).kind == "f":
+        d = _ulp_diff(np.ascontiguousarray(got, np.float32), np.ascontiguousarray(want, np.float32))
+        unit, bound = "ulp", (0 if c["exact"] else 1)
+    else:
+        d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+        unit, bound = "LSB", 0
+    print(f"\n{name}: |oracle - Halide| in {unit}: {_histogram(d)}  ({np.count_nonzero(d)} of {d.size} differ, max {int(d.max())})")
+    if name.startswith("local_laplacian") and d.max() > 0:
+        inp = c["args"][0][1]
+        for label, v in (("SOURCE", oracle.LL_VAR_SOURCE), ("FMA", oracle.LL_VAR_FMA), ("SOURCE|FMA", oracle.LL_VAR_SOURCE | oracle.LL_VAR_FMA),
+                         ("DIV", oracle.LL_VAR_DIV), ("DIV|FMA", oracle.LL_VAR_DIV | oracle.LL_VAR_FMA)):
+            dv = np.abs(oracle.local_laplacian(inp, 8, np.float32(1.0 / 7.0), 1.0, variant=v).astype(np.int64) - want.astype(np.int64))
+            print(f"  variant {label}: {_histogram(dv)}  ({np.count_nonzero(dv)} differ)")
+    assert d.max() <= bound, f"{name}: oracle and Halide differ by up to {int(d.max())} {unit} (allowed {bound}); histogram above"
+
+
+@pytest.mark.gpu
+def test_the_recipe_runs_end_to_end_with_the_library_runner(oracle, tmp_path):
+    """The command lines of the recipe, executed — with this repository's RunGen-compatible runner standing in for Halide's
+    (`<app>.rungen` -> hlmi_rungen, which picks the pipeline from argv[0] like the reference's per-generator binaries): every
+    argument name, scalar spelling, file layout and output extent of the manifest is what a RunGen accepts, and the outputs (the
+    GPU library's, NOT Halide's: they are written to a scratch directory and never pinned) equal the oracle."""
+    import subprocess
+    rungen = os.path.join(ROOT, "halide_amd", "bin", "hlmi_rungen")
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    for c in CASES.values():
+        link = bindir / (c["rungen"] + ".rungen")
+        if not link.exists():
+            os.symlink(rungen, link)
+    env = dict(os.environ, HLMI_PIN_DIR=str(tmp_path / "gold"), HALIDE_RUNGEN_DIR=str(bindir))
+    p = subprocess.run(["bash", os.path.join(ROOT, "scripts", "pin_against_halide.sh")], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    for name, c in CASES.items():
+        _, shape, dtype = c["output"]
+        got = pin.load_halide_npy(str(tmp_path / "gold" / f"{name}.npy"), shape)
+        want = np.asarray(c["oracle"](oracle))
+        if c["rungen"] == "conv_layer":   # the library's f32 conv is bit-exact against the fma-chain oracle
+            assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(want, np.float32).view(np.uint32)), name
+        elif np.dtype(dtype).kind == "f":
+            assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(want, np.float32).view(np.uint32)), name
+        else:
+            assert np.array_equal(got, want), name
