@@ -74,7 +74,7 @@ def cases():
                              r(11).uniform(-1, 1, (8, 5)).astype(np.float32), r(12).uniform(-1, 1, 5).astype(np.float32))
     c["depthwise_separable_conv_2x6x7"] = dict(rungen="depthwise_separable_conv",
                                                args=[("input", d_in), ("depthwise_filter", d_dw), ("pointwise_filter", d_pw), ("bias", d_b)],
-                                               output=("output", (2, 4, 5, 5), np.float32), oracle=lambda o: o.depthwise_separable_conv(d_in, d_dw, d_pw, d_b), exact=False)
+                                               output=("output", (2, 6, 7, 5), np.float32), oracle=lambda o: o.depthwise_separable_conv(d_in, d_dw, d_pw, d_b), exact=False)
     u_in = f32(13, (3, 40, 50)) * np.float32(0.9) + np.float32(0.05)
     c["unsharp_50x40"] = dict(rungen="unsharp", args=[("input", u_in)], output=("output", (3, 40, 50), np.float32), oracle=lambda o: o.unsharp(u_in), exact=False)
     mf_in = f32(17, (3, 64, 70))

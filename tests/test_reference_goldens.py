@@ -93,6 +93,7 @@ def test_the_recipe_runs_end_to_end_with_the_library_runner(oracle, tmp_path):
         _, shape, dtype = c["output"]
         got = pin.load_halide_npy(str(tmp_path / "gold" / f"{name}.npy"), shape)
         want = np.asarray(c["oracle"](oracle))
+        assert got.shape == want.shape, name
         if c["rungen"] == "conv_layer":   # the library's f32 conv is bit-exact against the fma-chain oracle
             assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(want, np.float32).view(np.uint32)), name
         elif np.dtype(dtype).kind == "f":
