@@ -956,18 +956,21 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         const float2 r = hpair<ODD0>(d4);
         return f2{r.x, r.y};
     };
-    // ---- outLPyramid[0] of one level-0 row (the lane's quad): rq / rt = the lane's float2 of plane 0 in the level-1 row whose
+    // ---- outLPyramid[0] of the lane's quad in one level-0 row: rq / rt = the lane's float2 of plane 0 in the level-1 row whose
     // vertical weight is 1/4 / 3/4 (plane stride 128 float2 = 4 x 64 dwords in both the window slots and the published rows).
     // The arithmetic is ll_up0f's stage 2 (hl0 / hl1 / vl: lerps with the exact quarter product folded into an fma, :276-282
     // with the parities known).  Per pixel the pair is (plane li, plane li + 1): one ds_read2st64_b32 fetches both planes of a
     // coarse value (or both table entries), and every pass up to the final blend runs on the two planes at once.  The gathers
-    // are issued by hand (the compiler pairs adjacent dwords instead, and then shuffles them into plane pairs with v_mov's):
-    // all 20 of a row first, one s_waitcnt that every result is routed through, then the arithmetic.
-    auto emit_row = [&](const Row &n, const f2 *rq, const f2 *rt, float (&r)[4]) {
+    // are issued by hand (the compiler pairs adjacent dwords instead and then shuffles them into plane pairs with v_mov's), five
+    // per pixel; the LDS returns them in order, so a pixel's five are complete when at most 5 x (pixels requested after it) are
+    // outstanding — em_wait routes the five results through that s_waitcnt.
+    struct EmPix {
+        f2 lut, qa, qb, ta, tb;
+        float lif;
+    };
+    auto em_gather = [&](const Row &n, int i, const f2 *rq, const f2 *rt, EmPix &g) {
         constexpr int COL[4] = {ODD0 ? -1 : -2, -1, ODD0 ? 0 : -1, 0};   // first float of the coarse column pair, relative to the lane's own .x
         const uint32_t aq0 = (uint32_t)(size_t)rq, at0 = (uint32_t)(size_t)rt, alut = (uint32_t)(size_t)slut + 1024u * (KCH - 2);
-        f2 lut[4], qa[4], qb[4], ta[4], tb[4];
-        float lif[4];
         auto rd2 = [](uint32_t addr, auto swap_tag) {   // (dword at addr, dword at addr + 1024 bytes), or swapped
             f2 v;
 #if HLMI_D01E_ABL & 8
@@ -980,35 +983,51 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         };
         constexpr std::false_type asc{};
         constexpr std::true_type desc{};
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int pos = n.l[i] - lbase * 4;                        // 4 x table index of the pixel
-            const int li = min(pos >> 10, KCH - 2);                    // (int)(gray * (K-1)), clamped (:66); gray >= 0
-            const uint32_t po = (uint32_t)(li << 10) + (uint32_t)(COL[i] * 4);
-            lut[i] = rd2(alut + (uint32_t)n.l[i] - (uint32_t)(li << 10), desc);   // plane li + 1's entry is the lower address
-            qa[i] = rd2(aq0 + po, asc), qb[i] = rd2(aq0 + po + 4u, asc);
-            ta[i] = rd2(at0 + po, asc), tb[i] = rd2(at0 + po + 4u, asc);
-            lif[i] = (float)li;
-        }
+        const int pos = n.l[i] - lbase * 4;                        // 4 x table index of the pixel
+        const int li = min(pos >> 10, KCH - 2);                    // (int)(gray * (K-1)), clamped (:66); gray >= 0
+        const uint32_t po = (uint32_t)(li << 10) + (uint32_t)(COL[i] * 4);
+        g.lut = rd2(alut + (uint32_t)n.l[i] - (uint32_t)(li << 10), desc);   // plane li + 1's entry is the lower address
+        g.qa = rd2(aq0 + po, asc), g.qb = rd2(aq0 + po + 4u, asc);
+        g.ta = rd2(at0 + po, asc), g.tb = rd2(at0 + po + 4u, asc);
+        g.lif = (float)li;
+    };
+    auto em_wait = [&](EmPix &g, auto after_tag) {   // `after` = gathers of how many pixels were requested after this one's
 #if !(HLMI_D01E_ABL & 8)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lut[0]), "+v"(qa[0]), "+v"(qb[0]), "+v"(ta[0]), "+v"(tb[0]), "+v"(lut[1]), "+v"(qa[1]), "+v"(qb[1]), "+v"(ta[1]), "+v"(tb[1]));
-        asm volatile("" : "+v"(lut[2]), "+v"(qa[2]), "+v"(qb[2]), "+v"(ta[2]), "+v"(tb[2]), "+v"(lut[3]), "+v"(qa[3]), "+v"(qb[3]), "+v"(ta[3]), "+v"(tb[3]));
+        constexpr int AFTER = decltype(after_tag)::value;
+        static_assert(AFTER >= 0 && AFTER <= 3, "");
+        if (AFTER == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(g.lut), "+v"(g.qa), "+v"(g.qb), "+v"(g.ta), "+v"(g.tb));
+        if (AFTER == 1) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(g.lut), "+v"(g.qa), "+v"(g.qb), "+v"(g.ta), "+v"(g.tb));
+        if (AFTER == 2) asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(g.lut), "+v"(g.qa), "+v"(g.qb), "+v"(g.ta), "+v"(g.tb));
+        if (AFTER == 3) asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(g.lut), "+v"(g.qa), "+v"(g.qb), "+v"(g.ta), "+v"(g.tb));
 #endif
+    };
+    auto em_arith = [&](const Row &n, int i, const EmPix &g) {
+        const bool xodd = ODD0 ? (i & 1) == 0 : (i & 1) == 1;
+        // even x: lerp(f[c], f[c-1], 1/4) = f[c-1]/4 + 3 f[c]/4; odd x: lerp(f[c+1], f[c], 3/4) = f[c+1]/4 + 3 f[c]/4
+        auto hl = [&](f2 fa, f2 fb) { return xodd ? fma2(fb, f2s(0.25f), fa * 0.75f) : fma2(fa, f2s(0.25f), fb * 0.75f); };
+        auto vl = [](f2 uq, f2 ut) { return fma2(uq, f2s(0.25f), ut * 0.75f); };
+        const float gr = n.g[i & 1][i >> 1];
+        const float lf = gr * gm.Km1 - g.lif;
+        const f2 lev = f2{g.lif, g.lif + 1.0f} * gm.inv_Km1;
+        const f2 u = vl(hl(g.qa, g.qb), hl(g.ta, g.tb));
+        const f2 g2 = f2s(gr);
+        const f2 l = (B1 ? ((g2 - lev) + lev) + g.lut : (p.beta * (g2 - lev) + lev) + g.lut) - u;   // g0_val of planes li, li + 1
+        const f2 m = f2{1.0f - lf, lf} * l;
+        return m.x + m.y;
+    };
+    constexpr std::integral_constant<int, 0> after0{};
+    constexpr std::integral_constant<int, 1> after1{};
+    constexpr std::integral_constant<int, 2> after2{};
+    constexpr std::integral_constant<int, 3> after3{};
+    // one row on its own (the seam pair after the walk): all four pixels requested, then finished in order
+    auto emit_row = [&](const Row &n, const f2 *rq, const f2 *rt, float (&r)[4]) {
+        EmPix g[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const bool xodd = ODD0 ? (i & 1) == 0 : (i & 1) == 1;
-            // even x: lerp(f[c], f[c-1], 1/4) = f[c-1]/4 + 3 f[c]/4; odd x: lerp(f[c+1], f[c], 3/4) = f[c+1]/4 + 3 f[c]/4
-            auto hl = [&](f2 fa, f2 fb) { return xodd ? fma2(fb, f2s(0.25f), fa * 0.75f) : fma2(fa, f2s(0.25f), fb * 0.75f); };
-            auto vl = [](f2 uq, f2 ut) { return fma2(uq, f2s(0.25f), ut * 0.75f); };
-            const float g = n.g[i & 1][i >> 1];
-            const float lf = g * gm.Km1 - lif[i];
-            const f2 lev = f2{lif[i], lif[i] + 1.0f} * gm.inv_Km1;
-            const f2 u = vl(hl(qa[i], qb[i]), hl(ta[i], tb[i]));
-            const f2 g2 = f2s(g);
-            const f2 l = (B1 ? ((g2 - lev) + lev) + lut[i] : (p.beta * (g2 - lev) + lev) + lut[i]) - u;   // g0_val of planes li, li + 1
-            const f2 m = f2{1.0f - lf, lf} * l;
-            r[i] = m.x + m.y;
-        }
+        for (int i = 0; i < 4; i++) em_gather(n, i, rq, rt, g[i]);
+        em_wait(g[0], after3), r[0] = em_arith(n, 0, g[0]);
+        em_wait(g[1], after2), r[1] = em_arith(n, 1, g[1]);
+        em_wait(g[2], after1), r[2] = em_arith(n, 2, g[2]);
+        em_wait(g[3], after0), r[3] = em_arith(n, 3, g[3]);
     };
     auto emit_store = [&](int y, const float (&r)[4]) {
         if (em_ok && y >= pe.oy0 && y < pe.oy0 + pe.oh && !(HLMI_D01E_ABL & 2 && p.nunits > 0)) {
@@ -1090,6 +1109,22 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        // Level-1 rows T - 1 and T of the planes 0 .. KCH-1 are in the two slots now (inGPyramid's plane follows below); other
+        // lanes' entries are read from here on: the wave runs its LDS instructions in order, the compiler must not move reads above
+        // the writes.  The emission's first gathers (level-0 row 2T - 1) are requested NOW — their round trip to the LDS passes under
+        // the last plane, the published copy and the level-1 selection instead of stalling the wave (two waves per SIMD hide nothing).
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        f2 *const rowT = st2 + (PH == 0 ? 0 : 64), *const rowP = st2 + (PH == 0 ? 64 : 0);   // rows T and T - 1
+        const bool st1_row = T >= Ts0 && T <= Ts1;                                                  // wave-uniform
+        const bool em_rows = T >= 2 * A && T <= 2 * B + 1 && !(HLMI_D01E_ABL & 1 && p.nunits > 0);   // wave-uniform
+        EmPix eg[4];
+        if (em_rows) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) em_gather(n0, i, rowT, rowP, eg[i]);   // odd row 2T - 1: coarse row T weighs 1/4
+        }
+        __builtin_amdgcn_sched_barrier(0);
         state_issue(KCH);
         res[KCH] = hpair2(dy[KCH & 1]);
         level2(KCH);
@@ -1097,18 +1132,12 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
 #pragma unroll
             for (int kk = 0; kk <= KCH; kk++) pub[(2 * kk) * 64] = res[kk];
         }
-        // level-1 rows T - 1 and T of every plane are in the two slots now; other lanes' entries are read below: the wave runs
-        // its LDS instructions in order, the compiler must not move the reads above the writes
         asm volatile("" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_sched_barrier(0);
         LL_PROBE_T(ps1);
-        f2 *const rowT = st2 + (PH == 0 ? 0 : 64), *const rowP = st2 + (PH == 0 ? 64 : 0);   // rows T and T - 1
         // Everything that is stored is computed first and stored AFTER prep_row: prep_row waits for the input rows requested at
         // the end of the previous step, and vmcnt counts in order — with this step's (conditional) stores issued before it, the
         // only wait that covers the loads is vmcnt(0), i.e. a round trip of the stores to memory in every step.
-        const bool st1_row = T >= Ts0 && T <= Ts1;                                                  // wave-uniform
-        const bool em_rows = T >= 2 * A && T <= 2 * B + 1 && !(HLMI_D01E_ABL & 1 && p.nunits > 0);   // wave-uniform
         float2 s0 = make_float2(0.0f, 0.0f), s1 = s0;
         const f2 sK = res[KCH];
         if (st1_row) {
@@ -1119,9 +1148,29 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         }
         float eo[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ee[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (em_rows) {
-            emit_row(n0, rowT, rowP, eo);   // odd row 2T - 1: coarse row T weighs 1/4
+            // row 2T - 1's pixels are finished one by one while row 2T's are requested into the registers they free: twenty
+            // gathers stay in flight from the first request to the last pixel
+            EmPix fg[4];
+            em_wait(eg[0], after3), eo[0] = em_arith(n0, 0, eg[0]);
             __builtin_amdgcn_sched_barrier(0);
-            emit_row(n1, rowP, rowT, ee);   // even row 2T
+            em_gather(n1, 0, rowP, rowT, fg[0]);   // even row 2T
+            __builtin_amdgcn_sched_barrier(0);
+            em_wait(eg[1], after3), eo[1] = em_arith(n0, 1, eg[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            em_gather(n1, 1, rowP, rowT, fg[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            em_wait(eg[2], after3), eo[2] = em_arith(n0, 2, eg[2]);
+            __builtin_amdgcn_sched_barrier(0);
+            em_gather(n1, 2, rowP, rowT, fg[2]);
+            __builtin_amdgcn_sched_barrier(0);
+            em_wait(eg[3], after3), eo[3] = em_arith(n0, 3, eg[3]);
+            __builtin_amdgcn_sched_barrier(0);
+            em_gather(n1, 3, rowP, rowT, fg[3]);
+            __builtin_amdgcn_sched_barrier(0);
+            em_wait(fg[0], after3), ee[0] = em_arith(n1, 0, fg[0]);
+            em_wait(fg[1], after2), ee[1] = em_arith(n1, 1, fg[1]);
+            em_wait(fg[2], after1), ee[2] = em_arith(n1, 2, fg[2]);
+            em_wait(fg[3], after0), ee[3] = em_arith(n1, 3, fg[3]);
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -2275,7 +2324,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             a.nsy_magic = a.nsy == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)a.nsy + 1ull);   // 0: nsy == 1
             a.rows_base = e.h / a.nsy, a.rows_rem = e.h % a.nsy;
             dim3 grid2((a.nunits + WPB - 1) / WPB);
-            const size_t sh2 = sizeof(float) * ((nlut + 1) & ~1) + sizeof(float2) * D01_STATE * (WPB + (exch ? WPB - 1 : 0));
+            const size_t sh2 = sizeof(float) * ((nlut + 1) & ~1) + sizeof(float2) * D01_STATE * (WPB + (exch ? WPB - 1 : 0)) + (size_t)env_int("HLMI_LL_LDS_PAD", 0);   // pad: occupancy experiment
             if (emit) {
                 // input read once; outLPyramid[0] (4 B per output pixel), three level-1 planes and K + 1 level-2 planes written
                 timing_note_bytes(6.0 * iw * (gm.iy1 - gm.iy0 + 1) + 4.0 * iw * oh + 4.0 * 3.0 * d.w * d.h + 4.0 * (levels + 1) * e.w * e.h);
