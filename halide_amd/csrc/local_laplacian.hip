@@ -1037,6 +1037,7 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
 #if HLMI_LL_PROBE
     unsigned long long pr_planes = 0, pr_emit = 0, pr_prep = 0, pr_steps = 0;
     LL_PROBE_T(pe0);
+    const unsigned long long pc0 = __builtin_readcyclecounter();
 #endif
     f2 a[KCH + 1][2], b[KCH + 1][2], a2[KCH + 1][2], b2[KCH + 1][2];
     f2 pcr[KCH + 1];           // a + 3 (b + c) of the level-2 window between its third and fourth row
@@ -1244,6 +1245,8 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
     }
 #if HLMI_LL_PROBE
     LL_PROBE_T(pe2);
+    LL_PROBE_ADD(27, __builtin_readcyclecounter() - pc0);   // s_memtime: shader-clock cycles of the wave's life (pe2 - pe0: 100 MHz ticks)
+    LL_PROBE_ADD(28, pe2 - pe0);
     LL_PROBE_ADD(20, pr_planes); LL_PROBE_ADD(21, pr_emit); LL_PROBE_ADD(22, pr_prep); LL_PROBE_ADD(23, pr_steps);
     LL_PROBE_ADD(24, 1); LL_PROBE_ADD(25, pe1 - pe0); LL_PROBE_ADD(26, pe2 - pe1);
 #endif
@@ -2200,8 +2203,11 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         return (v >= J - 4 && v <= J - 2) ? v : J;
     }();
     // the collapse (outGPyramid[J-1] .. outGPyramid[SU]) is ONE launch (ll_up_multi); opt-in: on the large levels its per-pixel overhead exceeds the saved launches
+    // Default 3 when the down pass fuses from 4: outGPyramid[3] joins the collapse launch (one ll_up launch and its ~4.5 us of
+    // dependent-launch latency less: 110.8 -> 108.9 us per frame on one stream); from level 2 the kernel's per-pixel overhead
+    // costs more than the launch it saves (114.2).  0: SU = S.
     const int SU = [&] {
-        int v = env_int("HLMI_LL_UPCHAIN_FROM", 0);
+        int v = env_int("HLMI_LL_UPCHAIN_FROM", S == 4 ? 3 : 0);
         return (v >= 1 && v <= J - 2) ? v : S;
     }();
     // ---- level 0 arguments first: whether the level-1 collapse is fused into ll_up0f decides if ll_up:1 is launched

@@ -36,3 +36,5 @@ if v[24]:
     print(f"down01e: waves {w / N:.0f}; per wave [ns]: steps {v[23] / w:.1f}; plane loop {v[20] / w * tick:.0f}, sel + emission {v[21] / w * tick:.0f}, "
           f"prep + loads {v[22] / w * tick:.0f}; prologue + walk {v[25] / w * tick:.0f}, tail {v[26] / w * tick:.0f}")
     print(f"  per step [ns]: planes {v[20] / v[23] * tick:.0f}, sel + emission {v[21] / v[23] * tick:.0f}, prep + loads {v[22] / v[23] * tick:.0f}")
+    if v[28]:
+        print(f"  shader clock during the walk: {v[27] / v[28] / 10.0:.0f} MHz (s_memtime cycles per 10 ns s_memrealtime tick), {v[27] / w:.0f} cycles per wave")
