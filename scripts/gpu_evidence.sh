@@ -1,6 +1,7 @@
 #!/bin/bash
-# Round-3 evidence: gpu_full (tests, smoke, bench lines, kernel stats, PMC traffic) + apps profile + ceiling sweep + width calibration
-TAG=${1:-r03a}
+# Round evidence: gpu_full (tests, smoke, bench lines, kernel stats, PMC traffic) + apps profile + ceiling sweep; `python scripts/make_profiles.py <tag> <round>`
+# turns the directory into the tracked summaries under profiles/ (and stamps profiles/traffic.json with the kernel source's hash)
+TAG=${1:-r04a}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 bash scripts/gpu_full.sh $TAG
@@ -20,10 +21,6 @@ for nb in (1 << 30, 1 << 28):
     json.dump(sw, open(os.path.join(out, f"membench_sweep_{nb >> 20}MB.json"), "w"))
     print(nb >> 20, "MB best:", sw["best"], "memcpy_d2d", sw["memcpy_d2d_gbs"])
 print("naive:", hl.membench_naive(1 << 30, 10))
-print("widths:", hl.membench_widths(1 << 30, 4))
 PY
-W="python -c \"import halide_amd as hl; print(hl.membench_widths(1<<30, 2))\""
-PMC_CMD="$W" bash scripts/gpu_pmc_cmd.sh $TAG/pmc_w "FETCH_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum" 2>&1 | grep -E "mb_width" | tee $OUT/pmc_widths.txt
-PMC_CMD="python scripts/ll_once.py 3" bash scripts/gpu_pmc_cmd.sh $TAG/pmc_ll "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum" 2>&1 | grep -E "ll_" | tee $OUT/pmc_ll_tcc.txt
 find $OUT -name "*.csv" -size +3M -delete
 ls $OUT | head -60

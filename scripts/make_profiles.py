@@ -79,8 +79,9 @@ if rows:
     first_strip = 2 if any(r[0].startswith("ll_down01") for r in rows) else 1
     for i, r in enumerate(strips):
         per[f"ll_down_strip:{i + first_strip}"] = r[5]
-    ups = sorted([r for r in rows if r[0] == "ll_up"], key=lambda r: -r[5])
-    first_up = 2 if len(ups) == 2 else 1
+    ups = sorted([r for r in rows if r[0] == "ll_up" or r[0].startswith("ll_up<")], key=lambda r: -r[5])
+    # the level-1 collapse is part of ll_up0f / ll_up0h (no ll_up:1 launch) whenever one of those ran
+    first_up = 2 if any(r[0].startswith("ll_up0f") or r[0].startswith("ll_up0h") for r in rows) else 1
     for i, r in enumerate(ups):
         per[f"ll_up:{i + first_up}"] = r[5]
     for r in rows:
