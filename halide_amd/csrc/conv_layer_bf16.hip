@@ -762,9 +762,9 @@ extern "C" int conv_layer_bf16(halide_buffer_t *input, halide_buffer_t *filter, 
         const long NQ = (long)g.N * (g.H + 2) * (g.W + 2);
         const bool lin = AR <= 32 * 12 && NQ < (1L << 31) && NQ * g.CI < (1L << 31) && !getenv("HLMI_CONV_IM2COL");   // W <= 125
         // conv3x3_bf16_p: 256-position tiles, B through LDS (see the kernel); the older kernels stay for what it does not take
-        const char *half_e = getenv("HLMI_CONVP_HALF");   // A/B: 128-position tiles, two workgroups per CU
-        const bool halfp = half_e && *half_e && *half_e != '0' && 128 + 2 * (g.W + 2) + 2 <= 32 * 8;
-        const int TQp = halfp ? 128 : TQ;
+        // (the A/B switches of round 3 — 128-position tiles with two workgroups per CU, staggered starts, the ablation masks —
+        // are retired: profiles/r03_conv_bf16_ablation.txt has what they measured; the kernel keeps its template parameters)
+        const int TQp = TQ;
         const int ARp = TQp + 2 * (g.W + 2) + 2;
         const size_t sh_p = ((size_t)2 * ARp * PL + 2 * BSLOT) * sizeof(uint16_t);   // two A windows, two B slots
         const bool pers = lin && ARp <= 64 * 8 && sh_p <= 160 * 1024 && g.CO % TC == 0 && g.CI % (2 * KL) == 0 &&
@@ -793,30 +793,8 @@ extern "C" int conv_layer_bf16(halide_buffer_t *input, halide_buffer_t *filter, 
         if (pers) {
             dim3 grid((unsigned)((NQ + TQp - 1) / TQp), g.CO / TC);
             timing_note_bytes(4.0 * ((double)NQ * g.CI + (double)g.npix * g.CO) + (double)wb_bytes);
-            const char *stag_e = getenv("HLMI_CONVP_STAG");
-            const int stag = stag_e ? atoi(stag_e) : 1;
-            const char *abl_e = getenv("HLMI_CONVP_ABL");
-            const int abl = abl_e ? atoi(abl_e) : 0;
-            if (halfp) {
-                HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_p<8, 0, true>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_p));
-                HLMI_LAUNCH(uc, "conv3x3_bf16_mfma", ctx.stream, (conv3x3_bf16_p<8, 0, true>), grid, dim3(256), sh_p, dev_ptr<float>(input), wb,
-                            dev_ptr<float>(bias), dev_ptr<float>(relu), g, ARp, d_img, d_row, stag);
-            } else if (ARp <= 64 * 6 && abl >= 1) {
-#define CONVP_ABL(n)                                                                                                         \
-    case n:                                                                                                                  \
-        HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_p<6, n>),                              \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_p));                           \
-        HLMI_LAUNCH(uc, "conv3x3_bf16_mfma", ctx.stream, (conv3x3_bf16_p<6, n>), grid, dim3(PT), sh_p, dev_ptr<float>(input), wb, \
-                    dev_ptr<float>(bias), dev_ptr<float>(relu), g, ARp, d_img, d_row, stag);                                \
-        break;
-                switch (abl) {
-                    CONVP_ABL(1) CONVP_ABL(2) CONVP_ABL(64) CONVP_ABL(16) CONVP_ABL(48) CONVP_ABL(188) CONVP_ABL(80) CONVP_ABL(112)
-                    CONVP_ABL(252) CONVP_ABL(32) CONVP_ABL(140)
-                    default: return report(uc, halide_error_code_generic_error, "HLMI_CONVP_ABL=%d is not one of the instantiated masks", abl);
-                }
-#undef CONVP_ABL
-            } else if (ARp <= 64 * 6) {
+            const int stag = 1;
+            if (ARp <= 64 * 6) {
                 HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_p<6>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_p));
                 HLMI_LAUNCH(uc, "conv3x3_bf16_mfma", ctx.stream, conv3x3_bf16_p<6>, grid, dim3(PT), sh_p, dev_ptr<float>(input), wb,

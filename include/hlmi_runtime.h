@@ -139,6 +139,18 @@ int hlmi_device_count(void);
 void hlmi_kernel_timing_enable(int on);
 void hlmi_kernel_timing_reset(void);
 size_t hlmi_kernel_timing_report(char *out, size_t cap);
+/* ---- environment variables -------------------------------------------------------------------------------------------
+ * The INTERFACE (what a deployment may set):
+ *   HL_GPU_DEVICE            device ordinal, as in the reference's GPU runtimes (src/runtime/HalideRuntime.h:1019-1026)
+ *   HLMI_ALLOC_CACHE_MB      cap of the device allocation cache (halide_reuse_device_allocations)
+ *   HLMI_LL_GRAPH=1          local_laplacian: replay the launch chain as a HIP graph from the second identical call (opt-in)
+ *   HLMI_LL_NO_LUT_CACHE=1, HLMI_CONV_NO_FILTER_CACHE=1, HLMI_CP_NO_SETUP_CACHE=1
+ *                            recompute the remap table / bf16 filter image / camera_pipe set-up in every call instead of
+ *                            memoising them per (device, parameters)
+ * Everything else named HLMI_* in halide_amd/csrc/ is a MEASUREMENT switch, not interface: it forces a slower or more general
+ * kernel of the same pipeline (every alternative is bit-identical and is what the parity tests use to cover the general
+ * paths on small inputs) or changes a launch geometry; DESIGN.md §7 lists them with what each one measured.  Switches whose
+ * experiment is closed are deleted together with their kernels (round 4: ten of local_laplacian's and conv_layer_bf16's). */
 /* Library identification: returns e.g. "hlmi 0.1 gfx950". */
 const char *hlmi_version(void);
 
