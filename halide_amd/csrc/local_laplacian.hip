@@ -194,38 +194,34 @@ __device__ __forceinline__ T pick4(T x, T y, T z, T w, int s) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// The u16 frames are touched exactly twice (input: ll_down0 and ll_up0; output: written once) and never again, while the
-// pyramid planes in between are re-read within tens of microseconds.  HLMI_LL_NT (compile-time bit mask; csrc/Makefile
-// VARIANT) marks frame accesses non-temporal so that they do not displace the planes from L2 / Infinity Cache:
-// 1 = the input read of ll_down0* (first touch), 2 = the input read of ll_up0* (last touch), 4 = the output stores.
-#ifndef HLMI_LL_NT
-#define HLMI_LL_NT 0
-#endif
+// The u16 frames are touched exactly twice (input: the down and the up kernel; output: written once) and never again, while the
+// pyramid planes in between are re-read within tens of microseconds.  NT marks a frame access non-temporal so that it does
+// not displace the planes from L2 / Infinity Cache.  Round 3 measured nothing from it (the frame rate was set elsewhere);
+// with the re-cut dataflow the CU-partitioned frame rate is set by how the memory system digests the traffic (§4: the three
+// parts of a frame add up, whatever runs beside them), and there the hints are worth 6-7 % (84.0 -> 77.9 us per frame,
+// five alternating runs each): non-temporal input loads in both kernels, outLPyramid[0] stores and loads, output stores; the
+// level-1 and level-2 planes stay cached (non-temporal: slower).  On a stream that owns the device they cost 2-3 %, so the
+// kernels take it as a template parameter and the host asks the runtime which kind of stream it is on.
 typedef unsigned short us4_t __attribute__((ext_vector_type(4)));
+template<bool NT = false>
 __device__ __forceinline__ ushort4 ld_frame4(const uint16_t *p) {
-#if HLMI_LL_NT & 1
-    us4_t v = __builtin_nontemporal_load(reinterpret_cast<const us4_t *>(p));
-    return make_ushort4(v.x, v.y, v.z, v.w);
-#else
+    if (NT) {
+        us4_t v = __builtin_nontemporal_load(reinterpret_cast<const us4_t *>(p));
+        return make_ushort4(v.x, v.y, v.z, v.w);
+    }
     return *reinterpret_cast<const ushort4 *>(p);
-#endif
 }
+template<bool NT = false>
 __device__ __forceinline__ ushort2 ld_frame2(const void *sbase, uint32_t byte_off) {
     const uint32_t *q = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(sbase) + byte_off);
-#if HLMI_LL_NT & 2
-    const uint32_t w = __builtin_nontemporal_load(q);
-#else
-    const uint32_t w = *q;
-#endif
+    const uint32_t w = NT ? __builtin_nontemporal_load(q) : *q;
     return make_ushort2((uint16_t)(w & 0xffffu), (uint16_t)(w >> 16));
 }
+template<bool NT = false>
 __device__ __forceinline__ void st_frame2(void *p, uint16_t a, uint16_t b) {
     const uint32_t w = (uint32_t)a | ((uint32_t)b << 16);
-#if HLMI_LL_NT & 4
-    __builtin_nontemporal_store(w, reinterpret_cast<uint32_t *>(p));
-#else
-    *reinterpret_cast<uint32_t *>(p) = w;
-#endif
+    if (NT) __builtin_nontemporal_store(w, reinterpret_cast<uint32_t *>(p));
+    else *reinterpret_cast<uint32_t *>(p) = w;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -237,13 +233,13 @@ struct Levels {
     float v[MAX_K];      // level_k = k * (1 / (levels - 1))  (:41), kernel-argument (scalar) operands
 };
 
-template<bool VEC>
+template<bool VEC, bool NT = false>
 __device__ __forceinline__ void load_raw(Raw &r, const uint16_t *__restrict__ rp, long co0, long co1, long co2,
                                          int oq, const int (&xo)[4]) {
     if (VEC) {
-        r.c0 = ld_frame4(rp + co0 + oq);
-        r.c1 = ld_frame4(rp + co1 + oq);
-        r.c2 = ld_frame4(rp + co2 + oq);
+        r.c0 = ld_frame4<NT>(rp + co0 + oq);
+        r.c1 = ld_frame4<NT>(rp + co1 + oq);
+        r.c2 = ld_frame4<NT>(rp + co2 + oq);
     } else {
         r.c0 = make_ushort4(rp[co0 + xo[0]], rp[co0 + xo[1]], rp[co0 + xo[2]], rp[co0 + xo[3]]);
         r.c1 = make_ushort4(rp[co1 + xo[0]], rp[co1 + xo[1]], rp[co1 + xo[2]], rp[co1 + xo[3]]);
@@ -814,7 +810,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 f2s(float v) { return f2{v, v}; }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-template<bool ODD0, bool ODD1, bool B1, bool EXCH>
+template<bool ODD0, bool ODD1, bool B1, bool EXCH, bool NT>
 __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometry gm, Levels lev) {
     const D01Args &p = pe.d;
     extern __shared__ float slut[];
@@ -881,7 +877,7 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
     constexpr bool EDGE = decltype(edge_tag)::value;
     auto load_row = [&](Raw &r, int y_abs) {
         const uint16_t *rp = p.in + (long)(dev::clampi(y_abs - gm.iy0, 0, ih)) * p.in_sy;
-        load_raw<true>(r, rp, p.co0, p.co1, p.co2, qs.oq, xo);
+        load_raw<true, NT>(r, rp, p.co0, p.co1, p.co2, qs.oq, xo);
     };
     auto u16s = [&](const ushort4 &c, uint16_t (&o)[4]) {
         const uint2 w = __builtin_bit_cast(uint2, c);
@@ -1031,7 +1027,10 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
     };
     auto emit_store = [&](int y, const float (&r)[4]) {
         if (em_ok && y >= pe.oy0 && y < pe.oy0 + pe.oh && !(HLMI_D01E_ABL & 2 && p.nunits > 0)) {
-            *reinterpret_cast<float4 *>(em_col + (size_t)(y - pe.oy0) * iw) = make_float4(r[0], r[1], r[2], r[3]);
+            typedef float f4_t __attribute__((ext_vector_type(4)));
+            f4_t *const dst = reinterpret_cast<f4_t *>(em_col + (size_t)(y - pe.oy0) * iw);
+            if (NT) __builtin_nontemporal_store(f4_t{r[0], r[1], r[2], r[3]}, dst);
+            else *dst = f4_t{r[0], r[1], r[2], r[3]};
         }
     };
 #if HLMI_LL_PROBE
@@ -1865,6 +1864,7 @@ struct Up0HArgs {
     int l0_ws;                 // its row stride in floats (= input width)
 };
 constexpr int U0H_PF = 4;      // rows in flight per wave
+template<bool NT>
 __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
     const Up0Args &p = ph.u;
     extern __shared__ float s_out1[];
@@ -1909,8 +1909,12 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
     auto load_frame = [&](int y, Frame &f) {
         const int yc = min(y, y1 - 1);
         const uint16_t *irow = p.in + (long)(p.oy0 + yc - gm.iy0) * p.in_sy;
-        f.c0 = ld_frame2(irow + p.gco[0], inb), f.c1 = ld_frame2(irow + p.gco[1], inb), f.c2 = ld_frame2(irow + p.gco[2], inb);
-        f.l0 = ld_su<float2>(ph.outl0 + (size_t)yc * ph.l0_ws, l0b);
+        f.c0 = ld_frame2<NT>(irow + p.gco[0], inb), f.c1 = ld_frame2<NT>(irow + p.gco[1], inb), f.c2 = ld_frame2<NT>(irow + p.gco[2], inb);
+        {
+            const f2 *const lp = reinterpret_cast<const f2 *>(reinterpret_cast<const char *>(ph.outl0 + (size_t)yc * ph.l0_ws) + l0b);
+            const f2 v = NT ? __builtin_nontemporal_load(lp) : *lp;
+            f.l0 = make_float2(v.x, v.y);
+        }
     };
     auto finish = [&](int y, const Frame &f) {
         const int Y = p.oy0 + min(y, y1 - 1);
@@ -1938,7 +1942,7 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
         if (y < y1) {
             uint16_t *orow = p.out + (long)y * p.out_sy;
 #pragma unroll
-            for (int c = 0; c < 3; c++) st_frame2(reinterpret_cast<char *>(orow + (long)c * p.out_sc) + outb, res[c][0], res[c][1]);
+            for (int c = 0; c < 3; c++) st_frame2<NT>(reinterpret_cast<char *>(orow + (long)c * p.out_sc) + outb, res[c][0], res[c][1]);
         }
     };
     Frame f[U0H_PF];
@@ -2040,7 +2044,7 @@ uint64_t g_graph_clock = 0;
 uint64_t ll_env_signature() {
     static const char *const names[] = {"HLMI_LL_NO_LUT_CACHE", "HLMI_LL_UNITS0", "HLMI_LL_NO_VEC",
                                         "HLMI_LL_D01_EXCH", "HLMI_LL_FUSE_FROM", "HLMI_LL_UNITSB", "HLMI_LL_UPCHAIN_FROM",
-                                        "HLMI_LL_UP0_OLD", "HLMI_LL_FUSE_UP1", "HLMI_LL_RU", "HLMI_LL_EMIT"};
+                                        "HLMI_LL_UP0_OLD", "HLMI_LL_FUSE_UP1", "HLMI_LL_RU", "HLMI_LL_EMIT", "HLMI_LL_NT", "HLMI_LL_LDS_PAD"};
     uint64_t h = 1469598103934665603ull;
     for (const char *n : names) {
         const char *e = getenv(n);
@@ -2256,6 +2260,8 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     // ll_up0h has no data-dependent gathers to amortise over a tall tile: short tiles (more, smaller workgroups) are faster on a
     // stream that owns the device (31.7 us at 8 rows per wave against 33.5 / 38.4 at 16 / 32); on CU partitions 8..32 measure the same
     if (emit) p.RU = max(1, env_int("HLMI_LL_RU", partitioned ? 16 : 8));
+    // non-temporal frame / outLPyramid[0] accesses: +6-7 % frames per second on CU partitions, -2-3 % on a stream that owns the device
+    const bool nt = env_int("HLMI_LL_NT", partitioned ? 1 : 0) != 0;
     bool fuse1_out = false;
     auto enqueue = [&]() -> int {   // the launch chain of one frame (everything below depends only on what GraphKey holds)
     bool fuse_d2 = false;
@@ -2337,10 +2343,12 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
                 D01EArgs ae;
                 ae.d = a, ae.outl0 = outl0, ae.oy0 = output->dim[1].min, ae.oh = oh;
                 ae.nsx_magic = a.nsx == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)a.nsx + 1ull);
-#define LL_D01E(O0, O1, B)                                                                                             \
-    do {                                                                                                               \
-        if (exch) HLMI_LAUNCH(uc, "ll_down01", st, (ll_down01e<O0, O1, B, true>), grid2, block, sh2, ae, gm, lev);     \
-        else HLMI_LAUNCH(uc, "ll_down01", st, (ll_down01e<O0, O1, B, false>), grid2, block, sh2, ae, gm, lev);         \
+#define LL_D01E(O0, O1, B)                                                                                                    \
+    do {                                                                                                                      \
+        if (exch && nt) HLMI_LAUNCH(uc, "ll_down01", st, (ll_down01e<O0, O1, B, true, true>), grid2, block, sh2, ae, gm, lev);  \
+        else if (exch) HLMI_LAUNCH(uc, "ll_down01", st, (ll_down01e<O0, O1, B, true, false>), grid2, block, sh2, ae, gm, lev);   \
+        else if (nt) HLMI_LAUNCH(uc, "ll_down01", st, (ll_down01e<O0, O1, B, false, true>), grid2, block, sh2, ae, gm, lev);    \
+        else HLMI_LAUNCH(uc, "ll_down01", st, (ll_down01e<O0, O1, B, false, false>), grid2, block, sh2, ae, gm, lev);          \
     } while (0)
                 switch ((odd0 ? 4 : 0) | (odd1 ? 2 : 0) | (b1 ? 1 : 0)) {
                     case 0: LL_D01E(false, false, false); break;
@@ -2479,7 +2487,8 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             timing_note_bytes(2.0 * (3 + nc) * ow * oh + 4.0 * ow * oh + 4.0 * 3.0 * n1 + 4.0 * 3.0 * n2);
             Up0HArgs ph;
             ph.u = p, ph.outl0 = outl0, ph.l0_ws = gm.ix1 - gm.ix0 + 1;
-            HLMI_LAUNCH(uc, "ll_up0", st, ll_up0h, grid, block, sizeof(float) * U0_TS * (p.RU + 2), ph, gm);
+            if (nt) HLMI_LAUNCH(uc, "ll_up0", st, ll_up0h<true>, grid, block, sizeof(float) * U0_TS * (p.RU + 2), ph, gm);
+            else HLMI_LAUNCH(uc, "ll_up0", st, ll_up0h<false>, grid, block, sizeof(float) * U0_TS * (p.RU + 2), ph, gm);
             return 0;
         }
         timing_note_bytes(u0_bytes);

@@ -473,10 +473,12 @@ def test_hip_emit_and_materialised_dataflows_match_oracle(hl, oracle, monkeypatc
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("units,ru,exch", [(0, 0, "1"), (1024, 8, "1"), (300, 32, "1"), (4096, 3, "1"), (600, 16, "0")])
-def test_hip_emit_launch_geometries_match_oracle(hl, oracle, monkeypatch, units, ru, exch):
-    """Unit heights (ll_down01e), tile heights (ll_up0h) and the seam treatment only change who computes what."""
+@pytest.mark.parametrize("units,ru,exch,nt", [(0, 0, "1", "0"), (1024, 8, "1", "1"), (300, 32, "1", "0"), (4096, 3, "1", "1"), (600, 16, "0", "1")])
+def test_hip_emit_launch_geometries_match_oracle(hl, oracle, monkeypatch, units, ru, exch, nt):
+    """Unit heights (ll_down01e), tile heights (ll_up0h), the seam treatment and the non-temporal variants (what a CU-partitioned
+    stream runs) only change who computes what and how it travels."""
     monkeypatch.setenv("HLMI_LL_D01_EXCH", exch)
+    monkeypatch.setenv("HLMI_LL_NT", nt)
     if units:
         monkeypatch.setenv("HLMI_LL_UNITS0", str(units))
     if ru:
