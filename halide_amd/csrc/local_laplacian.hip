@@ -1393,13 +1393,14 @@ __device__ __forceinline__ Range2 clamp_to_box(const DevLevel &L, int x0, int x1
 }
 template<int DEPTH>
 __global__ __launch_bounds__(256) void ll_down_multi(CoarseArgs a, int ntx, int nty) {
-    constexpr int W1 = dm_win(DEPTH - 1), W2 = DEPTH >= 2 ? dm_win(DEPTH - 2) : 1, W3 = DEPTH >= 3 ? dm_win(DEPTH - 3) : 1;
-    __shared__ float tile1[W1 * W1], tile2[W2 * W2], tile3[W3 * W3];  // windows of levels S+1, S+2, S+3
-    float *const tiles[4] = {nullptr, tile1, tile2, tile3};
-    const int ws_[4] = {0, W1, W2, W3};
+    constexpr int W1 = dm_win(DEPTH - 1), W2 = DEPTH >= 2 ? dm_win(DEPTH - 2) : 1, W3 = DEPTH >= 3 ? dm_win(DEPTH - 3) : 1,
+                  W4 = DEPTH >= 4 ? dm_win(DEPTH - 4) : 1;
+    __shared__ float tile1[W1 * W1], tile2[W2 * W2], tile3[W3 * W3], tile4[W4 * W4];  // windows of levels S+1 .. S+4
+    float *const tiles[5] = {nullptr, tile1, tile2, tile3, tile4};
+    const int ws_[5] = {0, W1, W2, W3, W4};
     const int tx = blockIdx.x % ntx, ty = (blockIdx.x / ntx) % nty, plane = blockIdx.x / (ntx * nty);
     // windows (win[d]) and owned ranges (own[d]) of levels S+d, deepest first
-    Range2 win[4], own[4];
+    Range2 win[5], own[5];
     {
         const DevLevel &T = a.lv[DEPTH];
         win[DEPTH] = own[DEPTH] = clamp_to_box(T, T.lox + tx * DM_T, T.lox + tx * DM_T + DM_T - 1, T.loy + ty * DM_T,
@@ -1862,8 +1863,16 @@ struct Up0HArgs {
     Up0Args u;
     const float *outl0;        // outLPyramid[0] on [ix0, ix1] x [oy0, oy0 + oh - 1]
     int l0_ws;                 // its row stride in floats (= input width)
+    // FUSE2: outGPyramid[2] on the part of R_2 the workgroup's level-1 tile reads is produced here too (phase 0, an LDS tile of at
+    // most 68 x (RU / 2 + 3) values, by the expression of ll_up) instead of by an ll_up:2 launch: one dependent launch less in the
+    // chain between the two big kernels, which costs a CU partition 8 us of every frame
+    int fuse2;
+    const float *g3, *out3;
+    int lox3, loy3, ws3;
+    size_t ps3;
 };
 constexpr int U0H_PF = 4;      // rows in flight per wave
+constexpr int U0H_T2 = 68;     // row stride of the level-2 tile
 template<bool NT>
 __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
     const Up0Args &p = ph.u;
@@ -1883,13 +1892,38 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
     const int Yw1 = min(Yw0 + 2 * p.RU, p.oy0 + p.oh) - 1;
     const int cx0 = (X0 >> 1) - 1, cy0 = dev::fdiv2(Yw0 - 1);
     const int th = dev::fdiv2(Yw1 + 1) - cy0 + 1;
+    float *const s_out2 = s_out1 + U0_TS * (p.RU + 2);
+    const int cx1 = min(cx0 + U0_TW - 1, p.rx1_1);                               // last level-1 column of the tile
+    const int c2x0 = dev::fdiv2(cx0 - 1), c2y0 = dev::fdiv2(cy0 - 1);             // level-2 window the level-1 tile's upsampling reads
+    if (ph.fuse2) {
+        const int n2x = dev::fdiv2(cx1 + 1) - c2x0 + 1, n2y = dev::fdiv2(cy0 + th) - c2y0 + 1;
+        for (int e = threadIdx.x; e < n2x * n2y; e += 256) {
+            const int ty = e / n2x, tx = e - ty * n2x;
+            const int X2 = c2x0 + tx, Y2 = c2y0 + ty;
+            // outGPyramid[2] = upsample(outGPyramid[3]) + outLPyramid[2]   (:76-79), exactly as ll_up computes it
+            const float outL = outl_value<false>(p.g2, p.ws2, p.ps2, p.lox2, p.loy2, ph.g3, ph.ws3, ph.ps3, ph.lox3, ph.loy3, X2, Y2, gm.K, gm.Km1);
+            s_out2[ty * U0H_T2 + tx] = up_at(ph.out3, ph.lox3, ph.loy3, ph.ws3, X2, Y2) + outL;
+        }
+        __syncthreads();
+    }
     for (int e = threadIdx.x; e < U0_TW * th; e += 256) {
         const int ty = e / U0_TW, tx = e - ty * U0_TW;
         const int cx = cx0 + tx, cy = cy0 + ty;
         if (cx > p.rx1_1) continue;
         // outGPyramid[1] = upsample(outGPyramid[2]) + outLPyramid[1]   (:76-79), exactly as ll_up computes it
         const float outL = outl_value<true>(p.g1, p.ws1, p.ps1, p.lox1, p.loy1, p.g2, p.ws2, p.ps2, p.lox2, p.loy2, cx, cy, gm.K, gm.Km1);
-        s_out1[ty * U0_TS + tx] = up_at(p.out2, p.lox2, p.loy2, p.ws2, cx, cy) + outL;
+        float up2;
+        if (ph.fuse2) {   // up_at on the LDS tile: the same taps, weights and lerps
+            const int xa = dev::fdiv2(cx + 1) - c2x0, xb = dev::fdiv2(cx - 1) - c2x0;
+            const int ya = dev::fdiv2(cy + 1) - c2y0, yb = dev::fdiv2(cy - 1) - c2y0;
+            const float wx = (float)(dev::fmod2(cx) * 2 + 1) * 0.25f, wy = (float)(dev::fmod2(cy) * 2 + 1) * 0.25f;
+            const float ua = dev::lerpf(s_out2[ya * U0H_T2 + xa], s_out2[ya * U0H_T2 + xb], wx);
+            const float ub = dev::lerpf(s_out2[yb * U0H_T2 + xa], s_out2[yb * U0H_T2 + xb], wx);
+            up2 = dev::lerpf(ua, ub, wy);
+        } else {
+            up2 = up_at(p.out2, p.lox2, p.loy2, p.ws2, cx, cy);
+        }
+        s_out1[ty * U0_TS + tx] = up2 + outL;
     }
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1986,6 +2020,7 @@ int env_int(const char *name, int dflt) {
 thread_local Level t_dbg_lv[J];
 thread_local hipStream_t t_dbg_stream = nullptr;
 thread_local bool t_dbg_out1_pending = false;  // the last call fused level 1's collapse: outGPyramid[1] was never stored
+thread_local bool t_dbg_out2_pending = false;  // ... and level 2's (ll_up0h phase 0)
 thread_local bool t_dbg_emit = false;         // ... by ll_up0h: level 1 holds its three planes only (ll_down01e)
 thread_local int t_dbg_K = 0;
 thread_local float t_dbg_Km1 = 0;
@@ -2034,7 +2069,7 @@ struct GraphEntry {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     bool failed = false;       // capture or instantiation was refused once: stay eager for this key
-    bool out1_pending = false; // debug bookkeeping of the captured call (hlmi_debug_local_laplacian_outg)
+    bool out1_pending = false, out2_pending = false; // debug bookkeeping of the captured call (hlmi_debug_local_laplacian_outg)
     uint64_t used = 0;
 };
 std::mutex g_graph_mu;
@@ -2044,7 +2079,7 @@ uint64_t g_graph_clock = 0;
 uint64_t ll_env_signature() {
     static const char *const names[] = {"HLMI_LL_NO_LUT_CACHE", "HLMI_LL_UNITS0", "HLMI_LL_NO_VEC",
                                         "HLMI_LL_D01_EXCH", "HLMI_LL_FUSE_FROM", "HLMI_LL_UNITSB", "HLMI_LL_UPCHAIN_FROM",
-                                        "HLMI_LL_UP0_OLD", "HLMI_LL_FUSE_UP1", "HLMI_LL_RU", "HLMI_LL_EMIT", "HLMI_LL_NT", "HLMI_LL_LDS_PAD"};
+                                        "HLMI_LL_UP0_OLD", "HLMI_LL_FUSE_UP1", "HLMI_LL_RU", "HLMI_LL_EMIT", "HLMI_LL_NT", "HLMI_LL_LDS_PAD", "HLMI_LL_FUSE_UP2"};
     uint64_t h = 1469598103934665603ull;
     for (const char *n : names) {
         const char *e = getenv(n);
@@ -2204,14 +2239,14 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     // levels >= S are produced / collapsed by the two multi-level kernels (S = 4: 2 launches instead of 7)
     const int S = [&] {
         int v = env_int("HLMI_LL_FUSE_FROM", 4);
-        return (v >= J - 4 && v <= J - 2) ? v : J;
+        return (v >= J - 5 && v <= J - 2) ? v : J;
     }();
     // the collapse (outGPyramid[J-1] .. outGPyramid[SU]) is ONE launch (ll_up_multi); opt-in: on the large levels its per-pixel overhead exceeds the saved launches
     // Default 3 when the down pass fuses from 4: outGPyramid[3] joins the collapse launch (one ll_up launch and its ~4.5 us of
     // dependent-launch latency less: 110.8 -> 108.9 us per frame on one stream); from level 2 the kernel's per-pixel overhead
     // costs more than the launch it saves (114.2).  0: SU = S.
     const int SU = [&] {
-        int v = env_int("HLMI_LL_UPCHAIN_FROM", S == 4 ? 3 : 0);
+        int v = env_int("HLMI_LL_UPCHAIN_FROM", S == 4 ? 3 : 0);   // (S == 3: SU = S)
         return (v >= 1 && v <= J - 2) ? v : S;
     }();
     // ---- level 0 arguments first: whether the level-1 collapse is fused into ll_up0f decides if ll_up:1 is launched
@@ -2262,7 +2297,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     if (emit) p.RU = max(1, env_int("HLMI_LL_RU", partitioned ? 16 : 8));
     // non-temporal frame / outLPyramid[0] accesses: +6-7 % frames per second on CU partitions, -2-3 % on a stream that owns the device
     const bool nt = env_int("HLMI_LL_NT", partitioned ? 1 : 0) != 0;
-    bool fuse1_out = false;
+    bool fuse1_out = false, fuse2_out = false;
     auto enqueue = [&]() -> int {   // the launch chain of one frame (everything below depends only on what GraphKey holds)
     bool fuse_d2 = false;
     {
@@ -2412,7 +2447,8 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             char nm[32];
             snprintf(nm, sizeof nm, "ll_down_multi:%d", S);
             timing_note_bytes(4.0 * ((double)(levels + 1) * lv[S].w * lv[S].h + (double)total));
-            if (J - 1 - S == 3) HLMI_LAUNCH(uc, nm, st, (ll_down_multi<3>), grid, block, 0, ca, ntx, nty);
+            if (J - 1 - S == 4) HLMI_LAUNCH(uc, nm, st, (ll_down_multi<4>), grid, block, 0, ca, ntx, nty);
+            else if (J - 1 - S == 3) HLMI_LAUNCH(uc, nm, st, (ll_down_multi<3>), grid, block, 0, ca, ntx, nty);
             else if (J - 1 - S == 2) HLMI_LAUNCH(uc, nm, st, (ll_down_multi<2>), grid, block, 0, ca, ntx, nty);
             else HLMI_LAUNCH(uc, nm, st, (ll_down_multi<1>), grid, block, 0, ca, ntx, nty);
             break;
@@ -2462,7 +2498,12 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         HLMI_LAUNCH(uc, "ll_top", st, ll_top, dim3((rw + 63) / 64, rh), dim3(64), 0, t.g, t.ws, t.ps, t.lox, t.loy, t.rx0,
                     t.ry0, rw, rh, levels, gm.Km1, t.out);
     }
-    for (int j = min(SU, J - 1) - 1; j >= (fuse1 ? 2 : 1); j--) {
+    // ll_up0h also collapses level 2 (into an LDS tile) when level 3 is a stored level of its own
+    // (on CU partitions, where every dependent launch of the chain idles the partition: 79.4 -> 76.4 us per frame; on a stream that
+    // owns the device the tile redundancy costs what the launch saved: 109 -> 111 us)
+    const bool fuse2 = emit && SU >= 3 && SU < J && env_int("HLMI_LL_FUSE_UP2", partitioned ? 1 : 0);
+    fuse2_out = fuse2;
+    for (int j = min(SU, J - 1) - 1; j >= (fuse1 ? (fuse2 ? 3 : 2) : 1); j--) {
         const Level &a = lv[j], &c = lv[j + 1];
         int rw = a.rx1 - a.rx0 + 1, rh = a.ry1 - a.ry0 + 1;
         char nm[32];
@@ -2487,8 +2528,11 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             timing_note_bytes(2.0 * (3 + nc) * ow * oh + 4.0 * ow * oh + 4.0 * 3.0 * n1 + 4.0 * 3.0 * n2);
             Up0HArgs ph;
             ph.u = p, ph.outl0 = outl0, ph.l0_ws = gm.ix1 - gm.ix0 + 1;
-            if (nt) HLMI_LAUNCH(uc, "ll_up0", st, ll_up0h<true>, grid, block, sizeof(float) * U0_TS * (p.RU + 2), ph, gm);
-            else HLMI_LAUNCH(uc, "ll_up0", st, ll_up0h<false>, grid, block, sizeof(float) * U0_TS * (p.RU + 2), ph, gm);
+            ph.fuse2 = fuse2 ? 1 : 0;
+            ph.g3 = lv[3].g, ph.out3 = lv[3].out, ph.lox3 = lv[3].lox, ph.loy3 = lv[3].loy, ph.ws3 = lv[3].ws, ph.ps3 = lv[3].ps;
+            const size_t sh_h = sizeof(float) * ((size_t)U0_TS * (p.RU + 2) + (size_t)U0H_T2 * (p.RU / 2 + 4));
+            if (nt) HLMI_LAUNCH(uc, "ll_up0", st, ll_up0h<true>, grid, block, sh_h, ph, gm);
+            else HLMI_LAUNCH(uc, "ll_up0", st, ll_up0h<false>, grid, block, sh_h, ph, gm);
             return 0;
         }
         timing_note_bytes(u0_bytes);
@@ -2545,7 +2589,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         }
         if (ge && ge->exec) {
             ge->used = ++g_graph_clock;
-            t_dbg_out1_pending = ge->out1_pending;
+            t_dbg_out1_pending = ge->out1_pending, t_dbg_out2_pending = ge->out2_pending;
             HLMI_HIP(uc, hipGraphLaunch(ge->exec, st));   // under the lock: an entry cannot be evicted while it is launched
             mark_output_written(output);
             return 0;
@@ -2599,7 +2643,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             for (auto &e : g_graphs) {
                 if (e.key == key) {
                     if (ok && !e.exec) {
-                        e.graph = graph, e.exec = exec, e.out1_pending = fuse1_out, e.used = ++g_graph_clock;
+                        e.graph = graph, e.exec = exec, e.out1_pending = fuse1_out, e.out2_pending = fuse2_out, e.used = ++g_graph_clock;
                         graph = nullptr, exec = nullptr;
                     } else if (!ok) {
                         e.failed = true;
@@ -2613,7 +2657,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             (void)hipStreamSynchronize(st);
             (void)hipGraphExecDestroy(exec);
             (void)hipGraphDestroy(graph);
-            t_dbg_out1_pending = fuse1_out;
+            t_dbg_out1_pending = fuse1_out, t_dbg_out2_pending = fuse2_out;
             mark_output_written(output);
             return 0;
         }
@@ -2621,7 +2665,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             std::lock_guard<std::mutex> lock(g_graph_mu);
             for (auto &e : g_graphs) {
                 if (e.key == key && e.exec) {
-                    t_dbg_out1_pending = e.out1_pending;
+                    t_dbg_out1_pending = e.out1_pending, t_dbg_out2_pending = e.out2_pending;
                     HLMI_HIP(uc, hipGraphLaunch(e.exec, st));
                     mark_output_written(output);
                     return 0;
@@ -2632,7 +2676,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         // capture refused: fall through to the eager path
     }
     if ((r = enqueue())) return r;
-    t_dbg_out1_pending = fuse1_out;
+    t_dbg_out1_pending = fuse1_out, t_dbg_out2_pending = fuse2_out;
     mark_output_written(output);
     return 0;
 }
@@ -2702,6 +2746,16 @@ extern "C" int hlmi_debug_local_laplacian_outg(int level, float *dst, int cap_fl
     if (rh_out) *rh_out = rh;
     if (!dst) return 0;
     if ((long)rw * rh > cap_floats) return -1;
+    if ((level == 1 || level == 2) && t_dbg_out2_pending) {
+        // ll_up0h kept outGPyramid[2] in LDS tiles: produce the plane with the stand-alone kernel (levels 2, 3 and outGPyramid[3] are
+        // still in the arena); level 1's own stand-alone collapse below reads it
+        const Level &a = t_dbg_lv[2], &c = t_dbg_lv[3];
+        const int rw2 = a.rx1 - a.rx0 + 1, rh2 = a.ry1 - a.ry0 + 1;
+        hipLaunchKernelGGL(ll_up<false>, dim3((rw2 + 255) / 256, rh2), dim3(256), 0, t_dbg_stream, a.g, a.ws, a.ps, a.lox, a.loy, c.g, c.out,
+                           c.ws, c.ps, c.lox, c.loy, a.rx0, a.ry0, rw2, rh2, t_dbg_K, t_dbg_Km1, a.out);
+        if (hipGetLastError() != hipSuccess) return -1;
+        t_dbg_out2_pending = false;
+    }
     if (level == 1 && t_dbg_out1_pending) {
         // the fused ll_up0f / ll_up0h kept outGPyramid[1] in LDS: produce the plane now with the stand-alone kernel (its inputs are
         // still in the arena) so that the tests can compare every level

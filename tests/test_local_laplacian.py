@@ -229,7 +229,7 @@ def test_hip_matches_oracle(hl, oracle, w, h, levels, kind):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fuse_from,upchain_from", [(8, 0), (6, 0), (5, 0), (4, 0), (4, 3), (4, 2), (4, 1)])
+@pytest.mark.parametrize("fuse_from,upchain_from", [(8, 0), (6, 0), (5, 0), (4, 0), (4, 3), (4, 2), (4, 1), (3, 0)])
 @pytest.mark.parametrize("w,h,origin", [(640, 480, (0, 0)), (1000, 300, (0, 0)), (301, 203, (17, 33)), (150, 90, (-6, 2))])
 def test_hip_pyramid_levels_match_oracle(hl, oracle, monkeypatch, w, h, origin, fuse_from, upchain_from):
     """Every outGPyramid level (coarse to fine) must be bit-identical to the oracle's: localises a mismatch
@@ -458,6 +458,7 @@ def test_hip_emit_and_materialised_dataflows_match_oracle(hl, oracle, monkeypatc
     is preceded by a DIFFERENT frame through the same workspace: outLPyramid[0] rows or level-1 planes that a unit fails to
     emit would hold the other frame's values."""
     monkeypatch.setenv("HLMI_LL_EMIT", emit)
+    monkeypatch.setenv("HLMI_LL_FUSE_UP2", "1")   # outGPyramid[2] only in LDS tiles of ll_up0h (what CU-partitioned streams run)
     other = _rand_image(w, h, seed=w + 3 * h + 2, kind="uniform" if kind == "smooth" else "smooth")
     inp = _rand_image(w, h, seed=w + h + 31, kind=kind)
     for img in (other, inp):
@@ -479,6 +480,7 @@ def test_hip_emit_launch_geometries_match_oracle(hl, oracle, monkeypatch, units,
     stream runs) only change who computes what and how it travels."""
     monkeypatch.setenv("HLMI_LL_D01_EXCH", exch)
     monkeypatch.setenv("HLMI_LL_NT", nt)
+    monkeypatch.setenv("HLMI_LL_FUSE_UP2", nt)   # the level-2 collapse inside ll_up0h: the other thing a partitioned stream switches on
     if units:
         monkeypatch.setenv("HLMI_LL_UNITS0", str(units))
     if ru:
