@@ -364,12 +364,7 @@ extern "C" int bilateral_grid(halide_buffer_t *input, float r_sigma, halide_buff
         HLMI_LAUNCH(uc, "bg_histogram_blurz", st, bg_histogram_blurz, dim3((g.HX + T - 1) / T, g.HY), dim3(T), sh, din, in_sy, g, bz);
     }
     if (g.ZD <= FZ && !getenv("HLMI_BG_UNFUSED")) {
-        const char *te = getenv("HLMI_BG_TILE");
-        const int tile_h = te ? atoi(te) : 32;
-        if (tile_h == 64) {
-            HLMI_LAUNCH(uc, "bg_blur_slice", st, bg_blur_slice<64>, dim3((ow + FPX - 1) / FPX, (oh + 63) / 64), dim3(256), 0, din, in_sy, g, bz,
-                        dev_ptr<float>(output), out_sy, ox0, oy0, ow, oh);
-        } else if (tile_h == 16 || getenv("HLMI_BG_TILE16")) {
+        if (getenv("HLMI_BG_TILE16")) {
             HLMI_LAUNCH(uc, "bg_blur_slice", st, bg_blur_slice<16>, dim3((ow + FPX - 1) / FPX, (oh + 15) / 16), dim3(256), 0, din, in_sy, g, bz,
                         dev_ptr<float>(output), out_sy, ox0, oy0, ow, oh);
         } else {
