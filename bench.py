@@ -367,7 +367,12 @@ def main():
                          # ... and against the float4-copy figure MI355X_MICROARCH.md measured (6.29 TB/s)
                          "pipeline_traffic_frac_of_guide_copy_6290": None if frame_traffic is None else
                          round(frame_traffic / (frame_ms * 1e-3) / 1e9 / 6290.0, 4),
-                         "kernel_ms_per_frame": {k: round(v, 5) for k, v in per_frame.items()}},
+                         "kernel_ms_per_frame": {k: round(v, 5) for k, v in per_frame.items()},
+                         # per-launch figures (HIP events, PMC) are taken on ONE device-wide stream; the headline loop runs on CU
+                         # partitions, where the kernels use non-temporal frame accesses and ll_up0h also collapses level 2 (same
+                         # bytes within 1 %), and where the package sits at its power limit from two busy partitions on
+                         "notes": "profiles/r04_power_and_partition_scaling.txt: 1040 W with one partition busy, ~1370 W (the limit) "
+                                  "with two or four; the frame rate on a whole device is energy per frame"},
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(frames[0])
