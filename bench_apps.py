@@ -37,7 +37,7 @@ def cpu_time(fn, budget_s=4.0, max_reps=8):
             return dt / n, n
 
 
-def run(only=(), samples=5, sink=None, cpu=False):
+def run(only=(), samples=5, sink=None, cpu=False, batched=True):
     """Times the pipelines named in `only` (all when empty) and hands one dict per pipeline to `sink` (default: print as a
     JSON line).  cpu=True adds a bounded `cpu_baseline` (the C oracle, OpenMP, kind "port") beside the BASELINE.json
     configs (bilateral_grid, nl_means, conv_layer_bf16) — bench.py's `other_configs` leg."""
@@ -81,6 +81,8 @@ def run(only=(), samples=5, sink=None, cpu=False):
         synchronisation — on one stream, and spread over 2 / 4 CU-partitioned streams (halide_hip_partition_stream, as bench.py
         runs the headline pipeline); returns (seconds per frame, scheduling) of the fastest.  The single-call figure is a
         latency: two or three short dependent launches cannot fill 256 CUs, several frames side by side can."""
+        if not batched:   # profiler runs (rocprofv3 over this script): one call at a time only
+            return None
         calls = [make_call(i) for i in range(nframes)]
         hip = hl.hip_runtime()
         best, how = 1e30, None
@@ -107,6 +109,8 @@ def run(only=(), samples=5, sink=None, cpu=False):
         return best, how
 
     def batched_fields(tb, unit_work, peak, what):
+        if tb is None:
+            return {}
         t, how = tb
         return {"batched": {"ms_per_frame": round(t * 1e3, 4), "frames_in_flight": 8, "streams": how,
                             "roofline_frac": round(unit_work / t / peak, 4), "bound": what}}
@@ -398,8 +402,9 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--samples", type=int, default=5)
     ap.add_argument("--cpu-baseline", action="store_true", help="time the C oracle beside the BASELINE.json configs")
+    ap.add_argument("--no-batched", action="store_true", help="skip the frames-in-flight leg (profiler runs)")
     a = ap.parse_args()
-    run(filter(None, a.only.split(",")), a.samples, None, a.cpu_baseline)
+    run(filter(None, a.only.split(",")), a.samples, None, a.cpu_baseline, not a.no_batched)
 
 
 if __name__ == "__main__":

@@ -7,9 +7,9 @@ export TMPDIR=/tmp
 bash scripts/gpu_full.sh $TAG
 cd $R
 echo "== apps: kernel stats + counters"
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_apps -o kt -- bash -c "cd $R && python bench_apps.py --samples 1" > $OUT/kt_apps.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_apps -o kt -- bash -c "cd $R && python bench_apps.py --samples 1 --no-batched" > $OUT/kt_apps.log 2>&1)
 find $OUT -name "*kernel_trace.csv" -delete
-PMC_CMD="python bench_apps.py --only nl_means,bilateral_grid,conv_layer_bf16,stencil_chain --samples 1" bash scripts/gpu_pmc_cmd.sh $TAG/pmc_apps \
+PMC_CMD="python bench_apps.py --only nl_means,bilateral_grid,conv_layer_bf16,stencil_chain --samples 1 --no-batched" bash scripts/gpu_pmc_cmd.sh $TAG/pmc_apps \
   "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" \
   "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES" "FETCH_SIZE" "WRITE_SIZE" 2>&1 | grep -E "^\(" | tee $OUT/apps_pmc.txt | cut -c1-200
 echo "== HBM ceiling sweep + access-width calibration"
