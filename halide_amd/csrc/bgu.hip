@@ -441,8 +441,7 @@ extern "C" int bgu(float r_sigma, int32_t s_sigma, halide_buffer_t *splat_loc, h
                       (long)(0 - slice_loc->dim[2].min) * q.s_sc;
     const size_t lds = (size_t)4 * q.nlc * g.nz * 12 * sizeof(float);
     timing_note_bytes(24.0 * ow * oh);
-    static const bool force_direct = getenv("HLMI_BGU_DIRECT") != nullptr;
-    if (lds <= 64 * 1024 && !force_direct) {
+    if (lds <= 64 * 1024) {   // (grids whose four cell rows do not fit: the direct kernel)
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)bgu_slice, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         HLMI_LAUNCH(uc, "bgu_slice", st, bgu_slice, dim3((ow + TW - 1) / TW, (g.ncy - 1) * q.nsub), dim3(TW), lds, line, sl, g, q,
                     dev_ptr<float>(output));

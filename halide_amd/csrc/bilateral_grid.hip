@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void bg_slice(const float *__restrict__ in, lo
 // blurz cells under those (14 x 10) are produced in LDS by the same blur5 chains the separate kernels run — two launches
 // and the write + re-read of two grids less (the pipeline is launch-latency bound: 4 launches took 30 us for 16 MB).
 constexpr int FPX = 64, FCX = 10, FZ = 16;
-template<int FPY>   // tile height: 32 (or 16: HLMI_BG_TILE16=1, an A/B switch)
+template<int FPY>   // tile height (32; 16 and 64 measured the same or slower)
 __global__ __launch_bounds__(256) void bg_blur_slice(const float *__restrict__ in, long in_sy, BGeom g, const float2 *__restrict__ bz,
                                                     float *__restrict__ out, long out_sy, int ox0, int oy0, int ow, int oh) {
     constexpr int FCY = FPY / S + 2;
@@ -348,12 +348,12 @@ extern "C" int bilateral_grid(halide_buffer_t *input, float r_sigma, halide_buff
     const long in_sy = input->dim[1].stride, out_sy = output->dim[1].stride;
     hipStream_t st = ctx.stream;
     // float4 staging: rows 16-byte aligned at every staged column group (cells start at multiples of 8 minus 4)
-    const int vec = ((uintptr_t)din % 16 == 0 && in_sy % 4 == 0 && floor_div(g.ix0, 4) * 4 == g.ix0 && !getenv("HLMI_BG_NO_VEC")) ? 1 : 0;
-    if (g.ZD <= 12 && !getenv("HLMI_BG_SERIAL")) {
+    const int vec = ((uintptr_t)din % 16 == 0 && in_sy % 4 == 0 && floor_div(g.ix0, 4) * 4 == g.ix0) ? 1 : 0;
+    if (g.ZD <= 12) {
         constexpr int HC = HTH / 12;
         HLMI_LAUNCH(uc, "bg_histogram_blurz", st, bg_histogram_blurz_par<12>, dim3((g.HX + HC - 1) / HC, g.HY), dim3(HC * 12), 0, din,
                     in_sy, g, bz, vec);
-    } else if (g.ZD <= 16 && !getenv("HLMI_BG_SERIAL")) {
+    } else if (g.ZD <= 16) {
         constexpr int HC = HTH / 16;
         HLMI_LAUNCH(uc, "bg_histogram_blurz", st, bg_histogram_blurz_par<16>, dim3((g.HX + HC - 1) / HC, g.HY), dim3(HC * 16), 0, din,
                     in_sy, g, bz, vec);
@@ -363,14 +363,9 @@ extern "C" int bilateral_grid(halide_buffer_t *input, float r_sigma, halide_buff
         size_t sh = (size_t)g.ZH * 2 * T * sizeof(float);
         HLMI_LAUNCH(uc, "bg_histogram_blurz", st, bg_histogram_blurz, dim3((g.HX + T - 1) / T, g.HY), dim3(T), sh, din, in_sy, g, bz);
     }
-    if (g.ZD <= FZ && !getenv("HLMI_BG_UNFUSED")) {
-        if (getenv("HLMI_BG_TILE16")) {
-            HLMI_LAUNCH(uc, "bg_blur_slice", st, bg_blur_slice<16>, dim3((ow + FPX - 1) / FPX, (oh + 15) / 16), dim3(256), 0, din, in_sy, g, bz,
-                        dev_ptr<float>(output), out_sy, ox0, oy0, ow, oh);
-        } else {
-            HLMI_LAUNCH(uc, "bg_blur_slice", st, bg_blur_slice<32>, dim3((ow + FPX - 1) / FPX, (oh + 31) / 32), dim3(256), 0, din, in_sy, g, bz,
-                        dev_ptr<float>(output), out_sy, ox0, oy0, ow, oh);
-        }
+    if (g.ZD <= FZ) {   // (grids of more planes — r_sigma < 1/14.5 — take the serial histogram and the three separate launches)
+        HLMI_LAUNCH(uc, "bg_blur_slice", st, bg_blur_slice<32>, dim3((ow + FPX - 1) / FPX, (oh + 31) / 32), dim3(256), 0, din, in_sy, g, bz,
+                    dev_ptr<float>(output), out_sy, ox0, oy0, ow, oh);
     } else {
         HLMI_LAUNCH(uc, "bg_blurx", st, bg_blurx, dim3((g.GX + 63) / 64, g.HY, g.ZD), dim3(64), 0, bz, g, bx);
         HLMI_LAUNCH(uc, "bg_blury", st, bg_blury, dim3((g.GX + 63) / 64, g.GY, g.ZD), dim3(64), 0, bx, g, by);

@@ -555,17 +555,17 @@ extern "C" int camera_pipe(halide_buffer_t *input, halide_buffer_t *matrix_3200,
     const long in_sy = input->dim[1].stride;
     const uint16_t *raw = dev_ptr<uint16_t>(input) + (long)(oy + 12 - input->dim[1].min) * in_sy + (ox + 16 - input->dim[0].min);
     const int nqx = floor_div(W, 2) + 2, nqy = floor_div(H, 2) + 2;
-    if (in_sy % 2 == 0 && (uintptr_t)raw % 4 == 0 && W % 2 == 0 && !getenv("HLMI_CP_SCALAR") && !getenv("HLMI_CP_QUAD")) {
+    if (in_sy % 2 == 0 && (uintptr_t)raw % 4 == 0 && W % 2 == 0) {
         HLMI_LAUNCH(uc, "cp_demosaic", st, cp_demosaic_tile, dim3((nqx + TQX - 1) / TQX, (nqy + TQY - 1) / TQY), dim3(256), 0, raw, in_sy,
                     setup, cv, CW, CH, CWL, W, H);
-    } else if (in_sy % 2 == 0 && (uintptr_t)raw % 4 == 0 && !getenv("HLMI_CP_SCALAR")) {
+    } else if (in_sy % 2 == 0 && (uintptr_t)raw % 4 == 0) {
         HLMI_LAUNCH(uc, "cp_demosaic", st, cp_demosaic<true>, dim3((nqx + 255) / 256, nqy), dim3(256), 0, raw, in_sy, setup, cv, CW, CH, CWL, nqx, nqy);
     } else {
         HLMI_LAUNCH(uc, "cp_demosaic", st, cp_demosaic<false>, dim3((nqx + 255) / 256, nqy), dim3(256), 0, raw, in_sy, setup, cv, CW, CH, CWL, nqx, nqy);
     }
     const long o_sy = processed->dim[1].stride, o_sc = processed->dim[2].stride;
     uint8_t *dout = dev_ptr<uint8_t>(processed);
-    if (W % 4 == 0 && o_sy % 4 == 0 && o_sc % 4 == 0 && (uintptr_t)dout % 4 == 0 && !getenv("HLMI_CP_SCALAR")) {
+    if (W % 4 == 0 && o_sy % 4 == 0 && o_sc % 4 == 0 && (uintptr_t)dout % 4 == 0) {
         HLMI_LAUNCH(uc, "cp_sharpen", st, cp_sharpen4, dim3((W / 4 + 255) / 256, H), dim3(256), 0, cv, CW, CH, setup, dout, o_sy, o_sc, W, H);
     } else {
         HLMI_LAUNCH(uc, "cp_sharpen", st, cp_sharpen, dim3((W + 255) / 256, H), dim3(256), 0, cv, CW, CH, setup, dout, o_sy, o_sc, W, H);

@@ -760,15 +760,14 @@ extern "C" int conv_layer_bf16(halide_buffer_t *input, halide_buffer_t *filter, 
         const int AR = TP + 2 * (g.W + 2) + 2;               // input-linear window of a 128-pixel tile
         const size_t sh_lin = (size_t)2 * AR * PL * sizeof(uint16_t);   // two windows of 32-ci chunks, 80-byte rows
         const long NQ = (long)g.N * (g.H + 2) * (g.W + 2);
-        const bool lin = AR <= 32 * 12 && NQ < (1L << 31) && NQ * g.CI < (1L << 31) && !getenv("HLMI_CONV_IM2COL");   // W <= 125
+        const bool lin = AR <= 32 * 12 && NQ < (1L << 31) && NQ * g.CI < (1L << 31);   // W <= 125
         // conv3x3_bf16_p: 256-position tiles, B through LDS (see the kernel); the older kernels stay for what it does not take
         // (the A/B switches of round 3 — 128-position tiles with two workgroups per CU, staggered starts, the ablation masks —
         // are retired: profiles/r03_conv_bf16_ablation.txt has what they measured; the kernel keeps its template parameters)
         const int TQp = TQ;
         const int ARp = TQp + 2 * (g.W + 2) + 2;
         const size_t sh_p = ((size_t)2 * ARp * PL + 2 * BSLOT) * sizeof(uint16_t);   // two A windows, two B slots
-        const bool pers = lin && ARp <= 64 * 8 && sh_p <= 160 * 1024 && g.CO % TC == 0 && g.CI % (2 * KL) == 0 &&
-                          !getenv("HLMI_CONV_OLD");
+        const bool pers = lin && ARp <= 64 * 8 && sh_p <= 160 * 1024 && g.CO % TC == 0 && g.CI % (2 * KL) == 0;
         const int layout = pers ? 2 : (lin ? 1 : 0);
         // The bf16 MFMA-B image of the filter is a function of the filter's contents only: it is kept per (filter
         // allocation, version, layout) and the pre-pass re-runs only when the filter changed (uploaded again because the

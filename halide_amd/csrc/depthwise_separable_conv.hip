@@ -263,7 +263,7 @@ extern "C" int depthwise_separable_conv(halide_buffer_t *input, halide_buffer_t 
                             (long)(0 - pointwise_filter->dim[1].min) * g.p_s1;
         const float *d_b = dev_ptr<float>(bias) + (long)(output->dim[0].min - bias->dim[0].min);
         timing_note_bytes(4.0 * ((double)g.CI * g.W * g.H * g.N + (double)g.CO * g.ow * g.oh * g.N));
-        if (g.FW == 3 && g.FH == 3 && g.IC == 32 && g.CO == 16 && g.CM == 1 && !getenv("HLMI_DSC_GENERIC")) {
+        if (g.FW == 3 && g.FH == 3 && g.IC == 32 && g.CO == 16 && g.CM == 1) {
             constexpr int TPX = 56;   // the driver's MobileNet-v2 layer (process.cpp:13): two tiles per 112-pixel row
             HLMI_LAUNCH(uc, "dsc_fused", ctx.stream, (dsc_fused_t<3, 3, 32, 16, TPX>), dim3((g.ow + TPX - 1) / TPX, g.oh, g.N), dim3(256), 0,
                         d_in, d_dw, d_pw, d_b, dev_ptr<float>(output), g);

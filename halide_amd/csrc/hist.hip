@@ -198,8 +198,7 @@ extern "C" int hist(halide_buffer_t *input, halide_buffer_t *output) {
                              (long)(0 - input->dim[2].min) * in_sc;
         HLMI_HIP(uc, hipMemsetAsync(ghist, 0, HSUB * 256 * sizeof(unsigned), st));
         const bool vec_in = (uintptr_t)din % 4 == 0 && in_sy % 4 == 0 && in_sc % 4 == 0;
-        static const int rpb_env = getenv("HLMI_HIST_RPB") ? atoi(getenv("HLMI_HIST_RPB")) : 0;   // A/B
-        const int rpb = rpb_env > 0 ? rpb_env : 4, nblk = (H + rpb - 1) / rpb;
+        const int rpb = 4, nblk = (H + rpb - 1) / rpb;   // rows per block (2 / 8 / 16 measured slower)
         timing_note_bytes(3.0 * W * H);
         if (vec_in && W % 4 == 0) HLMI_LAUNCH(uc, "hist_count", st, hist_count<true>, dim3(nblk), dim3(256), 0, din, in_sy, in_sc, W, H, rpb, ghist);
         else HLMI_LAUNCH(uc, "hist_count", st, hist_count<false>, dim3(nblk), dim3(256), 0, din, in_sy, in_sc, W, H, rpb, ghist);

@@ -396,9 +396,7 @@ extern "C" int interpolate(halide_buffer_t *input, halide_buffer_t *output) {
             dim3 grid((ds[l].w + 255) / 256, ds[l].h), block(256);
             snprintf(nm, sizeof nm, "ip_down:%d", l);
             if (l == 1) {
-                static const bool untiled = getenv("HLMI_IP_UNTILED") != nullptr;   // A/B: one thread per cell, 36 loads each
-                if (untiled) HLMI_LAUNCH(uc, nm, st, (ip_down<true, false>), grid, block, 0, g, ds[1], ds[1], cw, ch);
-                else HLMI_LAUNCH(uc, nm, st, ip_down0_tile, dim3((ds[1].w + I0W - 1) / I0W, (ds[1].h + I0H - 1) / I0H), dim3(256), 0, g, ds[1]);
+                HLMI_LAUNCH(uc, nm, st, ip_down0_tile, dim3((ds[1].w + I0W - 1) / I0W, (ds[1].h + I0H - 1) / I0H), dim3(256), 0, g, ds[1]);
             }
             else if (l == 4) HLMI_LAUNCH(uc, nm, st, (ip_down<false, true>), grid, block, 0, g, ds[l - 1], ds[l], cw, ch);
             else HLMI_LAUNCH(uc, nm, st, (ip_down<false, false>), grid, block, 0, g, ds[l - 1], ds[l], cw, ch);

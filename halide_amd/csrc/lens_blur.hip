@@ -847,10 +847,6 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
         if ((long)PB[i - 1].w * PB[i - 1].h <= 128 * 128 * 4 && (long)P[i].w * P[i].h <= 128 * 128) tail = i;
         else break;
     }
-    {
-        const char *e = getenv("HLMI_LB_TAIL_FROM");   // A/B: 8 = no tail launch
-        if (e && *e) tail = max(2, min(LV, atoi(e)));
-    }
     for (int i = fused ? 2 : 1; i < tail; i++) {
         char nm[24];
         snprintf(nm, sizeof nm, "lb_down:%d", i);
@@ -865,8 +861,7 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
         snprintf(nm, sizeof nm, "lb_tail:%d", tail);
         long need = 0;
         for (int i = tail; i < LV; i++) need += (long)PB[i].w * PB[i].h + (long)P[i].w * P[i].h;
-        const char *e = getenv("HLMI_LB_TAIL_GLOBAL");   // A/B: the levels of the tail in global memory
-        if (need <= TAIL_LDS && !(e && *e && atoi(e) != 0)) HLMI_LAUNCH(uc, nm, st, lb_tail_lds, dim3(zc), dim3(1024), 0, ta);
+        if (need <= TAIL_LDS) HLMI_LAUNCH(uc, nm, st, lb_tail_lds, dim3(zc), dim3(1024), 0, ta);
         else HLMI_LAUNCH(uc, nm, st, lb_tail, dim3(zc), dim3(1024), 0, ta);
     }
     for (int i = min(LV - 1, tail - 1); i >= 1; i--) {

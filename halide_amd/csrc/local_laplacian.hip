@@ -2078,8 +2078,8 @@ uint64_t g_graph_clock = 0;
 
 uint64_t ll_env_signature() {
     static const char *const names[] = {"HLMI_LL_NO_LUT_CACHE", "HLMI_LL_UNITS0", "HLMI_LL_NO_VEC",
-                                        "HLMI_LL_D01_EXCH", "HLMI_LL_FUSE_FROM", "HLMI_LL_UNITSB", "HLMI_LL_UPCHAIN_FROM",
-                                        "HLMI_LL_UP0_OLD", "HLMI_LL_FUSE_UP1", "HLMI_LL_RU", "HLMI_LL_EMIT", "HLMI_LL_NT", "HLMI_LL_LDS_PAD", "HLMI_LL_FUSE_UP2"};
+                                        "HLMI_LL_D01_EXCH", "HLMI_LL_FUSE_FROM", "HLMI_LL_UPCHAIN_FROM", "HLMI_LL_RU", "HLMI_LL_EMIT", "HLMI_LL_NT",
+                                        "HLMI_LL_FUSE_UP2"};
     uint64_t h = 1469598103934665603ull;
     for (const char *n : names) {
         const char *e = getenv(n);
@@ -2276,10 +2276,10 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
               out_sc % 2 == 0 && ((p.ox0 - gm.ix0) % 2 == 0) && !env_int("HLMI_LL_NO_VEC", 0);
         for (int ch = 0; ch < 3; ch++) vec = vec && p.gco[ch] % 2 == 0 && p.cco[ch] % 2 == 0;
         fast = vec && same && nc == 3 && (ow & 1) == 0 && (p.ox0 & 1) == 0 &&
-               (double)(levels + 1) * (4.0 * (double)c.ps) < 4.0e9 && !env_int("HLMI_LL_UP0_OLD", 0);
+               (double)(levels + 1) * (4.0 * (double)c.ps) < 4.0e9;
         // the fused collapse needs level 2 to be a stored level of its own (SU >= 2 always holds: SU >= S >= 4 or the
         // opt-in up-chain, which starts at >= 1 and then owns level 1 itself)
-        fuse1 = fast && SU >= 2 && env_int("HLMI_LL_FUSE_UP1", 1);
+        fuse1 = fast && SU >= 2;
         // rows per wave: taller tiles re-read less of level 1 (18 coarse rows per 16 output rows, 34 per 32) but keep a wave
         // busy longer.  On a CU-partitioned stream, where several frames share the memory system and the frame rate is set by
         // bytes, 32 rows measure 2.7 % faster (84.8 vs 82.6 Gpx/s); on a stream that owns the device 16 rows do (72.7 vs 68.2).
@@ -2371,7 +2371,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             a.nsy_magic = a.nsy == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)a.nsy + 1ull);   // 0: nsy == 1
             a.rows_base = e.h / a.nsy, a.rows_rem = e.h % a.nsy;
             dim3 grid2((a.nunits + WPB - 1) / WPB);
-            const size_t sh2 = sizeof(float) * ((nlut + 1) & ~1) + sizeof(float2) * D01_STATE * (WPB + (exch ? WPB - 1 : 0)) + (size_t)env_int("HLMI_LL_LDS_PAD", 0);   // pad: occupancy experiment
+            const size_t sh2 = sizeof(float) * ((nlut + 1) & ~1) + sizeof(float2) * D01_STATE * (WPB + (exch ? WPB - 1 : 0));
             if (emit) {
                 // input read once; outLPyramid[0] (4 B per output pixel), three level-1 planes and K + 1 level-2 planes written
                 timing_note_bytes(6.0 * iw * (gm.iy1 - gm.iy0 + 1) + 4.0 * iw * oh + 4.0 * 3.0 * d.w * d.h + 4.0 * (levels + 1) * e.w * e.h);
@@ -2457,7 +2457,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         const Level &s = lv[j], &d = lv[j + 1];
         // enough waves to fill the chip on the big levels, short strips on the small ones
         const int cols = d.nsx * (levels + 1);
-        const int target = env_int("HLMI_LL_UNITSB", 16 * stream_cu_count(ctx.device, nullptr));
+        const int target = 16 * stream_cu_count(ctx.device, nullptr);
         const int nsy = max(1, min(max(target / cols, (d.h + 31) / 32), max(1, d.h / 2)));
         const int nunits = cols * nsy;
         dim3 grid((nunits + 3) / 4), block(256);

@@ -30,163 +30,16 @@ namespace {
 constexpr int P = 7, SA = 7, HALF = 3;
 constexpr int TW = 58;                           // output tile width; the height TH is a template parameter (64 or 80)
 constexpr int IW = TW + 4 * HALF, IWP = 71;      // input window (halo 3 patch + 3 search), padded pitch
-constexpr int BWP = 65;                          // blur_d_y tile: TW + 6 = 64 columns, padded pitch
 // Threads per workgroup NT = 16 TH: a thread owns 4 rows of a blur_d_y column in phase 1 (ROWS1) and 4 pixels of a row in
 // phase 2 (SEG).  TH = 64 (1024 threads, 81 KB: one workgroup per CU) leaves a third of the chip idle at 1920 x 1080 —
 // 578 tiles on 256 CUs run as three rounds of ~95 us (scripts/nlm_scale.py) — TH = 16 (256 threads, 28 KB, five
 // workgroups per CU that interleave their phases) has 2312 tiles that back-fill the CUs as they finish.
-constexpr size_t lds_bytes(int th) { return sizeof(float) * ((size_t)3 * (th + 4 * HALF) * IWP + (size_t)2 * th * BWP + 4); }  // + 4: phase 2 reads whole SEG + 6 windows
 
 struct NGeom {
     int ix0, ix1, iy0, iy1, ic0, ic1;  // clamp box of the input (absolute)
     int ox0, oy0, ow, oh;              // output region (absolute origin, extents)
     float inv;                         // -1 / (sigma*sigma*patch*patch)
 };
-
-// TH: tile height (a multiple of GROUPS).  Phase 2 is thread <-> (row r2 = tid % TH, x segment s2 = tid / TH).
-template<int TH, int NT>
-__global__ __launch_bounds__(NT) void nlm_7x7(const float *__restrict__ in, long in_sy, long in_sc, NGeom g,
-                                              float *__restrict__ out, long out_sy, long out_sc) {
-    constexpr int IH = TH + 4 * HALF;
-    constexpr int GROUPS = NT / 64;                  // phase-1 row groups
-    constexpr int ROWS1 = TH / GROUPS;               // rows of blur_d_y a phase-1 thread produces
-    constexpr int NSEG = NT / TH;                    // phase-2 x segments
-    constexpr int SEG = (TW + NSEG - 1) / NSEG;      // pixels per segment (the last one shorter)
-    static_assert(TH % GROUPS == 0 && NSEG * SEG >= TW, "tile shape");
-    extern __shared__ float lds[];
-    float *sin = lds;                       // [3][IH][IWP]
-    float *sbdy0 = lds + 3 * IH * IWP;      // [2][TH][BWP]: blur_d_y of even / odd offsets — one barrier per offset instead of two
-                                            // (phase 1 of offset k+1 writes the buffer whose last readers finished before barrier k)
-    const int tid = threadIdx.x;
-    const int tx0 = g.ox0 + blockIdx.x * TW, ty0 = g.oy0 + blockIdx.y * TH;  // absolute coords of the tile
-
-    // stage the clamped input window (repeat_edge on x, y and c, generator :27)
-    for (int i = tid; i < 3 * IH * IW; i += NT) {
-        int c = i / (IH * IW), rem = i - c * (IH * IW), r = rem / IW, col = rem - r * IW;
-        int x = dev::clampi(tx0 - 2 * HALF + col, g.ix0, g.ix1) - g.ix0;
-        int y = dev::clampi(ty0 - 2 * HALF + r, g.iy0, g.iy1) - g.iy0;
-        int cc = dev::clampi(c, g.ic0, g.ic1) - g.ic0;
-        sin[(c * IH + r) * IWP + col] = in[(long)y * in_sy + x + (long)cc * in_sc];
-    }
-    __syncthreads();
-
-    // phase-1 role: column cx of the blur_d_y tile (abs x = tx0 - 3 + cx), rows [ROWS1*g1, ROWS1*g1 + ROWS1)
-    const int cx = tid & 63, g1 = tid >> 6;
-    // phase-2 role: row r2, pixels [SEG*s2, SEG*s2 + npx)
-    const int r2 = tid % TH, s2 = tid / TH;
-    const int xb = s2 * SEG, npx = (s2 < NSEG) ? max(0, min(SEG, TW - xb)) : 0;
-
-    float acc[SEG][4];
-#pragma unroll
-    for (int j = 0; j < SEG; j++) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f;
-
-    // The kernel is bound by LDS instruction issue (one ds_read_b32 = 2 LDS cycles per wave, 16 waves on one LDS pipe),
-    // so everything that does not change with the offset stays in registers:
-    //   * phase 1: the UNSHIFTED operand of d — the thread's ROWS1 + 6 rows x 3 channels at its own column — is read
-    //     once, before the offset loops (half of the phase-1 reads)
-    //   * both phases issue all their LDS reads first and compute afterwards (the dx loop is unrolled: every offset is a
-    //     compile-time constant folded into the read instructions)
-    const int col = cx + HALF;            // window column of abs x
-    const int row0 = ROWS1 * g1 + HALF;   // window row of abs y = ty0 + ROWS1*g1 - 3
-    constexpr bool HOIST = ROWS1 <= 4;   // taller row segments: both operands are read per offset (registers)
-    float u[HOIST ? ROWS1 + 6 : 1][3];
-    if (HOIST) {
-#pragma unroll
-        for (int i = 0; i < ROWS1 + 6; i++) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) u[i][c] = sin[(c * IH + row0 + i) * IWP + col];
-        }
-    }
-    const float *unshifted = sin + row0 * IWP + col;
-
-    int parity = 0;
-#pragma unroll 1
-    for (int dy = -HALF; dy <= HALF; dy++) {
-        const float *shifted = sin + (row0 + dy) * IWP + col;
-        const float *srow = sin + (r2 + 2 * HALF + dy) * IWP + xb + HALF;
-#pragma unroll
-        for (int dxi = 0; dxi < SA; dxi++) {
-            const int dx = dxi - HALF;
-            float *sbdy = sbdy0 + parity * (TH * BWP);
-            const float *brow = sbdy + r2 * BWP + xb;
-            parity ^= 1;
-            // ---- phase 1: d -> blur_d_y.  All reads first, then the arithmetic row-parallel: a wave that reads three
-            // values and waits for them ten times over exposes the LDS latency ten times.
-            {
-                float sh[ROWS1 + 6][3], uu[HOIST ? 1 : ROWS1 + 6][3];
-#pragma unroll
-                for (int i = 0; i < ROWS1 + 6; i++) {
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        sh[i][c] = shifted[(c * IH + i) * IWP + dx];
-                        if (!HOIST) uu[i][c] = unshifted[(c * IH + i) * IWP];
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                float d[ROWS1 + 6];
-#pragma unroll
-                for (int i = 0; i < ROWS1 + 6; i++) {
-                    // the oracle's sums start from 0; 0 + x is x for every x but -0, and a square or a sum of squares is
-                    // never -0: the first term is taken as it is (18 of 254 VALU instructions per offset)
-                    float dd;
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        const float t = (HOIST ? u[i][c] : uu[i][c]) - sh[i][c];
-                        dd = c == 0 ? t * t : dd + t * t;
-                    }
-                    d[i] = dd;
-                }
-#pragma unroll
-                for (int o = 0; o < ROWS1; o++) {
-                    float sum = d[o];
-#pragma unroll
-                    for (int q = 1; q < 7; q++) sum = sum + d[o + q];
-                    sbdy[(ROWS1 * g1 + o) * BWP + cx] = sum;
-                }
-            }
-            __syncthreads();
-            // ---- phase 2: blur_d, weight, accumulate
-            if (npx > 0) {
-                float bw[SEG + 6], sv[3][SEG];
-#pragma unroll
-                for (int q = 0; q < SEG + 6; q++) bw[q] = brow[q];   // q < npx + 6 is what is used; the rest stays inside the tile's LDS
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-#pragma unroll
-                    for (int j = 0; j < SEG; j++) sv[c][j] = srow[c * IH * IWP + j + dxi];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < SEG; j++) {
-                    if (j < npx) {
-                        float sum = bw[j];
-#pragma unroll
-                        for (int q = 1; q < 7; q++) sum = sum + bw[j + q];
-                        const float w = dev::fast_exp(sum * g.inv);
-#pragma unroll
-                        for (int c = 0; c < 3; c++) acc[j][c] = acc[j][c] + w * sv[c][j];
-                        acc[j][3] = acc[j][3] + w * 1.0f;
-                    }
-                }
-            }
-        }
-    }
-    // ---- normalise + store
-    const int Y = ty0 + r2 - g.oy0;
-    if (Y < g.oh) {
-#pragma unroll
-        for (int j = 0; j < SEG; j++) {
-            const int X = tx0 + xb + j - g.ox0;
-            if (j < npx && X < g.ow) {
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    out[(long)Y * out_sy + X + (long)c * out_sc] = dev::clampf(acc[j][c] / acc[j][3], 0.0f, 1.0f);
-                }
-            }
-        }
-    }
-}
-
 
 // ---- nlm_7x7w: the same computation with NO barrier inside the offset loop.  nlm_7x7 hands blur_d_y from its phase-1 threads
 // (a column, four rows) to its phase-2 threads (a row, four pixels) through LDS, one workgroup barrier per offset: all waves
@@ -422,53 +275,13 @@ extern "C" int nl_means(halide_buffer_t *input, int32_t patch_size, int32_t sear
     const long in_sy = input->dim[1].stride, in_sc = input->dim[2].stride;
     const long out_sy = output->dim[1].stride, out_sc = output->dim[2].stride;
     if (patch_size == P && search_area == SA) {
-        // tile height: 32 by default (512 threads, two or three workgroups per CU; see NT above); HLMI_NLM_TH = 16 / 64 / 80 for A/B
-        const char *e = getenv("HLMI_NLM_TH");
-        const int th = e ? atoi(e) : 32;
-#define NLM_LAUNCH(TH_, NT_)                                                                                                  \
-    do {                                                                                                                      \
-        HLMI_HIP(uc, hipFuncSetAttribute((const void *)nlm_7x7<TH_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize,           \
-                                         (int)lds_bytes(TH_)));                                                               \
-        dim3 grid((ow + TW - 1) / TW, (oh + TH_ - 1) / TH_);                                                                  \
-        HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, (nlm_7x7<TH_, NT_>), grid, dim3(NT_), lds_bytes(TH_), din, in_sy, in_sc, g, dout, \
-                    out_sy, out_sc);                                                                                          \
-    } while (0)
-#define NLM_LAUNCH_W(TH_)                                                                                                     \
-    do {                                                                                                                      \
-        const size_t sh_w = sizeof(float) * ((size_t)3 * (TH_ + 4 * HALF) * IWP + (xl ? (size_t)TH_ * XSP : 0));                 \
-        dim3 grid((ow + TW - 1) / TW, (oh + TH_ - 1) / TH_);                                                                  \
-        if (xl) {                                                                                                             \
-            HLMI_HIP(uc, hipFuncSetAttribute((const void *)nlm_7x7w<TH_, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_w)); \
-            HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, (nlm_7x7w<TH_, 4, true>), grid, dim3(16 * TH_), sh_w, din, in_sy, in_sc, g, dout, out_sy, \
-                        out_sc);                                                                                              \
-        } else {                                                                                                              \
-            HLMI_HIP(uc, hipFuncSetAttribute((const void *)nlm_7x7w<TH_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_w)); \
-            HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, (nlm_7x7w<TH_>), grid, dim3(16 * TH_), sh_w, din, in_sy, in_sc, g, dout, out_sy, \
-                        out_sc);                                                                                              \
-        }                                                                                                                     \
-    } while (0)
-        const char *xe = getenv("HLMI_NLM_XLDS");   // A/B: 0 = the column sum by DPP moves instead of a wave-private LDS row
-        const bool xl = !(xe && *xe == '0');
-        const char *lk = getenv("HLMI_NLM_LDS");   // A/B: the kernel that hands blur_d_y through LDS (a barrier per offset)
-        const char *r4 = getenv("HLMI_NLM_ROWS4");   // A/B: four rows per wave (512 threads) instead of eight (256)
-        const bool rows8 = getenv("HLMI_NLM_ROWS8") || (th == 32 && !(lk && *lk && *lk != '0') && !(r4 && *r4 && *r4 != '0'));
-        if (rows8) {
-            const size_t sh_w = sizeof(float) * ((size_t)3 * (32 + 4 * HALF) * IWP + (xl ? (size_t)32 * XSP : 0));
-            dim3 grid((ow + TW - 1) / TW, (oh + 31) / 32);
-            if (xl) HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, (nlm_7x7w<32, 8, true>), grid, dim3(256), sh_w, din, in_sy, in_sc, g, dout, out_sy, out_sc);
-            else HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, (nlm_7x7w<32, 8>), grid, dim3(256), sh_w, din, in_sy, in_sc, g, dout, out_sy, out_sc);
-        } else
-        if (!lk || !*lk || *lk == '0') {
-            if (th == 16) NLM_LAUNCH_W(16);
-            else if (th == 64) NLM_LAUNCH_W(64);
-            else NLM_LAUNCH_W(32);
-        } else
-        if (th == 80) NLM_LAUNCH(80, 1024);
-        else if (th == 64) NLM_LAUNCH(64, 1024);
-        else if (th == 16) NLM_LAUNCH(16, 256);
-        else NLM_LAUNCH(32, 512);
-#undef NLM_LAUNCH
-#undef NLM_LAUNCH_W
+        // nlm_7x7w<32, 8, true>: 58 x 32 output tiles, a wave owns 64 columns x 8 rows for both stages, the row sum through a
+        // wave-private LDS row.  (Round 2's kernel with a barrier per offset, four rows per wave, the DPP row sum and the other tile
+        // heights were A/B switches of rounds 2-3 — HLMI_NLM_LDS / ROWS4 / XLDS / TH — and went with their measurements,
+        // profiles/r03_nlm_pmc.txt.)
+        const size_t sh_w = sizeof(float) * ((size_t)3 * (32 + 4 * HALF) * IWP + (size_t)32 * XSP);
+        dim3 grid((ow + TW - 1) / TW, (oh + 31) / 32);
+        HLMI_LAUNCH(uc, "nlm_7x7", ctx.stream, (nlm_7x7w<32, 8, true>), grid, dim3(256), sh_w, din, in_sy, in_sc, g, dout, out_sy, out_sc);
     } else {
         HLMI_LAUNCH(uc, "nlm_generic", ctx.stream, nlm_generic, dim3((ow + 255) / 256, oh), dim3(256), 0, din, in_sy, in_sc, g,
                     patch_size, search_area, dout, out_sy, out_sc);

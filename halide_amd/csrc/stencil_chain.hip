@@ -23,17 +23,14 @@ constexpr int STENCILS = 32;  // GeneratorParam stencils (:7)
 constexpr int FUSE = 8;
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-// ---- stencil_fused8w: a WAVE owns whole rows of the window: lane l holds the column pair (2l, 2l+1), so the horizontal
-// neighbours are the adjacent lanes and come by DPP wave shifts instead of two more LDS reads.  Per stage a wave walks its
-// share of the rows top to bottom with the five-row vertical window of RAW dwords in registers (vertical pass first),
-// then runs the horizontal pass on the vertical sums.  All 64 lanes are always active: what the edge lanes compute from
-// their missing neighbours is garbage that moves inwards 2 pixels per stage — exactly the shrinking valid box — and is
-// never stored.  Per pair, row and stage: 1 LDS read, 8 v_pk_mad_u16, 2 DPP moves, 2 v_alignbit, 1 LDS write.  (The
-// first version — a 96 x 96 window, lanes = (column pair, row segment), three LDS reads per pair for the horizontal
-// pass, ~10 % idle lanes, element-wise window moves — took 0.200 ms at 1536 x 2560 against 0.117 ms now.)
-constexpr int WTW = 96, WTH = 64, WRW = WTW + 4 * FUSE, WRH = WTH + 4 * FUSE;   // 128 x 96 window
+// ---- lane layout of the fused kernel: a WAVE owns whole rows of the 128-column window, lane l holds the column pair
+// (2l, 2l+1), so the horizontal neighbours are the adjacent lanes and come by DPP wave shifts; all 64 lanes are always active:
+// what the edge lanes compute from their missing neighbours is garbage that moves inwards 2 pixels per stage — exactly the
+// shrinking valid box — and is never stored.  (Round 2's stencil_fused8w kept the window in LDS — one dependent ds_read and
+// ds_write per row and stage, a barrier per stage: 0.117 ms at 1536 x 2560 — and was retired in round 4 together with its
+// switch HLMI_SC_LDS, as was the eight-thin-waves variant HLMI_SC_THIN; the register-window kernel below runs 0.086 ms.)
+constexpr int WTW = 96, WRW = WTW + 4 * FUSE;   // output tile width; window width = 128
 static_assert(WRW == 128, "one wave = one window row: 64 lanes x 2 columns");
-constexpr int WLD = WRW / 2;                                                      // row pitch in dwords (64)
 __device__ __forceinline__ uint32_t sc_lane_prev(uint32_t v) {   // lane-1's value (0 for lane 0): DPP wave_shr:1
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
 }
@@ -42,114 +39,14 @@ __device__ __forceinline__ uint32_t sc_lane_next(uint32_t v) {   // lane+1's val
 }
 // PIN / POUT: the window / the tile moves as aligned dwords (even row strides and origins: always true between launches
 // when the width is even)
-template<bool CLAMP, bool PIN, bool POUT>
-__global__ __launch_bounds__(256) void stencil_fused8w(const uint16_t *__restrict__ src, long src_sy, int sx0, int sy0, int sw,
-                                                       int sh, uint16_t *__restrict__ dst, long dst_sy, int dx0, int dy0,
-                                                       int dw, int dh) {
-    __shared__ uint32_t buf[2][WRH * WLD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ox = dx0 + blockIdx.x * WTW, oy = dy0 + blockIdx.y * WTH;  // absolute coords of the output tile
-    const int gx = ox - 2 * FUSE, gy = oy - 2 * FUSE;                    // absolute coords of the window origin
-    // CLAMP (stage 0, the caller's input): dwords only for windows that lie inside the input (no clamp binds)
-    const bool inside = gx >= sx0 && gx + WRW <= sx0 + sw && gy >= sy0 && gy + WRH <= sy0 + sh;
-    if (PIN && (!CLAMP || inside)) {
-        for (int i = tid; i < WLD * WRH; i += 256) {
-            const int r = i / WLD, cd = i - r * WLD;
-            const int x = gx + 2 * cd - sx0, y = gy + r - sy0;
-            const bool ok = CLAMP || (x >= 0 && x + 1 < sw && y >= 0 && y < sh);
-            buf[0][i] = ok ? *reinterpret_cast<const uint32_t *>(src + (long)y * src_sy + x) : 0u;
-        }
-    } else {
-        uint16_t *b0 = reinterpret_cast<uint16_t *>(buf[0]);
-        for (int i = tid; i < WRW * WRH; i += 256) {
-            const int r = i / WRW, c = i - r * WRW;
-            int x = gx + c - sx0, y = gy + r - sy0;
-            if (CLAMP) {
-                x = min(max(x, 0), sw - 1);
-                y = min(max(y, 0), sh - 1);
-                b0[r * WRW + c] = src[(long)y * src_sy + x];
-            } else {
-                // windows of edge tiles may poke outside the producer's domain; those cells only ever feed outputs
-                // outside the destination domain, which are not stored
-                const bool ok = x >= 0 && x < sw && y >= 0 && y < sh;
-                b0[r * WRW + c] = ok ? src[(long)y * src_sy + x] : (uint16_t)0;
-            }
-        }
-    }
-    __syncthreads();
-    int cur = 0;
-    auto U = [](uint32_t v) { return __builtin_bit_cast(u16x2, v); };
-    // the weights live in scalar registers the compiler cannot see through: with literal 2 and 4 it strength-reduces the
-    // products to v_pk_lshlrev_b16 + v_pk_add_u16 (12 packed ops per row instead of 8 v_pk_mad_u16)
-    uint32_t w2 = 0x00020002u, w3 = 0x00030003u, w4 = 0x00040004u, w5 = 0x00050005u;
-    asm volatile("" : "+s"(w2), "+s"(w3), "+s"(w4), "+s"(w5));
-    const u16x2 k2 = U(w2), k3 = U(w3), k4 = U(w4), k5 = U(w5);
-#pragma unroll 1
-    for (int m = 0; m < FUSE; m++) {
-        const int lo = 2 * (m + 1), oh = WRH - 2 * lo;   // valid output rows [lo, lo + oh)
-        const int seglen = (oh + 3) / 4;
-        const int ys = lo + wave * seglen, ye = min(ys + seglen, lo + oh);
-        const uint32_t *s = buf[cur] + lane;
-        uint32_t *d = buf[cur ^ 1] + lane;
-        if (ys < ye) {
-            u16x2 r0 = U(s[(ys - 2) * WLD]), r1 = U(s[(ys - 1) * WLD]), r2 = U(s[ys * WLD]), r3 = U(s[(ys + 1) * WLD]), r4;
-            // one output row: a..dd = rows y-2..y+1 (oldest first), e receives row y+2
-            auto step = [&](int y, const u16x2 &a, const u16x2 &b, const u16x2 &c, const u16x2 &dd, u16x2 &e) {
-                e = U(s[(y + 2) * WLD]);
-                const u16x2 v = a + k2 * b + k3 * c + k4 * dd + k5 * e;                    // pair (x, x+1), vertical sums
-                const uint32_t vb = __builtin_bit_cast(uint32_t, v);
-                const uint32_t va = sc_lane_prev(vb), vc = sc_lane_next(vb);               // (x-2, x-1), (x+2, x+3)
-                const u16x2 S1 = U(__builtin_amdgcn_alignbit(vb, va, 16)), S2 = U(__builtin_amdgcn_alignbit(vc, vb, 16));
-                d[y * WLD] = __builtin_bit_cast(uint32_t, (u16x2)(U(va) + k2 * S1 + k3 * v + k4 * S2 + k5 * U(vc)));
-            };
-            int y = ys;
-            // five rows per trip: the rotation of the five-row window is a renaming of the arguments (the DPP moves are
-            // convergent operations, which keeps the compiler from unrolling a loop with a remainder by itself)
-            for (; y + 5 <= ye; y += 5) {
-                step(y, r0, r1, r2, r3, r4);
-                step(y + 1, r1, r2, r3, r4, r0);
-                step(y + 2, r2, r3, r4, r0, r1);
-                step(y + 3, r3, r4, r0, r1, r2);
-                step(y + 4, r4, r0, r1, r2, r3);
-            }
-            for (; y < ye; y++) {
-                step(y, r0, r1, r2, r3, r4);
-                r0 = r1, r1 = r2, r2 = r3, r3 = r4;
-            }
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-    if (POUT) {
-        for (int i = tid; i < (WTW / 2) * WTH; i += 256) {
-            const int r = i / (WTW / 2), cd = i - r * (WTW / 2);
-            const int X = ox + 2 * cd - dx0, Y = oy + r - dy0;
-            if (X + 1 < dw && Y < dh) {
-                *reinterpret_cast<uint32_t *>(dst + (long)Y * dst_sy + X) = buf[cur][(r + 2 * FUSE) * WLD + cd + FUSE];
-            } else if (X < dw && Y < dh) {
-                dst[(long)Y * dst_sy + X] = (uint16_t)(buf[cur][(r + 2 * FUSE) * WLD + cd + FUSE] & 0xffffu);
-            }
-        }
-        return;
-    }
-    const uint16_t *res = reinterpret_cast<const uint16_t *>(buf[cur]);
-    for (int i = tid; i < WTW * WTH; i += 256) {
-        const int r = i / WTW, c = i - r * WTW;
-        const int X = ox + c - dx0, Y = oy + r - dy0;
-        if (X < dw && Y < dh) dst[(long)Y * dst_sy + X] = res[(r + 2 * FUSE) * WRW + c + 2 * FUSE];
-    }
-}
-
-
-// ---- stencil_fused8r: the same 8 fused stages with the window in REGISTERS.  stencil_fused8w moves every row of every stage
-// through LDS (one dependent ds_read + one ds_write per 12 packed multiply-adds, a barrier per stage) and its waves spend more
-// time waiting for the LDS round trips than computing (0.117 ms where the executed multiply-adds need 0.035 ms).  Here a wave
+// ---- stencil_fused8r: 8 fused stages with the window in REGISTERS (the LDS-window kernel spent more time waiting for LDS
+// round trips than computing: 0.117 ms where the executed multiply-adds need 0.035 ms).  A wave
 // keeps its RW rows of the window — lane l = column pair (2l, 2l+1), one dword per row — in RW registers for all 8 stages
 // and updates them in place, top to bottom, with the two previous ORIGINAL rows carried in temporaries; the four waves of a
 // workgroup are stacked vertically (window = 128 columns x 4 RW rows) and only exchange their two top and two bottom rows
 // through LDS once per stage (8 LDS instructions per wave and stage instead of 2 per row; double-buffered by stage parity:
 // one barrier per stage).  The window comes from global memory straight into the registers and the central
-// 96 x (4 RW - 32) block goes straight back: no staging pass.  As in stencil_fused8w all lanes and rows are always computed;
+// 96 x (4 RW - 32) block goes straight back: no staging pass.  All lanes and rows are always computed;
 // what the edge lanes / edge rows make of their missing neighbours is garbage that moves inwards 2 pixels per stage — the
 // shrinking valid box — and is never stored.  RW = 32: 96 x 96 outputs per workgroup (1.78x halo recomputation instead of the
 // LDS version's 2.0x), 476 workgroups at 1536 x 2560.
@@ -202,7 +99,8 @@ __global__ __launch_bounds__(64 * NW) void stencil_fused8r(const uint16_t *__res
             }
         }
     }
-    // the weights live in scalar registers the compiler cannot see through (see stencil_fused8w)
+    // the weights live in scalar registers the compiler cannot see through: with literal 2 and 4 it strength-reduces the
+    // products to v_pk_lshlrev_b16 + v_pk_add_u16 (12 packed ops per row instead of 8 v_pk_mad_u16)
     uint32_t w2 = 0x00020002u, w3 = 0x00030003u, w4 = 0x00040004u, w5 = 0x00050005u;
     asm volatile("" : "+s"(w2), "+s"(w3), "+s"(w4), "+s"(w5));
     const u16x2 k2 = U(w2), k3 = U(w3), k4 = U(w4), k5 = U(w5);
@@ -313,41 +211,22 @@ extern "C" int stencil_chain(halide_buffer_t *input, halide_buffer_t *output) {
         const int dx0 = ox0 - g, dy0 = oy0 - g, dw = W + 2 * g, dh = H + 2 * g;
         uint16_t *dst = (L == NL - 1) ? dev_ptr<uint16_t>(output) : tmp[L & 1];
         long dst_sy = (L == NL - 1) ? (long)output->dim[1].stride : (long)dw;
-        dim3 gridw((dw + WTW - 1) / WTW, (dh + WTH - 1) / WTH);
         constexpr int RW = 32, ORW = 4 * RW - 4 * FUSE;   // stencil_fused8r: rows per wave, output rows per workgroup
         dim3 gridr((dw + WTW - 1) / WTW, (dh + ORW - 1) / ORW);
-        const bool regs = !getenv("HLMI_SC_LDS");
         // dword moves: the intermediates are dense planes on even origins (their offsets from the tile grid are
         // multiples of 2 FUSE), so an even width makes every pair an aligned dword; the user's output needs checking
         const bool pin = L > 0 ? (sw % 2 == 0 && src_sy % 2 == 0)
                                : (src_sy % 2 == 0 && (uintptr_t)src % 4 == 0 && ((dx0 - 2 * FUSE - sx0) & 1) == 0);
         const bool pout = dst_sy % 2 == 0 && (uintptr_t)dst % 4 == 0;
-#define SC_W(C, I, O)                                                                                                          \
-HLMI_LAUNCH(uc, "stencil_fused8", ctx.stream, (stencil_fused8w<C, I, O>), gridw, dim3(256), 0, src, src_sy, sx0, sy0, sw, sh, dst, \
-            dst_sy, dx0, dy0, dw, dh)
 #define SC_R(C, I, O)                                                                                                          \
-do {                                                                                                                           \
-    if (thin) HLMI_LAUNCH(uc, "stencil_fused8", ctx.stream, (stencil_fused8r<C, I, O, 16, 8>), gridr, dim3(512), 0, src, src_sy, sx0, sy0, sw, \
-                          sh, dst, dst_sy, dx0, dy0, dw, dh);                                                                   \
-    else HLMI_LAUNCH(uc, "stencil_fused8", ctx.stream, (stencil_fused8r<C, I, O, RW>), gridr, dim3(256), 0, src, src_sy, sx0, sy0, sw, sh, dst, \
-                     dst_sy, dx0, dy0, dw, dh);                                                                                \
-} while (0)
-        const bool thin = getenv("HLMI_SC_THIN") != nullptr;   // A/B: eight waves of 16 rows instead of four of 32
-        if (regs) {
-            if (L == 0) {
-                if (pin) { if (pout) SC_R(true, true, true); else SC_R(true, true, false); }
-                else { if (pout) SC_R(true, false, true); else SC_R(true, false, false); }
-            }
-            else if (pin) { if (pout) SC_R(false, true, true); else SC_R(false, true, false); }
-            else { if (pout) SC_R(false, false, true); else SC_R(false, false, false); }
-        } else
+HLMI_LAUNCH(uc, "stencil_fused8", ctx.stream, (stencil_fused8r<C, I, O, RW>), gridr, dim3(256), 0, src, src_sy, sx0, sy0, sw, sh, dst, \
+            dst_sy, dx0, dy0, dw, dh)
         if (L == 0) {
-            if (pin) { if (pout) SC_W(true, true, true); else SC_W(true, true, false); }
-            else { if (pout) SC_W(true, false, true); else SC_W(true, false, false); }
+            if (pin) { if (pout) SC_R(true, true, true); else SC_R(true, true, false); }
+            else { if (pout) SC_R(true, false, true); else SC_R(true, false, false); }
         }
-        else if (pin) { if (pout) SC_W(false, true, true); else SC_W(false, true, false); }
-        else { if (pout) SC_W(false, false, true); else SC_W(false, false, false); }
-#undef SC_W
+        else if (pin) { if (pout) SC_R(false, true, true); else SC_R(false, true, false); }
+        else { if (pout) SC_R(false, false, true); else SC_R(false, false, false); }
 #undef SC_R
         src = dst, src_sy = dst_sy, sx0 = dx0, sy0 = dy0, sw = dw, sh = dh;
     }
