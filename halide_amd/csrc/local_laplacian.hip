@@ -17,16 +17,19 @@
 //   16-byte aligned.  The storage origin so_j is chosen (one column left of lo_j when necessary) so that the
 //   4-column groups the down-sampling waves load and the 2-column groups they store are naturally aligned.
 //
-// Kernels (one frame = 1 + 1 + 6 + 1 + 6 + 1 launches on one stream):
-//   ll_remap_lut   remap LUT (generator :23-25)
-//   ll_down0       level 0 -> 1, all K+1 planes; gray and gPyramid[0] never touch memory.  One WAVE owns a
-//                  strip of 126 level-1 columns x TY rows: each lane holds 4 adjacent level-0 columns, streams
-//                  down the rows with the vertical 1-3-3-1 window in registers (2 rows of state per plane),
-//                  exchanges the two edge columns with its neighbour lanes by DPP wave shifts for the
-//                  horizontal 1-3-3-1, and stores float2.  HBM-bound by design: 6 B/px read, 9 B/px written.
-//   ll_down_strip  level j -> j+1 (j >= 1), same wave-strip scheme, one plane per wave, float4 loads.
-//   ll_top, ll_up  outGPyramid[J-1], outGPyramid[j] (1 <= j <= J-2): pointwise, data-dependent plane gathers.
-//   ll_up0         outGPyramid[0] + recolour + u16 store, 2 columns per lane, LUT in LDS.
+// Kernels (DESIGN.md §4 has the measurements).  The common geometry — levels == 8, 8-byte-aligned u16 planes whose width is a
+// multiple of 4, three channels, even output origin and width — runs 6 launches per frame (7 on a stream that owns the device):
+//   ll_remap_lut    remap LUT (generator :23-25); cached per (device, levels, alpha)
+//   ll_down01e      levels 0 -> 1 -> 2 of all K+1 planes in ONE walk; emits outLPyramid[0] (one plane) and three planes of level 1
+//                   instead of the K+1-plane level-1 pyramid (round 4's dataflow; ll_down01f = round 3's, which stores them all)
+//   ll_down_strip   level j -> j+1 (j = 2, 3): wave-strip scheme, one plane per wave, float4 loads
+//   ll_down_multi   levels 5..7 from level 4 in one launch;  ll_up_multi: outGPyramid[3] from levels 3..7 in one launch
+//   ll_up           outGPyramid[2] (only on a stream that owns the device: on CU partitions ll_up0h collapses level 2 itself)
+//   ll_up0h         outGPyramid[1] (LDS tile) -> outGPyramid[0] = upsample + outLPyramid[0] -> recolour -> u16 store
+// Everything else (other `levels`, odd widths or strides, fewer channels, odd output origins) takes the general kernels:
+//   ll_down0        level 0 -> 1, any K (chunks of 8 planes), vector or element-wise loads;  ll_down_strip:1
+//   ll_top, ll_up   outGPyramid[J-1], outGPyramid[j]: pointwise, data-dependent plane gathers
+//   ll_up0 / ll_up0f  outGPyramid[0] + recolour from the materialised level-1 planes
 #include "hlmi_device_math.h"
 #include "hlmi_internal.h"
 
@@ -782,8 +785,8 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry 
 // data-dependent plane gathers from memory in the up pass: uniform noise costs what a smooth frame costs.
 // The up pass becomes outGPyramid[0] = upsample(outGPyramid[1]) + outLPyramid[0] + recolouring (ll_up0h).  Every Func is
 // still evaluated by the same operations on the same values: bit-identical to ll_down01f + ll_up0f.
-//   * Level-1 -> 2 window state: the two LDS slots per (plane, lane) now hold RAW level-1 rows only (slot T & 1... see the
-//     step); the partial sum pc = a + 3 (b + c) between an odd step and the even step that completes a level-2 row stays in
+//   * Level-1 -> 2 window state: the two LDS slots per (plane, lane) hold RAW level-1 rows only (rows T - 1 and T after step T);
+//     the partial sum pc = a + 3 (b + c) between an odd step and the even step that completes a level-2 row stays in
 //     registers (18; the kernel is launch-bound to two waves per SIMD = 256 VGPRs).  Same LDS footprint as ll_down01f.
 //   * Who emits what: the steps T in [2A, 2B + 1] of a unit owning level-2 rows [A, B] emit level-0 rows [4A - 1, 4B + 2]; a
 //     wave that takes rows 2B + 1, 2B + 2 from the wave below (EXCH) emits the last pair after its walk, from its own row 2B and
