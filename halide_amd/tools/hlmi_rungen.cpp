@@ -12,8 +12,8 @@
 //
 // Image files: PNG (8 / 16 bit, gray / gray+alpha / RGB / RGBA, non-interlaced — the formats tools/halide_image_io.h:856-1040
 // reads and writes; own codec over zlib in hlmi_png.h, this image has no libpng), binary PGM / PPM, and the reference's three raw
-// array formats: .npy, .mat (MATLAB level 5) and .tmp (ImageStack).  JPG and TIFF are not read (libjpeg is not linked; the
-// apps' drivers feed neither) — printed by --help.
+// array formats: .npy, .mat (MATLAB level 5) and .tmp (ImageStack), plus uncompressed TIFF (which the reference only writes).  JPG is
+// not handled (libjpeg is not linked; the apps' drivers feed none) — printed by --help.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -400,6 +400,127 @@ void save_tmp(const std::string &path, const Arg &a) {
     f.write((const char *)a.storage.data(), (std::streamsize)(count(a) * elem_bytes(a.md->type)));
 }
 
+// ---- .tiff: uncompressed baseline TIFF, one strip per sample plane.  The reference only WRITES TIFF (tools/halide_image_io.h:2109-2113
+// declines to read, :2230-2384 writes); the writer here produces the same kind of file -- little endian, planar when there is more
+// than one sample per pixel, SampleFormat from the element type, a third dimension beyond 4 samples stored as tag 32997 (ImageDepth)
+// -- and the reader accepts that family (either byte order, chunky or planar, any strip split), so a runner's output can be fed back.
+struct TiffField { uint16_t tag, type; uint32_t count, value; };
+void put16(std::vector<uint8_t> &o, uint16_t v) { o.push_back(v & 255), o.push_back(v >> 8); }
+void put32(std::vector<uint8_t> &o, uint32_t v) { for (int i = 0; i < 4; i++) o.push_back((v >> (8 * i)) & 255); }
+
+void save_tiff(const std::string &path, const Arg &a) {
+    if (a.dims.size() > 4) fail(path + ": TIFF holds at most 4 dimensions");
+    const halide_type_t t = a.md->type;
+    if (t.code > halide_type_float || t.bits < 8) fail(path + ": element type " + type_name(t) + " cannot be stored in a TIFF file");
+    uint32_t e[4] = {1, 1, 1, 1};
+    for (size_t d = 0; d < a.dims.size(); d++) e[d] = (uint32_t)a.dims[d].extent;
+    uint32_t depth = e[2], samples = e[3];
+    if (samples <= 1 && depth < 5) samples = depth, depth = 1;     // x, y, c with few channels: the third dimension is the sample
+    const uint64_t plane = (uint64_t)e[0] * e[1] * depth * (t.bits / 8);
+    if (plane * samples >> 31) fail(path + ": too large for a TIFF file");
+    const uint16_t sample_format = t.code == halide_type_uint ? 1 : t.code == halide_type_int ? 2 : 3;
+    // layout: header (8) | IFD (2 + 12 n + 4) | two rationals | strip offsets | strip byte counts | samples
+    const uint32_t n_fields = 15, ifd = 8, rationals = ifd + 2 + 12 * n_fields + 4, arrays = rationals + 16;
+    const uint32_t data = arrays + (samples > 1 ? 8 * samples : 0);
+    const TiffField fields[n_fields] = {
+        {256, 4, 1, e[0]}, {257, 4, 1, e[1]}, {258, 3, 1, (uint32_t)t.bits}, {259, 3, 1, 1},
+        {262, 3, 1, samples >= 3 ? 2u : 1u},                                       // RGB, or black is zero
+        {273, 4, samples, samples > 1 ? arrays : data}, {277, 3, 1, samples}, {278, 4, 1, e[1]},
+        {279, 4, samples, samples > 1 ? arrays + 4 * samples : (uint32_t)plane},
+        {282, 5, 1, rationals}, {283, 5, 1, rationals + 8}, {284, 3, 1, samples > 1 ? 2u : 1u}, {296, 3, 1, 1},
+        {339, 3, 1, sample_format}, {32997, 4, 1, depth}};
+    std::vector<uint8_t> o;
+    o.push_back('I'), o.push_back('I'), put16(o, 42), put32(o, ifd);
+    put16(o, n_fields);
+    for (const TiffField &f : fields) put16(o, f.tag), put16(o, f.type), put32(o, f.count), put32(o, f.value);
+    put32(o, 0);                                                                   // no further IFD
+    for (int i = 0; i < 4; i++) put32(o, 1);                                       // resolution 1/1 twice
+    if (samples > 1) {
+        for (uint32_t c = 0; c < samples; c++) put32(o, data + (uint32_t)(c * plane));
+        for (uint32_t c = 0; c < samples; c++) put32(o, (uint32_t)plane);
+    }
+    std::ofstream f(path, std::ios::binary);
+    f.write((const char *)o.data(), (std::streamsize)o.size());
+    f.write((const char *)a.storage.data(), (std::streamsize)(plane * samples));   // dense, dimension 0 innermost: already planar
+}
+
+void load_tiff(const std::string &path, Arg &a) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) fail("cannot open " + path);
+    std::vector<uint8_t> b((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (b.size() < 8 || (b[0] != 'I' && b[0] != 'M') || b[1] != b[0]) fail(path + ": not a TIFF file");
+    const bool be = b[0] == 'M';
+    auto need = [&](uint64_t off, uint64_t n) { if (off + n > b.size()) fail(path + ": file is truncated"); };
+    auto rd16 = [&](uint64_t off) { need(off, 2); return (uint32_t)(be ? b[off] << 8 | b[off + 1] : b[off + 1] << 8 | b[off]); };
+    auto rd32 = [&](uint64_t off) { need(off, 4); return be ? (uint32_t)b[off] << 24 | b[off + 1] << 16 | b[off + 2] << 8 | b[off + 3]
+                                                             : (uint32_t)b[off + 3] << 24 | b[off + 2] << 16 | b[off + 1] << 8 | b[off]; };
+    if (rd16(2) != 42) fail(path + ": not a TIFF file (BigTIFF is not supported)");
+    const uint64_t ifd = rd32(4);
+    const uint32_t n = rd16(ifd);
+    uint32_t width = 0, height = 0, bits = 1, compression = 1, samples = 1, rows_per_strip = 0xffffffffu, planar = 1, format = 1, depth = 1;
+    std::vector<uint32_t> offsets, counts;
+    // a field's values: inline in the entry when they fit in 4 bytes, else at the offset the entry holds
+    auto values = [&](uint64_t entry) {
+        const uint32_t type = rd16(entry + 2), cnt = rd32(entry + 4);
+        const uint32_t size = type == 3 ? 2 : type == 4 ? 4 : type == 1 ? 1 : 0;
+        if (!size || cnt > (1u << 24)) fail(path + ": unsupported TIFF field type");
+        const uint64_t at = (uint64_t)size * cnt <= 4 ? entry + 8 : rd32(entry + 8);
+        std::vector<uint32_t> v(cnt);
+        for (uint32_t i = 0; i < cnt; i++) v[i] = size == 2 ? rd16(at + 2 * i) : size == 4 ? rd32(at + 4 * i) : (need(at + i, 1), b[at + i]);
+        return v;
+    };
+    for (uint32_t i = 0; i < n; i++) {
+        const uint64_t entry = ifd + 2 + 12 * (uint64_t)i;
+        const uint32_t tag = rd16(entry);
+        if (tag == 282 || tag == 283) continue;                                    // rationals: not needed
+        auto first = [&]() { auto v = values(entry); if (v.empty()) fail(path + ": empty TIFF field"); return v[0]; };
+        switch (tag) {
+        case 256: width = first(); break;
+        case 257: height = first(); break;
+        case 258: { auto v = values(entry); bits = v.at(0); for (uint32_t x : v) if (x != bits) fail(path + ": mixed sample sizes"); break; }
+        case 259: compression = first(); break;
+        case 273: offsets = values(entry); break;
+        case 277: samples = first(); break;
+        case 278: rows_per_strip = first(); break;
+        case 279: counts = values(entry); break;
+        case 284: planar = first(); break;
+        case 339: format = first(); break;
+        case 32997: depth = first(); break;
+        default: break;
+        }
+    }
+    if (compression != 1) fail(path + ": compressed TIFF files are not supported");
+    if (!width || !height || !samples || !depth || width > (1u << 20) || height > (1u << 20) || samples > 65535) fail(path + ": bad TIFF dimensions");
+    if ((bits != 8 && bits != 16 && bits != 32 && bits != 64) || format < 1 || format > 3 || (format == 3 && bits < 32)) fail(path + ": unsupported TIFF sample type");
+    if (offsets.empty() || offsets.size() != counts.size()) fail(path + ": bad TIFF strip tables");
+    RawArray r;
+    r.type = {format == 1 ? halide_type_uint : format == 2 ? halide_type_int : halide_type_float, (uint8_t)bits, 1};
+    const size_t eb = bits / 8;
+    const uint64_t total = (uint64_t)width * height * depth * samples * eb;
+    if (total > (uint64_t)1 << 34) fail(path + ": TIFF extents are implausible");
+    std::vector<uint8_t> flat;                                                     // the strips, concatenated in file order
+    flat.reserve(total);
+    for (size_t s = 0; s < offsets.size(); s++) {
+        need(offsets[s], counts[s]);
+        flat.insert(flat.end(), b.begin() + offsets[s], b.begin() + offsets[s] + counts[s]);
+    }
+    if (flat.size() < total) fail(path + ": the strips hold fewer samples than the image");
+    (void)rows_per_strip;
+    if (be && eb > 1)
+        for (uint64_t i = 0; i < total; i += eb) std::reverse(flat.begin() + i, flat.begin() + i + eb);
+    r.bytes.resize(total);
+    const uint64_t px = (uint64_t)width * height * depth;
+    if (planar == 2 || samples == 1) {
+        memcpy(r.bytes.data(), flat.data(), total);
+    } else {                                                                       // chunky: sample index innermost in the file
+        for (uint64_t p = 0; p < px; p++)
+            for (uint32_t c = 0; c < samples; c++) memcpy(&r.bytes[(c * px + p) * eb], &flat[(p * samples + c) * eb], eb);
+    }
+    r.extents = {(int)width, (int)height, (int)depth, (int)samples};
+    if (depth == 1) r.extents = {(int)width, (int)height, (int)samples};
+    assign_raw(path, a, r);
+}
+
 void load_mat(const std::string &path, Arg &a) {
     std::ifstream f(path, std::ios::binary);
     if (!f) fail("cannot open " + path);
@@ -522,7 +643,7 @@ void usage() {
         "Usage: hlmi_rungen --name=PIPELINE argument=value [argument=value ...] [flags]\n"
         "   or: PIPELINE.rungen argument=value ... (pipeline = basename of argv[0] up to the first '.')\n\n"
         "Arguments follow the reference's RunGen (tools/RunGenMain.cpp): scalars as literals or `default` / `estimate`;\n"
-        "buffers as a file (.png .pgm .ppm .npy .mat .tmp) or a pseudo-file: zero:[e0,e1,..]  constant:V:[..]  identity:[..]\n"
+        "buffers as a file (.png .pgm .ppm .npy .mat .tmp .tiff) or a pseudo-file: zero:[e0,e1,..]  constant:V:[..]  identity:[..]\n"
         "random:SEED:[..]; `auto` or `estimate` may stand for the extents.\n\n"
         "Flags: --help --describe --output_extents=[..]|estimate --benchmarks=all --benchmark_min_time=SEC\n"
         "       --parsable_output --estimate_all --default_input_buffers[=V] --default_input_scalars[=V]\n"
@@ -682,11 +803,13 @@ int main(int argc, char **argv) {
         } else if (ends_with(spec, ".mat")) {
             load_mat(spec, a);
             a.spec.clear();
+        } else if (ends_with(spec, ".tiff") || ends_with(spec, ".tif")) {
+            load_tiff(spec, a);
         } else if (ends_with(spec, ".tmp")) {
             load_tmp(spec, a);
             a.spec.clear();
         } else {
-            fail("cannot read '" + spec + "': supported are .png .pgm .ppm .npy .mat .tmp and the pseudo-files of --help");
+            fail("cannot read '" + spec + "': supported are .png .pgm .ppm .npy .mat .tmp .tiff and the pseudo-files of --help");
         }
     }
     // ---- outputs: shape from --output_extents, the estimates, or a bounds query constrained by the inputs
@@ -787,7 +910,8 @@ int main(int argc, char **argv) {
         else if (ends_with(a.out_path, ".pgm") || ends_with(a.out_path, ".ppm")) save_pnm(a.out_path, a);
         else if (ends_with(a.out_path, ".mat")) save_mat(a.out_path, a);
         else if (ends_with(a.out_path, ".tmp")) save_tmp(a.out_path, a);
-        else fail("cannot write '" + a.out_path + "': supported are .png .pgm .ppm .npy .mat .tmp");
+        else if (ends_with(a.out_path, ".tiff") || ends_with(a.out_path, ".tif")) save_tiff(a.out_path, a);
+        else fail("cannot write '" + a.out_path + "': supported are .png .pgm .ppm .npy .mat .tmp .tiff");
     }
     for (auto &a : args)
         if (a.md->kind != halide_argument_kind_input_scalar && a.buf.device_interface) a.buf.device_interface->device_free(nullptr, &a.buf);

@@ -194,3 +194,92 @@ def test_damaged_mat_and_tmp_files_are_rejected(tmp_path):
     for name in ("short.tmp", "code.tmp", "huge.tmp", "junk.mat"):
         p = _run("--name=stencil_chain", f"input={tmp_path / name}", "output=/dev/null", check=False)
         assert p.returncode != 0, name
+
+
+def _parse_tiff(raw):
+    """A baseline-TIFF reader for the test: the IFD as {tag: values} and the concatenated strips."""
+    import struct
+    assert raw[:4] == b"II*\0"
+    ifd, = struct.unpack("<I", raw[4:8])
+    n, = struct.unpack("<H", raw[ifd:ifd + 2])
+    fields = {}
+    for i in range(n):
+        tag, typ, cnt, val = struct.unpack("<HHII", raw[ifd + 2 + 12 * i:ifd + 14 + 12 * i])
+        size = {3: 2, 4: 4, 5: 8}[typ]
+        if typ == 5:
+            fields[tag] = struct.unpack("<2I", raw[val:val + 8])
+        elif size * cnt <= 4:
+            fields[tag] = struct.unpack("<" + "HI"[typ - 3] * cnt, raw[ifd + 10 + 12 * i:ifd + 10 + 12 * i + size * cnt])
+        else:
+            fields[tag] = struct.unpack("<" + "HI"[typ - 3] * cnt, raw[val:val + size * cnt])
+    assert struct.unpack("<I", raw[ifd + 2 + 12 * n:ifd + 6 + 12 * n]) == (0,)
+    data = b"".join(raw[o:o + c] for o, c in zip(fields[273], fields[279]))
+    return fields, data
+
+
+@pytest.mark.gpu
+def test_tiff_out_and_back_in(hl, oracle, tmp_path):
+    """TIFF the way the reference writes it (tools/halide_image_io.h:2230-2384): uncompressed, little endian, one strip per
+    channel in planar configuration, SampleFormat from the element type.  The reference declines to read TIFF (:2109-2113);
+    this runner reads the family it writes, plus chunky and big-endian files, so outputs can be fed back."""
+    import struct
+    rng = np.random.default_rng(6)
+    inp = rng.integers(0, 65536, (3, 96, 160), dtype=np.uint16)
+    want = oracle.local_laplacian(inp, 8, np.float32(0.14285714285714285), 1.0)
+    np.save(tmp_path / "in.npy", inp.reshape(160, 96, 3))              # the reference's .npy convention: extents x-first
+    args = ["--name=local_laplacian", "levels=8", "alpha=0.14285714285714285", "beta=1", "--output_extents=[160,96,3]"]
+    _run(*args, f"input={tmp_path / 'in.npy'}", f"output={tmp_path / 'out.tiff'}")
+    fields, data = _parse_tiff(open(tmp_path / "out.tiff", "rb").read())
+    assert fields[256] == (160,) and fields[257] == (96,) and fields[258] == (16,) and fields[259] == (1,)
+    assert fields[262] == (2,) and fields[277] == (3,) and fields[278] == (96,) and fields[284] == (2,)
+    assert fields[339] == (1,) and fields[32997] == (1,) and fields[282] == (1, 1) and fields[283] == (1, 1)
+    assert fields[279] == (160 * 96 * 2,) * 3 and len(fields[273]) == 3
+    assert sorted(fields) == [256, 257, 258, 259, 262, 273, 277, 278, 279, 282, 283, 284, 296, 339, 32997]
+    assert np.array_equal(np.frombuffer(data, np.uint16).reshape(3, 96, 160), want)
+    # that file as the input
+    _run(*args, f"input={tmp_path / 'out.tiff'}", f"output={tmp_path / 'twice.npy'}")
+    assert np.array_equal(np.load(tmp_path / "twice.npy").reshape(3, 96, 160), oracle.local_laplacian(want, 8, np.float32(0.14285714285714285), 1.0))
+    # a chunky big-endian file in two strips, as other writers produce
+    chunky = np.ascontiguousarray(inp.transpose(1, 2, 0)).astype(">u2").tobytes()
+    half = 48 * 160 * 3 * 2
+    tags = [(256, 4, 1, 160), (257, 4, 1, 96), (258, 3, 3, None), (259, 3, 1, 1 << 16), (262, 3, 1, 2 << 16), (273, 4, 2, None),
+            (277, 3, 1, 3 << 16), (278, 4, 1, 48), (279, 4, 2, None), (284, 3, 1, 1 << 16), (339, 3, 1, 1 << 16)]
+    extra_at = 8 + 2 + 12 * len(tags) + 4
+    extra = struct.pack(">3H", 16, 16, 16) + b"\0\0"
+    data_at = extra_at + len(extra) + 16
+    extra += struct.pack(">2I", data_at, data_at + half) + struct.pack(">2I", half, half)
+    offs = {258: extra_at, 273: extra_at + 8, 279: extra_at + 16}
+    ifd = struct.pack(">H", len(tags)) + b"".join(struct.pack(">HHII", t, ty, c, offs.get(t, v)) for t, ty, c, v in tags) + struct.pack(">I", 0)
+    (tmp_path / "be.tif").write_bytes(b"MM\0*" + struct.pack(">I", 8) + ifd + extra + chunky)
+    _run(*args, f"input={tmp_path / 'be.tif'}", f"output={tmp_path / 'be.npy'}")
+    assert np.array_equal(np.load(tmp_path / "be.npy").reshape(3, 96, 160), want)
+    # float output: SampleFormat 3, one sample per pixel -> contiguous configuration with the byte count inline
+    src = rng.random((3, 64, 96), dtype=np.float32)
+    np.save(tmp_path / "f.npy", src.reshape(96, 64, 3))
+    _run("--name=iir_blur", f"input={tmp_path / 'f.npy'}", "alpha=0.5", f"output={tmp_path / 'f.tiff'}")
+    fields, data = _parse_tiff(open(tmp_path / "f.tiff", "rb").read())
+    assert fields[258] == (32,) and fields[339] == (3,) and fields[277] == (3,)
+    assert np.array_equal(np.frombuffer(data, np.float32).reshape(3, 64, 96), oracle.iir_blur(src, np.float32(0.5)))
+    _run("--name=iir_blur", f"input={tmp_path / 'f.tiff'}", "alpha=0.5", f"output={tmp_path / 'f2.npy'}")
+    assert np.array_equal(np.load(tmp_path / "f2.npy").reshape(3, 64, 96), oracle.iir_blur(oracle.iir_blur(src, np.float32(0.5)), np.float32(0.5)))
+
+
+def test_damaged_tiff_files_are_rejected(tmp_path):
+    import struct
+    def tiff(tags, tail=b""):
+        return b"II*\0" + struct.pack("<IH", 8, len(tags)) + b"".join(struct.pack("<HHII", *t) for t in tags) + struct.pack("<I", 0) + tail
+    base = [(256, 4, 1, 4), (257, 4, 1, 4), (258, 3, 1, 8), (259, 3, 1, 1), (273, 4, 1, 200), (277, 3, 1, 1), (279, 4, 1, 16)]
+    cases = {
+        "magic.tiff": b"II+\0" + b"\0" * 64,
+        "lzw.tiff": tiff([t if t[0] != 259 else (259, 3, 1, 5) for t in base], b"\0" * 300),
+        "short.tiff": tiff(base, b"\0" * 20),                                  # the strip lies beyond the end of the file
+        "huge.tiff": tiff([t if t[0] != 256 else (256, 4, 1, 1 << 30) for t in base], b"\0" * 300),
+        "bits.tiff": tiff([t if t[0] != 258 else (258, 3, 1, 12) for t in base], b"\0" * 300),
+        "few.tiff": tiff([t if t[0] != 279 else (279, 4, 1, 8) for t in base], b"\0" * 300),   # strips hold half the image
+        "ifd.tiff": b"II*\0" + struct.pack("<I", 4000),
+    }
+    for name, blob in cases.items():
+        (tmp_path / name).write_bytes(blob)
+        p = _run("--name=stencil_chain", f"input={tmp_path / name}", "output=/dev/null", check=False)
+        assert p.returncode != 0 and "Segmentation" not in p.stderr, name
+        assert p.returncode > 0, (name, p.returncode)                         # an error exit, not a signal
