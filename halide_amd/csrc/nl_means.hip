@@ -41,6 +41,43 @@ struct NGeom {
     float inv;                         // -1 / (sigma*sigma*patch*patch)
 };
 
+// The clamped input window (repeat_edge on x, y and c, generator :27) of a tile: WH rows x WW columns (64 < WW <= 128, LDS
+// pitch IWP) x 3 channels from (wx0, wy0).  A wave takes every NW-th row: a lane loads its column and lanes below WW - 64 the
+// row's tail, and a wave requests half of its rows before it writes the first to LDS — two memory round trips per tile
+// instead of one per pair of elements (the flat-index loop this replaces waited for each pair of loads).
+template<int WH, int WW, int NW>
+__device__ __forceinline__ void stage_window(float *sin, const float *__restrict__ in, long in_sy, long in_sc, const NGeom &g, int wx0,
+                                             int wy0, int lane, int wave) {
+    constexpr int ROWS_ALL = 3 * WH, PER = (ROWS_ALL + NW - 1) / NW, BATCH = (PER + 1) / 2;
+    const int xa = dev::clampi(wx0 + lane, g.ix0, g.ix1) - g.ix0;
+    const int xb = dev::clampi(wx0 + 64 + lane, g.ix0, g.ix1) - g.ix0;
+    const bool tail = lane < WW - 64;
+#pragma unroll 1
+    for (int b0 = 0; b0 < PER; b0 += BATCH) {
+        float va[BATCH], vb[BATCH];
+#pragma unroll
+        for (int b = 0; b < BATCH; b++) {
+            const int rr = wave + NW * (b0 + b);
+            va[b] = vb[b] = 0.0f;
+            if (b0 + b < PER && rr < ROWS_ALL) {
+                const int c = rr / WH, r = rr - c * WH;
+                const int y = dev::clampi(wy0 + r, g.iy0, g.iy1) - g.iy0, cc = dev::clampi(c, g.ic0, g.ic1) - g.ic0;
+                const float *row = in + (long)y * in_sy + (long)cc * in_sc;
+                va[b] = row[xa];
+                if (tail) vb[b] = row[xb];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < BATCH; b++) {
+            const int rr = wave + NW * (b0 + b);
+            if (b0 + b < PER && rr < ROWS_ALL) {
+                sin[rr * IWP + lane] = va[b];
+                if (tail) sin[rr * IWP + 64 + lane] = vb[b];
+            }
+        }
+    }
+}
+
 // ---- nlm_7x7w: the same computation with NO barrier inside the offset loop.  nlm_7x7 hands blur_d_y from its phase-1 threads
 // (a column, four rows) to its phase-2 threads (a row, four pixels) through LDS, one workgroup barrier per offset: all waves
 // of a workgroup read at the same time, compute at the same time and wait for each other 49 times (a third of all
@@ -77,15 +114,9 @@ __global__ __launch_bounds__(64 * TH / ROWS) void nlm_7x7w(const float *__restri
     float *sin = lds;                       // [3][IH][IWP]
     const int tid = threadIdx.x;
     const int tx0 = g.ox0 + blockIdx.x * TW, ty0 = g.oy0 + blockIdx.y * TH;  // absolute coords of the tile
-    for (int i = tid; i < 3 * IH * IW; i += NT) {   // the clamped input window (repeat_edge on x, y and c, generator :27)
-        int c = i / (IH * IW), rem = i - c * (IH * IW), r = rem / IW, col = rem - r * IW;
-        int x = dev::clampi(tx0 - 2 * HALF + col, g.ix0, g.ix1) - g.ix0;
-        int y = dev::clampi(ty0 - 2 * HALF + r, g.iy0, g.iy1) - g.iy0;
-        int cc = dev::clampi(c, g.ic0, g.ic1) - g.ic0;
-        sin[(c * IH + r) * IWP + col] = in[(long)y * in_sy + x + (long)cc * in_sc];
-    }
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    stage_window<IH, IW, NT / 64>(sin, in, in_sy, in_sc, g, tx0 - 2 * HALF, ty0 - 2 * HALF, lane, wave);
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
     const int col = lane + HALF;             // window column of abs x = tx0 - 3 + lane
     const int row0 = ROWS * wave + HALF;     // window row of abs y = ty0 + ROWS * wave - 3
     float *xs = lds + 3 * IH * IWP + wave * ROWS * XSP + HALF + lane;   // XL: this lane's column of the wave's rows
