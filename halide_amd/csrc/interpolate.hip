@@ -9,7 +9,7 @@
 //   I_0 = [0, W-1],  I_{l+1} = [floor(lo/2), floor((hi+1)/2)]                 interpolated[l]  (read by the level below)
 //   D_9 = I_9,  D_l = I_l  U  [2 lo(D_{l+1}) - 1, 2 hi(D_{l+1}) + 1]           downsampled[l]   (clamped to [0, W/8] for l = 3)
 // as float4 {r a, g a, b a, a} per pixel (one 16-byte load serves all four channels).  downsampled[0] and
-// interpolated[0] are never stored.  Sums left to right as written, one rounding per operator (oracle/
+// interpolated[0], [1], [2] are never stored (the last three exist tile by tile in ip_final's LDS).  Sums left to right as written, one rounding per operator (oracle/
 // interpolate_oracle.c).  One thread per pixel.  Levels >= 6 (at most 25 x 41 pixels) are launch-latency bound, so ONE
 // workgroup walks them all — down 6..9, then up 8..6 — with a barrier between levels (ip_tail): 12 launches instead of 18
 // (0.090 instead of 0.095 ms; starting the tail at level 5 or 4 is slower, 0.103 / 0.152 ms: a level costs a lone
@@ -272,13 +272,43 @@ __global__ __launch_bounds__(1024) void ip_tail(TailArgs a) {
     }
 }
 
-// level 0: interpolated[0] (never stored) and the normalisation (:74-75), planar output
-__global__ __launch_bounds__(256) void ip_final(InGeom g, Lvl up, float *__restrict__ out, long out_sy, long out_sc) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= g.W) return;
-    const float4 v = interp_value(ds0(g, x, y), up, x, y);
-    float *o = out + (long)y * out_sy + x;
-    o[0] = v.x / v.w, o[out_sc] = v.y / v.w, o[2 * out_sc] = v.z / v.w;
+// levels 2, 1 and 0: interpolated[2] and [1] of a tile's neighbourhood in LDS (from downsampled[2], [1] and interpolated[3]; each
+// is read only by the level below, so neither is stored: 16 B per pixel of those levels less each way, and two launches less than
+// ip_up:2 + ip_up:1 + a per-pixel final kernel), then interpolated[0] (never stored either) and the normalisation (:74-75),
+// planar output.  A workgroup owns F0W x F0H output pixels, four rows of them per thread; cells on a tile's edge are recomputed
+// by the neighbour with the same operations.
+constexpr int F0W = 64, F0H = 16, F1W = F0W / 2 + 1, F1H = F0H / 2 + 1, F2W = F1W / 2 + 2, F2H = F1H / 2 + 2;
+__global__ __launch_bounds__(256) void ip_final(InGeom g, Lvl d1, Lvl d2, Lvl up3, float *__restrict__ out, long out_sy, long out_sc) {
+    __shared__ float4 s1[F1H * F1W], s2[F2H * F2W];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * F0W, y0 = blockIdx.y * F0H;
+    const int x1 = min(x0 + F0W, g.W) - 1, y1 = min(y0 + F0H, g.H) - 1;
+    // the cells of interpolated[1] the tile reads, and those of interpolated[2] they read
+    const int ax0 = x0 >> 1, ay0 = y0 >> 1, w1 = ((x1 + 1) >> 1) - ax0 + 1, h1 = ((y1 + 1) >> 1) - ay0 + 1;
+    const int bx0 = ax0 >> 1, by0 = ay0 >> 1, w2 = ((ax0 + w1) >> 1) - bx0 + 1, h2 = ((ay0 + h1) >> 1) - by0 + 1;
+    for (int i = tid; i < w2 * h2; i += 256) {
+        const int yy = i / w2, xx = i - yy * w2, x = bx0 + xx, y = by0 + yy;
+        s2[yy * F2W + xx] = interp_value(at(d2, x, y), up3, x, y);
+    }
+    __syncthreads();
+    for (int i = tid; i < w1 * h1; i += 256) {
+        const int yy = i / w1, xx = i - yy * w1, x = ax0 + xx, y = ay0 + yy;
+        const int xa = (x >> 1) - bx0, xb = ((x + 1) >> 1) - bx0, ya = (y >> 1) - by0, yb = ((y + 1) >> 1) - by0;
+        s1[yy * F1W + xx] = interp_from(at(d1, x, y), s2[ya * F2W + xa], s2[ya * F2W + xb], s2[yb * F2W + xa], s2[yb * F2W + xb]);
+    }
+    __syncthreads();
+    const int x = x0 + (tid & 63);
+    if (x > x1) return;
+    const int xa = (x >> 1) - ax0, xb = ((x + 1) >> 1) - ax0;
+#pragma unroll
+    for (int k = 0; k < F0H / 4; k++) {
+        const int y = y0 + (tid >> 6) + 4 * k;
+        if (y > y1) break;
+        const int ya = (y >> 1) - ay0, yb = ((y + 1) >> 1) - ay0;
+        const float4 v = interp_from(ds0(g, x, y), s1[ya * F1W + xa], s1[ya * F1W + xb], s1[yb * F1W + xa], s1[yb * F1W + xb]);
+        float *o = out + (long)y * out_sy + x;
+        o[0] = v.x / v.w, o[out_sc] = v.y / v.w, o[2 * out_sc] = v.z / v.w;
+    }
 }
 
 const int64_t e0 = 0, ew = 1536, eh = 2560, e4 = 4, e3 = 3;
@@ -344,14 +374,14 @@ extern "C" int interpolate(halide_buffer_t *input, halide_buffer_t *output) {
         size_t off_d[IL], off_i[IL], total = 0;
         auto area = [](const Box &b) { return ((size_t)(b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1) + 15) & ~(size_t)15; };
         for (int l = 1; l < IL; l++) off_d[l] = total, total += area(D[l]);
-        for (int l = 1; l < IL - 1; l++) off_i[l] = total, total += area(I[l]);
+        for (int l = 3; l < IL - 1; l++) off_i[l] = total, total += area(I[l]);   // interpolated[2] and [1] live in ip_final's LDS
         void *ws = nullptr;
         if ((r = get_workspace(uc, ctx, total * sizeof(float4), &ws))) return r;
         float4 *base = (float4 *)ws;
         auto lvl = [&](float4 *p, const Box &b) { return Lvl{p, b.x0, b.y0, b.x1 - b.x0 + 1, b.y1 - b.y0 + 1}; };
         Lvl ds[IL] = {}, ip[IL] = {};
         for (int l = 1; l < IL; l++) ds[l] = lvl(base + off_d[l], D[l]);
-        for (int l = 1; l < IL - 1; l++) ip[l] = lvl(base + off_i[l], I[l]);
+        for (int l = 3; l < IL - 1; l++) ip[l] = lvl(base + off_i[l], I[l]);
         ip[IL - 1] = ds[IL - 1];   // interpolated[9] = downsampled[9], and D_9 == I_9
         InGeom g{dev_ptr<float>(input), input->dim[1].stride, input->dim[2].stride, W, H};
         hipStream_t st = ctx.stream;
@@ -359,7 +389,7 @@ extern "C" int interpolate(halide_buffer_t *input, halide_buffer_t *output) {
         // levels >= T go through ip_tail (default 6: 25 x 41 pixels and below)
         const char *te = getenv("HLMI_IP_TAIL_FROM");
         int T = te ? atoi(te) : 6;
-        if (T < 2 || T > IL - 2) T = IL;
+        if (T < 3 || T > IL - 2) T = IL;   // (interpolated[2] and [1] are not stored: the tail cannot start below level 3)
         // levels 3, 4, 5 in one launch per direction (ip_down_multi / ip_up_multi) when the tail starts at 6 and every tile's
         // windows fit the kernels' LDS arrays (they do for any image: the check guards the constants, not the input)
         bool fused = T == 6 && !getenv("HLMI_IP_UNFUSED");
@@ -408,7 +438,7 @@ extern "C" int interpolate(halide_buffer_t *input, halide_buffer_t *output) {
             snprintf(nm, sizeof nm, "ip_tail:%d", T);
             HLMI_LAUNCH(uc, nm, st, ip_tail, dim3(1), dim3(1024), 0, ta);
         }
-        for (int l = (T < IL ? T - 1 : IL - 2); l >= 1; l--) {
+        for (int l = (T < IL ? T - 1 : IL - 2); l >= 3; l--) {   // (levels 2 and 1 are made inside ip_final)
             if (fused && l >= 3) {
                 if (l == 3) {
                     const int ntx3 = (ip[3].w + UM3 - 1) / UM3, nty3 = (ip[3].h + UM3 - 1) / UM3;
@@ -421,7 +451,7 @@ extern "C" int interpolate(halide_buffer_t *input, halide_buffer_t *output) {
             HLMI_LAUNCH(uc, nm, st, ip_up, grid, block, 0, ds[l], ip[l + 1], ip[l]);
         }
         timing_note_bytes(28.0 * W * H);
-        HLMI_LAUNCH(uc, "ip_final", st, ip_final, dim3((W + 255) / 256, H), dim3(256), 0, g, ip[1], dev_ptr<float>(output),
+        HLMI_LAUNCH(uc, "ip_final", st, ip_final, dim3((W + F0W - 1) / F0W, (H + F0H - 1) / F0H), dim3(256), 0, g, ds[1], ds[2], ip[3], dev_ptr<float>(output),
                     (long)output->dim[1].stride, (long)output->dim[2].stride);
     }
     mark_output_written(output);
