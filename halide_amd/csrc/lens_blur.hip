@@ -193,6 +193,62 @@ __global__ __launch_bounds__(256) void lb_pull(const float *__restrict__ push, B
     dst[((size_t)zc * db.h + (y - db.y0)) * db.w + xi] = v;
 }
 
+// pull[1] on P_1 in ONE launch from pull[4] and push[3], [2], [1]: a workgroup owns a 64 x 16 tile of one plane of pull[1] and
+// makes the cells of pull[3] and pull[2] its tile reads (at most 21 x 9 and 35 x 11: P_i is by construction what level i - 1
+// reads of level i) in LDS with lb_pull's expressions — their only reader is the level below, so neither level is stored, and
+// two launches of a few microseconds of work each go (lb_pull:3, lb_pull:2).  Cells in a tile's halo are recomputed by its
+// neighbours with identical operations.
+constexpr int PMW = 64, PMH = 16, PM2W = PMW / 2 + 3, PM2H = PMH / 2 + 3, PM3W = PM2W / 2 + 4, PM3H = PM2H / 2 + 4;
+__device__ __forceinline__ float up_lds(const float *s, int pitch, int wx0, int wy0, int x, int y) {   // upsample (:288-294) of a window in LDS
+    const int xa = (x >> 1) - 1 + 2 * (x & 1) - wx0, xb = (x >> 1) - wx0, ya = (y >> 1) - 1 + 2 * (y & 1) - wy0, yb = (y >> 1) - wy0;
+    const float ua = 0.25f * s[ya * pitch + xa] + 0.75f * s[ya * pitch + xb];
+    const float ub = 0.25f * s[yb * pitch + xa] + 0.75f * s[yb * pitch + xb];
+    return 0.25f * ua + 0.75f * ub;
+}
+__global__ __launch_bounds__(256) void lb_pull_multi(const float *__restrict__ push1, Box pb1, const float *__restrict__ push2, Box pb2,
+                                                    const float *__restrict__ push3, Box pb3, const float *__restrict__ pull4, Box p4,
+                                                    float *__restrict__ pull1, Box p1) {
+    __shared__ float s2[PM2H * PM2W], s3[PM3H * PM3W];
+    const int tid = threadIdx.x, zc = blockIdx.z;
+    const int x0 = p1.x0 + blockIdx.x * PMW, x1 = min(x0 + PMW, p1.x0 + p1.w) - 1;
+    const int y0 = p1.y0 + blockIdx.y * PMH, y1 = min(y0 + PMH, p1.y0 + p1.h) - 1;
+    const int ax0 = (x0 >> 1) - 1, ay0 = (y0 >> 1) - 1, w2 = (x1 >> 1) + 1 - ax0 + 1, h2 = (y1 >> 1) + 1 - ay0 + 1;                     // pull[2] cells read
+    const int bx0 = (ax0 >> 1) - 1, by0 = (ay0 >> 1) - 1, w3 = ((ax0 + w2 - 1) >> 1) + 1 - bx0 + 1, h3 = ((ay0 + h2 - 1) >> 1) + 1 - by0 + 1;   // pull[3]
+    // every push value a thread will need is requested before the first phase (as three dependent phases of load -> use,
+    // a workgroup waited out three memory round trips in a row)
+    constexpr int N2 = (PM2H * PM2W + 255) / 256, N1 = PMH / 4;
+    float q2[N2], q1[N1];
+#pragma unroll
+    for (int k = 0; k < N2; k++) {
+        const int i = min(tid + 256 * k, w2 * h2 - 1), yy = i / w2, xx = i - yy * w2;
+        q2[k] = src_at<true>(push2, pb2, zc, ax0 + xx, ay0 + yy);
+    }
+    const int x = min(x0 + (tid & 63), x1);
+#pragma unroll
+    for (int k = 0; k < N1; k++) q1[k] = src_at<true>(push1, pb1, zc, x, min(y0 + (tid >> 6) + 4 * k, y1));
+    for (int i = tid; i < w3 * h3; i += 256) {
+        const int yy = i / w3, xx = i - yy * w3, x3 = bx0 + xx, y3 = by0 + yy;
+        s3[yy * PM3W + xx] = dev::lerpf(up_at(pull4, p4, zc, x3, y3), src_at<true>(push3, pb3, zc, x3, y3), 0.5f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N2; k++) {
+        const int i = tid + 256 * k;
+        if (i < w2 * h2) {
+            const int yy = i / w2, xx = i - yy * w2;
+            s2[yy * PM2W + xx] = dev::lerpf(up_lds(s3, PM3W, bx0, by0, ax0 + xx, ay0 + yy), q2[k], 0.5f);
+        }
+    }
+    __syncthreads();
+    if (x0 + (tid & 63) > x1) return;
+#pragma unroll
+    for (int k = 0; k < N1; k++) {
+        const int y = y0 + (tid >> 6) + 4 * k;
+        if (y > y1) break;
+        pull1[((size_t)zc * p1.h + (y - p1.y0)) * p1.w + (x - p1.x0)] = dev::lerpf(up_lds(s2, PM2W, ax0, ay0, x, y), q1[k], 0.5f);
+    }
+}
+
 // The planes of the two pyramids never mix (down- and up-sampling are per plane), so below some level one workgroup can take
 // a plane all the way down and back up with a barrier between levels — its own stores are visible to it after the barrier —
 // instead of one launch per level: levels `from`..7 of the push pyramid, then levels 7..`from` of the pull pyramid.
@@ -864,7 +920,19 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
         if (need <= TAIL_LDS) HLMI_LAUNCH(uc, nm, st, lb_tail_lds, dim3(zc), dim3(1024), 0, ta);
         else HLMI_LAUNCH(uc, nm, st, lb_tail, dim3(zc), dim3(1024), 0, ta);
     }
-    for (int i = min(LV - 1, tail - 1); i >= 1; i--) {
+    // levels 3, 2, 1 in one launch when all three lie above the tail (pull[3] and pull[2] then exist only in LDS)
+    const bool pull_multi = tail >= 4;
+    if (pull_multi) {
+        for (int i = min(LV - 1, tail - 1); i >= 4; i--) {
+            char nm[24];
+            snprintf(nm, sizeof nm, "lb_pull:%d", i);
+            if (i == LV - 1) HLMI_LAUNCH(uc, nm, st, lb_pull<true>, dim3((P[i].w + 63) / 64, (P[i].h + 3) / 4, zc), dim3(256), 0, push[i], PB[i], (const float *)nullptr, P[i], pull[i], P[i]);
+            else HLMI_LAUNCH(uc, nm, st, lb_pull<false>, dim3((P[i].w + 63) / 64, (P[i].h + 3) / 4, zc), dim3(256), 0, push[i], PB[i], pull[i + 1], P[i + 1], pull[i], P[i]);
+        }
+        HLMI_LAUNCH(uc, "lb_pull_multi:1", st, lb_pull_multi, dim3((P[1].w + PMW - 1) / PMW, (P[1].h + PMH - 1) / PMH, zc), dim3(256), 0, push[1], PB[1],
+                    push[2], PB[2], push[3], PB[3], pull[4], P[4], pull[1], P[1]);
+    }
+    for (int i = pull_multi ? 0 : min(LV - 1, tail - 1); i >= 1; i--) {
         char nm[24];
         snprintf(nm, sizeof nm, "lb_pull:%d", i);
         if (i == LV - 1) HLMI_LAUNCH(uc, nm, st, lb_pull<true>, dim3((P[i].w + 63) / 64, (P[i].h + 3) / 4, zc), dim3(256), 0, push[i], PB[i], (const float *)nullptr, P[i], pull[i], P[i]);
