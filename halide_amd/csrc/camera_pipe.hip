@@ -17,6 +17,8 @@
 #include "hlmi_device_math.h"
 #include "hlmi_internal.h"
 
+#include <stdio.h>
+
 #include <stdlib.h>
 
 using namespace hlmi;
@@ -173,60 +175,80 @@ __global__ __launch_bounds__(256) void cp_demosaic(const uint16_t *__restrict__ 
     }
 }
 
-// ---- cp_demosaic_tile: the same stages for a tile of 32 x 8 Bayer quads (64 x 16 pixels) per workgroup, staged through
-// LDS so that every raw pixel is loaded once and every hot-pixel clamp is evaluated once (cp_demosaic loads a 10 x 10
-// window and clamps 36 pixels per quad: 9x redundant):
-//   raw window 72 x 24 (aligned dword pairs) -> LDS;  clamped pairs (sites {Gr,R} and {B,Gb} of a quad are adjacent
-//   pixels: v_pk_max_u16 / v_pk_min_u16) for 34 x 10 quads -> LDS;  one thread per quad: 18 LDS dwords -> demosaic ->
-//   matrix -> curve (LUT in LDS) -> staged u8 rows -> coalesced dword stores of the curved planes.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+constexpr int TQX = 32;                               // quad columns of output per tile (64 pixels)
+// ---- cp_fused_tile: every stage in ONE launch, a tile of 64 x 40 OUTPUT pixels per workgroup, staged through LDS so that every
+// raw pixel is loaded once and every hot-pixel clamp is evaluated once (cp_demosaic loads a 10 x 10 window and clamps 36 pixels
+// per quad: 9x redundant):
+//   raw window 76 x 52 (aligned dword pairs) -> LDS;  clamped pairs (sites {Gr,R} and {B,Gb} of a quad are adjacent pixels:
+//   v_pk_max_u16 / v_pk_min_u16) for 36 x 24 quads -> LDS;  a thread per quad, 34 x 22 quads in three passes: 18 LDS dwords ->
+//   demosaic -> matrix -> curve (LUT in LDS) -> staged u8 rows of the curved planes (66 x 42 used: the tile and one pixel
+//   around it);  sharpen from the staged rows, four pixels per thread as cp_sharpen4 does -> the output.
+// Round 4: the curved planes used to go out to a 14.7 MB workspace from a 32 x 8-quad tile kernel and come back in a sharpen
+// launch (0.036 ms per call); making the one-pixel ring of curved values again in the neighbour tiles costs 1.13 x the quad
+// arithmetic and saves a launch and both passes over that workspace: 0.027 ms.  Per-workgroup time stamps (1920 workgroups, one
+// round of eight per CU): raw window 2.4 us, clamp 4.1 (with the wait for the window), quads 3.4, sharpen + stores 1.6,
+// 14 us in all at the median and 25 for the launch — the youngest workgroups of a CU issue last; reading ONE window from every
+// tile changes nothing, i.e. it is not the raw reads.  Tiles of 64 x 16 / 64 x 24 pixels (2.3 / 1.6 rounds): 0.028.
 // Needs the PAIRS alignment (even row stride, 4-byte aligned origin) and an even W.  Raw pixels outside the footprint the
 // boundary guarantees ([-6, W+5] x [-6, H+5] around the output) are read as 0; they only feed pixels that are not stored.
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-constexpr int TQX = 32, TQY = 8;                      // quads per tile
-constexpr int RWD = (2 * TQX + 8) / 2, RH = 2 * TQY + 8, RPD = RWD + 1;   // raw window in dwords (36) x rows (24), pitch 37
-constexpr int DQX = TQX + 2, DQY = TQY + 2, DPD = DQX + 1;              // clamped quads 34 x 10, pitch 35 dwords
-constexpr int OP = 68;                                // staged output row pitch in bytes (column c sits at byte c + 3)
-__global__ __launch_bounds__(256) void cp_demosaic_tile(const uint16_t *__restrict__ raw, long in_sy, const CPSetup *__restrict__ s,
-                                                       uint8_t *__restrict__ cv, int CW, int CH, int CWL, int W, int H) {
-    __shared__ uint32_t s_raw[RH * RPD];
-    __shared__ uint32_t s_d[2 * DQY * DPD];           // [cy][j][i]: sites (2 cy, 2 cy + 1) of clamped quad (i, j)
+constexpr int FTY = 20;                                                      // quad rows of OUTPUT per tile: 64 x 40 pixels
+constexpr int FQX = TQX + 2, FQY = FTY + 2;                                  // quads made per tile: 34 x 22 = 748 on 256 threads, three passes
+constexpr int FRWD = (2 * FQX + 8) / 2, FRH = 2 * FQY + 8, FRPD = FRWD + 1;  // raw window: 38 dwords x 28 rows
+constexpr int FDQX = FQX + 2, FDQY = FQY + 2, FDPD = FDQX + 1;               // clamped quads 36 x 12
+constexpr int FOP = 72;                                                      // staged row pitch in bytes (column k at byte k + 3)
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void cp_fused_tile(const uint16_t *__restrict__ raw, long in_sy, const CPSetup *__restrict__ s,
+                                                    uint8_t *__restrict__ out, long out_sy, long out_sc, int W, int H, int dwords, int gx) {
+    // the raw window is dead once the clamped quads exist, the staged output rows are first written after that: one array
+    constexpr int RAW_DW = FRH * FRPD, OUT_DW = 3 * 2 * FQY * FOP / 4;
+    __shared__ uint32_t s_buf[RAW_DW > OUT_DW ? RAW_DW : OUT_DW];
+    __shared__ uint32_t s_d[2 * FDQY * FDPD];           // [cy][j][i]: sites (2 cy, 2 cy + 1) of clamped quad (i, j)
     __shared__ uint32_t s_curve[256];
-    __shared__ __attribute__((aligned(4))) uint8_t s_out[3 * 2 * TQY * OP];
+    uint32_t *s_raw = s_buf;
+    uint8_t *s_out = reinterpret_cast<uint8_t *>(s_buf);
     const int tid = threadIdx.x;
-    const int QX0 = -1 + TQX * (int)blockIdx.x, QY0 = -1 + TQY * (int)blockIdx.y;   // quads start at fdiv(-1, 2) = -1
+    // tiles in row-major order, a contiguous run of them per XCD (blocks are dealt round-robin over the 8 XCDs): a tile's raw
+    // window shares its outer cache lines and its halo rows with its neighbours' — they should meet in one L2
+    const int nb8 = gridDim.x >> 3, lb = (int)blockIdx.x < (nb8 << 3) ? ((int)blockIdx.x & 7) * nb8 + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int tbx = lb % gx, tby = lb / gx;
+    const int QX0 = -1 + TQX * tbx, QY0 = -1 + FTY * tby;   // first quad made: quads start at fdiv(-1, 2) = -1
     s_curve[tid] = reinterpret_cast<const uint32_t *>(s->curve)[tid];
     const int rx0 = 2 * QX0 - 4, ry0 = 2 * QY0 - 4;   // raw window origin (even)
     {
         // the thread's window dwords are requested together (a loop waited for each before asking for the next); sites outside
         // the raw image read its first dword and become 0
-        constexpr int N1 = (RH * RWD + 255) / 256;
+        constexpr int N1 = (FRH * FRWD + 255) / 256;
         uint32_t v[N1];
         bool ok[N1];
 #pragma unroll
         for (int k = 0; k < N1; k++) {
-            const int i = min(tid + 256 * k, RH * RWD - 1), r = i / RWD, cdw = i - r * RWD;
+            const int i = min(tid + 256 * k, FRH * FRWD - 1), r = i / FRWD, cdw = i - r * FRWD;
             const int x = rx0 + 2 * cdw, y = ry0 + r;
             ok[k] = x >= -6 && x + 1 <= W + 5 && y >= -6 && y <= H + 5;
-            v[k] = *reinterpret_cast<const uint32_t *>(raw + (ok[k] ? (long)y * in_sy + x : 0l));
+                        v[k] = *reinterpret_cast<const uint32_t *>(raw + (ok[k] ? (long)y * in_sy + x : 0l));
         }
 #pragma unroll
         for (int k = 0; k < N1; k++) {
             const int i = tid + 256 * k;
-            if (i < RH * RWD) s_raw[(i / RWD) * RPD + (i - (i / RWD) * RWD)] = ok[k] ? v[k] : 0u;
+            if (i < FRH * FRWD) s_raw[(i / FRWD) * FRPD + (i - (i / FRWD) * FRWD)] = ok[k] ? v[k] : 0u;
         }
     }
     __syncthreads();
     // hot-pixel suppression (:240-250) on pixel pairs: clamped quad (i, j), pair cy -> raw window dword (i + 1, 2 j + cy + 2)
-    for (int it = tid; it < 2 * DQY * DQX; it += 256) {
-        const int cy = it / (DQY * DQX), rem = it - cy * (DQY * DQX), j = rem / DQX, i = rem - j * DQX;
-        const uint32_t *p = s_raw + (2 * j + cy + 2) * RPD + (i + 1);
+    for (int it = tid; it < 2 * FDQY * FDQX; it += 256) {
+        const int cy = it / (FDQY * FDQX), rem = it - cy * (FDQY * FDQX), j = rem / FDQX, i = rem - j * FDQX;
+        const uint32_t *p = s_raw + (2 * j + cy + 2) * FRPD + (i + 1);
         const u16x2 c0 = __builtin_bit_cast(u16x2, p[0]), l = __builtin_bit_cast(u16x2, p[-1]), r = __builtin_bit_cast(u16x2, p[1]),
-                    u = __builtin_bit_cast(u16x2, p[-2 * RPD]), d = __builtin_bit_cast(u16x2, p[2 * RPD]);
+                    u = __builtin_bit_cast(u16x2, p[-2 * FRPD]), d = __builtin_bit_cast(u16x2, p[2 * FRPD]);
         const u16x2 a = __builtin_elementwise_max(__builtin_elementwise_max(l, r), __builtin_elementwise_max(u, d));
-        s_d[(cy * DQY + j) * DPD + i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(c0, a));
+        s_d[(cy * FDQY + j) * FDPD + i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(c0, a));
     }
     __syncthreads();
-    const int tx = tid & (TQX - 1), ty = tid >> 5;
+    const uint8_t *curve = reinterpret_cast<const uint8_t *>(s_curve);
+#pragma unroll 1
+    for (int qi = tid; qi < FQX * FQY; qi += 256) {
+    const int ty = qi / FQX, tx = qi - ty * FQX;
     // deinterleave (:252-263): D[c][dy+1][dx+1]
     uint16_t D[4][3][3];
 #pragma unroll
@@ -235,7 +257,7 @@ __global__ __launch_bounds__(256) void cp_demosaic_tile(const uint16_t *__restri
         for (int dy = 0; dy < 3; dy++)
 #pragma unroll
             for (int dx = 0; dx < 3; dx++) {
-                const uint32_t w = s_d[(cy * DQY + ty + dy) * DPD + tx + dx];
+                const uint32_t w = s_d[(cy * FDQY + ty + dy) * FDPD + tx + dx];
                 D[2 * cy][dy][dx] = (uint16_t)(w & 0xffffu), D[2 * cy + 1][dy][dx] = (uint16_t)(w >> 16);
             }
 #define G_GR(dx, dy) D[0][(dy) + 1][(dx) + 1]
@@ -284,7 +306,6 @@ __global__ __launch_bounds__(256) void cp_demosaic_tile(const uint16_t *__restri
 #undef B_B
 #undef G_GB
     // colour matrix (Q8.8, floor /256) + tone curve -> u8, staged: pixel (2 tx + sx, 2 ty + sy) of channel c
-    const uint8_t *curve = reinterpret_cast<const uint8_t *>(s_curve);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const int16_t *m = &s->matrix[4 * c];
@@ -299,34 +320,52 @@ __global__ __launch_bounds__(256) void cp_demosaic_tile(const uint16_t *__restri
                 o[sx] = curve[dev::clampi((int16_t)(v >> 8), 0, 1023)];
             }
             // column 2 tx sits at byte 2 tx + 3: an odd address, two byte stores
-            uint8_t *q = s_out + (c * 2 * TQY + 2 * ty + sy) * OP + 2 * tx + 3;
+            uint8_t *q = s_out + (c * 2 * FQY + 2 * ty + sy) * FOP + 2 * tx + 3;
             q[0] = o[0], q[1] = o[1];
         }
     }
+    }
     __syncthreads();
-    // write-out: staged row (c, r) = curved row cyy = 2 QY0 + r + 1, staged column k = curved column cxx = 2 QX0 + 1 + k
-    // (= 64 bx - 1 + k): columns 1..60 are 15 aligned dwords, columns 0, 61, 62, 63 single bytes
-    const size_t plane = (size_t)CW * CH;
-    const int cx0 = 2 * QX0 + 1, cy0 = 2 * QY0 + 1;
-    for (int it = tid; it < 3 * 2 * TQY * 19; it += 256) {
-        const int rc = it / 19, k = it - rc * 19, c = rc / (2 * TQY), r = rc - c * (2 * TQY);
-        const int cyy = cy0 + r;
-        if (cyy < 0 || cyy >= CH) continue;
-        const uint8_t *srow = s_out + rc * OP + 3;
-        uint8_t *grow = cv + (size_t)c * plane + (size_t)cyy * CW;
-        if (k < 15) {
-            const int col = 1 + 4 * k, cxx = cx0 + col;
-            if (cxx >= 0 && cxx + 3 < CWL) {
-                *reinterpret_cast<uint32_t *>(grow + cxx) = *reinterpret_cast<const uint32_t *>(srow + col);
-            } else {
+    // sharpen (:398-404) from the staged planes: staged row r = curved row 24 by - 1 + r, staged column k (at byte k + 3) = curved
+    // column 64 bx - 1 + k; output pixel (64 bx + j, 24 by + i) reads rows i + 1 .. i + 3, columns j + 1 .. j + 3.  A thread owns
+    // four adjacent pixels of one row, as cp_sharpen4 does: two aligned dwords per row, v_lerp_u8 rounding averages, packed i16.
+    const short st = (short)s->strength_x32;
+    const i16x2 strength = {st, st}, zero = {0, 0}, top = {255, 255};
+    const uint32_t one = 0x01010101u;
+    auto avg4 = [&](uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, one); };
+    for (int t = tid; t < 16 * 2 * FTY; t += 256) {
+    const int i = t >> 4, mg = t & 15;
+    const int x = 64 * tbx + 4 * mg, y = 2 * FTY * tby + i;
+    if (x >= W || y >= H) continue;
 #pragma unroll
-                for (int b = 0; b < 4; b++)
-                    if (cxx + b >= 0 && cxx + b < CWL) grow[cxx + b] = srow[col + b];
-            }
+    for (int c = 0; c < 3; c++) {
+        const uint32_t *r0 = reinterpret_cast<const uint32_t *>(s_out + (c * 2 * FQY + i + 1) * FOP + 4 + 4 * mg);
+        const uint32_t *r1 = r0 + FOP / 4, *r2 = r0 + 2 * (FOP / 4);
+        const uint32_t a0 = r0[0], b0 = r0[1], a1 = r1[0], b1 = r1[1], a2 = r2[0], b2 = r2[1];
+        const uint32_t uya = avg4(avg4(a0, a2), a1), uyb = avg4(avg4(b0, b2), b1);
+        const uint32_t L = uya, C = __builtin_amdgcn_alignbyte(uyb, uya, 1), R = __builtin_amdgcn_alignbyte(uyb, uya, 2);
+        const uint32_t un = avg4(avg4(L, R), C);
+        const uint32_t P = __builtin_amdgcn_alignbyte(b1, a1, 1);
+        auto sharpen2 = [&](uint32_t p2, uint32_t u2) -> uint32_t {
+            const i16x2 p = __builtin_bit_cast(i16x2, p2), u = __builtin_bit_cast(i16x2, u2);
+            const i16x2 mask = p - u;
+            const i16x2 q = (i16x2)(mask * strength) >> 5;   // int16 product wraps (src/IROperator.cpp:769-816); floor /32
+            i16x2 v = p + q;
+            v = v < zero ? zero : v;
+            v = v > top ? top : v;
+            return __builtin_bit_cast(uint32_t, v);
+        };
+        const uint32_t even = sharpen2(P & 0x00ff00ffu, un & 0x00ff00ffu), odd = sharpen2((P >> 8) & 0x00ff00ffu, (un >> 8) & 0x00ff00ffu);
+        const uint32_t v4 = even | (odd << 8);
+        uint8_t *o = out + (long)y * out_sy + x + (long)c * out_sc;
+        if (dwords && x + 3 < W) {
+            *reinterpret_cast<uint32_t *>(o) = v4;
         } else {
-            const int col = k == 15 ? 0 : 45 + k, cxx = cx0 + col;   // k = 16, 17, 18 -> columns 61, 62, 63
-            if (cxx >= 0 && cxx < CWL) grow[cxx] = srow[col];
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (x + b < W) o[b] = (uint8_t)(v4 >> (8 * b));
         }
+    }
     }
 }
 
@@ -355,7 +394,6 @@ __global__ __launch_bounds__(256) void cp_sharpen(const uint8_t *__restrict__ cv
 // Rows arrive as aligned dwords; the rounding byte averages avg8(a, b) = (a + b + 1) >> 1 of :398-404 are v_lerp_u8 with
 // the rounding bit set in every byte; the horizontal neighbours are v_alignbyte shifts of the two dwords of a row; the
 // int16 part (mask, product, floor /32, saturating cast) runs on packed i16 pairs (even bytes / odd bytes).
-typedef short i16x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void cp_sharpen4(const uint8_t *__restrict__ cv, int CW, int CH, const CPSetup *__restrict__ s,
                                                   uint8_t *__restrict__ out, long out_sy, long out_sc, int W, int H) {
     const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x), y = blockIdx.y;
@@ -555,16 +593,21 @@ extern "C" int camera_pipe(halide_buffer_t *input, halide_buffer_t *matrix_3200,
     const long in_sy = input->dim[1].stride;
     const uint16_t *raw = dev_ptr<uint16_t>(input) + (long)(oy + 12 - input->dim[1].min) * in_sy + (ox + 16 - input->dim[0].min);
     const int nqx = floor_div(W, 2) + 2, nqy = floor_div(H, 2) + 2;
+    const long o_sy = processed->dim[1].stride, o_sc = processed->dim[2].stride;
+    uint8_t *dout = dev_ptr<uint8_t>(processed);
     if (in_sy % 2 == 0 && (uintptr_t)raw % 4 == 0 && W % 2 == 0) {
-        HLMI_LAUNCH(uc, "cp_demosaic", st, cp_demosaic_tile, dim3((nqx + TQX - 1) / TQX, (nqy + TQY - 1) / TQY), dim3(256), 0, raw, in_sy,
-                    setup, cv, CW, CH, CWL, W, H);
-    } else if (in_sy % 2 == 0 && (uintptr_t)raw % 4 == 0) {
+        const int dwords = o_sy % 4 == 0 && o_sc % 4 == 0 && (uintptr_t)dout % 4 == 0;
+        HLMI_LAUNCH(uc, "cp_fused", st, cp_fused_tile, dim3(((W + 63) / 64) * ((H + 2 * FTY - 1) / (2 * FTY))), dim3(256), 0, raw, in_sy, setup, dout, o_sy, o_sc,
+                    W, H, dwords, (W + 63) / 64);
+        mark_output_written(processed);
+        return 0;
+    }
+    // any other geometry: one thread per quad from global memory, the curved planes through the workspace, a sharpen launch
+    if (in_sy % 2 == 0 && (uintptr_t)raw % 4 == 0) {
         HLMI_LAUNCH(uc, "cp_demosaic", st, cp_demosaic<true>, dim3((nqx + 255) / 256, nqy), dim3(256), 0, raw, in_sy, setup, cv, CW, CH, CWL, nqx, nqy);
     } else {
         HLMI_LAUNCH(uc, "cp_demosaic", st, cp_demosaic<false>, dim3((nqx + 255) / 256, nqy), dim3(256), 0, raw, in_sy, setup, cv, CW, CH, CWL, nqx, nqy);
     }
-    const long o_sy = processed->dim[1].stride, o_sc = processed->dim[2].stride;
-    uint8_t *dout = dev_ptr<uint8_t>(processed);
     if (W % 4 == 0 && o_sy % 4 == 0 && o_sc % 4 == 0 && (uintptr_t)dout % 4 == 0) {
         HLMI_LAUNCH(uc, "cp_sharpen", st, cp_sharpen4, dim3((W / 4 + 255) / 256, H), dim3(256), 0, cv, CW, CH, setup, dout, o_sy, o_sc, W, H);
     } else {
