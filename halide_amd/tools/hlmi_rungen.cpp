@@ -179,12 +179,20 @@ void load_pnm(const std::string &path, Arg &a) {
     std::ifstream f(path, std::ios::binary);
     if (!f) fail("cannot open " + path);
     std::string magic;
-    int w, h, maxv;
+    int w = 0, h = 0, maxv = 0;
     f >> magic >> w >> h >> maxv;
     f.get();
     const int ch = magic == "P6" ? 3 : magic == "P5" ? 1 : 0;
     if (!ch) fail(path + ": only binary PGM (P5) / PPM (P6) are supported");
+    if (!f || w <= 0 || h <= 0 || maxv <= 0 || maxv > 65535) fail(path + ": damaged PGM / PPM header");
     const int bps = maxv > 255 ? 2 : 1;
+    {   // the samples must be in the file before anything of their size is allocated
+        const std::streampos here = f.tellg();
+        f.seekg(0, std::ios::end);
+        const double left = (double)(f.tellg() - here);
+        f.seekg(here);
+        if ((double)w * h * ch * bps > left) fail(path + ": file is truncated");
+    }
     std::vector<uint8_t> raw((size_t)w * h * ch * bps);
     f.read((char *)raw.data(), raw.size());
     std::vector<int> ext = {w, h};
@@ -293,12 +301,14 @@ void save_npy(const std::string &path, const Arg &a) {
 void load_npy(const std::string &path, Arg &a) {
     std::ifstream f(path, std::ios::binary);
     if (!f) fail("cannot open " + path);
-    char magic[8];
+    char magic[8] = {0};
     f.read(magic, 8);
-    uint16_t hl;
+    if (f.gcount() != 8 || memcmp(magic, "\x93NUMPY", 6) != 0 || magic[6] != 1) fail(path + ": not a version-1 .npy file");
+    uint16_t hl = 0;
     f.read((char *)&hl, 2);
     std::string hdr(hl, ' ');
     f.read(&hdr[0], hl);
+    if ((size_t)f.gcount() != hl || hdr.find("shape") == std::string::npos || hdr.find('(') == std::string::npos) fail(path + ": damaged .npy header");
     if (hdr.find(npy_descr(a.md->type)) == std::string::npos) fail(path + ": dtype must be " + npy_descr(a.md->type) + " for this argument");
     if (hdr.find("'fortran_order': False") == std::string::npos) fail(path + ": fortran_order arrays are not supported");
     const size_t p0 = hdr.find('(', hdr.find("shape")), p1 = hdr.find(')', p0);
@@ -306,6 +316,19 @@ void load_npy(const std::string &path, Arg &a) {
     for (const auto &t : split(hdr.substr(p0 + 1, p1 - p0 - 1), ','))
         if (t.find_first_of("0123456789") != std::string::npos) np.push_back(atoi(t.c_str()));
     if ((int)np.size() != a.md->dimensions) fail(path + ": expected " + std::to_string(a.md->dimensions) + " dimensions");
+    double want = elem_bytes(a.md->type);
+    for (int e : np) {
+        if (e < 0) fail(path + ": negative extent");
+        want *= e;
+    }
+    // (bytes_left is defined with the other raw formats below; the samples must be in the file before anything is allocated)
+    {
+        const std::streampos here = f.tellg();
+        f.seekg(0, std::ios::end);
+        const double left = (double)(f.tellg() - here);
+        f.seekg(here);
+        if (want > left) fail(path + ": file is truncated");
+    }
     a.dims = dense_shape({}, np);   // dimension 0 first, as the reference writes them
     allocate(a);
     f.read((char *)a.storage.data(), count(a) * elem_bytes(a.md->type));
@@ -369,6 +392,16 @@ void assign_raw(const std::string &path, Arg &a, const RawArray &r) {
     }
 }
 
+// bytes between the read position and the end of the file: a header that promises more than that is rejected BEFORE anything
+// of that size is allocated
+uint64_t bytes_left(std::ifstream &f) {
+    const std::streampos here = f.tellg();
+    f.seekg(0, std::ios::end);
+    const std::streampos end = f.tellg();
+    f.seekg(here);
+    return here < 0 || end < here ? 0 : (uint64_t)(end - here);
+}
+
 void read_exact(std::ifstream &f, void *dst, size_t n, const std::string &path) {
     f.read((char *)dst, (std::streamsize)n);
     if ((size_t)f.gcount() != n) fail(path + ": file is truncated");
@@ -384,7 +417,9 @@ void load_tmp(const std::string &path, Arg &a) {
     RawArray r;
     r.type = kTmpTypes[h[4]];
     r.extents = {h[0], h[1], h[2], h[3]};
-    r.bytes.resize((size_t)h[0] * h[1] * h[2] * h[3] * (r.type.bits / 8));
+    const uint64_t payload = (uint64_t)h[0] * h[1] * h[2] * h[3] * (r.type.bits / 8);
+    if (payload > bytes_left(f)) fail(path + ": file is truncated");
+    r.bytes.resize((size_t)payload);
     read_exact(f, r.bytes.data(), r.bytes.size(), path);
     assign_raw(path, a, r);
 }
@@ -497,7 +532,7 @@ void load_tiff(const std::string &path, Arg &a) {
     r.type = {format == 1 ? halide_type_uint : format == 2 ? halide_type_int : halide_type_float, (uint8_t)bits, 1};
     const size_t eb = bits / 8;
     const uint64_t total = (uint64_t)width * height * depth * samples * eb;
-    if (total > (uint64_t)1 << 34) fail(path + ": TIFF extents are implausible");
+    if (total > b.size()) fail(path + ": the strips hold fewer samples than the image");   // uncompressed: the samples are in the file
     std::vector<uint8_t> flat;                                                     // the strips, concatenated in file order
     flat.reserve(total);
     for (size_t s = 0; s < offsets.size(); s++) {
@@ -555,6 +590,7 @@ void load_mat(const std::string &path, Arg &a) {
     bool known = false;
     for (const MatType &m : kMatTypes) if (m.mi == w[0]) r.type = m.t, known = true;
     if (!known) fail(path + ": unsupported sample type " + std::to_string(w[0]));
+    if (total * (r.type.bits / 8) > (double)bytes_left(f)) fail(path + ": file is truncated");
     r.bytes.resize((size_t)total * (r.type.bits / 8));
     read_exact(f, r.bytes.data(), r.bytes.size(), path);
     assign_raw(path, a, r);

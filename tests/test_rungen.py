@@ -191,9 +191,18 @@ def test_damaged_mat_and_tmp_files_are_rejected(tmp_path):
     (tmp_path / "code.tmp").write_bytes(struct.pack("<5i", 4, 4, 1, 1, 12) + b"\0" * 64)
     (tmp_path / "huge.tmp").write_bytes(struct.pack("<5i", 1 << 30, 1 << 30, 4, 4, 2))
     (tmp_path / "junk.mat").write_bytes(b"MATLAB 5.0".ljust(128) + struct.pack("<2I", 15, 64) + b"\0" * 64)   # a compressed element
-    for name in ("short.tmp", "code.tmp", "huge.tmp", "junk.mat"):
+    # headers that promise more samples than the file holds must be refused before anything of that size is allocated
+    (tmp_path / "big.tmp").write_bytes(struct.pack("<5i", 40000, 40000, 4, 1, 1) + b"\0" * 64)          # 51 GB of doubles
+    body = struct.pack("<4I", 6, 8, 6, 1) + struct.pack("<2I", 5, 8) + struct.pack("<2i", 50000, 50000) + struct.pack("<2I", 1, 1) + b"m".ljust(8, b"\0")
+    body += struct.pack("<2I", 9, 64) + b"\0" * 64
+    (tmp_path / "big.mat").write_bytes(b"MATLAB 5.0".ljust(124) + b"\0\x01IM" + struct.pack("<2I", 14, len(body)) + body)
+    (tmp_path / "big.npy").write_bytes(b"\x93NUMPY\x01\x00" + struct.pack("<H", 118) + b"{'descr': '<u2', 'fortran_order': False, 'shape': (60000, 60000), }".ljust(117) + b"\n" + b"\0" * 64)
+    (tmp_path / "junk.npy").write_bytes(b"NUMPY" + b"\0" * 200)
+    (tmp_path / "big.pgm").write_bytes(b"P5\n50000 50000\n65535\n" + b"\0" * 64)
+    (tmp_path / "junk.ppm").write_bytes(b"P6\nabc def\n255\n" + b"\0" * 64)
+    for name in ("short.tmp", "code.tmp", "huge.tmp", "junk.mat", "big.tmp", "big.mat", "big.npy", "junk.npy", "big.pgm", "junk.ppm"):
         p = _run("--name=stencil_chain", f"input={tmp_path / name}", "output=/dev/null", check=False)
-        assert p.returncode != 0, name
+        assert p.returncode > 0, (name, p.returncode, p.stderr[-200:])    # an error exit, not a signal (bad_alloc, SIGSEGV)
 
 
 def _parse_tiff(raw):
