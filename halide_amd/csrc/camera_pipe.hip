@@ -531,7 +531,11 @@ extern "C" int camera_pipe(halide_buffer_t *input, halide_buffer_t *matrix_3200,
                                                                  // columns (cp_sharpen4 reads two dwords per row)
     const size_t setup_bytes = (sizeof(CPSetup) + 255) & ~(size_t)255;
     void *ws = nullptr;
-    if ((r = get_workspace(uc, ctx, setup_bytes + (size_t)3 * CW * CH + 256, &ws))) return r;
+    // shifted(x, y) = input(x + 16, y + 12) in ABSOLUTE coordinates; output pixel (ox, oy) is X = 0 of the kernels
+    const long in_sy = input->dim[1].stride;
+    const uint16_t *raw = dev_ptr<uint16_t>(input) + (long)(oy + 12 - input->dim[1].min) * in_sy + (ox + 16 - input->dim[0].min);
+    const bool one_launch = in_sy % 2 == 0 && (uintptr_t)raw % 4 == 0 && W % 2 == 0;   // cp_fused_tile's preconditions
+    if ((r = get_workspace(uc, ctx, setup_bytes + (one_launch ? 0 : (size_t)3 * CW * CH + 256), &ws))) return r;   // the curved planes: only on the two-launch path
     CPSetup *setup = (CPSetup *)ws;
     uint8_t *cv = (uint8_t *)ws + setup_bytes;
     hipStream_t st = ctx.stream;
@@ -589,13 +593,10 @@ extern "C" int camera_pipe(halide_buffer_t *input, halide_buffer_t *matrix_3200,
             si_lock.unlock();
         }
     }
-    // shifted(x, y) = input(x + 16, y + 12) in ABSOLUTE coordinates; output pixel (ox, oy) is X = 0 of the kernels
-    const long in_sy = input->dim[1].stride;
-    const uint16_t *raw = dev_ptr<uint16_t>(input) + (long)(oy + 12 - input->dim[1].min) * in_sy + (ox + 16 - input->dim[0].min);
     const int nqx = floor_div(W, 2) + 2, nqy = floor_div(H, 2) + 2;
     const long o_sy = processed->dim[1].stride, o_sc = processed->dim[2].stride;
     uint8_t *dout = dev_ptr<uint8_t>(processed);
-    if (in_sy % 2 == 0 && (uintptr_t)raw % 4 == 0 && W % 2 == 0) {
+    if (one_launch) {
         const int dwords = o_sy % 4 == 0 && o_sc % 4 == 0 && (uintptr_t)dout % 4 == 0;
         HLMI_LAUNCH(uc, "cp_fused", st, cp_fused_tile, dim3(((W + 63) / 64) * ((H + 2 * FTY - 1) / (2 * FTY))), dim3(256), 0, raw, in_sy, setup, dout, o_sy, o_sc,
                     W, H, dwords, (W + 63) / 64);
