@@ -220,12 +220,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // 64-ci chunk is staged in LDS once (f32 -> bf16) and the nine taps are nine row offsets into it — 9x less A traffic
 // through L1 / LDS than re-staging an im2col slice per tap; B streams from L2 into registers.
 // Positions q with x >= W or y >= H are not outputs (7 % of a 56x56 image): computed, never stored.
-// timing experiments (make VARIANT=_cabl1 EXTRA=-DHLMI_CONV_ABL=1): 1 = no output stores, 2 = no main loop, 3 = only the first
-// A window is loaded, 4 = only the first three taps' B fragments are loaded, 5 = every A fragment read from one LDS address, 6 = no LDS reads of A, 7 = neither A reads nor B loads (MFMAs only).  At configs[4]: 29.4 us as built, 28.5 / 9.8 / 27.2 / 24.0 / 29.7 us — the main loop is 19-20 us whatever the A loads
-// and the stores do, 14 us of it without any B traffic, against 7.7 us of MFMA time per SIMD.  (s_memrealtime stamps inside the tap loop made the kernel 6x slower and were removed.)
-#ifndef HLMI_CONV_ABL
-#define HLMI_CONV_ABL 0
-#endif
+// Measured with compile-time ablations in round 2 (profiles/r02_conv_bf16_pmc.txt; the switches are gone): 29.4 us as built at
+// configs[4]; without output stores 28.5, without the main loop 9.8, with only the first A window loaded 27.2, with only the first
+// three taps' B fragments 24.0 — the main loop is 19-20 us whatever the A loads and the stores do, 14 us of it without any B
+// traffic, against 7.7 us of MFMA time per SIMD.
 constexpr int KL = 32;        // ci per window chunk of conv3x3_bf16_lin
 constexpr int PL = KL + 8;    // its LDS row pitch in bf16 elements (80 B)
 // NP: staging passes of 32 window rows per thread (window rows AR <= 32 NP)
@@ -294,18 +292,14 @@ void conv3x3_bf16_lin(const float *__restrict__ in, const uint16_t *__restrict__
 #pragma unroll
         for (int ks = 0; ks < KL / 16; ks++) {
             bf16x8 a0, a1;
-            if (HLMI_CONV_ABL == 6 || HLMI_CONV_ABL == 7) {   // no LDS reads: whatever the B registers hold
-                a0 = bs[0][ks], a1 = bs[1][ks];
-            } else {
-                a0 = *reinterpret_cast<const bf16x8 *>((HLMI_CONV_ABL == 5 ? sA + (lane & 31) * PL : pa) + 16 * ks);
-                a1 = *reinterpret_cast<const bf16x8 *>((HLMI_CONV_ABL == 5 ? sA + (lane & 31) * PL : pa + 32 * PL) + 16 * ks);
-            }
+            a0 = *reinterpret_cast<const bf16x8 *>(pa + 16 * ks);
+            a1 = *reinterpret_cast<const bf16x8 *>(pa + 32 * PL + 16 * ks);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bs[0][ks], acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bs[1][ks], acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bs[0][ks], acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bs[1][ks], acc[1][1], 0, 0, 0);
         }
-        if (t + 3 < ntap && HLMI_CONV_ABL != 4 && HLMI_CONV_ABL != 7) load_b(t + 3, bs);   // refill the stage just consumed
+        if (t + 3 < ntap) load_b(t + 3, bs);   // refill the stage just consumed
     };
     load_a(0);
     load_b(0, bfr[0]);
@@ -314,8 +308,8 @@ void conv3x3_bf16_lin(const float *__restrict__ in, const uint16_t *__restrict__
     store_a(0);
     __syncthreads();
 #pragma unroll 1
-    for (int cc = 0; cc < (HLMI_CONV_ABL == 2 ? 0 : cpk); cc++) {
-        if (cc + 1 < cpk && HLMI_CONV_ABL != 3) load_a(cc + 1);
+    for (int cc = 0; cc < cpk; cc++) {
+        if (cc + 1 < cpk) load_a(cc + 1);
         const uint16_t *sA = smem + (size_t)(cc & 1) * AR * PL;
 #pragma unroll 1
         for (int k3 = 0; k3 < 9; k3 += 3) {
@@ -341,7 +335,7 @@ void conv3x3_bf16_lin(const float *__restrict__ in, const uint16_t *__restrict__
 #pragma unroll
                     for (int b = 0; b < 2; b++) {
                         const float v = acc[a][b][r];
-                        if (HLMI_CONV_ABL != 1 || v != v) out[p * g.CO + co0 + 64 * wn + 32 * b + (lane & 31)] = v > 0.0f ? v : 0.0f;
+                        out[p * g.CO + co0 + 64 * wn + 32 * b + (lane & 31)] = v > 0.0f ? v : 0.0f;
                     }
                 }
             }
@@ -369,25 +363,19 @@ void conv3x3_bf16_lin(const float *__restrict__ in, const uint16_t *__restrict__
 // Only plain loads are in flight at a barrier (no stores before the epilogue), so __syncthreads() costs lgkmcnt(0) + s_barrier.
 // All requests are unconditional (indices clamped at the end of the K loop): a load behind a branch makes the compiler's
 // vmcnt bookkeeping assume nothing younger may be in flight, and every wait for a ring slot became vmcnt(0).
-#ifndef HLMI_CONVP_AGPR
-#define HLMI_CONVP_AGPR 0
-#endif
 constexpr int TQ = 256;        // input-linear positions per workgroup
 constexpr int PT = 512;        // threads per workgroup
 constexpr int BD = 6;          // B taps in flight
 constexpr int BSLOT = 4096;    // bf16 elements of one tap's B slot in LDS: [2 k-steps][4 co-fragments][64 lanes][8]
-// ABL: timing experiments (HLMI_CONVP_ABL=mask at run time, results wrong): 1 no output stores, 2 no K loop, 4 no B loads in
-// the loop, 8 no A loads in the loop, 16 no fragment reads, 32 no barriers, 64 no MFMAs, 128 no LDS staging writes
-// HALF: 128-position tiles, four waves (256 threads), TWO workgroups per CU.  The 256-position kernel runs ONE round of one
-// workgroup per CU: its prologue (first A window + the B ring, ~6 us) and its epilogue (131 KB of stores, 2.4 us) are exposed,
-// 8.3 of 24.7 us with the matrix pipe idle.  Two independent half-size workgroups per CU have independent barriers: one's
-// staging, fragment reads and stores can sit under the other's MFMAs.
-template<int NP, int ABL = 0, bool HALF = false>  // A staging passes of PT / 8 window rows (AR <= PT / 8 * NP)
-__global__ __launch_bounds__(HALF ? 256 : 512) void conv3x3_bf16_p(const float *__restrict__ in, const uint16_t *__restrict__ wb,
+// What round 3's ablation masks and the two-workgroups-per-CU variant measured is in profiles/r03_conv_bf16_ablation.txt (the
+// switches are gone): prologue (first A window + the B ring) ~6 us and epilogue (131 KB of stores) 2.4 us exposed, 8.3 of 24.7 us
+// with the matrix pipe idle; 128-position tiles with four waves and two workgroups per CU: 26.5 us.
+template<int NP>  // A staging passes of PT / 8 window rows (AR <= PT / 8 * NP)
+__global__ __launch_bounds__(512) void conv3x3_bf16_p(const float *__restrict__ in, const uint16_t *__restrict__ wb,
                                                     const float *__restrict__ bias, float *__restrict__ out, CGeom g, int AR,
-                                                    FastDiv d_img, FastDiv d_row, int stag) {
+                                                    FastDiv d_img, FastDiv d_row) {
     extern __shared__ uint16_t smem[];                       // [A window 0][A window 1][B slot 0][B slot 1]
-    constexpr int TQ = HALF ? 128 : 256, PT = HALF ? 256 : 512, RPP = PT / 8, NBP = 512 / PT;   // shadow the file-scope pair
+    constexpr int RPP = PT / 8, NBP = 512 / PT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wq = wave >> 1, wc = wave & 1;                 // the wave's 64 positions / 64 channels of the tile
@@ -464,13 +452,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void conv3x3_bf16_p(const float *
     auto mfma2 = [&](int fs, int a) {
 #pragma unroll
         for (int b = 0; b < 2; b++) {
-#if HLMI_CONVP_AGPR
-            // accumulators in the AGPR half of the register file (experiment: does C/D traffic in the VGPR file keep the
-            // LDS returns out?)
-            asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[a][b]) : "v"(fa[fs][a]), "v"(fb[fs][b]));
-#else
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[fs][a], fb[fs][b], acc[a][b], 0, 0, 0);
-#endif
         }
     };
     const int WpPL = Wp * PL;
@@ -490,20 +472,20 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void conv3x3_bf16_p(const float *
         const int T = Tb + t, cc = Tb / 9 + half;
         uint16_t *const sAc = half ? sA1 : sA0, *const sAo = half ? sA0 : sA1;
         // requests: B of tap T + BD into the ring slot tap T's data left when it went to LDS; next chunk's A window
-        if (!(ABL & 4)) load_b(min(T + BD, ntap - 1), rb[t % BD]);
-        if (kk == 0 && !(ABL & 8)) load_a(min(cc + 1, cpk - 1));
+        load_b(min(T + BD, ntap - 1), rb[t % BD]);
+        if (kk == 0) load_a(min(cc + 1, cpk - 1));
         __builtin_amdgcn_sched_barrier(0);
-        if (!(ABL & 16)) read_frags(1, sAc, ky * WpPL + kx * PL, 1, t & 1);   // second k-step of this tap
-        if (!(ABL & 64)) mfma2(0, 0);
+        read_frags(1, sAc, ky * WpPL + kx * PL, 1, t & 1);   // second k-step of this tap
+        mfma2(0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (!(ABL & 128)) store_b((t + 1) & 1, rb[(t + 1) % BD]);
-        if (kk == 8 && !(ABL & 128)) store_a(sAo);
-        if (!(ABL & 32)) __syncthreads();
+        store_b((t + 1) & 1, rb[(t + 1) % BD]);
+        if (kk == 8) store_a(sAo);
+        __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
-        if (!(ABL & 64)) mfma2(0, 1);
+        mfma2(0, 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (!(ABL & 16)) read_frags(0, kk == 8 ? sAo : sAc, kyn * WpPL + kxn * PL, 0, (t + 1) & 1);   // first k-step of the next tap
-        if (!(ABL & 64)) mfma2(1, 0), mfma2(1, 1);
+        read_frags(0, kk == 8 ? sAo : sAc, kyn * WpPL + kxn * PL, 0, (t + 1) & 1);   // first k-step of the next tap
+        mfma2(1, 0), mfma2(1, 1);
         __builtin_amdgcn_sched_barrier(0);
     };
     // ---- prologue
@@ -514,9 +496,8 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void conv3x3_bf16_p(const float *
     store_b(0, rb[0]);
     __syncthreads();
     read_frags(0, sA0, 0, 0, 0);
-    (void)stag;
 #pragma unroll 1
-    for (int Tb = 0; Tb < ((ABL & 2) ? 0 : ntap); Tb += 18) {
+    for (int Tb = 0; Tb < ntap; Tb += 18) {
         tap(std::integral_constant<int, 0>{}, Tb);
         tap(std::integral_constant<int, 1>{}, Tb);
         tap(std::integral_constant<int, 2>{}, Tb);
@@ -550,7 +531,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void conv3x3_bf16_p(const float *
 #pragma unroll
                     for (int b = 0; b < 2; b++) {
                         const float v = acc[a][b][r];
-                        if (!(ABL & 1) || v != v) o[32 * b] = v > 0.0f ? v : 0.0f;
+                        o[32 * b] = v > 0.0f ? v : 0.0f;
                     }
                 }
             }
@@ -762,8 +743,6 @@ extern "C" int conv_layer_bf16(halide_buffer_t *input, halide_buffer_t *filter, 
         const long NQ = (long)g.N * (g.H + 2) * (g.W + 2);
         const bool lin = AR <= 32 * 12 && NQ < (1L << 31) && NQ * g.CI < (1L << 31);   // W <= 125
         // conv3x3_bf16_p: 256-position tiles, B through LDS (see the kernel); the older kernels stay for what it does not take
-        // (the A/B switches of round 3 — 128-position tiles with two workgroups per CU, staggered starts, the ablation masks —
-        // are retired: profiles/r03_conv_bf16_ablation.txt has what they measured; the kernel keeps its template parameters)
         const int TQp = TQ;
         const int ARp = TQp + 2 * (g.W + 2) + 2;
         const size_t sh_p = ((size_t)2 * ARp * PL + 2 * BSLOT) * sizeof(uint16_t);   // two A windows, two B slots
@@ -792,17 +771,16 @@ extern "C" int conv_layer_bf16(halide_buffer_t *input, halide_buffer_t *filter, 
         if (pers) {
             dim3 grid((unsigned)((NQ + TQp - 1) / TQp), g.CO / TC);
             timing_note_bytes(4.0 * ((double)NQ * g.CI + (double)g.npix * g.CO) + (double)wb_bytes);
-            const int stag = 1;
             if (ARp <= 64 * 6) {
                 HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_p<6>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_p));
                 HLMI_LAUNCH(uc, "conv3x3_bf16_mfma", ctx.stream, conv3x3_bf16_p<6>, grid, dim3(PT), sh_p, dev_ptr<float>(input), wb,
-                            dev_ptr<float>(bias), dev_ptr<float>(relu), g, ARp, d_img, d_row, stag);
+                            dev_ptr<float>(bias), dev_ptr<float>(relu), g, ARp, d_img, d_row);
             } else {
                 HLMI_HIP(uc, hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_bf16_p<8>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_p));
                 HLMI_LAUNCH(uc, "conv3x3_bf16_mfma", ctx.stream, conv3x3_bf16_p<8>, grid, dim3(PT), sh_p, dev_ptr<float>(input), wb,
-                            dev_ptr<float>(bias), dev_ptr<float>(relu), g, ARp, d_img, d_row, stag);
+                            dev_ptr<float>(bias), dev_ptr<float>(relu), g, ARp, d_img, d_row);
             }
         } else if (lin) {
             dim3 grid((unsigned)((NQ + TP - 1) / TP), g.CO / TC);
