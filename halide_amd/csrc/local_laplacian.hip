@@ -800,9 +800,6 @@ struct D01EArgs {
     // 128-byte line, which its left neighbour reads too — from the same L2 then (68.8 -> 58.8 MB fetched per 4K frame)
     unsigned nsx_magic;        // floor(2^32 / nsx) + 1, 0 when nsx == 1
 };
-#ifndef HLMI_D01E_ABL
-#define HLMI_D01E_ABL 0   // timing experiments only (csrc/Makefile VARIANT): 1 no emission at all, 2 no outL0 stores, 4 no sel-plane stores, 8 emission without its LDS reads, 16 no table gathers in the plane loop
-#endif
 // Packed arithmetic: at two waves per SIMD this kernel is bound by how often ONE wave can issue (a wave issues an
 // independent VALU instruction every ~2.1 ns whatever it is, scripts/ubench/valu_pk.hip: v_pk_add / mul / fma_f32 2.4 ns for
 // two results against 2.1 ns for one), so every pointwise pass runs on column PAIRS held as <2 x float>: pair A = the
@@ -919,11 +916,7 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
     // table values of plane kk for two rows: dst[0], dst[1] = row r0 pairs A, B; dst[2], dst[3] = row r1
     auto lut_issue = [&](int kk, const Row &r0, const Row &r1, f2 (&dst)[4]) {
         auto rd = [&](int l) {
-#if HLMI_D01E_ABL & 16
-            return __builtin_bit_cast(float, l + kk);
-#else
             return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(slut) + l + 1024 * (KCH - 1 - kk));
-#endif
         };
         dst[0].x = rd(r0.l[0]), dst[1].x = rd(r0.l[1]), dst[0].y = rd(r0.l[2]), dst[1].y = rd(r0.l[3]);
         dst[2].x = rd(r1.l[0]), dst[3].x = rd(r1.l[1]), dst[2].y = rd(r1.l[2]), dst[3].y = rd(r1.l[3]);
@@ -972,12 +965,8 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         const uint32_t aq0 = (uint32_t)(size_t)rq, at0 = (uint32_t)(size_t)rt, alut = (uint32_t)(size_t)slut + 1024u * (KCH - 2);
         auto rd2 = [](uint32_t addr, auto swap_tag) {   // (dword at addr, dword at addr + 1024 bytes), or swapped
             f2 v;
-#if HLMI_D01E_ABL & 8
-            v = f2{__builtin_bit_cast(float, addr), 1.0f};
-#else
             if (decltype(swap_tag)::value) asm volatile("ds_read2st64_b32 %0, %1 offset0:4" : "=v"(v) : "v"(addr) : "memory");
             else asm volatile("ds_read2st64_b32 %0, %1 offset1:4" : "=v"(v) : "v"(addr) : "memory");
-#endif
             return v;
         };
         constexpr std::false_type asc{};
@@ -991,14 +980,12 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         g.lif = (float)li;
     };
     auto em_wait = [&](EmPix &g, auto after_tag) {   // `after` = gathers of how many pixels were requested after this one's
-#if !(HLMI_D01E_ABL & 8)
         constexpr int AFTER = decltype(after_tag)::value;
         static_assert(AFTER >= 0 && AFTER <= 3, "");
         if (AFTER == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(g.lut), "+v"(g.qa), "+v"(g.qb), "+v"(g.ta), "+v"(g.tb));
         if (AFTER == 1) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(g.lut), "+v"(g.qa), "+v"(g.qb), "+v"(g.ta), "+v"(g.tb));
         if (AFTER == 2) asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(g.lut), "+v"(g.qa), "+v"(g.qb), "+v"(g.ta), "+v"(g.tb));
         if (AFTER == 3) asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(g.lut), "+v"(g.qa), "+v"(g.qb), "+v"(g.ta), "+v"(g.tb));
-#endif
     };
     auto em_arith = [&](const Row &n, int i, const EmPix &g) {
         const bool xodd = ODD0 ? (i & 1) == 0 : (i & 1) == 1;
@@ -1029,7 +1016,7 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         em_wait(g[3], after0), r[3] = em_arith(n, 3, g[3]);
     };
     auto emit_store = [&](int y, const float (&r)[4]) {
-        if (em_ok && y >= pe.oy0 && y < pe.oy0 + pe.oh && !(HLMI_D01E_ABL & 2 && p.nunits > 0)) {
+        if (em_ok && y >= pe.oy0 && y < pe.oy0 + pe.oh) {
             typedef float f4_t __attribute__((ext_vector_type(4)));
             f4_t *const dst = reinterpret_cast<f4_t *>(em_col + (size_t)(y - pe.oy0) * iw);
             if (NT) __builtin_nontemporal_store(f4_t{r[0], r[1], r[2], r[3]}, dst);
@@ -1121,7 +1108,7 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         __builtin_amdgcn_sched_barrier(0);
         f2 *const rowT = st2 + (PH == 0 ? 0 : 64), *const rowP = st2 + (PH == 0 ? 64 : 0);   // rows T and T - 1
         const bool st1_row = T >= Ts0 && T <= Ts1;                                                  // wave-uniform
-        const bool em_rows = T >= 2 * A && T <= 2 * B + 1 && !(HLMI_D01E_ABL & 1 && p.nunits > 0);   // wave-uniform
+        const bool em_rows = T >= 2 * A && T <= 2 * B + 1;   // wave-uniform
         EmPix eg[4];
         if (em_rows) {
 #pragma unroll
@@ -1182,7 +1169,7 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         prep_row(rc, n0);
         prep_row(rd, n1);
         __builtin_amdgcn_sched_barrier(0);
-        if (st1_row && st1_ok && !(HLMI_D01E_ABL & 4 && p.nunits > 0)) {
+        if (st1_row && st1_ok) {
             float *drow = p.g1 + (size_t)(T - p.loy1) * p.ws1 + off1;
             *reinterpret_cast<float2 *>(drow) = s0;
             *reinterpret_cast<float2 *>(drow + p.ps1) = s1;
@@ -1237,7 +1224,7 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         }
         // outLPyramid[0] rows 4B + 1, 4B + 2 (the pair the last step brought in: p2 / p3) from level-1 rows 2B (slot 1) and 2B + 1
         // (published)
-        if (!(HLMI_D01E_ABL & 1 && p.nunits > 0)) {
+        {
             float eo[4], ee[4];
             emit_row(p2, pub_next, st2 + 64, eo);
             emit_row(p3, st2 + 64, pub_next, ee);
