@@ -201,15 +201,21 @@ def run(only=(), samples=5, sink=None, cpu=False, batched=True):
         # executed multiply-adds per output pixel; bound: the packed 16-bit integer VALU rate (v_pk_mad_u16: 2 MACs per lane
         # and clock = the packed-f32 figure).  Next to it the figure on the ALGORITHMIC count (32 stages x 25 taps = 1600 MACs
         # per pixel) and the fraction of the HBM roofline SURVEY.md §8(d) assigns the pipeline (4 B/px: read + write once).
-        halo = (128.0 * 96.0) / (96.0 * 64.0) if os.environ.get("HLMI_SC_LDS") else (128.0 * 128.0) / (96.0 * 96.0)
+        halo = (128.0 * 128.0) / (96.0 * 96.0)
         ops_exec = 2.0 * 32 * 10 * halo * W * H
         ops_alg = 2.0 * 1600 * W * H
+        sc_src = rng.integers(0, 65536, (H, W), dtype=np.uint16)
+
+        def mk_sc(i):
+            ai, oi = hl.Buffer(np.roll(sc_src, 13 * i, 1).copy()), hl.Buffer(np.zeros((H, W), np.uint16))
+            return lambda: hl.stencil_chain(ai, oi)
+        tb = timed_batched(mk_sc, rounds=3)
         emit("stencil_chain", "apps/stencil_chain 32 stages 5x5, u16 1536x2560", t, W * H, "valu", ops_exec / t / 1e12,
              VALU_F32_PEAK_TF, "TOP/s (u16, packed, executed)",
              {"executed_ops": ops_exec, "halo_recompute": halo, "alg_ops": ops_alg,
               "alg_ops_frac": round(ops_alg / t / 1e12 / VALU_F32_PEAK_TF, 4), "alg_bytes": 4 * W * H,
               "hbm_gbs": 4.0 * W * H / t / 1e9, "hbm_frac": round(4.0 * W * H / t / 1e9 / HBM_PEAK_GBS, 4),
-              "kernels_ms": kernels(call, o)})
+              "kernels_ms": kernels(call, o), **batched_fields(tb, ops_exec / 1e12, VALU_F32_PEAK_TF, "valu")})
 
     # ---- camera_pipe 2592x1968 raw -> 2560x1920x3 u8
     if not only or "camera_pipe" in only:
@@ -222,8 +228,15 @@ def run(only=(), samples=5, sink=None, cpu=False, batched=True):
         o = hl.Buffer(np.zeros((3, OH, OW), np.uint8))
         call = lambda: hl.camera_pipe(raw, m3, m7, 3700.0, 2.0, 50.0, 1.0, 25, 1023, o)
         t = timed(call, o, 50)
+        cp_src = rng.integers(0, 1024, (IH, IW), dtype=np.uint16)
+
+        def mk_cp(i):
+            ri, oi = hl.Buffer(np.roll(cp_src, 2 * i, 1).copy()), hl.Buffer(np.zeros((3, OH, OW), np.uint8))
+            return lambda: hl.camera_pipe(ri, m3, m7, 3700.0, 2.0, 50.0, 1.0, 25, 1023, oi)
+        tb = timed_batched(mk_cp)
         emit("camera_pipe", "apps/camera_pipe u16 2592x1968 -> u8 2560x1920x3", t, OW * OH, "hbm", 5.0 * OW * OH / t / 1e9,
-             HBM_PEAK_GBS, "GB/s", {"alg_bytes": 5 * OW * OH, "kernels_ms": kernels(call, o)})
+             HBM_PEAK_GBS, "GB/s", {"alg_bytes": 5 * OW * OH, "kernels_ms": kernels(call, o),
+                                   **batched_fields(tb, 5.0 * OW * OH / 1e9, HBM_PEAK_GBS, "hbm")})
 
     # ---- configs[3]: nl_means 7x7 / 7x7, f32 1920x1080x3 (one frame per call; frames of a batch are independent)
     if not only or "nl_means" in only:
