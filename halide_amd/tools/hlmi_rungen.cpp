@@ -12,8 +12,8 @@
 //
 // Image files: PNG (8 / 16 bit, gray / gray+alpha / RGB / RGBA, non-interlaced — the formats tools/halide_image_io.h:856-1040
 // reads and writes; own codec over zlib in hlmi_png.h, this image has no libpng), binary PGM / PPM, and the reference's three raw
-// array formats: .npy, .mat (MATLAB level 5) and .tmp (ImageStack), plus uncompressed TIFF (which the reference only writes).  JPG is
-// not handled (libjpeg is not linked; the apps' drivers feed none) — printed by --help.
+// array formats: .npy, .mat (MATLAB level 5) and .tmp (ImageStack), plus uncompressed TIFF (which the reference only writes) and baseline
+// JPEG as an INPUT (hlmi_jpeg.h: the samples libjpeg's defaults return; nothing is written as JPEG) — printed by --help.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -31,6 +31,7 @@
 #include <sstream>
 #include <string>
 
+#include "hlmi_jpeg.h"
 #include "hlmi_png.h"
 #include <vector>
 
@@ -224,6 +225,24 @@ void load_png(const std::string &path, Arg &a) {
     for_each_element(a, [&](size_t i, const std::vector<int> &c) {
         const int cc = c.size() >= 3 ? std::min(c[2], ch - 1) : 0;
         store_value(a, i, convert_sample((double)im.at((uint32_t)c[0], (uint32_t)c[1], cc), file_max, a.md->type));
+    });
+}
+
+// JPEG (input only): hlmi_jpeg.h decodes baseline files to the samples libjpeg's default settings return — what the reference's
+// load_jpg (tools/halide_image_io.h:1506-1548) hands on; conversion to the argument's type as for PNG
+void load_jpg(const std::string &path, Arg &a) {
+    hlmi_jpeg::Image im;
+    const std::string err = hlmi_jpeg::read(path, im);
+    if (!err.empty()) fail(err);
+    const int w = (int)im.width, h = (int)im.height, ch = im.channels;
+    std::vector<int> ext = {w, h};
+    if ((int)a.md->dimensions >= 3) ext.push_back(ch);
+    while ((int)ext.size() < a.md->dimensions) ext.push_back(1);
+    a.dims = dense_shape({}, ext);
+    allocate(a);
+    for_each_element(a, [&](size_t i, const std::vector<int> &c) {
+        const int cc = c.size() >= 3 ? std::min(c[2], ch - 1) : 0;
+        store_value(a, i, convert_sample((double)im.at((uint32_t)c[0], (uint32_t)c[1], cc), 255.0, a.md->type));
     });
 }
 
@@ -679,12 +698,12 @@ void usage() {
         "Usage: hlmi_rungen --name=PIPELINE argument=value [argument=value ...] [flags]\n"
         "   or: PIPELINE.rungen argument=value ... (pipeline = basename of argv[0] up to the first '.')\n\n"
         "Arguments follow the reference's RunGen (tools/RunGenMain.cpp): scalars as literals or `default` / `estimate`;\n"
-        "buffers as a file (.png .pgm .ppm .npy .mat .tmp .tiff) or a pseudo-file: zero:[e0,e1,..]  constant:V:[..]  identity:[..]\n"
+        "buffers as a file (.png .jpg (input only) .pgm .ppm .npy .mat .tmp .tiff) or a pseudo-file: zero:[e0,e1,..]  constant:V:[..]  identity:[..]\n"
         "random:SEED:[..]; `auto` or `estimate` may stand for the extents.\n\n"
         "Flags: --help --describe --output_extents=[..]|estimate --benchmarks=all --benchmark_min_time=SEC\n"
         "       --parsable_output --estimate_all --default_input_buffers[=V] --default_input_scalars[=V]\n"
         "       --success --verbose --quiet\n\n"
-        "PNG: 8 / 16 bit, gray / gray+alpha / RGB / RGBA, non-interlaced.  JPG files are not supported by this build (no libjpeg).\n";
+        "PNG: 8 / 16 bit, gray / gray+alpha / RGB / RGBA, non-interlaced.  JPG: baseline (sequential, Huffman, 8 bit, gray or YCbCr), input only.\n";
 }
 
 }  // namespace
@@ -830,6 +849,8 @@ int main(int argc, char **argv) {
         } else if (ends_with(spec, ".png")) {
             load_png(spec, a);
             a.spec.clear();
+        } else if (ends_with(spec, ".jpg") || ends_with(spec, ".jpeg")) {
+            load_jpg(spec, a);
         } else if (ends_with(spec, ".pgm") || ends_with(spec, ".ppm")) {
             load_pnm(spec, a);
             a.spec.clear();
@@ -845,7 +866,7 @@ int main(int argc, char **argv) {
             load_tmp(spec, a);
             a.spec.clear();
         } else {
-            fail("cannot read '" + spec + "': supported are .png .pgm .ppm .npy .mat .tmp .tiff and the pseudo-files of --help");
+            fail("cannot read '" + spec + "': supported are .png .jpg .pgm .ppm .npy .mat .tmp .tiff and the pseudo-files of --help");
         }
     }
     // ---- outputs: shape from --output_extents, the estimates, or a bounds query constrained by the inputs

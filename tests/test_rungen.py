@@ -292,3 +292,68 @@ def test_damaged_tiff_files_are_rejected(tmp_path):
         p = _run("--name=stencil_chain", f"input={tmp_path / name}", "output=/dev/null", check=False)
         assert p.returncode != 0 and "Segmentation" not in p.stderr, name
         assert p.returncode > 0, (name, p.returncode)                         # an error exit, not a signal
+
+
+JPEG_DIR = os.path.join(ROOT, "tests", "golden", "jpeg")
+JPEG_CASES = ["rgb444_q95", "rgb422_q75", "rgb420_q75", "rgb420_q30_opt", "rgb420_q90_rst", "rgb420_narrow", "gray_q85", "gray_q100_rst"]
+
+
+def _jpeg_tool(tmp_path):
+    exe = tmp_path / "jpeg_decode_test"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "halide_amd", "tools"),
+                    os.path.join(ROOT, "tests", "cpp", "jpeg_decode_test.cpp"), "-o", str(exe)], check=True)
+    return str(exe)
+
+
+def test_jpeg_decoder_returns_libjpegs_samples(tmp_path):
+    """The runner's JPEG decoder against libjpeg-turbo (through Pillow, scripts/make_jpeg_golden.py): 4:4:4 / 4:2:2 / 4:2:0, gray,
+    optimised Huffman tables, restart intervals, a component too narrow for the triangle filter — every sample identical
+    (the reference reads JPEG through libjpeg's defaults, tools/halide_image_io.h:1506-1548)."""
+    tool = _jpeg_tool(tmp_path)
+    want = np.load(os.path.join(JPEG_DIR, "expected.npz"))
+    assert sorted(want.files) == sorted(JPEG_CASES)
+    for name in JPEG_CASES:
+        out = str(tmp_path / (name + ".bin"))
+        p = subprocess.run([tool, os.path.join(JPEG_DIR, name + ".jpg"), out], capture_output=True, text=True)
+        assert p.returncode == 0, (name, p.stderr)
+        w, h, c = map(int, p.stdout.split())
+        got = np.fromfile(out, np.uint8).reshape(h, w, c)
+        assert got.shape == want[name].shape and np.array_equal(got, want[name]), name
+
+
+def test_jpeg_decoder_refuses_what_it_does_not_decode(tmp_path):
+    tool = _jpeg_tool(tmp_path)
+    good = open(os.path.join(JPEG_DIR, "rgb420_q75.jpg"), "rb").read()
+    sof = good.index(b"\xff\xc0")
+    cases = {
+        "progressive.jpg": good[:sof] + b"\xff\xc2" + good[sof + 2:],          # SOF2
+        "twelve_bit.jpg": good[:sof + 4] + b"\x0c" + good[sof + 5:],           # sample precision 12
+        "cut_header.jpg": good[:sof + 6],
+        "cut_scan.jpg": good[:len(good) * 2 // 3],                              # ends inside the entropy-coded data
+        "not_jpeg.jpg": b"\x89PNG\r\n\x1a\n" + good[8:],
+        "no_tables.jpg": good[:2] + good[good.index(b"\xff\xc0"):],             # frame and scan without DQT / DHT
+    }
+    for name, blob in cases.items():
+        (tmp_path / name).write_bytes(blob)
+        p = subprocess.run([tool, str(tmp_path / name), str(tmp_path / "x.bin")], capture_output=True, text=True)
+        assert p.returncode == 1 and p.stderr.strip(), (name, p.returncode, p.stderr)
+    # random damage: an answer or a refusal, never a crash
+    rng = np.random.default_rng(11)
+    for trial in range(60):
+        d = bytearray(good)
+        for _ in range(int(rng.integers(1, 6))):
+            d[int(rng.integers(2, len(d)))] = int(rng.integers(0, 256))
+        (tmp_path / "fz.jpg").write_bytes(bytes(d))
+        p = subprocess.run([tool, str(tmp_path / "fz.jpg"), str(tmp_path / "x.bin")], capture_output=True, text=True)
+        assert p.returncode in (0, 1), (trial, p.returncode, p.stderr[-200:])
+
+
+@pytest.mark.gpu
+def test_jpeg_input_through_the_runner(oracle, tmp_path):
+    """A JPEG file as a pipeline input: decoded, converted like every other 8-bit image file (u8 -> u16: x 257) and run."""
+    want_rgb = np.load(os.path.join(JPEG_DIR, "expected.npz"))["rgb420_q75"]                  # (37, 61, 3) u8
+    inp = np.ascontiguousarray(want_rgb.transpose(2, 0, 1)).astype(np.uint16) * 257
+    _run("--name=local_laplacian", f"input={os.path.join(JPEG_DIR, 'rgb420_q75.jpg')}", "levels=4", "alpha=0.3333333333333333", "beta=1",
+         "--output_extents=[61,37,3]", f"output={tmp_path / 'out.npy'}")
+    got = np.load(tmp_path / "out.npy").reshape(3, 37, 61)
+    assert np.array_equal(got, oracle.local_laplacian(inp, 4, np.float32(0.3333333333333333), 1.0))
