@@ -1,4 +1,4 @@
-// hlmi_jpeg.h — baseline JPEG input for the command-line runner (hlmi_rungen).  The reference's image I/O reads JPEG through
+// hlmi_jpeg.h — baseline JPEG for the command-line runner (hlmi_rungen): a decoder and (further down) an encoder.  The reference's image I/O reads JPEG through
 // libjpeg with its default settings (tools/halide_image_io.h:1506-1548 load_jpg: jpeg_read_header, jpeg_start_decompress,
 // 8-bit scanlines of output_components samples); this image has no libjpeg headers, so the decoder is written out here
 // against ITU-T T.81 and does what libjpeg's defaults do, step for step, so that the samples are the ones libjpeg returns:
@@ -8,8 +8,7 @@
 //     "fancy upsampling" (3/4 nearer + 1/4 further sample, the two roundings alternating), edges by replication;
 //   * YCbCr -> RGB with 16-bit fixed-point tables (1.402, 1.772, 0.71414, 0.34414) and the usual range limiting.
 // tests/test_rungen.py compares the output with what libjpeg-turbo (through Pillow) returned for the files in
-// tests/golden/jpeg/ — bit for bit.  Progressive, arithmetic-coded, 12-bit and CMYK files are refused; nothing is written as
-// JPEG (the apps' drivers neither feed nor produce any).
+// tests/golden/jpeg/ — bit for bit.  Progressive, arithmetic-coded, 12-bit and CMYK files are refused.
 #pragma once
 
 #include <stdint.h>
@@ -120,7 +119,7 @@ inline void idct_islow(const int *coef /* dequantized, natural order */, uint8_t
         long z1 = (z2 + z3) * F_0_541196100;
         long tmp2 = z1 + z3 * (-F_1_847759065), tmp3 = z1 + z2 * F_0_765366865;
         z2 = in[0], z3 = in[32];
-        long tmp0 = (z2 + z3) << CB, tmp1 = (z2 - z3) << CB;
+        long tmp0 = (z2 + z3) * (1L << CB), tmp1 = (z2 - z3) * (1L << CB);
         const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = in[56], tmp1 = in[40], tmp2 = in[24], tmp3 = in[8];
         z1 = tmp0 + tmp3, z2 = tmp1 + tmp2, z3 = tmp0 + tmp2;
@@ -140,7 +139,7 @@ inline void idct_islow(const int *coef /* dequantized, natural order */, uint8_t
         long z2 = w[2], z3 = w[6];
         long z1 = (z2 + z3) * F_0_541196100;
         long tmp2 = z1 + z3 * (-F_1_847759065), tmp3 = z1 + z2 * F_0_765366865;
-        long tmp0 = (w[0] + w[4]) << CB, tmp1 = (w[0] - w[4]) << CB;
+        long tmp0 = (w[0] + w[4]) * (1L << CB), tmp1 = (w[0] - w[4]) * (1L << CB);
         const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = w[7], tmp1 = w[5], tmp2 = w[3], tmp3 = w[1];
         z1 = tmp0 + tmp3, z2 = tmp1 + tmp2, z3 = tmp0 + tmp2;
@@ -409,6 +408,264 @@ inline std::string read(const std::string &path, Image &im) {
         im.bytes[3 * i] = clamp8(r), im.bytes[3 * i + 1] = clamp8(g), im.bytes[3 * i + 2] = clamp8(bl);
     }
     return "";
+}
+
+// ---- encoder: what libjpeg writes with jpeg_set_defaults + jpeg_set_quality(quality, TRUE) — the reference's save_jpg
+// (tools/halide_image_io.h:1558-1610, quality 99): JFIF 1.01 header, the Annex K quantization tables scaled by the quality,
+// YCbCr with the chroma averaged 2 x 2 (gray: one component), accurate integer forward DCT, the Annex K Huffman tables, one scan.
+// Written step for step after libjpeg so that the FILE is the one libjpeg produces: tests/test_rungen.py compares with files
+// libjpeg-turbo wrote (through Pillow) byte for byte.
+namespace detail {
+
+const uint8_t kStdLumQ[64] = {16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,  14, 13, 16, 24, 40,  57,
+                              69, 56, 14, 17, 22,  29,  51,  87,  80, 62, 18, 22, 37,  56,  68,  109, 103, 77, 24, 35, 55,  64,
+                              81, 104, 113, 92, 49, 64,  78,  87,  103, 121, 120, 101, 72, 92,  95,  98,  112, 100, 103, 99};
+const uint8_t kStdChrQ[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99,
+                              99, 99, 47, 66, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                              99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+// T.81 Annex K.3: code-length counts and symbols of the four typical tables
+const uint8_t kDcLumBits[16] = {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+const uint8_t kDcChrBits[16] = {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+const uint8_t kDcVals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+const uint8_t kAcLumBits[16] = {0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d};
+const uint8_t kAcLumVals[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1,
+    0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26,
+    0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56,
+    0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85,
+    0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa,
+    0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6,
+    0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9,
+    0xfa};
+const uint8_t kAcChrBits[16] = {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77};
+const uint8_t kAcChrVals[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42,
+    0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19,
+    0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55,
+    0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83,
+    0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8,
+    0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4,
+    0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9,
+    0xfa};
+
+struct EncTable {
+    uint16_t code[256];
+    uint8_t size[256];
+};
+inline void build_enc(const uint8_t *bits, const uint8_t *vals, EncTable &t) {   // T.81 Annex C
+    memset(&t, 0, sizeof t);
+    int code = 0, k = 0;
+    for (int l = 1; l <= 16; l++) {
+        for (int i = 0; i < bits[l - 1]; i++, k++) t.code[vals[k]] = (uint16_t)code++, t.size[vals[k]] = (uint8_t)l;
+        code <<= 1;
+    }
+}
+
+// jfdctint.c: forward DCT, results scaled up by 8 (the quantizer divides by 8 q)
+inline void fdct_islow(int *d) {
+    constexpr int CB = 13, P1 = 2;
+    constexpr long F_0_298631336 = 2446, F_0_390180644 = 3196, F_0_541196100 = 4433, F_0_765366865 = 6270, F_0_899976223 = 7373,
+                   F_1_175875602 = 9633, F_1_501321110 = 12299, F_1_847759065 = 15137, F_1_961570560 = 16069, F_2_053119869 = 16819,
+                   F_2_562915447 = 20995, F_3_072711026 = 25172;
+    auto descale = [](long x, int n) { return (x + (1L << (n - 1))) >> n; };
+    for (int pass = 0; pass < 2; pass++) {
+        const int step = pass ? 8 : 1, next = pass ? 1 : 8;   // pass 0: along rows, pass 1: down columns
+        for (int i = 0; i < 8; i++) {
+            int *p = d + i * next;
+            const long tmp0 = p[0] + p[7 * step], tmp7 = p[0] - p[7 * step], tmp1 = p[step] + p[6 * step], tmp6 = p[step] - p[6 * step];
+            const long tmp2 = p[2 * step] + p[5 * step], tmp5 = p[2 * step] - p[5 * step], tmp3 = p[3 * step] + p[4 * step], tmp4 = p[3 * step] - p[4 * step];
+            const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+            if (pass == 0) p[0] = (int)((tmp10 + tmp11) * (1 << P1)), p[4 * step] = (int)((tmp10 - tmp11) * (1 << P1));
+            else p[0] = (int)descale(tmp10 + tmp11, P1), p[4 * step] = (int)descale(tmp10 - tmp11, P1);
+            const int S = pass == 0 ? CB - P1 : CB + P1;
+            long z1 = (tmp12 + tmp13) * F_0_541196100;
+            p[2 * step] = (int)descale(z1 + tmp13 * F_0_765366865, S), p[6 * step] = (int)descale(z1 + tmp12 * (-F_1_847759065), S);
+            z1 = tmp4 + tmp7;
+            long z2 = tmp5 + tmp6, z3 = tmp4 + tmp6, z4 = tmp5 + tmp7;
+            const long z5 = (z3 + z4) * F_1_175875602;
+            const long t4 = tmp4 * F_0_298631336, t5 = tmp5 * F_2_053119869, t6 = tmp6 * F_3_072711026, t7 = tmp7 * F_1_501321110;
+            z1 *= -F_0_899976223, z2 *= -F_2_562915447, z3 *= -F_1_961570560, z4 *= -F_0_390180644;
+            z3 += z5, z4 += z5;
+            p[7 * step] = (int)descale(t4 + z1 + z3, S), p[5 * step] = (int)descale(t5 + z2 + z4, S);
+            p[3 * step] = (int)descale(t6 + z2 + z3, S), p[step] = (int)descale(t7 + z1 + z4, S);
+        }
+    }
+}
+
+struct BitWriter {
+    std::vector<uint8_t> &out;
+    uint32_t acc = 0;
+    int n = 0;
+    explicit BitWriter(std::vector<uint8_t> &o) : out(o) {}
+    void put(unsigned code, int size) {
+        if (!size) return;
+        acc |= (code & ((1u << size) - 1)) << (24 - n - size + 8);   // keep the pending bits left-aligned in a 32-bit window
+        n += size;
+        while (n >= 8) {
+            const uint8_t b = (uint8_t)(acc >> 24);
+            out.push_back(b);
+            if (b == 0xff) out.push_back(0);
+            acc <<= 8, n -= 8;
+        }
+    }
+    void flush() { put(0x7f, 7); acc = 0, n = 0; }   // pad the last byte with ones
+};
+
+}  // namespace detail
+
+// `im`: 1 (gray) or 3 (RGB) channels of 8-bit samples.  Returns "" on success.
+inline std::string write(const std::string &path, const Image &im, int quality = 99) {
+    using namespace detail;
+    if (im.channels != 1 && im.channels != 3) return path + ": JPEG files hold 1 or 3 channels";
+    if (!im.width || !im.height || im.width > 65535 || im.height > 65535) return path + ": JPEG dimensions are 1 .. 65535";
+    const int W = (int)im.width, H = (int)im.height, nc = im.channels;
+    quality = quality < 1 ? 1 : quality > 100 ? 100 : quality;
+    const int scale = quality < 50 ? 5000 / quality : 200 - 2 * quality;
+    uint8_t q[2][64];
+    for (int t = 0; t < 2; t++)
+        for (int i = 0; i < 64; i++) {
+            long v = ((long)(t ? kStdChrQ[i] : kStdLumQ[i]) * scale + 50) / 100;
+            q[t][i] = (uint8_t)(v < 1 ? 1 : v > 255 ? 255 : v);
+        }
+    // ---- component planes, padded as libjpeg pads them: columns by repeating the last one up to whole blocks (before the chroma
+    // is averaged), rows by repeating the last row — of the full-size data up to an even count, of each plane up to whole MCUs
+    const int hs = nc == 3 ? 2 : 1;                                     // luma sampling factor in both directions
+    struct Plane {
+        int wb, hb, wpad, hpad;                                         // blocks that exist; samples stored (whole MCUs down)
+        std::vector<uint8_t> s;
+    } pl[3];
+    const int mcux = (W + 8 * hs - 1) / (8 * hs), mcuy = (H + 8 * hs - 1) / (8 * hs);
+    const int Hfull = nc == 3 ? (H + 1) / 2 * 2 : H;                    // full-size rows after the bottom edge is repeated
+    std::vector<uint8_t> ycc[3];
+    for (int c = 0; c < nc; c++) ycc[c].assign((size_t)W * Hfull, 0);
+    for (int y = 0; y < Hfull; y++) {
+        const int sy = y < H ? y : H - 1;
+        for (int x = 0; x < W; x++) {
+            const uint8_t *p = &im.bytes[((size_t)sy * W + x) * nc];
+            if (nc == 1) {
+                ycc[0][(size_t)y * W + x] = p[0];
+            } else {   // jccolor.c: SCALEBITS 16; the chroma rows carry ONE_HALF - 1 so that the maximum stays below 256
+                const long r = p[0], g = p[1], b = p[2];
+                ycc[0][(size_t)y * W + x] = (uint8_t)((19595 * r + 38470 * g + 7471 * b + 32768) >> 16);
+                ycc[1][(size_t)y * W + x] = (uint8_t)((-11059 * r - 21709 * g + 32768 * b + (128L << 16) + 32767) >> 16);
+                ycc[2][(size_t)y * W + x] = (uint8_t)((32768 * r - 27439 * g - 5329 * b + (128L << 16) + 32767) >> 16);
+            }
+        }
+    }
+    for (int c = 0; c < nc; c++) {
+        Plane &P = pl[c];
+        const int samp = c == 0 ? hs : 1, cw = (W * samp + hs - 1) / hs, chh = (H * samp + hs - 1) / hs;   // true component size
+        P.wb = (cw + 7) / 8, P.hb = (chh + 7) / 8;
+        P.wpad = P.wb * 8, P.hpad = mcuy * samp * 8;
+        P.s.assign((size_t)P.wpad * P.hpad, 0);
+        const int rows = c == 0 || nc == 1 ? Hfull : Hfull / 2;          // rows that come out of the (down)sampler
+        for (int y = 0; y < P.hpad; y++) {
+            const int sy = y < rows ? y : rows - 1;
+            uint8_t *o = &P.s[(size_t)y * P.wpad];
+            if (c == 0 || nc == 1) {
+                const uint8_t *in = &ycc[c][(size_t)sy * W];
+                for (int x = 0; x < P.wpad; x++) o[x] = in[x < W ? x : W - 1];
+            } else {   // jcsample.c h2v2_downsample: the rounding bias alternates 1, 2 along a row
+                const uint8_t *in0 = &ycc[c][(size_t)(2 * sy) * W], *in1 = &ycc[c][(size_t)(2 * sy + 1) * W];
+                int bias = 1;
+                for (int x = 0; x < P.wpad; x++, bias ^= 3) {
+                    const int x0 = 2 * x < W ? 2 * x : W - 1, x1 = 2 * x + 1 < W ? 2 * x + 1 : W - 1;
+                    o[x] = (uint8_t)((in0[x0] + in0[x1] + in1[x0] + in1[x1] + bias) >> 2);
+                }
+            }
+        }
+    }
+    // ---- headers
+    std::vector<uint8_t> f;
+    auto put8 = [&](int v) { f.push_back((uint8_t)v); };
+    auto put16 = [&](int v) { f.push_back((uint8_t)(v >> 8)), f.push_back((uint8_t)v); };
+    put16(0xffd8);
+    put16(0xffe0), put16(16), put8('J'), put8('F'), put8('I'), put8('F'), put8(0), put16(0x0101), put8(0), put16(1), put16(1), put8(0), put8(0);
+    for (int t = 0; t < (nc == 3 ? 2 : 1); t++) {
+        put16(0xffdb), put16(67), put8(t);
+        for (int k = 0; k < 64; k++) put8(q[t][kZigzag[k]]);
+    }
+    put16(0xffc0), put16(8 + 3 * nc), put8(8), put16(H), put16(W), put8(nc);
+    for (int c = 0; c < nc; c++) put8(c + 1), put8(c == 0 ? (hs << 4 | hs) : 0x11), put8(c ? 1 : 0);
+    auto dht = [&](int tc_th, const uint8_t *bits, const uint8_t *vals, int nv) {
+        put16(0xffc4), put16(19 + nv), put8(tc_th);
+        for (int i = 0; i < 16; i++) put8(bits[i]);
+        for (int i = 0; i < nv; i++) put8(vals[i]);
+    };
+    dht(0x00, kDcLumBits, kDcVals, 12), dht(0x10, kAcLumBits, kAcLumVals, 162);
+    if (nc == 3) dht(0x01, kDcChrBits, kDcVals, 12), dht(0x11, kAcChrBits, kAcChrVals, 162);
+    put16(0xffda), put16(6 + 2 * nc), put8(nc);
+    for (int c = 0; c < nc; c++) put8(c + 1), put8(c ? 0x11 : 0x00);
+    put8(0), put8(63), put8(0);
+    // ---- the scan
+    EncTable edc[2], eac[2];
+    build_enc(kDcLumBits, kDcVals, edc[0]), build_enc(kAcLumBits, kAcLumVals, eac[0]);
+    build_enc(kDcChrBits, kDcVals, edc[1]), build_enc(kAcChrBits, kAcChrVals, eac[1]);
+    BitWriter bw(f);
+    int pred[3] = {0, 0, 0};
+    auto nbits_of = [](int v) { int n = 0; while (v) n++, v >>= 1; return n; };
+    auto encode_block = [&](const int *zz /* quantized, natural order */, int c) {
+        const EncTable &D = edc[c ? 1 : 0], &A = eac[c ? 1 : 0];
+        int diff = zz[0] - pred[c];
+        pred[c] = zz[0];
+        int t = diff, t2 = diff;
+        if (t < 0) t = -t, t2--;
+        int nb = nbits_of(t);
+        bw.put(D.code[nb], D.size[nb]);
+        if (nb) bw.put((unsigned)t2, nb);
+        int run = 0;
+        for (int k = 1; k < 64; k++) {
+            int v = zz[kZigzag[k]];
+            if (v == 0) { run++; continue; }
+            while (run > 15) bw.put(A.code[0xf0], A.size[0xf0]), run -= 16;
+            t = v, t2 = v;
+            if (t < 0) t = -t, t2--;
+            nb = nbits_of(t);
+            bw.put(A.code[(run << 4) + nb], A.size[(run << 4) + nb]);
+            bw.put((unsigned)t2, nb);
+            run = 0;
+        }
+        if (run > 0) bw.put(A.code[0], A.size[0]);
+    };
+    int blk[64], prev_dc[3] = {0, 0, 0};
+    for (int my = 0; my < mcuy; my++) {
+        for (int mx = 0; mx < mcux; mx++) {
+            for (int c = 0; c < nc; c++) {
+                const Plane &P = pl[c];
+                const int samp = c == 0 ? hs : 1;
+                for (int by = 0; by < samp; by++) {
+                    for (int bx = 0; bx < samp; bx++) {
+                        const int bxx = mx * samp + bx, byy = my * samp + by;
+                        if (bxx < P.wb && byy < P.hb) {
+                            const uint8_t *src = &P.s[(size_t)byy * 8 * P.wpad + (size_t)bxx * 8];
+                            for (int i = 0; i < 64; i++) blk[i] = (int)src[(size_t)(i >> 3) * P.wpad + (i & 7)] - 128;
+                            fdct_islow(blk);
+                            const uint8_t *qt = q[c ? 1 : 0];
+                            for (int i = 0; i < 64; i++) {   // jcdctmgr.c: divide by 8 q, rounding half away from zero
+                                const int qv = qt[i] << 3;
+                                int v = blk[i];
+                                if (v < 0) v = -((-v + (qv >> 1)) / qv);
+                                else v = (v + (qv >> 1)) / qv;
+                                blk[i] = v;
+                            }
+                        } else {   // a block that only pads the MCU: no AC, the DC of the block coded before it in this MCU
+                            memset(blk, 0, sizeof blk);
+                            blk[0] = prev_dc[c];
+                        }
+                        prev_dc[c] = blk[0];
+                        encode_block(blk, c);
+                    }
+                }
+            }
+        }
+    }
+    bw.flush();
+    put16(0xffd9);
+    FILE *fp = fopen(path.c_str(), "wb");
+    if (!fp) return "cannot write " + path;
+    const bool ok = fwrite(f.data(), 1, f.size(), fp) == f.size();
+    fclose(fp);
+    return ok ? "" : path + ": short write";
 }
 
 }  // namespace hlmi_jpeg

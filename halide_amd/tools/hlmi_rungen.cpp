@@ -13,7 +13,7 @@
 // Image files: PNG (8 / 16 bit, gray / gray+alpha / RGB / RGBA, non-interlaced — the formats tools/halide_image_io.h:856-1040
 // reads and writes; own codec over zlib in hlmi_png.h, this image has no libpng), binary PGM / PPM, and the reference's three raw
 // array formats: .npy, .mat (MATLAB level 5) and .tmp (ImageStack), plus uncompressed TIFF (which the reference only writes) and baseline
-// JPEG as an INPUT (hlmi_jpeg.h: the samples libjpeg's defaults return; nothing is written as JPEG) — printed by --help.
+// JPEG (hlmi_jpeg.h: reads to the samples libjpeg's defaults return, writes the file libjpeg writes at quality 99) — printed by --help.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -244,6 +244,34 @@ void load_jpg(const std::string &path, Arg &a) {
         const int cc = c.size() >= 3 ? std::min(c[2], ch - 1) : 0;
         store_value(a, i, convert_sample((double)im.at((uint32_t)c[0], (uint32_t)c[1], cc), 255.0, a.md->type));
     });
+}
+
+// JPEG out: what the reference's save_jpg writes (tools/halide_image_io.h:1558-1610: libjpeg's defaults at quality 99) — the
+// encoder in hlmi_jpeg.h reproduces libjpeg's file byte for byte.  8-bit samples; wider or float buffers are narrowed the way
+// the reference narrows them before it saves (:143-186: u16 by (x + 128) * 255 + 255 >> 16, floats by lround(x * 255)).
+void save_jpg(const std::string &path, const Arg &a) {
+    const int w = a.dims.size() > 0 ? a.dims[0].extent : 1, h = a.dims.size() > 1 ? a.dims[1].extent : 1;
+    const int ch = a.dims.size() > 2 ? a.dims[2].extent : 1;
+    if (ch != 1 && ch != 3) fail(path + ": JPEG needs 1 or 3 channels, the buffer has " + std::to_string(ch));
+    const halide_type_t t = a.md->type;
+    hlmi_jpeg::Image im;
+    im.width = (uint32_t)w, im.height = (uint32_t)h, im.channels = ch;
+    im.bytes.assign((size_t)w * h * ch, 0);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            for (int c = 0; c < ch; c++) {
+                const size_t i = (size_t)x * a.dims[0].stride + (a.dims.size() > 1 ? (size_t)y * a.dims[1].stride : 0) +
+                                 (a.dims.size() > 2 ? (size_t)c * a.dims[2].stride : 0);
+                const double v = load_value(a, i);
+                unsigned o;
+                if (t.code == halide_type_float) o = (unsigned)std::lround(std::min(1.0, std::max(0.0, v)) * 255.0);
+                else if (t.bits == 8) o = (unsigned)std::min(255.0, std::max(0.0, v));
+                else if (t.bits == 16) o = (((unsigned)std::min(65535.0, std::max(0.0, v)) + 0x80u) * 255u + 255u) >> 16;
+                else o = (unsigned)(((uint64_t)std::min(4294967295.0, std::max(0.0, v)) + 0x00808080u) / 0x01010101u);
+                im.bytes[((size_t)y * w + x) * ch + c] = (uint8_t)(o > 255 ? 255 : o);
+            }
+    const std::string err = hlmi_jpeg::write(path, im, 99);
+    if (!err.empty()) fail(err);
 }
 
 void save_png(const std::string &path, const Arg &a) {
@@ -698,12 +726,12 @@ void usage() {
         "Usage: hlmi_rungen --name=PIPELINE argument=value [argument=value ...] [flags]\n"
         "   or: PIPELINE.rungen argument=value ... (pipeline = basename of argv[0] up to the first '.')\n\n"
         "Arguments follow the reference's RunGen (tools/RunGenMain.cpp): scalars as literals or `default` / `estimate`;\n"
-        "buffers as a file (.png .jpg (input only) .pgm .ppm .npy .mat .tmp .tiff) or a pseudo-file: zero:[e0,e1,..]  constant:V:[..]  identity:[..]\n"
+        "buffers as a file (.png .jpg .pgm .ppm .npy .mat .tmp .tiff) or a pseudo-file: zero:[e0,e1,..]  constant:V:[..]  identity:[..]\n"
         "random:SEED:[..]; `auto` or `estimate` may stand for the extents.\n\n"
         "Flags: --help --describe --output_extents=[..]|estimate --benchmarks=all --benchmark_min_time=SEC\n"
         "       --parsable_output --estimate_all --default_input_buffers[=V] --default_input_scalars[=V]\n"
         "       --success --verbose --quiet\n\n"
-        "PNG: 8 / 16 bit, gray / gray+alpha / RGB / RGBA, non-interlaced.  JPG: baseline (sequential, Huffman, 8 bit, gray or YCbCr), input only.\n";
+        "PNG: 8 / 16 bit, gray / gray+alpha / RGB / RGBA, non-interlaced.  JPG: baseline (sequential, Huffman, 8 bit, gray or YCbCr); written as libjpeg writes it at quality 99.\n";
 }
 
 }  // namespace
@@ -964,11 +992,12 @@ int main(int argc, char **argv) {
         if (a.out_path.empty()) continue;
         if (ends_with(a.out_path, ".npy")) save_npy(a.out_path, a);
         else if (ends_with(a.out_path, ".png")) save_png(a.out_path, a);
+        else if (ends_with(a.out_path, ".jpg") || ends_with(a.out_path, ".jpeg")) save_jpg(a.out_path, a);
         else if (ends_with(a.out_path, ".pgm") || ends_with(a.out_path, ".ppm")) save_pnm(a.out_path, a);
         else if (ends_with(a.out_path, ".mat")) save_mat(a.out_path, a);
         else if (ends_with(a.out_path, ".tmp")) save_tmp(a.out_path, a);
         else if (ends_with(a.out_path, ".tiff") || ends_with(a.out_path, ".tif")) save_tiff(a.out_path, a);
-        else fail("cannot write '" + a.out_path + "': supported are .png .pgm .ppm .npy .mat .tmp .tiff");
+        else fail("cannot write '" + a.out_path + "': supported are .png .jpg .pgm .ppm .npy .mat .tmp .tiff");
     }
     for (auto &a : args)
         if (a.md->kind != halide_argument_kind_input_scalar && a.buf.device_interface) a.buf.device_interface->device_free(nullptr, &a.buf);

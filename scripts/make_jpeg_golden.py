@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""tests/golden/jpeg/: small baseline JPEG files and the samples libjpeg-turbo (through Pillow) decodes them to — the pin of
-halide_amd/tools/hlmi_jpeg.h.  Needs Pillow (present in the build container, not on the GPU box): the files and the expected
+"""tests/golden/jpeg/: small baseline JPEG files and the samples libjpeg-turbo (through Pillow) decodes them to, and source images
+with the files libjpeg-turbo writes for them — the pin of halide_amd/tools/hlmi_jpeg.h (decoder and encoder).  Needs Pillow (present in the build container, not on the GPU box): the files and the expected
 arrays are committed; this script is how they were made.
 
     python scripts/make_jpeg_golden.py"""
@@ -30,6 +30,13 @@ CASES = [  # name, (h, w), mode, subsampling, quality, extra save options
     ("gray_q100_rst", (16, 16), "L", 0, 100, {"restart_marker_blocks": 1}),
 ]
 
+ENC_CASES = [  # name, (h, w), mode, quality: what libjpeg writes with its defaults (4:2:0 for RGB, the Annex K tables)
+    ("enc_rgb_q99", (37, 61), "RGB", 99),          # the reference's save_jpg setting; 61 columns: an MCU padded with a dummy block
+    ("enc_rgb_q75_odd", (17, 23), "RGB", 75),
+    ("enc_gray_q99", (29, 43), "L", 99),
+    ("enc_rgb_q30_tiny", (3, 5), "RGB", 30),
+]
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     expected = {}
@@ -40,4 +47,9 @@ if __name__ == "__main__":
         dec = np.asarray(Image.open(path))
         expected[name] = dec if dec.ndim == 3 else dec[..., None]
         print(name, dec.shape, os.path.getsize(path), "bytes")
+    for seed, (name, (h, w), mode, q) in enumerate(ENC_CASES):
+        img = scene(h, w, 3 if mode == "RGB" else 1, 100 + seed)
+        Image.fromarray(img if mode == "RGB" else img[..., 0], mode).save(os.path.join(OUT, name + ".jpg"), "JPEG", quality=q)
+        expected["src_" + name] = img
+        print(name, img.shape, os.path.getsize(os.path.join(OUT, name + ".jpg")), "bytes")
     np.savez_compressed(os.path.join(OUT, "expected.npz"), **expected)

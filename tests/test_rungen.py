@@ -299,9 +299,10 @@ JPEG_CASES = ["rgb444_q95", "rgb422_q75", "rgb420_q75", "rgb420_q30_opt", "rgb42
 
 
 def _jpeg_tool(tmp_path):
-    exe = tmp_path / "jpeg_decode_test"
-    subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "halide_amd", "tools"),
-                    os.path.join(ROOT, "tests", "cpp", "jpeg_decode_test.cpp"), "-o", str(exe)], check=True)
+    exe = tmp_path / "jpeg_codec_test"
+    if not exe.exists():
+        subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "halide_amd", "tools"),
+                        os.path.join(ROOT, "tests", "cpp", "jpeg_codec_test.cpp"), "-o", str(exe)], check=True)
     return str(exe)
 
 
@@ -311,10 +312,10 @@ def test_jpeg_decoder_returns_libjpegs_samples(tmp_path):
     (the reference reads JPEG through libjpeg's defaults, tools/halide_image_io.h:1506-1548)."""
     tool = _jpeg_tool(tmp_path)
     want = np.load(os.path.join(JPEG_DIR, "expected.npz"))
-    assert sorted(want.files) == sorted(JPEG_CASES)
+    assert sorted(n for n in want.files if not n.startswith("src_")) == sorted(JPEG_CASES)
     for name in JPEG_CASES:
         out = str(tmp_path / (name + ".bin"))
-        p = subprocess.run([tool, os.path.join(JPEG_DIR, name + ".jpg"), out], capture_output=True, text=True)
+        p = subprocess.run([tool, "decode", os.path.join(JPEG_DIR, name + ".jpg"), out], capture_output=True, text=True)
         assert p.returncode == 0, (name, p.stderr)
         w, h, c = map(int, p.stdout.split())
         got = np.fromfile(out, np.uint8).reshape(h, w, c)
@@ -335,7 +336,7 @@ def test_jpeg_decoder_refuses_what_it_does_not_decode(tmp_path):
     }
     for name, blob in cases.items():
         (tmp_path / name).write_bytes(blob)
-        p = subprocess.run([tool, str(tmp_path / name), str(tmp_path / "x.bin")], capture_output=True, text=True)
+        p = subprocess.run([tool, "decode", str(tmp_path / name), str(tmp_path / "x.bin")], capture_output=True, text=True)
         assert p.returncode == 1 and p.stderr.strip(), (name, p.returncode, p.stderr)
     # random damage: an answer or a refusal, never a crash
     rng = np.random.default_rng(11)
@@ -344,8 +345,27 @@ def test_jpeg_decoder_refuses_what_it_does_not_decode(tmp_path):
         for _ in range(int(rng.integers(1, 6))):
             d[int(rng.integers(2, len(d)))] = int(rng.integers(0, 256))
         (tmp_path / "fz.jpg").write_bytes(bytes(d))
-        p = subprocess.run([tool, str(tmp_path / "fz.jpg"), str(tmp_path / "x.bin")], capture_output=True, text=True)
+        p = subprocess.run([tool, "decode", str(tmp_path / "fz.jpg"), str(tmp_path / "x.bin")], capture_output=True, text=True)
         assert p.returncode in (0, 1), (trial, p.returncode, p.stderr[-200:])
+
+
+def test_jpeg_encoder_writes_libjpegs_file(tmp_path):
+    """The runner's JPEG encoder against libjpeg-turbo (through Pillow): the same FILE, byte for byte — JFIF header, scaled
+    Annex K quantization tables, 4:2:0 chroma with libjpeg's edge padding and dummy blocks, accurate integer DCT, Annex K Huffman
+    tables (the reference writes JPEG through libjpeg's defaults at quality 99, tools/halide_image_io.h:1558-1610)."""
+    tool = _jpeg_tool(tmp_path)
+    gold = np.load(os.path.join(JPEG_DIR, "expected.npz"))
+    for name, q in (("enc_rgb_q99", 99), ("enc_rgb_q75_odd", 75), ("enc_gray_q99", 99), ("enc_rgb_q30_tiny", 30)):
+        src = gold["src_" + name]
+        h, w, c = src.shape
+        (tmp_path / "src.bin").write_bytes(src.tobytes())
+        out = tmp_path / (name + ".jpg")
+        p = subprocess.run([tool, "encode", str(tmp_path / "src.bin"), str(w), str(h), str(c), str(out), str(q)], capture_output=True, text=True)
+        assert p.returncode == 0, (name, p.stderr)
+        assert out.read_bytes() == open(os.path.join(JPEG_DIR, name + ".jpg"), "rb").read(), name
+        # and what was written reads back through the decoder as libjpeg reads it (checked against Pillow when the fixtures were made)
+        p = subprocess.run([tool, "decode", str(out), str(tmp_path / "back.bin")], capture_output=True, text=True)
+        assert p.returncode == 0 and p.stdout.split() == [str(w), str(h), str(c)], (name, p.stderr)
 
 
 @pytest.mark.gpu
@@ -356,4 +376,13 @@ def test_jpeg_input_through_the_runner(oracle, tmp_path):
     _run("--name=local_laplacian", f"input={os.path.join(JPEG_DIR, 'rgb420_q75.jpg')}", "levels=4", "alpha=0.3333333333333333", "beta=1",
          "--output_extents=[61,37,3]", f"output={tmp_path / 'out.npy'}")
     got = np.load(tmp_path / "out.npy").reshape(3, 37, 61)
-    assert np.array_equal(got, oracle.local_laplacian(inp, 4, np.float32(0.3333333333333333), 1.0))
+    want = oracle.local_laplacian(inp, 4, np.float32(0.3333333333333333), 1.0)
+    assert np.array_equal(got, want)
+    # ... and a JPEG file as the output: the u16 result narrowed the way the reference narrows it, then libjpeg's file
+    _run("--name=local_laplacian", f"input={os.path.join(JPEG_DIR, 'rgb420_q75.jpg')}", "levels=4", "alpha=0.3333333333333333", "beta=1",
+         "--output_extents=[61,37,3]", f"output={tmp_path / 'out.jpg'}")
+    narrowed = (((want.astype(np.uint32) + 0x80) * 255 + 255) >> 16).astype(np.uint8).transpose(1, 2, 0)
+    tool = _jpeg_tool(tmp_path)
+    (tmp_path / "n.bin").write_bytes(np.ascontiguousarray(narrowed).tobytes())
+    subprocess.run([tool, "encode", str(tmp_path / "n.bin"), "61", "37", "3", str(tmp_path / "ref.jpg"), "99"], check=True)
+    assert (tmp_path / "out.jpg").read_bytes() == (tmp_path / "ref.jpg").read_bytes()
