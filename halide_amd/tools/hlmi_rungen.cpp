@@ -749,19 +749,27 @@ int main(int argc, char **argv) {
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&](const std::string &flag) { return a.size() > flag.size() + 1 ? a.substr(flag.size() + 1) : std::string(); };
+        // boolean flags as RunGen takes them (tools/RunGenMain.cpp:421-500): --flag, --flag=true, --flag=false
+        auto bool_flag = [&](const std::string &flag, bool *dst) {
+            if (a != flag && a.rfind(flag + "=", 0) != 0) return false;
+            const std::string v = val(flag);
+            if (v.empty() || v == "true") *dst = true;
+            else if (v == "false") *dst = false;
+            else fail("Invalid value for flag: " + flag.substr(2));
+            return true;
+        };
+        bool ignored = false;
         if (a == "--help") { usage(); return 0; }
         else if (a.rfind("--name=", 0) == 0) name = val("--name");
-        else if (a == "--describe") describe = true;
+        else if (bool_flag("--describe", &describe) || bool_flag("--parsable_output", &parsable) || bool_flag("--success", &success) ||
+                 bool_flag("--verbose", &verbose) || bool_flag("--quiet", &ignored) || bool_flag("--track_memory", &ignored) ||
+                 bool_flag("--skip_bad_environment", &ignored)) {}
         else if (a.rfind("--output_extents", 0) == 0) output_extents = val("--output_extents");
         else if (a.rfind("--benchmarks", 0) == 0) { if (val("--benchmarks") != "all") fail("--benchmarks only supports 'all'"); benchmarks = true; }
         else if (a.rfind("--benchmark_min_time", 0) == 0) min_time = atof(val("--benchmark_min_time").c_str());
-        else if (a == "--parsable_output") parsable = true;
         else if (a == "--estimate_all") { default_bufs = "estimate_then_auto", default_scalars = "estimate", output_extents = "estimate"; }
         else if (a.rfind("--default_input_buffers", 0) == 0) { default_bufs = val("--default_input_buffers"); if (default_bufs.empty()) default_bufs = "zero:auto"; }
         else if (a.rfind("--default_input_scalars", 0) == 0) { default_scalars = val("--default_input_scalars"); if (default_scalars.empty()) default_scalars = "estimate,default"; }
-        else if (a == "--success") success = true;
-        else if (a == "--verbose") verbose = true;
-        else if (a == "--quiet" || a == "--track_memory" || a == "--skip_bad_environement") {}
         else if (a.rfind("--", 0) == 0) fail("unknown flag " + a);
         else {
             const size_t eq = a.find('=');
@@ -859,8 +867,10 @@ int main(int argc, char **argv) {
         auto parts = split(spec, ':');
         const std::string kind = parts[0];
         if (kind == "zero" || kind == "constant" || kind == "identity" || kind == "random") {
-            const std::string ext_s = parts.back();
+            std::string ext_s = parts.back();
             std::vector<int> mins, ext;
+            // estimate_then_auto (tools/RunGenMain.cpp:90-100): the estimate when the generator declared one, else the bounds query
+            if (ext_s == "estimate_then_auto") ext_s = a.md->buffer_estimates && estimate_extents(a, &mins, &ext) ? "estimate" : "auto";
             if (ext_s == "auto") {
                 a.spec = spec;
                 auto_inputs.push_back(&a);
@@ -879,6 +889,7 @@ int main(int argc, char **argv) {
             a.spec.clear();
         } else if (ends_with(spec, ".jpg") || ends_with(spec, ".jpeg")) {
             load_jpg(spec, a);
+            a.spec.clear();
         } else if (ends_with(spec, ".pgm") || ends_with(spec, ".ppm")) {
             load_pnm(spec, a);
             a.spec.clear();
@@ -890,6 +901,7 @@ int main(int argc, char **argv) {
             a.spec.clear();
         } else if (ends_with(spec, ".tiff") || ends_with(spec, ".tif")) {
             load_tiff(spec, a);
+            a.spec.clear();
         } else if (ends_with(spec, ".tmp")) {
             load_tmp(spec, a);
             a.spec.clear();

@@ -27,6 +27,19 @@ def test_describe_lists_the_generator_arguments():
     assert 'Input "sigma" is of type float32' in out and 'Output "non_local_means"' in out
 
 
+def test_boolean_flags_take_values_like_rungens():
+    """--flag, --flag=true and --flag=false (tools/RunGenMain.cpp:421-500), --skip_bad_environment spelled as the reference spells it."""
+    want = _run("--name=hist", "--describe").stdout
+    assert "Filter name" in want
+    assert _run("--name=hist", "--describe=true", "--quiet", "--track_memory=false", "--skip_bad_environment").stdout == want
+    p = _run("--name=hist", "--describe=false", check=False)
+    assert p.returncode != 0 and "no value for buffer" in p.stderr           # not describing: it wants its inputs
+    p = _run("--name=hist", "--describe=maybe", check=False)
+    assert p.returncode != 0 and "Invalid value for flag: describe" in p.stderr
+    p = _run("--name=hist", "--skip_bad_environement", check=False)
+    assert p.returncode != 0 and "unknown flag" in p.stderr
+
+
 def test_unknown_pipeline_and_argument_are_errors():
     assert _run("--name=no_such_filter", "--describe", check=False).returncode != 0
     p = _run("--name=halide_blur", "bogus=1", "--describe", check=False)
@@ -38,6 +51,15 @@ def test_argv0_basename_selects_the_pipeline(tmp_path):
     os.symlink(RUNGEN, link)
     p = subprocess.run([str(link), "--describe"], capture_output=True, text=True, env={**os.environ, "HLMI_LIB": os.path.join(ROOT, "halide_amd", "lib", "libhlmi.so")})
     assert p.returncode == 0 and 'Filter name: "stencil_chain"' in p.stdout
+
+
+@pytest.mark.gpu
+def test_estimate_then_auto_inside_a_pseudo_file(tmp_path):
+    """`random:0:estimate_then_auto` — what --estimate_all stands for (tools/RunGenMain.cpp:479-486) — written out by hand."""
+    a = _run("--name=hist", "--estimate_all", f"output={tmp_path / 'a.npy'}")
+    b = _run("--name=hist", "--default_input_buffers=random:0:estimate_then_auto", "--output_extents=estimate", f"output={tmp_path / 'b.npy'}")
+    assert a.returncode == 0 and b.returncode == 0
+    assert np.array_equal(np.load(tmp_path / "a.npy"), np.load(tmp_path / "b.npy"))
 
 
 @pytest.mark.gpu
