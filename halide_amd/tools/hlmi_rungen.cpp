@@ -763,7 +763,8 @@ int main(int argc, char **argv) {
         else if (a.rfind("--name=", 0) == 0) name = val("--name");
         else if (bool_flag("--describe", &describe) || bool_flag("--parsable_output", &parsable) || bool_flag("--success", &success) ||
                  bool_flag("--verbose", &verbose) || bool_flag("--quiet", &ignored) || bool_flag("--track_memory", &ignored) ||
-                 bool_flag("--skip_bad_environment", &ignored)) {}
+                 bool_flag("--skip_bad_environment", &ignored) ||   // what RunGen parses (tools/RunGenMain.cpp:494) ...
+                 bool_flag("--skip_bad_environement", &ignored)) {}  // ... and what its usage text prints (:179)
         else if (a.rfind("--output_extents", 0) == 0) output_extents = val("--output_extents");
         else if (a.rfind("--benchmarks", 0) == 0) { if (val("--benchmarks") != "all") fail("--benchmarks only supports 'all'"); benchmarks = true; }
         else if (a.rfind("--benchmark_min_time", 0) == 0) min_time = atof(val("--benchmark_min_time").c_str());

@@ -28,7 +28,7 @@ def test_describe_lists_the_generator_arguments():
 
 
 def test_boolean_flags_take_values_like_rungens():
-    """--flag, --flag=true and --flag=false (tools/RunGenMain.cpp:421-500), --skip_bad_environment spelled as the reference spells it."""
+    """--flag, --flag=true and --flag=false (tools/RunGenMain.cpp:421-500); --skip_bad_environment in both of the reference's spellings."""
     want = _run("--name=hist", "--describe").stdout
     assert "Filter name" in want
     assert _run("--name=hist", "--describe=true", "--quiet", "--track_memory=false", "--skip_bad_environment").stdout == want
@@ -36,7 +36,8 @@ def test_boolean_flags_take_values_like_rungens():
     assert p.returncode != 0 and "no value for buffer" in p.stderr           # not describing: it wants its inputs
     p = _run("--name=hist", "--describe=maybe", check=False)
     assert p.returncode != 0 and "Invalid value for flag: describe" in p.stderr
-    p = _run("--name=hist", "--skip_bad_environement", check=False)
+    assert _run("--name=hist", "--describe", "--skip_bad_environement").stdout == want   # the spelling of RunGen's usage text (:179)
+    p = _run("--name=hist", "--skip_bad_env", check=False)
     assert p.returncode != 0 and "unknown flag" in p.stderr
 
 
