@@ -74,6 +74,12 @@ std::string type_name(halide_type_t t) {
     return std::string(base) + std::to_string((int)t.bits);
 }
 
+bool g_quiet_warnings = false;
+// RunGen's warnings (tools/RunGenMain.cpp:297-300: "Warning: " + text on stderr), same wording
+void warn(const std::string &msg) {
+    if (!g_quiet_warnings) std::cerr << "Warning: " << msg << "\n";
+}
+
 // one argument of the pipeline
 struct Arg {
     const halide_filter_argument_t *md = nullptr;
@@ -176,6 +182,34 @@ double convert_sample(double v, double file_max, halide_type_t t) {
     return std::floor(v * (tmax / file_max) + 0.5);
 }
 
+// what RunGen says when a file does not have the argument's shape or type (tools/RunGen.h:433-477)
+void note_loaded(const Arg &a, const std::vector<int> &file_extents, halide_type_t file_type) {
+    const int have = (int)file_extents.size(), need = a.md->dimensions;
+    if (have > need) {
+        bool trivial = true;
+        for (int d = need; d < have; d++) trivial = trivial && file_extents[d] == 1;
+        if (!trivial) {
+            warn(std::string("Image for Input \"") + a.md->name + "\" has " + std::to_string(have) + " dimensions, but only the first " +
+                 std::to_string(need) + " were used; data loss may have occurred.");
+        }
+    } else if (have < need) {
+        warn(std::string("Image for Input \"") + a.md->name + "\" has " + std::to_string(have) + " dimensions, but this argument requires at least " +
+             std::to_string(need) + " dimensions: adding dummy dimensions of extent 1.");
+    }
+    if (file_type.code != a.md->type.code || file_type.bits != a.md->type.bits) {
+        warn(std::string("Image loaded for argument \"") + a.md->name + "\" is type " + type_name(file_type) + " but this argument expects type " +
+             type_name(a.md->type) + "; data loss may have occurred.");
+    }
+}
+// ... and when an output is not stored as what it is (tools/RunGen.h:1116-1121)
+void note_saved(const Arg &a, halide_type_t saved) {
+    if (saved.code != a.md->type.code || saved.bits != a.md->type.bits) {
+        warn(std::string("Image for argument \"") + a.md->name + "\" is of type " + type_name(a.md->type) + " but is being saved as type " +
+             type_name(saved) + "; data loss may have occurred.");
+    }
+}
+const halide_type_t kU8 = {halide_type_uint, 8, 1}, kU16 = {halide_type_uint, 16, 1};
+
 void load_pnm(const std::string &path, Arg &a) {
     std::ifstream f(path, std::ios::binary);
     if (!f) fail("cannot open " + path);
@@ -196,6 +230,7 @@ void load_pnm(const std::string &path, Arg &a) {
     }
     std::vector<uint8_t> raw((size_t)w * h * ch * bps);
     f.read((char *)raw.data(), raw.size());
+    note_loaded(a, ch > 1 ? std::vector<int>{w, h, ch} : std::vector<int>{w, h}, bps == 2 ? kU16 : kU8);
     std::vector<int> ext = {w, h};
     if ((int)a.md->dimensions >= 3) ext.push_back(ch);
     while ((int)ext.size() < a.md->dimensions) ext.push_back(1);
@@ -216,6 +251,7 @@ void load_png(const std::string &path, Arg &a) {
     const std::string err = hlmi_png::read(path, im);
     if (!err.empty()) fail(err);
     const int w = (int)im.width, h = (int)im.height, ch = im.channels;
+    note_loaded(a, ch > 1 ? std::vector<int>{w, h, ch} : std::vector<int>{w, h}, im.bit_depth == 16 ? kU16 : kU8);
     std::vector<int> ext = {w, h};
     if ((int)a.md->dimensions >= 3) ext.push_back(ch);
     while ((int)ext.size() < a.md->dimensions) ext.push_back(1);
@@ -235,6 +271,7 @@ void load_jpg(const std::string &path, Arg &a) {
     const std::string err = hlmi_jpeg::read(path, im);
     if (!err.empty()) fail(err);
     const int w = (int)im.width, h = (int)im.height, ch = im.channels;
+    note_loaded(a, ch > 1 ? std::vector<int>{w, h, ch} : std::vector<int>{w, h}, kU8);
     std::vector<int> ext = {w, h};
     if ((int)a.md->dimensions >= 3) ext.push_back(ch);
     while ((int)ext.size() < a.md->dimensions) ext.push_back(1);
@@ -254,6 +291,7 @@ void save_jpg(const std::string &path, const Arg &a) {
     const int ch = a.dims.size() > 2 ? a.dims[2].extent : 1;
     if (ch != 1 && ch != 3) fail(path + ": JPEG needs 1 or 3 channels, the buffer has " + std::to_string(ch));
     const halide_type_t t = a.md->type;
+    note_saved(a, kU8);
     hlmi_jpeg::Image im;
     im.width = (uint32_t)w, im.height = (uint32_t)h, im.channels = ch;
     im.bytes.assign((size_t)w * h * ch, 0);
@@ -282,6 +320,7 @@ void save_png(const std::string &path, const Arg &a) {
     hlmi_png::Image im;
     im.width = (uint32_t)w, im.height = (uint32_t)h, im.channels = ch;
     im.bit_depth = (t.code == halide_type_float || t.bits > 8) ? 16 : 8;
+    note_saved(a, im.bit_depth == 16 ? kU16 : kU8);
     const double maxv = im.bit_depth == 16 ? 65535.0 : 255.0;
     im.bytes.assign((size_t)w * h * ch * (im.bit_depth / 8), 0);
     for (int y = 0; y < h; y++)
@@ -304,6 +343,7 @@ void save_pnm(const std::string &path, const Arg &a) {
     if (ch != 1 && ch != 3) fail(path + ": PGM/PPM need 1 or 3 channels, the buffer has " + std::to_string(ch));
     const halide_type_t t = a.md->type;
     const bool wide = t.code == halide_type_float || t.bits > 8;
+    note_saved(a, wide ? kU16 : kU8);
     const int maxv = wide ? 65535 : 255;
     std::ofstream f(path, std::ios::binary);
     f << (ch == 3 ? "P6" : "P5") << "\n" << w << " " << h << "\n" << maxv << "\n";
@@ -413,6 +453,7 @@ double raw_value(const RawArray &r, size_t i) {
 }
 
 void assign_raw(const std::string &path, Arg &a, const RawArray &r) {
+    note_loaded(a, r.extents, r.type);
     std::vector<int> ext = r.extents;
     while ((int)ext.size() > a.md->dimensions && ext.back() == 1) ext.pop_back();
     while ((int)ext.size() < a.md->dimensions) ext.push_back(1);
@@ -921,9 +962,21 @@ int main(int argc, char **argv) {
             ext = out_ext;
             if ((int)ext.size() != a.md->dimensions) fail("--output_extents has the wrong number of dimensions");
         }
+        if (ext.empty() && output_extents.empty()) {
+            // no --output_extents: RunGen lets every output assume the shape of the first input buffer — first by argument name —
+            // cut or extended to the output's dimension count, missing extents guessed as 1000 (x, y) or 4 (tools/RunGen.h:378-389,
+            // :1077-1090); the bounds query below then has something to constrain
+            const Arg *first = nullptr;
+            for (auto &in : args)
+                if (in.md->kind == halide_argument_kind_input_buffer && !in.dims.empty() && !in.storage.empty() &&
+                    (!first || strcmp(in.md->name, first->md->name) < 0)) first = &in;
+            if (first) {
+                for (int d = 0; d < a.md->dimensions; d++) ext.push_back(d < (int)first->dims.size() ? first->dims[d].extent : (d < 2 ? 1000 : 4));
+            }
+        }
         if (!ext.empty()) {
             a.dims = dense_shape(mins, ext);
-            allocate(a);
+            if (out_estimate || !out_ext.empty()) allocate(a);   // an assumed shape still goes through the bounds query
         }
     }
     auto call = [&](std::vector<Arg> &as) {

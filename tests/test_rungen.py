@@ -41,6 +41,29 @@ def test_boolean_flags_take_values_like_rungens():
     assert p.returncode != 0 and "unknown flag" in p.stderr
 
 
+@pytest.mark.gpu
+def test_conversion_warnings_use_rungens_wording(tmp_path):
+    """RunGen warns when a file's type or shape is not the argument's (tools/RunGen.h:433-477, :1116-1121); same sentences here."""
+    rng = np.random.default_rng(2)
+    rgb8 = rng.integers(0, 256, (24, 40, 3), dtype=np.uint8)
+    with open(tmp_path / "c.ppm", "wb") as f:
+        f.write(b"P6\n40 24\n255\n" + rgb8.tobytes())
+    p = _run("--name=bilateral_grid", f"input={tmp_path / 'c.ppm'}", "r_sigma=0.1", f"bilateral_grid={tmp_path / 'o.pgm'}")
+    assert 'Warning: Image for Input "input" has 3 dimensions, but only the first 2 were used; data loss may have occurred.' in p.stderr
+    assert 'Warning: Image loaded for argument "input" is type uint8 but this argument expects type float32; data loss may have occurred.' in p.stderr
+    assert 'Warning: Image for argument "bilateral_grid" is of type float32 but is being saved as type uint16; data loss may have occurred.' in p.stderr
+    p = _run("--name=bilateral_grid", f"input={tmp_path / 'c.ppm'}", "r_sigma=0.1", f"bilateral_grid={tmp_path / 'o.jpg'}")
+    assert 'Warning: Image for argument "bilateral_grid" is of type float32 but is being saved as type uint8; data loss may have occurred.' in p.stderr
+    # (no --output_extents above: the output assumed the shape of the first input, tools/RunGen.h:1077-1090)
+    assert open(tmp_path / "o.pgm", "rb").read(12).split()[:3] == [b"P5", b"40", b"24"]
+    gray8 = rgb8[..., 0]
+    with open(tmp_path / "g.pgm", "wb") as f:
+        f.write(b"P5\n40 24\n255\n" + gray8.tobytes())
+    p = _run("--name=hist", f"input={tmp_path / 'g.pgm'}", f"output={tmp_path / 'h.npy'}", check=False)   # a gray file for an RGB argument
+    assert 'Warning: Image for Input "input" has 2 dimensions, but this argument requires at least 3 dimensions: adding dummy dimensions of extent 1.' in p.stderr
+    assert "is type uint8 but" not in p.stderr                                  # u8 file, u8 argument
+
+
 def test_unknown_pipeline_and_argument_are_errors():
     assert _run("--name=no_such_filter", "--describe", check=False).returncode != 0
     p = _run("--name=halide_blur", "bogus=1", "--describe", check=False)
