@@ -158,9 +158,9 @@ int conv_check_args(void *uc, BufArg *args, int *CI, int *CO, int *W, int *H, in
     if ((r = check_type_and_dims(uc, args, 4))) return r;
     *query = false;
     if (any_bounds_query(args, 4)) {
-        // Shapes follow from whichever buffers are real; the reference's estimates (:35-50) fill the rest.
+        // Shapes follow from whichever buffers are real or came shaped (the output first); the reference's estimates (:35-50) fill the rest.
         int co = 128, ci = 128, w = 100, h = 80, n = 5;
-        auto real = [](halide_buffer_t *b) { return !(b->host == nullptr && b->device == 0); };
+        auto real = [](halide_buffer_t *b) { return buffer_known(b); };   // real, or a query buffer the caller shaped
         if (real(relu)) co = relu->dim[0].extent, w = relu->dim[1].extent, h = relu->dim[2].extent, n = relu->dim[3].extent;
         else if (real(input)) w = input->dim[1].extent - 2, h = input->dim[2].extent - 2, n = input->dim[3].extent;
         if (real(input)) ci = input->dim[0].extent;

@@ -189,9 +189,9 @@ extern "C" int depthwise_separable_conv(halide_buffer_t *input, halide_buffer_t 
     int r = check_not_null(uc, args, 5);
     if (r) return r;
     if ((r = check_type_and_dims(uc, args, 5))) return r;
-    auto real = [](halide_buffer_t *b) { return !(b->host == nullptr && b->device == 0); };
+    auto real = [](halide_buffer_t *b) { return buffer_known(b); };   // real, or a query buffer the caller shaped
     if (any_bounds_query(args, 5)) {
-        // shapes follow from whichever buffers are real; the generator's estimates (:78-99, with CM = 1) fill the rest
+        // shapes follow from whichever buffers are real or came shaped; the generator's estimates (:78-99, with CM = 1) fill the rest
         int ci = 32, w = 112, h = 112, n = 4, cm = 1, fw = 3, fh = 3, co = 16;
         if (real(input)) ci = input->dim[0].extent, w = input->dim[1].extent, h = input->dim[2].extent, n = input->dim[3].extent;
         else if (real(output)) w = output->dim[1].extent, h = output->dim[2].extent, n = output->dim[3].extent;

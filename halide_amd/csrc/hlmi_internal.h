@@ -121,6 +121,18 @@ uint64_t buffer_version(const halide_buffer_t *buf);
 // compute units a launch on `stream` can use (a CU-partitioned stream of halide_hip_partition_stream: its share)
 int stream_cu_count(int device, hipStream_t stream);
 
+// Bounds-query helpers.  A buffer takes part in deriving the other buffers' regions when it is real (host or device set) or,
+// in query mode, when the caller gave it a shape: RunGen's queries pass EVERY buffer with host == device == 0 — outputs shaped
+// by --output_extents / the estimates / the first input, inputs shaped as loaded (tools/RunGen.h:1212-1250) — and Halide's
+// bounds inference takes the outputs' shapes as the request whether or not they are allocated.
+inline bool buffer_is_real(const halide_buffer_t *b) { return !(b->host == nullptr && b->device == 0); }
+inline bool buffer_has_shape(const halide_buffer_t *b) {
+    for (int d = 0; d < b->dimensions; d++)
+        if (b->dim[d].extent <= 0) return false;
+    return b->dimensions > 0;
+}
+inline bool buffer_known(const halide_buffer_t *b) { return buffer_is_real(b) || buffer_has_shape(b); }
+
 // ---- events across streams.  The special stream handles (NULL, hipStreamLegacy — which callers on torch's default stream pass
 // to halide_hip_set_stream — and hipStreamPerThread) launch kernels fine, but they are not safe partners for events in ROCm
 // 7.2: an event RECORDED on hipStreamLegacy crashes the next hipStreamWaitEvent on it (scripts/legacy_event_probe.py), and

@@ -419,8 +419,10 @@ extern "C" int iir_blur(halide_buffer_t *input, float alpha, halide_buffer_t *ou
     if ((r = check_type_and_dims(uc, args, 2))) return r;
     auto real = [](halide_buffer_t *b) { return !(b->host == nullptr && b->device == 0); };
     if (any_bounds_query(args, 2)) {
-        halide_buffer_t *k = real(input) ? input : output;
-        const bool any = real(input) || real(output);
+        // a real input pins the box; otherwise the output's shape is the request (real, or shaped by the caller: RunGen passes
+        // every buffer without a host), otherwise a shaped input, otherwise the generator's estimates
+        halide_buffer_t *k = real(input) ? input : buffer_known(output) ? output : input;
+        const bool any = real(input) || buffer_known(output) || buffer_has_shape(input);
         int z[3] = {0, 0, 0}, e[3] = {any ? k->dim[0].extent : 1536, any ? k->dim[1].extent : 2560, any ? k->dim[2].extent : 3};
         answer_query(input, z, e);
         answer_query(output, z, e);

@@ -337,8 +337,11 @@ extern "C" int interpolate(halide_buffer_t *input, halide_buffer_t *output) {
     auto real = [](halide_buffer_t *b) { return !(b->host == nullptr && b->device == 0); };
     if (any_bounds_query(args, 2)) {
         // output = input's [0,W) x [0,H) with 3 channels (:83-87); input has channels [0,4) (:23)
-        halide_buffer_t *k = real(input) ? input : output;
-        const int w = real(input) || real(output) ? k->dim[0].extent : 1536, h = real(input) || real(output) ? k->dim[1].extent : 2560;
+        // (a real input pins the box; else the output's shape — real, or given by the caller of an all-null query — else a shaped
+        // input, else the estimates)
+        halide_buffer_t *k = real(input) ? input : buffer_known(output) ? output : input;
+        const bool any = real(input) || buffer_known(output) || buffer_has_shape(input);
+        const int w = any ? k->dim[0].extent : 1536, h = any ? k->dim[1].extent : 2560;
         int z[3] = {0, 0, 0}, ei[3] = {w, h, 4}, eo[3] = {w, h, 3};
         answer_query(input, z, ei);
         answer_query(output, z, eo);

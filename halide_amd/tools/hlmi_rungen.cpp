@@ -984,23 +984,55 @@ int main(int argc, char **argv) {
         for (auto &a : as) av.push_back(a.md->kind == halide_argument_kind_input_scalar ? (void *)&a.scalar : (void *)&a.buf);
         return f_argv(av.data());
     };
-    // bounds query (tools/RunGen.h:1212-1250): every buffer whose shape is still unknown goes in with host == device == 0
-    // and comes back with the shape the pipeline proposes given the others
+    // bounds query (tools/RunGen.h:1212-1250): EVERY buffer goes in with host == device == 0 and the shape it has so far (zeros
+    // where nothing is known yet) and comes back with the region the pipeline wants of it given the others.  Buffers without
+    // a shape take what comes back; an input that was loaded but does not cover its region is re-allocated on the region and
+    // the loaded samples copied in (adapt_input_buffer, tools/RunGen.h:774-817).
     {
-        bool need = false;
-        for (auto &a : args) need |= (a.md->kind != halide_argument_kind_input_scalar && a.storage.empty());
-        if (need) {
-            for (auto &a : args) {
-                if (a.md->kind == halide_argument_kind_input_scalar || !a.storage.empty()) continue;
-                if (a.dims.empty()) a.dims = dense_shape({}, std::vector<int>(a.md->dimensions, 0));
-                a.buf = halide_buffer_t{};
-                a.buf.type = a.md->type, a.buf.dimensions = a.md->dimensions, a.buf.dim = a.dims.data();
-            }
-            if (int r = call(args)) fail("bounds query failed with error " + std::to_string(r));
-            for (auto &a : args) {
-                if (a.md->kind == halide_argument_kind_input_scalar || !a.storage.empty()) continue;
+        std::vector<Shape> q(args.size());
+        std::vector<halide_buffer_t> qb(args.size());
+        std::vector<void *> av;
+        for (size_t i = 0; i < args.size(); i++) {
+            Arg &a = args[i];
+            if (a.md->kind == halide_argument_kind_input_scalar) { av.push_back(&a.scalar); continue; }
+            q[i] = a.dims.empty() ? dense_shape({}, std::vector<int>(a.md->dimensions, 0)) : a.dims;
+            qb[i] = halide_buffer_t{};
+            qb[i].type = a.md->type, qb[i].dimensions = a.md->dimensions, qb[i].dim = q[i].data();
+            av.push_back(&qb[i]);
+        }
+        if (int r = f_argv(av.data())) fail("bounds query failed with error " + std::to_string(r));
+        for (size_t i = 0; i < args.size(); i++) {
+            Arg &a = args[i];
+            if (a.md->kind == halide_argument_kind_input_scalar) continue;
+            if (a.storage.empty()) {                       // no shape of its own (auto input, output): the pipeline's proposal
+                a.dims = q[i];
                 allocate(a);
+                continue;
             }
+            if (a.md->kind != halide_argument_kind_input_buffer) continue;
+            Shape want = a.dims;
+            bool grow = false;
+            for (size_t d = 0; d < want.size(); d++) {
+                const int cur0 = a.dims[d].min, cur1 = cur0 + a.dims[d].extent - 1, c0 = q[i][d].min, c1 = c0 + q[i][d].extent - 1;
+                if (q[i][d].extent > 0 && (c0 < cur0 || c1 > cur1)) want[d].min = c0, want[d].extent = q[i][d].extent, grow = true;
+            }
+            if (!grow) continue;
+            Arg old = a;                                   // (its storage is copied with it)
+            std::vector<int> mins, ext;
+            for (auto &d : want) mins.push_back(d.min), ext.push_back(d.extent);
+            a.dims = dense_shape(mins, ext);
+            allocate(a);
+            const size_t eb = elem_bytes(a.md->type);
+            for_each_element(a, [&](size_t idx, const std::vector<int> &c) {
+                size_t o = 0;
+                for (size_t d = 0; d < c.size(); d++) {
+                    const int rel = a.dims[d].min + c[d] - old.dims[d].min;
+                    if (rel < 0 || rel >= old.dims[d].extent) return;
+                    o += (size_t)rel * old.dims[d].stride;
+                }
+                memcpy(a.storage.data() + idx * eb, old.storage.data() + o * eb, eb);
+            });
+            if (verbose) std::cout << "Input " << a.md->name << ": grown to the region the bounds query asks for\n";
         }
     }
     // ---- fill the pseudo-file inputs
@@ -1019,6 +1051,7 @@ int main(int argc, char **argv) {
             for (auto &d : a.dims) std::cout << " (" << d.min << "," << d.extent << "," << d.stride << ")";
             std::cout << " ]\n";
         }
+        std::cout.flush();   // (an error in the run aborts: what was said so far should still be seen)
     }
 
     // ---- run

@@ -214,3 +214,12 @@ def test_bounds_query_reports_reference_shapes(hl):
     hl.conv_layer(*q)
     assert q[0].extents == [128, 102, 82, 5] and q[1].extents == [128, 3, 3, 128]
     assert q[2].extents == [128] and q[3].extents == [128, 100, 80, 5]
+    # the same query with shapes on the (still host-less) buffers, as RunGen passes them: the shapes are taken, not the estimates
+    Q = hl.Buffer.bounds_query
+    q = [Q(np.float32, 4, extents=[64, 20, 12, 2]), Q(np.float32, 4, extents=[128, 3, 3, 64]), Q(np.float32, 1, extents=[128]),
+         Q(np.float32, 4, extents=[128, 18, 10, 2])]
+    hl.conv_layer(*q)
+    assert [b.extents for b in q] == [[64, 20, 12, 2], [128, 3, 3, 64], [128], [128, 18, 10, 2]]
+    q = [Q(np.float32, 4), Q(np.float32, 4), Q(np.float32, 1), Q(np.float32, 4, extents=[256, 30, 20, 3])]   # only the output shaped
+    hl.conv_layer(*q)
+    assert q[0].extents == [128, 32, 22, 3] and q[1].extents == [256, 3, 3, 128] and q[2].extents == [256]

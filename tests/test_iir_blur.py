@@ -77,3 +77,15 @@ def test_bounds_query(hl):
     q = hl.Buffer.bounds_query(np.float32, 3)
     hl.iir_blur(q, 0.5, hl.Buffer(np.zeros((3, 20, 30), np.float32)))
     assert q.extents == [30, 20, 3]
+    # RunGen's queries pass EVERY buffer without a host (tools/RunGen.h:1212-1250): the output's shape is then the request, as
+    # in Halide's bounds inference; only a query that names no shape at all falls back to the generator's estimates
+    Q = hl.Buffer.bounds_query
+    qi, qo = Q(np.float32, 3, extents=[96, 64, 3]), Q(np.float32, 3, extents=[40, 24, 3])
+    hl.iir_blur(qi, 0.5, qo)
+    assert qi.extents == [40, 24, 3] and qo.extents == [40, 24, 3]
+    qi, qo = Q(np.float32, 3, extents=[96, 64, 3]), Q(np.float32, 3)
+    hl.iir_blur(qi, 0.5, qo)
+    assert qi.extents == [96, 64, 3] and qo.extents == [96, 64, 3]
+    qi, qo = Q(np.float32, 3), Q(np.float32, 3)
+    hl.iir_blur(qi, 0.5, qo)
+    assert qi.extents == [1536, 2560, 3] and qo.extents == [1536, 2560, 3]

@@ -115,3 +115,10 @@ def test_bounds_query(hl):
     o = hl.Buffer(np.zeros((3, 20, 30), np.float32))
     hl.interpolate(q, o)
     assert q.extents == [30, 20, 4]
+    Q = hl.Buffer.bounds_query                       # all-null queries (RunGen's): the output's shape is the request
+    qi, qo = Q(np.float32, 3, extents=[50, 30, 4]), Q(np.float32, 3, extents=[60, 20, 3])
+    hl.interpolate(qi, qo)
+    assert qi.extents == [60, 20, 4] and qo.extents == [60, 20, 3]
+    qi, qo = Q(np.float32, 3, extents=[50, 30, 4]), Q(np.float32, 3)
+    hl.interpolate(qi, qo)
+    assert qi.extents == [50, 30, 4] and qo.extents == [50, 30, 3]

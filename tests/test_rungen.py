@@ -64,6 +64,20 @@ def test_conversion_warnings_use_rungens_wording(tmp_path):
     assert "is type uint8 but" not in p.stderr                                  # u8 file, u8 argument
 
 
+def test_loaded_input_is_grown_to_the_region_the_bounds_query_asks_for(tmp_path):
+    """RunGen's adapt_input_buffer (tools/RunGen.h:774-817): an input that does not cover its region is re-allocated on the region,
+    the loaded samples copied in.  halide_blur reads two pixels beyond its output; without --output_extents the output assumes
+    the input's shape (:1077-1090), so the 40 x 24 file becomes a 42 x 26 input.  (The shapes are settled by bounds queries, which
+    need no device: the run itself then fails here for want of one.)"""
+    rng = np.random.default_rng(3)
+    np.save(tmp_path / "u.npy", rng.integers(0, 65536, (24, 40), dtype=np.uint16).reshape(40, 24))
+    p = _run("--name=halide_blur", f"input={tmp_path / 'u.npy'}", f"blur_y={tmp_path / 'b.npy'}", "--verbose", check=False)
+    assert "Input input: grown to the region the bounds query asks for" in p.stdout
+    assert "Argument input: [ (0,42,1) (0,26,42) ]" in p.stdout and "Argument blur_y: [ (0,40,1) (0,24,40) ]" in p.stdout
+    p = _run("--name=halide_blur", f"input={tmp_path / 'u.npy'}", f"blur_y={tmp_path / 'b.npy'}", "--output_extents=[38,22]", "--verbose", check=False)
+    assert "grown" not in p.stdout and "Argument input: [ (0,40,1) (0,24,40) ]" in p.stdout
+
+
 def test_unknown_pipeline_and_argument_are_errors():
     assert _run("--name=no_such_filter", "--describe", check=False).returncode != 0
     p = _run("--name=halide_blur", "bogus=1", "--describe", check=False)
