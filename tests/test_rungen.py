@@ -64,6 +64,58 @@ def test_conversion_warnings_use_rungens_wording(tmp_path):
     assert "is type uint8 but" not in p.stderr                                  # u8 file, u8 argument
 
 
+def _fixture_lib(tmp_path):
+    """tests/cpp/runner_fixture_lib.cpp: two CPU stand-in pipelines, so that the runner's whole path runs here without a GPU."""
+    so = tmp_path / "librunner_fixture.so"
+    if not so.exists():
+        subprocess.run(["g++", "-shared", "-fPIC", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "cpp", "runner_fixture_lib.cpp"), "-o", str(so)], check=True)
+    return str(so)
+
+
+def _run_fixture(tmp_path, *args):
+    env = dict(os.environ, HLMI_LIB=_fixture_lib(tmp_path))
+    p = subprocess.run([RUNGEN, *args], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    return p
+
+
+def test_runner_end_to_end_on_the_cpu_fixture(tmp_path):
+    """Load (PPM into a 2-D float argument), RunGen's three conversion warnings, the output assuming the input's shape, a JPEG and a
+    16-bit PGM written, --track_memory's line and --success — the whole path of the runner, on tests/cpp/runner_fixture_lib.cpp."""
+    rng = np.random.default_rng(2)
+    rgb8 = rng.integers(0, 256, (24, 40, 3), dtype=np.uint8)
+    (tmp_path / "c.ppm").write_bytes(b"P6\n40 24\n255\n" + rgb8.tobytes())
+    p = _run_fixture(tmp_path, "--name=fixture_copy", f"input={tmp_path / 'c.ppm'}", f"output={tmp_path / 'o.pgm'}", "--track_memory", "--success")
+    assert 'Warning: Image for Input "input" has 3 dimensions, but only the first 2 were used; data loss may have occurred.' in p.stderr
+    assert 'Warning: Image loaded for argument "input" is type uint8 but this argument expects type float32; data loss may have occurred.' in p.stderr
+    assert 'Warning: Image for argument "output" is of type float32 but is being saved as type uint16; data loss may have occurred.' in p.stderr
+    assert p.stdout.splitlines() == ["Maximum Halide memory: 0 bytes for output of 0.000915527 mpix.", "Success!"]
+    raw = (tmp_path / "o.pgm").read_bytes()
+    assert raw.startswith(b"P5\n40 24\n65535\n")
+    got = np.frombuffer(raw[len(b"P5\n40 24\n65535\n"):], ">u2").reshape(24, 40)
+    assert np.array_equal(got, rgb8[..., 0].astype(np.uint16) * 257)            # u8 -> float (/255) -> u16 (x 65535, rounded)
+    p = _run_fixture(tmp_path, "--name=fixture_copy", f"input={tmp_path / 'c.ppm'}", f"output={tmp_path / 'o.jpg'}")
+    assert 'is of type float32 but is being saved as type uint8' in p.stderr
+    tool = _jpeg_tool(tmp_path)
+    (tmp_path / "g.bin").write_bytes(rgb8[..., 0].tobytes())
+    subprocess.run([tool, "encode", str(tmp_path / "g.bin"), "40", "24", "1", str(tmp_path / "ref.jpg"), "99"], check=True)
+    assert (tmp_path / "o.jpg").read_bytes() == (tmp_path / "ref.jpg").read_bytes()
+
+
+def test_runner_grows_a_loaded_input_and_runs_on_the_cpu_fixture(tmp_path):
+    """fixture_shift reads one pixel right of and below its output, two pixels of box more: the 40 x 24 file is re-allocated as a
+    42 x 26 input with the samples at their coordinates (RunGen's adapt_input_buffer), the output assumes 40 x 24."""
+    g = np.random.default_rng(1).integers(0, 256, (24, 40), dtype=np.uint8)
+    (tmp_path / "g.pgm").write_bytes(b"P5\n40 24\n255\n" + g.tobytes())
+    p = _run_fixture(tmp_path, "--name=fixture_shift", f"input={tmp_path / 'g.pgm'}", f"output={tmp_path / 'o.pgm'}", "--verbose")
+    assert "Input input: grown to the region the bounds query asks for" in p.stdout
+    out = np.frombuffer((tmp_path / "o.pgm").read_bytes()[len(b"P5\n40 24\n255\n"):], np.uint8).reshape(24, 40)
+    want = np.zeros((24, 40), np.uint8)
+    want[:23, :39] = g[1:, 1:]
+    assert np.array_equal(out, want)
+
+
 def test_loaded_input_is_grown_to_the_region_the_bounds_query_asks_for(tmp_path):
     """RunGen's adapt_input_buffer (tools/RunGen.h:774-817): an input that does not cover its region is re-allocated on the region,
     the loaded samples copied in.  halide_blur reads two pixels beyond its output; without --output_extents the output assumes
