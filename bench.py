@@ -210,6 +210,24 @@ def main():
             b.device_free()
         return round(nframes * steps * w * h / dt / 1e6, 1)
 
+    def one_call_protocol(kind, samples=10):
+        """The reference driver's own timing (apps/local_laplacian/process.cpp:36-39 = `benchmark(timing, 1, ...)` of
+        tools/halide_benchmark.h:82-95, with the `10` samples its CMakeLists.txt:52 passes): ONE call + output.device_sync() per
+        sample on the device's own stream, nothing else in flight, the minimum over the samples.  A latency, not a throughput."""
+        f = synth_frame(200, W, H, kind)
+        a, o = hl.Buffer(f), hl.Buffer(np.zeros_like(f))
+        hl.local_laplacian(a, LEVELS, ALPHA, BETA, o)     # first call: upload + allocation, as in process.cpp:31
+        o.device_sync()
+        best = float("inf")
+        for _ in range(samples):
+            t = time.perf_counter()
+            hl.local_laplacian(a, LEVELS, ALPHA, BETA, o)
+            o.device_sync()
+            best = min(best, time.perf_counter() - t)
+        a.device_free()
+        o.device_free()
+        return best
+
     streams, keep, mode = [], [], "1 stream"
     if args.partitions > 1:
         spp = max(1, args.streams_per_partition)
@@ -270,6 +288,11 @@ def main():
         except hl.HalideError:   # e.g. no room for two 1 GiB buffers: the headline line does not depend on it
             copy_ceiling = None
 
+    one_call = None
+    if rank == 0 and world == 1:
+        torch.cuda.synchronize()
+        one_call = {k: one_call_protocol(k) for k in ("smooth", "noise", "natural")}
+
     variants = None
     if rank == 0 and world == 1 and not args.no_variants:
         variants = {"unit": "Mpx/s", "uniform_noise_3840x2160": run_variant(W, H, "noise", 8, 100),
@@ -287,6 +310,9 @@ def main():
         import bench_apps
         other_configs = []
         bench_apps.run(("bilateral_grid", "nl_means", "conv_layer_bf16"), 3, other_configs.append, cpu=not args.no_cpu_baseline)
+        # configs[3] as BASELINE.json states it: the BATCH of 32 nl_means frames (bench_batch.py's workload at N = 1: resident on
+        # this GPU, no exchange step), enqueued back to back, one sync at the end
+        other_configs.append(bench_apps.nl_means_batch32())
 
     if rank == 0:
         frames_per_step = FRAMES_PER_STEP * args.passes
@@ -333,6 +359,10 @@ def main():
             # the reference's own benchmark protocol feeds (RunGen), `natural` the reference checkout's one natural image, tiled
             "value_uniform_noise": None if not variants else variants.get("uniform_noise_3840x2160"),
             "value_natural_tiled": None if not variants else variants.get("natural_tiled_3840x2160"),
+            # the reference driver's protocol beside the frames-in-flight `value`: one call + device_sync on the device's own
+            # stream, min over 10 samples (apps/local_laplacian/process.cpp:36-39) — ms per call and the Mpx/s that is
+            "ms_per_call_one_stream": None if not one_call else {k: round(v * 1e3, 4) for k, v in one_call.items()},
+            "mpx_per_s_one_call_one_stream": None if not one_call else {k: round(W * H / v / 1e6, 1) for k, v in one_call.items()},
             "config": {"workload": "apps/local_laplacian J=8 levels=8 alpha=1/7 beta=1, u16 RGB planar 3840x2160",
                        "frames_per_step_per_gpu": frames_per_step, "distinct_frames_per_gpu": FRAMES_PER_STEP,
                        "passes_per_step": args.passes, "frame_ms": round(frame_ms, 4),
@@ -367,7 +397,9 @@ def main():
                          # ... and against the float4-copy figure MI355X_MICROARCH.md measured (6.29 TB/s)
                          "pipeline_traffic_frac_of_guide_copy_6290": None if frame_traffic is None else
                          round(frame_traffic / (frame_ms * 1e-3) / 1e9 / 6290.0, 4),
-                         "kernel_ms_per_frame": {k: round(v, 5) for k, v in per_frame.items()},
+                         # HIP-event brackets around each launch on ONE stream: they include the gap to the previous launch and read
+                         # longer than the kernels run (rocprofv3's kernel trace, profiles/, has the durations) — relative weights
+                         "kernel_ms_hip_events_one_stream": {k: round(v, 5) for k, v in per_frame.items()},
                          # per-launch figures (HIP events, PMC) are taken on ONE device-wide stream; the headline loop runs on CU
                          # partitions, where the kernels use non-temporal frame accesses and ll_up0h also collapses level 2 (same
                          # bytes within 1 %), and where the package sits at its power limit from two busy partitions on

@@ -410,6 +410,48 @@ def run(only=(), samples=5, sink=None, cpu=False, batched=True):
               **(cpu_base(orc, flops / 1e6, "TFLOP/s", "N=16 56x56 128->128 k=3") if "bf16" in name else {})})
 
 
+def nl_means_batch32(samples=3):
+    """BASELINE.json configs[3] at N = 1: the batch of 32 nl_means frames (7x7 search / 7x7 patch, f32 1920x1080x3, seeds 0..31 as
+    SURVEY.md §8d names them) resident on one GPU — what every rank of bench_batch.py does with its share, without the exchange
+    step — enqueued back to back over four CU-partitioned streams, ONE sync at the end; min over `samples` batches."""
+    import numpy as np
+    import halide_amd as hl
+    W, H, B = 1920, 1080, 32
+    frames = [np.random.default_rng(seed).random((3, H, W), dtype=np.float32) for seed in range(B)]
+    ins = [hl.Buffer(f) for f in frames]
+    outs = [hl.Buffer(np.zeros((3, H, W), np.float32)) for _ in range(B)]
+    hip = hl.hip_runtime()
+    results = {}
+    for nparts in (1, 4):
+        streams = [None] if nparts == 1 else [hl.partition_stream(p, nparts) for p in range(nparts)]
+        if nparts > 1 and not all(streams):
+            continue
+
+        def batch():
+            for i, (a, o) in enumerate(zip(ins, outs)):
+                hl.set_stream(streams[i % nparts])
+                hl.nl_means(a, 7, 7, 0.12, o)
+            hl.set_stream(None)
+            hip.hipDeviceSynchronize()
+        batch()      # uploads the inputs, allocates the outputs
+        best = 1e30
+        for _ in range(samples):
+            t0 = time.perf_counter()
+            batch()
+            best = min(best, time.perf_counter() - t0)
+        results["1 stream" if nparts == 1 else f"{nparts} CU-partitioned streams"] = best
+    for b in ins + outs:
+        b.device_free()
+    how, t = min(results.items(), key=lambda kv: kv[1])
+    flops = 2200.0 * W * H * B
+    return {"pipeline": "nl_means_batch32", "workload": "BASELINE configs[3] at N=1: 32 frames of apps/nl_means patch 7 search 7 sigma 0.12, "
+            "f32 1920x1080x3, resident on one GPU (bench_batch.py shards the same batch over N GPUs with RCCL send/recv)",
+            "ms_per_batch": round(t * 1e3, 3), "ms_per_frame": round(t * 1e3 / B, 4), "value": round(B * W * H / t / 1e6, 1), "unit": "Mpx/s",
+            "streams": how, "ms_per_batch_by_scheduling": {k: round(v * 1e3, 3) for k, v in results.items()},
+            "roofline": {"bound": "valu", "achieved": round(flops / t / 1e12, 2), "peak": VALU_F32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": round(flops / t / 1e12 / VALU_F32_PEAK_TF, 4)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -417,7 +459,13 @@ def main():
     ap.add_argument("--cpu-baseline", action="store_true", help="time the C oracle beside the BASELINE.json configs")
     ap.add_argument("--no-batched", action="store_true", help="skip the frames-in-flight leg (profiler runs)")
     a = ap.parse_args()
-    run(filter(None, a.only.split(",")), a.samples, None, a.cpu_baseline, not a.no_batched)
+    names = [n for n in a.only.split(",") if n]
+    if "nl_means_batch32" in names:      # configs[3] as a batch (not one of run()'s per-call pipelines)
+        print(json.dumps(nl_means_batch32(a.samples)), flush=True)
+        names.remove("nl_means_batch32")
+        if not names:
+            return
+    run(names, a.samples, None, a.cpu_baseline, not a.no_batched)
 
 
 if __name__ == "__main__":

@@ -799,6 +799,7 @@ struct D01EArgs {
     // xcd_block() hands an XCD holds horizontal AND vertical neighbours: a strip's 512-byte row pieces start 16 bytes before a
     // 128-byte line, which its left neighbour reads too — from the same L2 then (68.8 -> 58.8 MB fetched per 4K frame)
     unsigned nsx_magic;        // floor(2^32 / nsx) + 1, 0 when nsx == 1
+    unsigned *ctl;             // 16 control words of the ll_coarse launch that follows on this stream: zeroed here (nullptr: none follows)
 };
 // Packed arithmetic: at two waves per SIMD this kernel is bound by how often ONE wave can issue (a wave issues an
 // independent VALU instruction every ~2.1 ns whatever it is, scripts/ubench/valu_pk.hip: v_pk_add / mul / fma_f32 2.4 ns for
@@ -814,6 +815,7 @@ template<bool ODD0, bool ODD1, bool B1, bool EXCH, bool NT>
 __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometry gm, Levels lev) {
     const D01Args &p = pe.d;
     extern __shared__ float slut[];
+    if (pe.ctl && blockIdx.x == 0 && threadIdx.x < 16) pe.ctl[threadIdx.x] = 0u;
     for (int i = threadIdx.x; i <= 2 * gm.half; i += D0_THREADS) slut[i] = p.lut_g[i];
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1245,80 +1247,135 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
 }
 
 // ---------------------------------------------------------------------------------------------------
+// ---- accesses that are coherent across the device WITHOUT cache maintenance.  The eight XCDs' L2s are not coherent with each
+// other for ordinary loads and stores; a kernel whose workgroups exchange data through memory (ll_coarse) either brackets every
+// exchange with an agent-scope release / acquire — a write-back and an invalidate of a whole L2 each time: measured 300-600 us
+// for ll_coarse's ~2000 work items — or makes the exchanged accesses themselves agent-coherent: relaxed agent-scope atomics are
+// ordinary global_load / global_store instructions with the sc1 bit, which write through to / re-validate at the memory side,
+// 4 or 8 bytes at a time.  COH selects them at compile time; the stand-alone kernels instantiate the plain flavour.
+template<bool COH>
+__device__ __forceinline__ float ldc(const float *p) {
+    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template<bool COH>
+__device__ __forceinline__ void stc(float *p, float v) {
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template<bool COH>
+__device__ __forceinline__ float2 ldc2(const float *p) {   // 8-byte aligned
+    if (COH) {
+        const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_float2(__uint_as_float((unsigned)w), __uint_as_float((unsigned)(w >> 32)));
+    }
+    return *reinterpret_cast<const float2 *>(p);
+}
+template<bool COH>
+__device__ __forceinline__ void stc2(float *p, float2 v) {   // 8-byte aligned
+    if (COH) {
+        const unsigned long long w = (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *reinterpret_cast<float2 *>(p) = v;
+    }
+}
+
 // level j -> j+1 (j >= 1): one wave = (strip of 126 destination columns, TY rows, one plane)
-template<bool ODD>
-__global__ __launch_bounds__(256) void ll_down_strip(const float *__restrict__ src, int slox, int sloy, int sw, int sh,
-                                                     int sws, size_t sps, float *__restrict__ dst, int Xs, int dloy,
-                                                     int dw, int dh, int dws, size_t dps, int nsx, int nsy, int nunits) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int unit = xcd_block() * 4 + wave;
-    if (unit >= nunits) return;
-    const int lane = threadIdx.x & 63;
-    const int sy = unit % nsy, rest = unit / nsy, sx = rest % nsx, plane = rest / nsx;
+struct StripArgs {
+    const float *src;        // level j: (K+1) planes
+    int slox, sloy, sw, sh, sws;
+    size_t sps;
+    float *dst;              // level j+1
+    int Xs, dloy, dw, dh, dws;
+    size_t dps;
+    int nsx, nsy, nunits;
+};
+// one unit; the whole wave is active (DPP exchanges, wave-uniform control flow)
+template<bool ODD, bool CL = false, bool CS = false>
+__device__ __forceinline__ void down_strip_unit(const StripArgs &a, int unit, int lane) {
+    const int sy = unit % a.nsy, rest = unit / a.nsy, sx = rest % a.nsx, plane = rest / a.nsx;
     const int off = STRIP * sx + 2 * lane;
-    const int P = Xs + off;
-    const QuadSel qs = quad_sel((ODD ? 2 * P - 1 : 2 * P - 2) - slox, sw);
+    const int P = a.Xs + off;
+    const QuadSel qs = quad_sel((ODD ? 2 * P - 1 : 2 * P - 2) - a.slox, a.sw);
     const bool edge_wave = __any(!qs.plain);
-    const bool store_ok = (lane < 63) && (off < dw);
-    const int t0 = (int)((long)sy * dh / nsy), t1 = (int)((long)(sy + 1) * dh / nsy) - 1;
-    const float *sp = src + (size_t)plane * sps + qs.oq;
-    float *dp = dst + (size_t)plane * dps + off;
+    const bool store_ok = (lane < 63) && (off < a.dw);
+    const int t0 = (int)((long)sy * a.dh / a.nsy), t1 = (int)((long)(sy + 1) * a.dh / a.nsy) - 1;
+    const float *sp = a.src + (size_t)plane * a.sps + qs.oq;
+    float *dp = a.dst + (size_t)plane * a.dps + off;
     auto row = [&](int y_abs) -> float4 {
-        float4 v = *reinterpret_cast<const float4 *>(sp + (size_t)dev::clampi(y_abs - sloy, 0, sh - 1) * sws);
+        const float *rp = sp + (size_t)dev::clampi(y_abs - a.sloy, 0, a.sh - 1) * a.sws;
+        float4 v;
+        if (CL) {
+            const float2 lo = ldc2<true>(rp), hi = ldc2<true>(rp + 2);
+            v = make_float4(lo.x, lo.y, hi.x, hi.y);
+        } else {
+            v = *reinterpret_cast<const float4 *>(rp);
+        }
         if (edge_wave) {
             v = make_float4(pick4(v.x, v.y, v.z, v.w, qs.sel[0]), pick4(v.x, v.y, v.z, v.w, qs.sel[1]),
                             pick4(v.x, v.y, v.z, v.w, qs.sel[2]), pick4(v.x, v.y, v.z, v.w, qs.sel[3]));
         }
         return v;
     };
-    const int T0 = dloy + t0;
-    float4 a = row(2 * T0 - 1), b = row(2 * T0), c = row(2 * T0 + 1), d = row(2 * T0 + 2);
+    const int T0 = a.dloy + t0;
+    float4 ra = row(2 * T0 - 1), rb = row(2 * T0), rc = row(2 * T0 + 1), rd = row(2 * T0 + 2);
     for (int t = t0; t <= t1; t++) {
-        const int T = dloy + t;
-        float4 nc = c, nd = d;
+        const int T = a.dloy + t;
+        float4 nc = rc, nd = rd;
         if (t < t1) {
             nc = row(2 * T + 3);
             nd = row(2 * T + 4);
         }
-        float dy[4] = {down4_raw(a.x, b.x, c.x, d.x), down4_raw(a.y, b.y, c.y, d.y), down4_raw(a.z, b.z, c.z, d.z),
-                       down4_raw(a.w, b.w, c.w, d.w)};
+        float dy[4] = {down4_raw(ra.x, rb.x, rc.x, rd.x), down4_raw(ra.y, rb.y, rc.y, rd.y), down4_raw(ra.z, rb.z, rc.z, rd.z),
+                       down4_raw(ra.w, rb.w, rc.w, rd.w)};
         float2 o = hpair<ODD>(dy);
-        if (store_ok) *reinterpret_cast<float2 *>(dp + (size_t)t * dws) = o;
-        a = c, b = d, c = nc, d = nd;
+        if (store_ok) stc2<CS>(dp + (size_t)t * a.dws, o);
+        ra = rc, rb = rd, rc = nc, rd = nd;
     }
+}
+template<bool ODD>
+__global__ __launch_bounds__(256) void ll_down_strip(StripArgs a) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int unit = xcd_block() * 4 + wave;
+    if (unit >= a.nunits) return;
+    down_strip_unit<ODD>(a, unit, threadIdx.x & 63);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // upsample(f)(X,Y) (:276-282) of a stored level plane `f` (origin lox/loy, row stride ws)
-__device__ __forceinline__ float up_at(const float *__restrict__ f, int lox, int loy, int ws, int X, int Y) {
+template<bool COH = false>
+__device__ __forceinline__ float up_at(const float *f, int lox, int loy, int ws, int X, int Y) {
     int xa = dev::fdiv2(X + 1) - lox, xb = dev::fdiv2(X - 1) - lox;
     int ya = dev::fdiv2(Y + 1) - loy, yb = dev::fdiv2(Y - 1) - loy;
     float wx = (float)(dev::fmod2(X) * 2 + 1) * 0.25f, wy = (float)(dev::fmod2(Y) * 2 + 1) * 0.25f;
-    float ua = dev::lerpf(f[(size_t)ya * ws + xa], f[(size_t)ya * ws + xb], wx);
-    float ub = dev::lerpf(f[(size_t)yb * ws + xa], f[(size_t)yb * ws + xb], wx);
+    float ua = dev::lerpf(ldc<COH>(f + (size_t)ya * ws + xa), ldc<COH>(f + (size_t)ya * ws + xb), wx);
+    float ub = dev::lerpf(ldc<COH>(f + (size_t)yb * ws + xa), ldc<COH>(f + (size_t)yb * ws + xb), wx);
     return dev::lerpf(ua, ub, wy);
 }
 
 // outGPyramid[J-1] = outLPyramid[J-1] (:76, :63-72 with lPyramid[J-1] = gPyramid[J-1], :51); o = element offset
-__device__ __forceinline__ float top_value(const float *__restrict__ g, size_t ps, size_t o, int K, float Km1) {
-    float level = g[(size_t)K * ps + o] * Km1;
+template<bool COH = false>
+__device__ __forceinline__ float top_value(const float *g, size_t ps, size_t o, int K, float Km1) {
+    float level = ldc<COH>(g + (size_t)K * ps + o) * Km1;
     int li = dev::clampi((int)level, 0, K - 2);
     float lf = level - (float)li;
-    return (1.0f - lf) * g[(size_t)li * ps + o] + lf * g[(size_t)(li + 1) * ps + o];
+    return (1.0f - lf) * ldc<COH>(g + (size_t)li * ps + o) + lf * ldc<COH>(g + (size_t)(li + 1) * ps + o);
 }
 // outLPyramid[j](X,Y), 0 < j < J-1 (:50-54, :63-72): g = level j (origin lox/loy), gc = level j+1
 // SEL: level j was stored by ll_down01e — plane 0 = gPyramid[j](., ., li), plane 1 = gPyramid[j](., ., li + 1) for the pixel's own
 // li (the only two values of level j this function reads), plane K = inGPyramid[j]
-template<bool SEL = false>
-__device__ __forceinline__ float outl_value(const float *__restrict__ g, int ws, size_t ps, int lox, int loy,
-                                            const float *__restrict__ gc, int cws, size_t cps, int clox, int cloy,
+// CG / CC: level j / level j+1 were written by other workgroups of THIS launch (ll_coarse): agent-coherent loads
+template<bool SEL = false, bool CG = false, bool CC = false>
+__device__ __forceinline__ float outl_value(const float *g, int ws, size_t ps, int lox, int loy,
+                                            const float *gc, int cws, size_t cps, int clox, int cloy,
                                             int X, int Y, int K, float Km1) {
     size_t o = (size_t)(Y - loy) * ws + (X - lox);
-    float level = g[(size_t)K * ps + o] * Km1;
+    float level = ldc<CG>(g + (size_t)K * ps + o) * Km1;
     int li = dev::clampi((int)level, 0, K - 2);
     float lf = level - (float)li;
-    float l0 = g[(SEL ? 0 : (size_t)li * ps) + o] - up_at(gc + (size_t)li * cps, clox, cloy, cws, X, Y);
-    float l1 = g[(SEL ? ps : (size_t)(li + 1) * ps) + o] - up_at(gc + (size_t)(li + 1) * cps, clox, cloy, cws, X, Y);
+    float l0 = ldc<CG>(g + (SEL ? 0 : (size_t)li * ps) + o) - up_at<CC>(gc + (size_t)li * cps, clox, cloy, cws, X, Y);
+    float l1 = ldc<CG>(g + (SEL ? ps : (size_t)(li + 1) * ps) + o) - up_at<CC>(gc + (size_t)(li + 1) * cps, clox, cloy, cws, X, Y);
     return (1.0f - lf) * l0 + lf * l1;
 }
 
@@ -1331,17 +1388,29 @@ __global__ void ll_top(const float *__restrict__ g, int ws, size_t ps, int lox, 
 }
 
 // outGPyramid[j] = upsample(outGPyramid[j+1]) + outLPyramid[j], 1 <= j <= J-2 (:50-54, :63-79)
+struct UpArgs {
+    const float *g;          // level j
+    int ws;
+    size_t ps;
+    int lox, loy;
+    const float *gc, *outc;  // level j+1: gPyramid planes, outGPyramid
+    int cws;
+    size_t cps;
+    int clox, cloy, rx0, ry0, rw, rh, K;
+    float Km1;
+    float *out;              // outGPyramid[j]
+};
+template<bool SEL, bool CC = false>
+__device__ __forceinline__ void up_pixel(const UpArgs &a, int x, int y) {   // (x, y) relative to R_j
+    if (x >= a.rw || y >= a.rh) return;
+    int X = a.rx0 + x, Y = a.ry0 + y;
+    size_t o = (size_t)(Y - a.loy) * a.ws + (X - a.lox);
+    float outL = outl_value<SEL, false, CC>(a.g, a.ws, a.ps, a.lox, a.loy, a.gc, a.cws, a.cps, a.clox, a.cloy, X, Y, a.K, a.Km1);
+    a.out[o] = up_at<CC>(a.outc, a.clox, a.cloy, a.cws, X, Y) + outL;
+}
 template<bool SEL = false>
-__global__ __launch_bounds__(256) void ll_up(const float *__restrict__ g, int ws, size_t ps, int lox, int loy,
-                                             const float *__restrict__ gc, const float *__restrict__ outc, int cws,
-                                             size_t cps, int clox, int cloy, int rx0, int ry0, int rw, int rh, int K,
-                                             float Km1, float *__restrict__ out) {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= rw || y >= rh) return;
-    int X = rx0 + x, Y = ry0 + y;
-    size_t o = (size_t)(Y - loy) * ws + (X - lox);
-    float outL = outl_value<SEL>(g, ws, ps, lox, loy, gc, cws, cps, clox, cloy, X, Y, K, Km1);
-    out[o] = up_at(outc, clox, cloy, cws, X, Y) + outL;
+__global__ __launch_bounds__(256) void ll_up(UpArgs a) {
+    up_pixel<SEL>(a, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1381,14 +1450,14 @@ __device__ __forceinline__ Range2 clamp_to_box(const DevLevel &L, int x0, int x1
     r.y0 = dev::clampi(y0, L.loy, L.loy + L.h - 1), r.y1 = dev::clampi(y1, L.loy, L.loy + L.h - 1);
     return r;
 }
-template<int DEPTH>
-__global__ __launch_bounds__(256) void ll_down_multi(CoarseArgs a, int ntx, int nty) {
+template<int DEPTH, bool COH = false>
+__device__ __forceinline__ void down_multi_tile(const CoarseArgs &a, int ntx, int nty, int b) {   // b = tile x + ntx (tile y + nty plane)
     constexpr int W1 = dm_win(DEPTH - 1), W2 = DEPTH >= 2 ? dm_win(DEPTH - 2) : 1, W3 = DEPTH >= 3 ? dm_win(DEPTH - 3) : 1,
                   W4 = DEPTH >= 4 ? dm_win(DEPTH - 4) : 1;
     __shared__ float tile1[W1 * W1], tile2[W2 * W2], tile3[W3 * W3], tile4[W4 * W4];  // windows of levels S+1 .. S+4
     float *const tiles[5] = {nullptr, tile1, tile2, tile3, tile4};
     const int ws_[5] = {0, W1, W2, W3, W4};
-    const int tx = blockIdx.x % ntx, ty = (blockIdx.x / ntx) % nty, plane = blockIdx.x / (ntx * nty);
+    const int tx = b % ntx, ty = (b / ntx) % nty, plane = b / (ntx * nty);
     // windows (win[d]) and owned ranges (own[d]) of levels S+d, deepest first
     Range2 win[5], own[5];
     {
@@ -1422,7 +1491,7 @@ __global__ __launch_bounds__(256) void ll_down_multi(CoarseArgs a, int ntx, int 
                 for (int k = 0; k < 4; k++) {
                     const int qx = dev::clampi(2 * X - 1 + i, Sx.lox, Sx.lox + Sx.w - 1);
                     const int qy = dev::clampi(2 * Y - 1 + k, Sx.loy, Sx.loy + Sx.h - 1);
-                    r[k] = (d == 1) ? src_g[(size_t)(qy - Sx.loy) * Sx.ws + (qx - Sx.lox)]
+                    r[k] = (d == 1) ? ldc<COH>(src_g + (size_t)(qy - Sx.loy) * Sx.ws + (qx - Sx.lox))
                                     : src_t[(qy - pw.y0) * pnx + (qx - pw.x0)];
                 }
                 v[i] = down4_raw(r[0], r[1], r[2], r[3]);
@@ -1430,11 +1499,15 @@ __global__ __launch_bounds__(256) void ll_down_multi(CoarseArgs a, int ntx, int 
             const float val = down4_tail(v[0], v[1], v[2], v[3]);
             dst[yy * ws_[d] + (X - w.x0)] = val;
             if (X >= o.x0 && X <= o.x1 && Y >= o.y0 && Y <= o.y1) {
-                L.g[(size_t)plane * L.ps + (size_t)(Y - L.loy) * L.ws + (X - L.lox)] = val;
+                stc<COH>(L.g + (size_t)plane * L.ps + (size_t)(Y - L.loy) * L.ws + (X - L.lox), val);
             }
         }
         if (d < DEPTH) __syncthreads();
     }
+}
+template<int DEPTH>
+__global__ __launch_bounds__(256) void ll_down_multi(CoarseArgs a, int ntx, int nty) {
+    down_multi_tile<DEPTH>(a, ntx, nty, (int)blockIdx.x);
 }
 
 // ---- ll_up_multi<TOP>: outGPyramid[S] on R_S from gPyramid / inGPyramid of levels S .. S+TOP (= J-1).
@@ -1453,10 +1526,10 @@ __host__ __device__ constexpr int um_off(int d) {  // offset of level S+d's regi
     for (int i = 0; i < d; i++) o += um_win(i) * um_win(i);
     return o;
 }
-template<int TOP>
-__global__ __launch_bounds__(256) void ll_up_multi(CoarseArgs a, int ntx) {
+template<int TOP, bool COH = false>
+__device__ __forceinline__ void up_multi_tile(const CoarseArgs &a, int ntx, int b) {
     __shared__ float tl[um_off(TOP + 1)];
-    const int tx = blockIdx.x % ntx, ty = blockIdx.x / ntx;
+    const int tx = b % ntx, ty = b / ntx;
     Range2 reg[TOP + 1];
     {
         const DevLevel &L = a.lv[0];
@@ -1481,10 +1554,10 @@ __global__ __launch_bounds__(256) void ll_up_multi(CoarseArgs a, int ntx) {
             const int yy = e / nx, X = r.x0 + (e - yy * nx), Y = r.y0 + yy;
             float v;
             if (d == TOP) {
-                v = top_value(L.g, L.ps, (size_t)(Y - L.loy) * L.ws + (X - L.lox), a.K, a.Km1);
+                v = top_value<COH>(L.g, L.ps, (size_t)(Y - L.loy) * L.ws + (X - L.lox), a.K, a.Km1);
             } else {
                 const DevLevel &C = a.lv[d + 1];
-                v = outl_value(L.g, L.ws, L.ps, L.lox, L.loy, C.g, C.ws, C.ps, C.lox, C.loy, X, Y, a.K, a.Km1);
+                v = outl_value<false, COH, COH>(L.g, L.ws, L.ps, L.lox, L.loy, C.g, C.ws, C.ps, C.lox, C.loy, X, Y, a.K, a.Km1);
             }
             tile[yy * tw + (X - r.x0)] = v;
         }
@@ -1508,12 +1581,126 @@ __global__ __launch_bounds__(256) void ll_up_multi(CoarseArgs a, int ntx) {
             const float v = dev::lerpf(ua, ub, wy) + tile[yy * tw + (X - r.x0)];
             if (d == 0) {
                 const DevLevel &L = a.lv[0];
-                L.out[(size_t)(Y - L.loy) * L.ws + (X - L.lox)] = v;
+                stc<COH>(L.out + (size_t)(Y - L.loy) * L.ws + (X - L.lox), v);
             } else {
                 tile[yy * tw + (X - r.x0)] = v;
             }
         }
         if (d > 0) __syncthreads();
+    }
+}
+template<int TOP>
+__global__ __launch_bounds__(256) void ll_up_multi(CoarseArgs a, int ntx) {
+    up_multi_tile<TOP>(a, ntx, (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ll_coarse: everything between the two big kernels of the common geometry in ONE launch — levels 3 and 4 (down_strip_unit),
+// levels 5..7 (down_multi_tile<3>), outGPyramid[3] from levels 3..7 (up_multi_tile<4>) and, where ll_up0h does not collapse level 2
+// itself, outGPyramid[2] (up_pixel).  The reference treats this end of the pyramid the same way: levels >= 5 are serial
+// compute_roots it calls negligible, levels 1..4 of the up pass live inside the output loop (local_laplacian_generator.cpp:164-198).
+// As separate launches the five stages cost a dependent-launch gap each (~4.5 us: end-of-kernel write-back, completion signal,
+// dispatch), 33 of the 112 us of a frame on one stream.
+//
+// Scheduling.  The stages depend on each other through whole levels, so the launch needs device-wide ordering, and a grid barrier
+// would deadlock whenever the launch's workgroups are not all resident (a CU-partitioned stream, other streams' kernels holding
+// the slots).  Instead the work of all stages is ONE queue of tickets in stage order (ChainArgs::base): a workgroup takes the next
+// ticket with an atomic counter, waits until the previous stage's completion counter is full, runs the item (the very device
+// functions of the stand-alone kernels: bit-identical), bumps its stage's counter.  A ticket only ever waits for LOWER tickets, and
+// the lowest unfinished ticket is always held by a running workgroup — progress does not depend on how many workgroups are
+// resident.  The next ticket is requested before the current item runs (its round trip to the L2 passes under the item).
+// Visibility: everything one stage writes for another (levels 3..7, outGPyramid[3]) moves with agent-coherent accesses (ldc / stc
+// above: sc1 loads and stores, no cache maintenance); an item's stores have completed when its waves pass `s_waitcnt vmcnt(0)` + the
+// workgroup barrier, and only then is its completion counted.  (The first build used agent-scope release / acquire fences around
+// plain accesses instead: every item then wrote back and invalidated a whole L2 — 300-600 us for the launch.)
+// The control words are zeroed by ll_down01e, the launch before this one on the same stream.
+struct ChainCtl {
+    unsigned next, bailed, done[6], pad[8];   // 16 words
+};
+constexpr int CHAIN_STAGES = 5;    // 0: level 2 -> 3, 1: level 3 -> 4, 2: levels 5..7, 3: outGPyramid[3], 4: outGPyramid[2] (may be empty)
+constexpr int CHAIN_UP_ROWS = 4;   // rows of outGPyramid[2] per stage-4 item (256 columns wide)
+struct ChainArgs {
+    StripArgs s0, s1;
+    int odd0, odd1;
+    CoarseArgs dm;                 // lv[0] = level 4
+    int dm_ntx, dm_nty;
+    CoarseArgs um;                 // lv[0] = level 3
+    int um_ntx;
+    UpArgs u2;
+    int u2_nbx;
+    unsigned base[CHAIN_STAGES + 1];   // first ticket of each stage; base[CHAIN_STAGES] = number of tickets
+    ChainCtl *ctl;
+};
+__global__ __launch_bounds__(256) void ll_coarse(ChainArgs a) {
+    __shared__ unsigned s_ticket;
+    __shared__ int s_ok;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    unsigned nxt = 0;
+    int known = 0;     // stages below this one are known to be complete (wave-uniform)
+    if (threadIdx.x == 0) nxt = __hip_atomic_fetch_add(&a.ctl->next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if (threadIdx.x == 0) s_ticket = nxt;
+        __syncthreads();
+        const unsigned t = s_ticket;
+        if (t >= a.base[CHAIN_STAGES]) break;
+        if (threadIdx.x == 0) nxt = __hip_atomic_fetch_add(&a.ctl->next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int st = 0;
+#pragma unroll
+        for (int q = 1; q < CHAIN_STAGES; q++) st += (t >= a.base[q]) ? 1 : 0;
+        const int item = (int)(t - a.base[st]);
+        if (st > known) {
+            // every ticket of the previous stage finished (the stages before it finished before any of ITS tickets ran)
+            if (threadIdx.x == 0) {
+                const unsigned need = a.base[st] - a.base[st - 1];
+                int ok = 1;
+                unsigned spins = 0;
+                while (__hip_atomic_load(&a.ctl->done[st - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                    __builtin_amdgcn_s_sleep(1);
+                    // a bug must not hang the device: give up after ~1 s (the frame is then wrong, and the tests say so)
+                    if ((++spins & 1023u) == 0 &&
+                        (spins > (1u << 21) || __hip_atomic_load(&a.ctl->bailed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                        __hip_atomic_store(&a.ctl->bailed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = 0;
+                        break;
+                    }
+                }
+                s_ok = ok;
+            }
+            __syncthreads();
+            if (!s_ok) break;
+            known = st;
+        }
+        asm volatile("" ::: "memory");   // the item's loads stay below the wait
+        switch (st) {
+            case 0: {   // level 2 (the previous launch's) -> level 3
+                const int unit = item * 4 + wave;
+                if (unit < a.s0.nunits) {
+                    if (a.odd0) down_strip_unit<true, false, true>(a.s0, unit, lane);
+                    else down_strip_unit<false, false, true>(a.s0, unit, lane);
+                }
+                break;
+            }
+            case 1: {   // level 3 -> level 4
+                const int unit = item * 4 + wave;
+                if (unit < a.s1.nunits) {
+                    if (a.odd1) down_strip_unit<true, true, true>(a.s1, unit, lane);
+                    else down_strip_unit<false, true, true>(a.s1, unit, lane);
+                }
+                break;
+            }
+            case 2: down_multi_tile<3, true>(a.dm, a.dm_ntx, a.dm_nty, item); break;
+            case 3: up_multi_tile<4, true>(a.um, a.um_ntx, item); break;
+            default: {  // outGPyramid[2]: level 2 is the previous launch's, level 3 and outGPyramid[3] are this launch's
+                const int bx = item % a.u2_nbx, by = item / a.u2_nbx;
+#pragma unroll
+                for (int r = 0; r < CHAIN_UP_ROWS; r++) up_pixel<false, true>(a.u2, bx * 256 + (int)threadIdx.x, by * CHAIN_UP_ROWS + r);
+                break;
+            }
+        }
+        // the item's (write-through) stores have been acknowledged, in every wave, before the item counts as done
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // ... and its LDS tiles are free for the next item
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(&a.ctl->done[st], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -2069,7 +2256,7 @@ uint64_t g_graph_clock = 0;
 uint64_t ll_env_signature() {
     static const char *const names[] = {"HLMI_LL_NO_LUT_CACHE", "HLMI_LL_UNITS0", "HLMI_LL_NO_VEC",
                                         "HLMI_LL_D01_EXCH", "HLMI_LL_FUSE_FROM", "HLMI_LL_UPCHAIN_FROM", "HLMI_LL_RU", "HLMI_LL_EMIT", "HLMI_LL_NT",
-                                        "HLMI_LL_FUSE_UP2"};
+                                        "HLMI_LL_FUSE_UP2", "HLMI_LL_COARSE", "HLMI_LL_COARSE_WGS"};
     uint64_t h = 1469598103934665603ull;
     for (const char *n : names) {
         const char *e = getenv(n);
@@ -2167,19 +2354,6 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         rx0 = floor_div(rx0 - 1, 2), rx1 = floor_div(rx1 + 1, 2);
         ry0 = floor_div(ry0 - 1, 2), ry1 = floor_div(ry1 + 1, 2);
     }
-    // outLPyramid[0] of the re-cut dataflow (ll_down01e -> ll_up0h): input width x output rows
-    const size_t off_l0 = ws_floats;
-    ws_floats += ((size_t)(gm.ix1 - gm.ix0 + 1) * (size_t)oh + 63) & ~(size_t)63;
-    void *ws = nullptr;
-    if ((r = get_workspace(uc, ctx, ws_floats * sizeof(float), &ws))) return r;
-    float *wsf = (float *)ws;
-    float *lut = wsf;
-    float *outl0 = wsf + off_l0;
-    for (int j = 1; j < J; j++) lv[j].g = wsf + off_g[j], lv[j].out = wsf + off_out[j];
-    lv[0].g = lv[0].out = nullptr;
-    for (int j = 0; j < J; j++) t_dbg_lv[j] = lv[j];
-    t_dbg_stream = ctx.stream;
-
     const uint16_t *din = dev_ptr<uint16_t>(input);
     uint16_t *dout = dev_ptr<uint16_t>(output);
     const long in_sy = input->dim[1].stride, in_sc = input->dim[2].stride;
@@ -2191,6 +2365,86 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     const bool lut_lds = levels <= 15;  // LUT must fit the default 64 KB dynamic-LDS window
     const int nlut = 2 * gm.half + 1;
     const size_t lut_sh = lut_lds ? sizeof(float) * nlut : 0;
+
+    // levels >= S are produced / collapsed by the two multi-level kernels (S = 4: 2 launches instead of 7)
+    const int S = [&] {
+        int v = env_int("HLMI_LL_FUSE_FROM", 4);
+        return (v >= J - 5 && v <= J - 2) ? v : J;
+    }();
+    // the collapse (outGPyramid[J-1] .. outGPyramid[SU]) is ONE launch (ll_up_multi); opt-in: on the large levels its per-pixel overhead exceeds the saved launches
+    // Default 3 when the down pass fuses from 4: outGPyramid[3] joins the collapse launch (one ll_up launch and its ~4.5 us of
+    // dependent-launch latency less: 110.8 -> 108.9 us per frame on one stream); from level 2 the kernel's per-pixel overhead
+    // costs more than the launch it saves (114.2).  0: SU = S.
+    const int SU = [&] {
+        int v = env_int("HLMI_LL_UPCHAIN_FROM", S == 4 ? 3 : 0);   // (S == 3: SU = S)
+        return (v >= 1 && v <= J - 2) ? v : S;
+    }();
+    // ---- which kernels run: decided before the workspace is sized (the re-cut dataflow's outLPyramid[0] plane is only requested
+    // by the calls that fill it)
+    Up0Args p;
+    bool vec, fast, fuse1;
+    const int stream_cus = stream_cu_count(ctx.device, ctx.stream);
+    const bool partitioned = stream_cus < stream_cu_count(ctx.device, nullptr);
+    {
+        p.in = din, p.in_sy = in_sy;
+        const int oc0 = output->dim[2].min;
+        bool same = (nc == 3);
+        for (int ch = 0; ch < 3; ch++) {
+            p.gco[ch] = gco[ch];
+            p.cco[ch] = ch < nc ? (long)(oc0 + ch - ic0) * in_sc : 0;
+            if (p.cco[ch] != p.gco[ch]) same = false;
+        }
+        p.same_ch = same ? 1 : 0;
+        p.out = dout, p.out_sy = out_sy, p.out_sc = out_sc;
+        p.ox0 = output->dim[0].min, p.oy0 = output->dim[1].min, p.ow = ow, p.oh = oh, p.nc = nc;
+        p.beta = beta;
+        vec = ((uintptr_t)din % 4 == 0) && ((uintptr_t)dout % 4 == 0) && in_sy % 2 == 0 && out_sy % 2 == 0 &&
+              out_sc % 2 == 0 && ((p.ox0 - gm.ix0) % 2 == 0) && !env_int("HLMI_LL_NO_VEC", 0);
+        for (int ch = 0; ch < 3; ch++) vec = vec && p.gco[ch] % 2 == 0 && p.cco[ch] % 2 == 0;
+        fast = vec && same && nc == 3 && (ow & 1) == 0 && (p.ox0 & 1) == 0 &&
+               (double)(levels + 1) * (4.0 * (double)lv[1].ps) < 4.0e9;
+        // the fused collapse needs level 2 to be a stored level of its own (SU >= 2 always holds: SU >= S >= 4 or the
+        // opt-in up-chain, which starts at >= 1 and then owns level 1 itself)
+        fuse1 = fast && SU >= 2;
+        // rows per wave: taller tiles re-read less of level 1 (18 coarse rows per 16 output rows, 34 per 32) but keep a wave
+        // busy longer.  On a CU-partitioned stream, where several frames share the memory system and the frame rate is set by
+        // bytes, 32 rows measure 2.7 % faster (84.8 vs 82.6 Gpx/s); on a stream that owns the device 16 rows do (72.7 vs 68.2).
+        p.RU = max(1, env_int("HLMI_LL_RU", fuse1 ? (partitioned ? 32 : 16) : 8));
+    }
+    // ll_down01f / ll_down01e: levels 1 and 2 from the input in one walk (levels == KCH planes in registers, 8-byte input loads)
+    const bool d01_possible = levels == KCH && lut_lds &&
+                              ((uintptr_t)din % 8 == 0) && in_sy % 4 == 0 && gco[0] % 4 == 0 && gco[1] % 4 == 0 && gco[2] % 4 == 0 &&
+                              (gm.ix1 - gm.ix0 + 1) % 4 == 0 && !env_int("HLMI_LL_NO_VEC", 0);
+    // The default for the common geometry: ll_down01e emits outLPyramid[0] and three planes of level 1, ll_up0h collapses
+    // (HLMI_LL_EMIT=0: the round-3 pair ll_down01f / ll_up0f with the materialised K + 1 level-1 planes)
+    const bool emit = d01_possible && fast && fuse1 && env_int("HLMI_LL_EMIT", 1);
+    // ll_up0h has no data-dependent gathers to amortise over a tall tile: short tiles (more, smaller workgroups) are faster on a
+    // stream that owns the device (31.7 us at 8 rows per wave against 33.5 / 38.4 at 16 / 32); on CU partitions 8..32 measure the same
+    if (emit) p.RU = max(1, env_int("HLMI_LL_RU", partitioned ? 16 : 8));
+    // non-temporal frame / outLPyramid[0] accesses: +6-7 % frames per second on CU partitions, -2-3 % on a stream that owns the device
+    const bool nt = env_int("HLMI_LL_NT", partitioned ? 1 : 0) != 0;
+    // ll_up0h also collapses level 2 (into an LDS tile) when level 3 is a stored level of its own
+    // (on CU partitions, where every dependent launch of the chain idles the partition: 79.4 -> 76.4 us per frame; on a stream that
+    // owns the device the tile redundancy costs what the launch saved: 109 -> 111 us)
+    const bool fuse2 = emit && SU >= 3 && SU < J && env_int("HLMI_LL_FUSE_UP2", partitioned ? 1 : 0);
+    // everything between ll_down01e and ll_up0h in one launch (ll_coarse); HLMI_LL_COARSE=0: the five stand-alone launches
+    const bool coarse = emit && S == 4 && SU == 3 && env_int("HLMI_LL_COARSE", 1);
+
+    // ---- workspace: the levels, outLPyramid[0] of the re-cut dataflow (input width x output rows) and ll_coarse's control words
+    const size_t off_l0 = ws_floats;
+    if (emit) ws_floats += ((size_t)(gm.ix1 - gm.ix0 + 1) * (size_t)oh + 63) & ~(size_t)63;
+    const size_t off_ctl = ws_floats;
+    ws_floats += 64;
+    void *ws = nullptr;
+    if ((r = get_workspace(uc, ctx, ws_floats * sizeof(float), &ws))) return r;
+    float *wsf = (float *)ws;
+    float *lut = wsf;
+    float *outl0 = wsf + off_l0;
+    ChainCtl *chain_ctl = reinterpret_cast<ChainCtl *>(wsf + off_ctl);
+    for (int j = 1; j < J; j++) lv[j].g = wsf + off_g[j], lv[j].out = wsf + off_out[j];
+    lv[0].g = lv[0].out = nullptr;
+    for (int j = 0; j < J; j++) t_dbg_lv[j] = lv[j];
+    t_dbg_stream = ctx.stream;
 
     if (!env_int("HLMI_LL_NO_LUT_CACHE", 0)) {
         uint32_t abits;
@@ -2226,67 +2480,44 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     } else {
         HLMI_LAUNCH(uc, "ll_remap_lut", st, ll_remap_lut, dim3((nlut + 255) / 256), dim3(256), 0, lut, gm.half, alpha);
     }
-    // levels >= S are produced / collapsed by the two multi-level kernels (S = 4: 2 launches instead of 7)
-    const int S = [&] {
-        int v = env_int("HLMI_LL_FUSE_FROM", 4);
-        return (v >= J - 5 && v <= J - 2) ? v : J;
-    }();
-    // the collapse (outGPyramid[J-1] .. outGPyramid[SU]) is ONE launch (ll_up_multi); opt-in: on the large levels its per-pixel overhead exceeds the saved launches
-    // Default 3 when the down pass fuses from 4: outGPyramid[3] joins the collapse launch (one ll_up launch and its ~4.5 us of
-    // dependent-launch latency less: 110.8 -> 108.9 us per frame on one stream); from level 2 the kernel's per-pixel overhead
-    // costs more than the launch it saves (114.2).  0: SU = S.
-    const int SU = [&] {
-        int v = env_int("HLMI_LL_UPCHAIN_FROM", S == 4 ? 3 : 0);   // (S == 3: SU = S)
-        return (v >= 1 && v <= J - 2) ? v : S;
-    }();
-    // ---- level 0 arguments first: whether the level-1 collapse is fused into ll_up0f decides if ll_up:1 is launched
-    Up0Args p;
-    bool vec, fast, fuse1;
-    const int stream_cus = stream_cu_count(ctx.device, ctx.stream);
-    const bool partitioned = stream_cus < stream_cu_count(ctx.device, nullptr);
     {
         const Level &c = lv[1];
-        p.in = din, p.in_sy = in_sy;
-        const int oc0 = output->dim[2].min;
-        bool same = (nc == 3);
-        for (int ch = 0; ch < 3; ch++) {
-            p.gco[ch] = gco[ch];
-            p.cco[ch] = ch < nc ? (long)(oc0 + ch - ic0) * in_sc : 0;
-            if (p.cco[ch] != p.gco[ch]) same = false;
-        }
-        p.same_ch = same ? 1 : 0;
         p.lut_g = lut, p.g1 = c.g, p.out1 = c.out;
         p.lox1 = c.lox, p.loy1 = c.loy, p.ws1 = c.ws, p.ps1 = c.ps;
-        p.out = dout, p.out_sy = out_sy, p.out_sc = out_sc;
-        p.ox0 = output->dim[0].min, p.oy0 = output->dim[1].min, p.ow = ow, p.oh = oh, p.nc = nc;
-        p.beta = beta;
         p.g2 = lv[2].g, p.out2 = lv[2].out, p.lox2 = lv[2].lox, p.loy2 = lv[2].loy, p.ws2 = lv[2].ws, p.ps2 = lv[2].ps;
         p.rx1_1 = c.rx1, p.rx0_1 = c.rx0, p.ry0_1 = c.ry0, p.ry1_1 = c.ry1;
-        vec = ((uintptr_t)din % 4 == 0) && ((uintptr_t)dout % 4 == 0) && in_sy % 2 == 0 && out_sy % 2 == 0 &&
-              out_sc % 2 == 0 && ((p.ox0 - gm.ix0) % 2 == 0) && !env_int("HLMI_LL_NO_VEC", 0);
-        for (int ch = 0; ch < 3; ch++) vec = vec && p.gco[ch] % 2 == 0 && p.cco[ch] % 2 == 0;
-        fast = vec && same && nc == 3 && (ow & 1) == 0 && (p.ox0 & 1) == 0 &&
-               (double)(levels + 1) * (4.0 * (double)c.ps) < 4.0e9;
-        // the fused collapse needs level 2 to be a stored level of its own (SU >= 2 always holds: SU >= S >= 4 or the
-        // opt-in up-chain, which starts at >= 1 and then owns level 1 itself)
-        fuse1 = fast && SU >= 2;
-        // rows per wave: taller tiles re-read less of level 1 (18 coarse rows per 16 output rows, 34 per 32) but keep a wave
-        // busy longer.  On a CU-partitioned stream, where several frames share the memory system and the frame rate is set by
-        // bytes, 32 rows measure 2.7 % faster (84.8 vs 82.6 Gpx/s); on a stream that owns the device 16 rows do (72.7 vs 68.2).
-        p.RU = max(1, env_int("HLMI_LL_RU", fuse1 ? (partitioned ? 32 : 16) : 8));
     }
-    // ll_down01f / ll_down01e: levels 1 and 2 from the input in one walk (levels == KCH planes in registers, 8-byte input loads)
-    const bool d01_possible = levels == KCH && lut_lds &&
-                              ((uintptr_t)din % 8 == 0) && in_sy % 4 == 0 && gco[0] % 4 == 0 && gco[1] % 4 == 0 && gco[2] % 4 == 0 &&
-                              (gm.ix1 - gm.ix0 + 1) % 4 == 0 && !env_int("HLMI_LL_NO_VEC", 0);
-    // The default for the common geometry: ll_down01e emits outLPyramid[0] and three planes of level 1, ll_up0h collapses
-    // (HLMI_LL_EMIT=0: the round-3 pair ll_down01f / ll_up0f with the materialised K + 1 level-1 planes)
-    const bool emit = d01_possible && fast && fuse1 && env_int("HLMI_LL_EMIT", 1);
-    // ll_up0h has no data-dependent gathers to amortise over a tall tile: short tiles (more, smaller workgroups) are faster on a
-    // stream that owns the device (31.7 us at 8 rows per wave against 33.5 / 38.4 at 16 / 32); on CU partitions 8..32 measure the same
-    if (emit) p.RU = max(1, env_int("HLMI_LL_RU", partitioned ? 16 : 8));
-    // non-temporal frame / outLPyramid[0] accesses: +6-7 % frames per second on CU partitions, -2-3 % on a stream that owns the device
-    const bool nt = env_int("HLMI_LL_NT", partitioned ? 1 : 0) != 0;
+    // the stages of the chain between the two big kernels, as the stand-alone launches and ll_coarse take them
+    auto strip_args = [&](int j, int target_units) {   // level j -> j + 1
+        const Level &sl = lv[j], &d = lv[j + 1];
+        const int cols = d.nsx * (levels + 1);
+        StripArgs a;
+        a.src = sl.g, a.slox = sl.lox, a.sloy = sl.loy, a.sw = sl.w, a.sh = sl.h, a.sws = sl.ws, a.sps = sl.ps;
+        a.dst = d.g, a.Xs = d.lox, a.dloy = d.loy, a.dw = d.w, a.dh = d.h, a.dws = d.ws, a.dps = d.ps;
+        a.nsx = d.nsx;
+        a.nsy = max(1, min(max(target_units / cols, (d.h + 31) / 32), max(1, d.h / 2)));
+        a.nunits = cols * a.nsy;
+        return a;
+    };
+    auto coarse_args = [&](int from) {
+        CoarseArgs ca;
+        for (int dl = 0; from + dl < J; dl++) {
+            const Level &L = lv[from + dl];
+            DevLevel &D = ca.lv[dl];
+            D.g = L.g, D.out = L.out, D.lox = L.lox, D.loy = L.loy, D.w = L.w, D.h = L.h, D.ws = L.ws, D.ps = (unsigned)L.ps;
+            D.rx0 = L.rx0, D.ry0 = L.ry0, D.rw = L.rx1 - L.rx0 + 1, D.rh = L.ry1 - L.ry0 + 1;
+        }
+        ca.K = levels, ca.Km1 = gm.Km1;
+        return ca;
+    };
+    auto up_args = [&](int j) {
+        const Level &a = lv[j], &c = lv[j + 1];
+        UpArgs u;
+        u.g = a.g, u.ws = a.ws, u.ps = a.ps, u.lox = a.lox, u.loy = a.loy, u.gc = c.g, u.outc = c.out, u.cws = c.ws, u.cps = c.ps;
+        u.clox = c.lox, u.cloy = c.loy, u.rx0 = a.rx0, u.ry0 = a.ry0, u.rw = a.rx1 - a.rx0 + 1, u.rh = a.ry1 - a.ry0 + 1;
+        u.K = levels, u.Km1 = gm.Km1, u.out = a.out;
+        return u;
+    };
     bool fuse1_out = false, fuse2_out = false;
     auto enqueue = [&]() -> int {   // the launch chain of one frame (everything below depends only on what GraphKey holds)
     bool fuse_d2 = false;
@@ -2368,6 +2599,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
                 D01EArgs ae;
                 ae.d = a, ae.outl0 = outl0, ae.oy0 = output->dim[1].min, ae.oh = oh;
                 ae.nsx_magic = a.nsx == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)a.nsx + 1ull);
+                ae.ctl = coarse ? &chain_ctl->next : nullptr;
 #define LL_D01E(O0, O1, B)                                                                                                    \
     do {                                                                                                                      \
         if (exch && nt) HLMI_LAUNCH(uc, "ll_down01", st, (ll_down01e<O0, O1, B, true, true>), grid2, block, sh2, ae, gm, lev);  \
@@ -2418,18 +2650,42 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
 #undef LL_D0
         if (r) return r;
     }
-    CoarseArgs ca;
-    if (S < J) {
-        for (int dl = 0; S + dl < J; dl++) {
-            const Level &L = lv[S + dl];
-            DevLevel &D = ca.lv[dl];
-            D.g = L.g, D.out = L.out, D.lox = L.lox, D.loy = L.loy, D.w = L.w, D.h = L.h, D.ws = L.ws, D.ps = (unsigned)L.ps;
-            D.rx0 = L.rx0, D.ry0 = L.ry0, D.rw = L.rx1 - L.rx0 + 1, D.rh = L.ry1 - L.ry0 + 1;
+    fuse2_out = fuse2;
+    if (coarse) {
+        // ---- one launch for levels 3..7 and the collapse down to outGPyramid[3] (or [2]): the stages' work items as one ticket queue
+        ChainArgs ch;
+        // enough workgroups to run the widest stage in one round; a ticket holder never depends on a workgroup that is not running, so
+        // the count is a matter of speed only
+        const int nwg_env = env_int("HLMI_LL_COARSE_WGS", 0);   // tests: any count must do, down to one workgroup
+        const int nwg = nwg_env > 0 ? nwg_env : max(64, (partitioned ? 4 : 2) * stream_cus);
+        ch.s0 = strip_args(2, 4 * nwg), ch.odd0 = lv[3].odd ? 1 : 0;
+        ch.s1 = strip_args(3, 4 * nwg), ch.odd1 = lv[4].odd ? 1 : 0;
+        ch.dm = coarse_args(4);
+        ch.dm_ntx = (lv[J - 1].w + DM_T - 1) / DM_T, ch.dm_nty = (lv[J - 1].h + DM_T - 1) / DM_T;
+        ch.um = coarse_args(3);
+        ch.um_ntx = (ch.um.lv[0].rw + UM_T - 1) / UM_T;
+        const int um_nty = (ch.um.lv[0].rh + UM_T - 1) / UM_T;
+        ch.u2 = up_args(2);
+        ch.u2_nbx = (ch.u2.rw + 255) / 256;
+        const unsigned items[CHAIN_STAGES] = {(unsigned)(ch.s0.nunits + 3) / 4, (unsigned)(ch.s1.nunits + 3) / 4,
+                                              (unsigned)(ch.dm_ntx * ch.dm_nty * (levels + 1)), (unsigned)(ch.um_ntx * um_nty),
+                                              fuse2 ? 0u : (unsigned)(ch.u2_nbx * ((ch.u2.rh + CHAIN_UP_ROWS - 1) / CHAIN_UP_ROWS))};
+        ch.base[0] = 0;
+        for (int q = 0; q < CHAIN_STAGES; q++) ch.base[q + 1] = ch.base[q] + items[q];
+        ch.ctl = chain_ctl;
+        {   // algorithmic bytes: levels 2..6 read and 3..7 written once by the down stages (K + 1 planes), then what ll_up_multi:3 and
+            // ll_up:2 declare
+            double b = 0;
+            for (int j = 2; j + 1 < J; j++) b += 4.0 * (levels + 1) * ((double)lv[j].w * lv[j].h + (double)lv[j + 1].w * lv[j + 1].h);
+            b += 4.0 * 4.0 * (double)ch.um.lv[0].rw * ch.um.lv[0].rh * (4.0 / 3.0);
+            if (!fuse2) b += 4.0 * (4.0 * ch.u2.rw * ch.u2.rh + 3.0 * (double)ch.um.lv[0].rw * ch.um.lv[0].rh);
+            timing_note_bytes(b);
         }
-        ca.K = levels, ca.Km1 = gm.Km1;
-    }
+        HLMI_LAUNCH(uc, "ll_coarse", st, ll_coarse, dim3((unsigned)min((unsigned)nwg, ch.base[CHAIN_STAGES])), dim3(256), 0, ch);
+    } else {
     for (int j = 1; j + 1 < J; j++) {
         if (j == S) {
+            const CoarseArgs ca = coarse_args(S);
             long total = 0;
             for (int dl = 1; S + dl < J; dl++) total += (long)(levels + 1) * lv[S + dl].w * lv[S + dl].h;
             const int ntx = (lv[J - 1].w + DM_T - 1) / DM_T, nty = (lv[J - 1].h + DM_T - 1) / DM_T;
@@ -2444,31 +2700,17 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             break;
         }
         if (j == 1 && fuse_d2) continue;   // level 2 came out of ll_down01f
-        const Level &s = lv[j], &d = lv[j + 1];
         // enough waves to fill the chip on the big levels, short strips on the small ones
-        const int cols = d.nsx * (levels + 1);
-        const int target = 16 * stream_cu_count(ctx.device, nullptr);
-        const int nsy = max(1, min(max(target / cols, (d.h + 31) / 32), max(1, d.h / 2)));
-        const int nunits = cols * nsy;
-        dim3 grid((nunits + 3) / 4), block(256);
+        const StripArgs sa = strip_args(j, 16 * stream_cu_count(ctx.device, nullptr));
+        dim3 grid((sa.nunits + 3) / 4), block(256);
         char nm[32];
         snprintf(nm, sizeof nm, "ll_down_strip:%d", j);
-        timing_note_bytes(4.0 * (levels + 1) * ((double)s.w * s.h + (double)d.w * d.h));
-#define LL_DS(O)                                                                                                 \
-    HLMI_LAUNCH(uc, nm, st, (ll_down_strip<O>), grid, block, 0, s.g, s.lox, s.loy, s.w, s.h, s.ws,   \
-                s.ps, d.g, d.lox, d.loy, d.w, d.h, d.ws, d.ps, d.nsx, nsy, nunits)
-        if (d.odd) LL_DS(true); else LL_DS(false);
-#undef LL_DS
+        timing_note_bytes(4.0 * (levels + 1) * ((double)lv[j].w * lv[j].h + (double)lv[j + 1].w * lv[j + 1].h));
+        if (lv[j + 1].odd) HLMI_LAUNCH(uc, nm, st, (ll_down_strip<true>), grid, block, 0, sa);
+        else HLMI_LAUNCH(uc, nm, st, (ll_down_strip<false>), grid, block, 0, sa);
     }
     if (SU < J) {
-        CoarseArgs cu;
-        for (int dl = 0; SU + dl < J; dl++) {
-            const Level &L = lv[SU + dl];
-            DevLevel &D = cu.lv[dl];
-            D.g = L.g, D.out = L.out, D.lox = L.lox, D.loy = L.loy, D.w = L.w, D.h = L.h, D.ws = L.ws, D.ps = (unsigned)L.ps;
-            D.rx0 = L.rx0, D.ry0 = L.ry0, D.rw = L.rx1 - L.rx0 + 1, D.rh = L.ry1 - L.ry0 + 1;
-        }
-        cu.K = levels, cu.Km1 = gm.Km1;
+        const CoarseArgs cu = coarse_args(SU);
         const int ntx = (cu.lv[0].rw + UM_T - 1) / UM_T, nty = (cu.lv[0].rh + UM_T - 1) / UM_T;
         dim3 grid((unsigned)(ntx * nty)), block(256);
         char nm[32];
@@ -2488,20 +2730,14 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         HLMI_LAUNCH(uc, "ll_top", st, ll_top, dim3((rw + 63) / 64, rh), dim3(64), 0, t.g, t.ws, t.ps, t.lox, t.loy, t.rx0,
                     t.ry0, rw, rh, levels, gm.Km1, t.out);
     }
-    // ll_up0h also collapses level 2 (into an LDS tile) when level 3 is a stored level of its own
-    // (on CU partitions, where every dependent launch of the chain idles the partition: 79.4 -> 76.4 us per frame; on a stream that
-    // owns the device the tile redundancy costs what the launch saved: 109 -> 111 us)
-    const bool fuse2 = emit && SU >= 3 && SU < J && env_int("HLMI_LL_FUSE_UP2", partitioned ? 1 : 0);
-    fuse2_out = fuse2;
     for (int j = min(SU, J - 1) - 1; j >= (fuse1 ? (fuse2 ? 3 : 2) : 1); j--) {
-        const Level &a = lv[j], &c = lv[j + 1];
-        int rw = a.rx1 - a.rx0 + 1, rh = a.ry1 - a.ry0 + 1;
+        const UpArgs ua = up_args(j);
         char nm[32];
         snprintf(nm, sizeof nm, "ll_up:%d", j);
         // per output: 2 planes of g_j + inG_j read, outG_j written; per coarse pixel: 2 planes of g_{j+1} + outG_{j+1}
-        timing_note_bytes(4.0 * (4.0 * rw * rh + 3.0 * (c.rx1 - c.rx0 + 1) * (c.ry1 - c.ry0 + 1)));
-        HLMI_LAUNCH(uc, nm, st, ll_up<false>, dim3((rw + 255) / 256, rh), dim3(256), 0, a.g, a.ws, a.ps, a.lox, a.loy, c.g,
-                    c.out, c.ws, c.ps, c.lox, c.loy, a.rx0, a.ry0, rw, rh, levels, gm.Km1, a.out);
+        timing_note_bytes(4.0 * (4.0 * ua.rw * ua.rh + 3.0 * (lv[j + 1].rx1 - lv[j + 1].rx0 + 1) * (lv[j + 1].ry1 - lv[j + 1].ry0 + 1)));
+        HLMI_LAUNCH(uc, nm, st, ll_up<false>, dim3((ua.rw + 255) / 256, ua.rh), dim3(256), 0, ua);
+    }
     }
     fuse1_out = fuse1;
     {
@@ -2511,7 +2747,6 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         // fused: + inG_1 and, per level-2 pixel, 2 planes of g_2 + outG_2
         const double n1 = (double)(c.rx1 - c.rx0 + 1) * (c.ry1 - c.ry0 + 1), n2 = (double)(lv[2].rx1 - lv[2].rx0 + 1) * (lv[2].ry1 - lv[2].ry0 + 1);
         const double u0_bytes = 2.0 * (3 + nc) * ow * oh + 4.0 * 3.0 * n1 + (fuse1 ? 4.0 * 3.0 * n2 : 0.0);
-        t_dbg_emit = emit;
         if (emit) {
             // input read + output written (u16 x 3 channels), outLPyramid[0] read, three planes of level 1, per level-2 pixel two
             // planes of g_2 + outG_2
@@ -2554,6 +2789,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     };  // enqueue
 
     t_dbg_K = levels, t_dbg_Km1 = gm.Km1;
+    t_dbg_emit = emit;   // decided outside `enqueue`: a graph replay leaves it right too
     // ---- replay / capture / eager
     GraphEntry *ge = nullptr;
     const bool graphs = env_int("HLMI_LL_GRAPH", 0) && !stream_is_special(st) && !timing_enabled() && !env_int("HLMI_LL_NO_LUT_CACHE", 0);
@@ -2729,6 +2965,13 @@ extern "C" int hlmi_debug_div3_check(const float *n, const float *d, int count) 
 // Test hook (tests/ only; not part of the reference ABI): copies outGPyramid[level] of the calling thread's
 // LAST local_laplacian call, restricted to R_level, to `dst` (row-major, rw x rh floats); returns 0, or -1.
 extern "C" int hlmi_debug_local_laplacian_outg(int level, float *dst, int cap_floats, int *rw_out, int *rh_out) {
+    auto dbg_up_args = [](const Level &a, const Level &c) {
+        UpArgs u;
+        u.g = a.g, u.ws = a.ws, u.ps = a.ps, u.lox = a.lox, u.loy = a.loy, u.gc = c.g, u.outc = c.out, u.cws = c.ws, u.cps = c.ps;
+        u.clox = c.lox, u.cloy = c.loy, u.rx0 = a.rx0, u.ry0 = a.ry0, u.rw = a.rx1 - a.rx0 + 1, u.rh = a.ry1 - a.ry0 + 1;
+        u.K = t_dbg_K, u.Km1 = t_dbg_Km1, u.out = a.out;
+        return u;
+    };
     if (level < 1 || level >= J || !t_dbg_lv[level].out) return -1;
     const Level &L = t_dbg_lv[level];
     int rw = L.rx1 - L.rx0 + 1, rh = L.ry1 - L.ry0 + 1;
@@ -2741,8 +2984,7 @@ extern "C" int hlmi_debug_local_laplacian_outg(int level, float *dst, int cap_fl
         // still in the arena); level 1's own stand-alone collapse below reads it
         const Level &a = t_dbg_lv[2], &c = t_dbg_lv[3];
         const int rw2 = a.rx1 - a.rx0 + 1, rh2 = a.ry1 - a.ry0 + 1;
-        hipLaunchKernelGGL(ll_up<false>, dim3((rw2 + 255) / 256, rh2), dim3(256), 0, t_dbg_stream, a.g, a.ws, a.ps, a.lox, a.loy, c.g, c.out,
-                           c.ws, c.ps, c.lox, c.loy, a.rx0, a.ry0, rw2, rh2, t_dbg_K, t_dbg_Km1, a.out);
+        hipLaunchKernelGGL(ll_up<false>, dim3((rw2 + 255) / 256, rh2), dim3(256), 0, t_dbg_stream, dbg_up_args(a, c));
         if (hipGetLastError() != hipSuccess) return -1;
         t_dbg_out2_pending = false;
     }
@@ -2751,11 +2993,9 @@ extern "C" int hlmi_debug_local_laplacian_outg(int level, float *dst, int cap_fl
         // still in the arena) so that the tests can compare every level
         const Level &a = t_dbg_lv[1], &c = t_dbg_lv[2];
         if (t_dbg_emit) {   // level 1 holds its three planes only (ll_down01e)
-            hipLaunchKernelGGL(ll_up<true>, dim3((rw + 255) / 256, rh), dim3(256), 0, t_dbg_stream, a.g, a.ws, a.ps, a.lox, a.loy, c.g, c.out,
-                               c.ws, c.ps, c.lox, c.loy, a.rx0, a.ry0, rw, rh, t_dbg_K, t_dbg_Km1, a.out);
+            hipLaunchKernelGGL(ll_up<true>, dim3((rw + 255) / 256, rh), dim3(256), 0, t_dbg_stream, dbg_up_args(a, c));
         } else {
-            hipLaunchKernelGGL(ll_up<false>, dim3((rw + 255) / 256, rh), dim3(256), 0, t_dbg_stream, a.g, a.ws, a.ps, a.lox, a.loy, c.g, c.out,
-                               c.ws, c.ps, c.lox, c.loy, a.rx0, a.ry0, rw, rh, t_dbg_K, t_dbg_Km1, a.out);
+            hipLaunchKernelGGL(ll_up<false>, dim3((rw + 255) / 256, rh), dim3(256), 0, t_dbg_stream, dbg_up_args(a, c));
         }
         if (hipGetLastError() != hipSuccess) return -1;
         t_dbg_out1_pending = false;

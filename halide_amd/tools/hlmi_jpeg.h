@@ -310,10 +310,12 @@ inline std::string read(const std::string &path, Image &im) {
             adobe = true, adobe_transform = s[11];
         } else if (m == 0xda) {                                // SOS: the one scan of a sequential file
             if (!have_frame) return path + ": scan before frame header";
+            if (n < 1) return path + ": empty scan header";
             const int ns = s[0];
             if (ns != (int)comps.size() || n < (size_t)1 + 2 * ns + 3) return path + ": non-interleaved scans are not supported";
             for (int i = 0; i < ns; i++) {
                 bool found = false;
+                if ((s[2 + 2 * i] >> 4) > 3 || (s[2 + 2 * i] & 15) > 3) return path + ": bad table selector";   // dc[] / ac[] hold four tables
                 for (auto &c : comps)
                     if (c.id == s[1 + 2 * i]) c.td = s[2 + 2 * i] >> 4, c.ta = s[2 + 2 * i] & 15, found = true;
                 if (!found) return path + ": scan names an unknown component";

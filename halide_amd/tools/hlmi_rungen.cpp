@@ -74,11 +74,8 @@ std::string type_name(halide_type_t t) {
     return std::string(base) + std::to_string((int)t.bits);
 }
 
-bool g_quiet_warnings = false;
 // RunGen's warnings (tools/RunGenMain.cpp:297-300: "Warning: " + text on stderr), same wording
-void warn(const std::string &msg) {
-    if (!g_quiet_warnings) std::cerr << "Warning: " << msg << "\n";
-}
+void warn(const std::string &msg) { std::cerr << "Warning: " << msg << "\n"; }
 
 // one argument of the pipeline
 struct Arg {
@@ -461,6 +458,7 @@ void assign_raw(const std::string &path, Arg &a, const RawArray &r) {
     a.dims = dense_shape({}, ext);
     allocate(a);
     const size_t n = count(a);
+    if (n * elem_bytes(r.type) > r.bytes.size()) fail(path + ": the file holds fewer samples than its header promises");
     if (same_type(r.type, a.md->type)) {
         memcpy(a.storage.data(), r.bytes.data(), n * elem_bytes(a.md->type));
         return;
@@ -613,14 +611,15 @@ void load_tiff(const std::string &path, Arg &a) {
         }
     }
     if (compression != 1) fail(path + ": compressed TIFF files are not supported");
-    if (!width || !height || !samples || !depth || width > (1u << 20) || height > (1u << 20) || samples > 65535) fail(path + ": bad TIFF dimensions");
+    if (!width || !height || !samples || !depth || width > (1u << 20) || height > (1u << 20) || depth > (1u << 20) || samples > 65535) fail(path + ": bad TIFF dimensions");
     if ((bits != 8 && bits != 16 && bits != 32 && bits != 64) || format < 1 || format > 3 || (format == 3 && bits < 32)) fail(path + ": unsupported TIFF sample type");
     if (offsets.empty() || offsets.size() != counts.size()) fail(path + ": bad TIFF strip tables");
     RawArray r;
     r.type = {format == 1 ? halide_type_uint : format == 2 ? halide_type_int : halide_type_float, (uint8_t)bits, 1};
     const size_t eb = bits / 8;
+    // width, height, depth <= 2^20, samples < 2^16, eb <= 8: the product can pass 2^64 — compared in double before it is formed
+    if ((double)width * height * depth * samples * (double)eb > (double)b.size()) fail(path + ": the strips hold fewer samples than the image");   // uncompressed: the samples are in the file
     const uint64_t total = (uint64_t)width * height * depth * samples * eb;
-    if (total > b.size()) fail(path + ": the strips hold fewer samples than the image");   // uncompressed: the samples are in the file
     std::vector<uint8_t> flat;                                                     // the strips, concatenated in file order
     flat.reserve(total);
     for (size_t s = 0; s < offsets.size(); s++) {

@@ -38,3 +38,14 @@ def test_seeded_fuzz_slice(fuzz, name):
     for i in range(N_CASES[name]):
         desc, ok = fuzz.CASES[name](rng)
         assert ok, f"{name} case {i}: {desc}"
+
+
+@pytest.mark.gpu
+def test_seeded_fuzz_slice_local_laplacian_on_a_cu_partition(fuzz, on_stream):
+    """The headline pipeline's cases again with the calling thread on a CU-partitioned stream (and, for symmetry, on the device's
+    own): partitions switch other defaults on inside local_laplacian (non-temporal frame accesses, level 2 collapsed inside
+    ll_up0h, taller units), and that is what bench.py times."""
+    rng = np.random.default_rng(20260924)
+    for i in range(2 * N_CASES["local_laplacian"]):
+        desc, ok = fuzz.CASES["local_laplacian"](rng)
+        assert ok, f"local_laplacian case {i} on the {on_stream} stream: {desc}"

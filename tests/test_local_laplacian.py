@@ -220,7 +220,7 @@ def _run_hip(hl, inp, levels, alpha, beta, out_arr=None):
     # beyond 32: the reference declares no upper bound for `levels` (generator :13)
     (96, 64, 33, "uniform"), (64, 48, 40, "smooth"),
 ])
-def test_hip_matches_oracle(hl, oracle, w, h, levels, kind):
+def test_hip_matches_oracle(hl, oracle, on_stream, w, h, levels, kind):
     inp = _rand_image(w, h, seed=w + 7 * h + levels, kind=kind)
     alpha, beta = 1.0 / (levels - 1), 1.0
     got = _run_hip(hl, inp, levels, alpha, beta)
@@ -346,8 +346,9 @@ def test_hip_output_crop_of_larger_input(hl, oracle):
 
 
 @pytest.mark.gpu
-def test_hip_full_4k_matches_oracle_and_is_deterministic(hl, oracle):
-    """BASELINE config: 3840x2160, 8 levels — the oracle finishes in seconds, so compare directly."""
+def test_hip_full_4k_matches_oracle_and_is_deterministic(hl, oracle, on_stream):
+    """BASELINE config: 3840x2160, 8 levels — the oracle finishes in seconds, so compare directly.  On the device-wide stream and
+    on a CU partition (the defaults bench.py times: HLMI_LL_NT / HLMI_LL_FUSE_UP2 on, taller units)."""
     inp = _rand_image(3840, 2160, seed=0)
     a = hl.Buffer(inp)
     o = hl.Buffer(np.zeros_like(inp))
@@ -360,6 +361,8 @@ def test_hip_full_4k_matches_oracle_and_is_deterministic(hl, oracle):
     # size-independent property: alpha=0, beta=1 reproduces the input within 1 LSB
     hl.local_laplacian(a, 8, 0.0, 1.0, o)
     assert np.max(np.abs(o.numpy().astype(np.int64) - inp.astype(np.int64))) <= 1
+    a.device_free()
+    o.device_free()
 
 
 @pytest.mark.gpu
@@ -491,3 +494,71 @@ def test_hip_emit_launch_geometries_match_oracle(hl, oracle, monkeypatch, units,
         o = hl.Buffer(np.zeros_like(inp)).set_min(origin[0], origin[1], 0)
         hl.local_laplacian(a, 8, 1.0 / 7, 1.0, o)
         assert np.array_equal(o.numpy(), oracle.local_laplacian(inp, 8, 1.0 / 7, 1.0, origin=origin))
+
+
+# ---- round 5: ll_coarse — levels 3..7 and the collapse down to outGPyramid[3] (or [2]) as ONE launch whose work items are a
+# ticket queue in stage order (HLMI_LL_COARSE=0: the five stand-alone launches)
+@pytest.mark.gpu
+@pytest.mark.parametrize("coarse,fuse2,wgs", [("1", "0", 0), ("1", "1", 0), ("1", "0", 1), ("1", "1", 3), ("1", "0", 5000), ("0", "0", 0), ("0", "1", 0)])
+@pytest.mark.parametrize("w,h,origin", [(640, 480, (0, 0)), (1000, 300, (2, -5)), (256, 64, (-4, 3)), (2048, 1100, (0, 0))])
+def test_hip_coarse_chain_in_one_launch_matches_oracle(hl, oracle, monkeypatch, w, h, origin, coarse, fuse2, wgs):
+    """The ticket queue must give the stand-alone launches' bits whatever number of workgroups drains it (one workgroup walks
+    all stages by itself; 5000 mostly find the queue empty) and whether or not ll_up0h collapses level 2 itself.  Two different
+    frames alternate through the SAME workspace: a stage that read a level before the stage before it had finished — or found
+    the other frame's lines in its L2 — would show the other frame's values."""
+    monkeypatch.setenv("HLMI_LL_COARSE", coarse)
+    monkeypatch.setenv("HLMI_LL_FUSE_UP2", fuse2)
+    if wgs:
+        monkeypatch.setenv("HLMI_LL_COARSE_WGS", str(wgs))
+    imgs = [_rand_image(w, h, seed=w + h + 11, kind="smooth"), _rand_image(w, h, seed=w + 5 * h, kind="uniform")]
+    want = [oracle.local_laplacian(im, 8, 1.0 / 7, 1.0, origin=origin) for im in imgs]
+    bufs = [(hl.Buffer(im).set_min(origin[0], origin[1], 0), hl.Buffer(np.zeros_like(im)).set_min(origin[0], origin[1], 0)) for im in imgs]
+    for rnd in range(3):
+        for k, (a, o) in enumerate(bufs):
+            hl.local_laplacian(a, 8, 1.0 / 7, 1.0, o)
+            if rnd == 2 and k == 1 and w * h < 1 << 20:
+                for level in range(3, 0, -1):
+                    got = hl.debug_local_laplacian_outg(level)
+                    ref = oracle.local_laplacian_outg(imgs[k], 8, 1.0 / 7, 1.0, level, origin=origin)
+                    assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"level {level}"
+        for k, (a, o) in enumerate(bufs):
+            assert np.array_equal(o.numpy(), want[k]), f"round {rnd} frame {k}: {np.count_nonzero(o.numpy() != want[k])} differ"
+    for a, o in bufs:
+        a.device_free()
+        o.device_free()
+
+
+@pytest.mark.gpu
+def test_hip_coarse_chain_on_concurrent_streams_4k(hl, oracle):
+    """Eight 4K frames in flight on four CU-partitioned streams and four plain streams at once (every stream has its own
+    workspace and control words; the launches' workgroups compete for the same slots): every frame equals the oracle's."""
+    hip = hl.hip_runtime()
+    import ctypes as C
+    plain = []
+    for _ in range(4):
+        s = C.c_void_p()
+        assert hip.hipStreamCreateWithFlags(C.byref(s), 1) == 0
+        plain.append(s)
+    streams = [hl.partition_stream(p, 4) for p in range(4)] + [s.value for s in plain]
+    imgs = [_rand_image(3840, 2160, seed=40 + i, kind="uniform" if i & 1 else "smooth") for i in range(8)]
+    want = [oracle.local_laplacian(im, 8, 1.0 / 7, 1.0) for im in imgs[:3]]
+    bufs = [(hl.Buffer(im), hl.Buffer(np.zeros_like(im))) for im in imgs]
+    for _ in range(6):
+        for s, (a, o) in zip(streams, bufs):
+            hl.set_stream(s)
+            hl.local_laplacian(a, 8, 1.0 / 7, 1.0, o)
+    hl.set_stream(None)
+    first = [o.numpy().copy() for (_, o) in bufs]
+    for k in range(3):
+        assert np.array_equal(first[k], want[k]), f"frame {k}"
+    # the frames without an oracle result: the same call alone on the device's own stream
+    for k in range(3, 8):
+        a, o = bufs[k]
+        hl.local_laplacian(a, 8, 1.0 / 7, 1.0, o)
+        assert np.array_equal(o.numpy(), first[k]), f"frame {k} differs between the concurrent and the lone call"
+    for a, o in bufs:
+        a.device_free()
+        o.device_free()
+    for s in plain:
+        hip.hipStreamSynchronize(s)
+        hip.hipStreamDestroy(s)
