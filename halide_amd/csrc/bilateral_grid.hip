@@ -10,8 +10,10 @@
 //                       RDom order (float sums are order-sensitive, :28-29), blur in z, write float2 {value, weight}
 //   bg_blurx, bg_blury  5-tap [1 4 6 4 1], left-to-right association (:38-47)
 //   bg_slice            trilinear lerp x->y->z of both channels, divide (:50-67)
-// Grid layout in HBM: float2 G[z][y][x] (c fastest), x,y covering the cells the output region touches (+2 halo
-// for the pre-blur stages), z in [0, zmax+1] with zmax = int(1/r_sigma + 0.5).
+// Grid layout in HBM: float2 {value, weight} per cell, x,y covering the cells the output region touches (+2 halo for the
+// pre-blur stages), z in [0, zmax+1] with zmax = int(1/r_sigma + 0.5).  Grids of at most 16 planes (the two-launch path) keep the
+// blurz grid z-INNERMOST, G[y][x][z]: the (cell, bin) threads of the histogram kernel store one contiguous run per workgroup and
+// a tile row of bg_blur_slice is one contiguous run too; larger grids (the serial histogram + three launches) keep G[z][y][x].
 #include "hlmi_device_math.h"
 #include "hlmi_internal.h"
 
@@ -89,11 +91,13 @@ __global__ void bg_histogram_blurz(const float *__restrict__ in, long in_sy, BGe
 //     workgroup of 252 threads), else 16 — idle bin lanes are pure loss in a kernel bound by VALU issue.
 //   * the weight channel is a COUNT (sums of 1.0f up to 64 are exact in any order): an integer add-with-carry per pixel
 //     instead of a select and a float add.
-//   * LDS rows are padded to 68 words: the 16 (or 12) threads of a cell read one address (broadcast), but unpadded rows put
+//   * LDS rows are padded to 72 words: the 16 (or 12) threads of a cell read one address (broadcast), but unpadded rows put
 //     every cell's row on the same banks (4-way conflicts on both 16-byte reads of each step; 1.1 M conflict cycles per launch
-//     in profiles/r02f_apps_pmc.txt — with four SIMDs sharing the LDS that, not the VALU, set the pace).
+//     in profiles/r02f_apps_pmc.txt — with four SIMDs sharing the LDS that, not the VALU, set the pace).  72, not 68: the
+//     staging's 16-byte stores are served eight lanes at a time on 32 banks, and a lane pair of the next cell landed on the
+//     banks of this cell's second half (scripts/model/lds_banks.py: 182 -> 86 cycles per workgroup).
 constexpr int HTH = 256;         // at most this many threads per workgroup
-constexpr int HROW = S * S + 4;  // padded row of the staged cell
+constexpr int HROW = S * S + 8;  // padded row of the staged cell
 template<int HZ>
 __global__ __launch_bounds__(HTH) void bg_histogram_blurz_par(const float *__restrict__ in, long in_sy, BGeom g,
                                                               float2 *__restrict__ bz, int vec) {
@@ -156,8 +160,8 @@ __global__ __launch_bounds__(HTH) void bg_histogram_blurz_par(const float *__res
     const int cx = cx0 + c;
     if (z < g.ZD && cx < g.HX) {
         const float2 a = s_h[c][z], b = s_h[c][z + 1], m = s_h[c][z + 2], d = s_h[c][z + 3], e = s_h[c][z + 4];
-        bz[(size_t)z * g.HX * g.HY + (size_t)cy * g.HX + cx] =
-            make_float2(blur5(a.x, b.x, m.x, d.x, e.x), blur5(a.y, b.y, m.y, d.y, e.y));
+        // z innermost: the workgroup's (cell, bin) threads store one contiguous run
+        bz[((size_t)cy * g.HX + cx) * g.ZD + z] = make_float2(blur5(a.x, b.x, m.x, d.x, e.x), blur5(a.y, b.y, m.y, d.y, e.y));
     }
 }
 
@@ -206,66 +210,81 @@ __global__ __launch_bounds__(256) void bg_slice(const float *__restrict__ in, lo
 // pixels; the blury cells they interpolate between (at most 10 x 6 x ZD), the blurx rows under those (10 x 10) and the
 // blurz cells under those (14 x 10) are produced in LDS by the same blur5 chains the separate kernels run — two launches
 // and the write + re-read of two grids less (the pipeline is launch-latency bound: 4 launches took 30 us for 16 MB).
+// Round 5, LDS layout: all three tiles are z-INNERMOST, [row][cell][ZP] float2 with ZP = 12 or 16 planes of pitch.
+//   * the slicing stage's eight taps per pixel are data-dependent in z: ds_read_b64 serves a wave in two 32-lane halves on 64
+//     banks, so a half must not put two distinct (z, cell) pairs on one bank pair.  With [z][row][cell] tiles a half covered four
+//     cells x up to 12 planes = 48 pairs on 32 bank pairs (planes z and z + 8 collided: 2 x the cycles on a noise image,
+//     1.4 conflict cycles per LDS instruction in profiles/r04f_apps_pmc.txt).  Now a half covers 16 pixels x 2 rows = TWO
+//     cells, and (cell, z) -> dword 2 ZP cell + 2 z: two windows of at most 32 dwords, no two pairs on one bank.
+//   * the two blur stages walk their elements z-fastest: every LDS access of a wave is one contiguous run.
+//   * staging copies contiguous runs of the z-innermost blurz grid (a tile row = 14 cells x ZD planes) to contiguous LDS.
+// (scripts/model/lds_banks.py models the three stages: 1684 -> 946 LDS cycles per workgroup on a noise image.)
 constexpr int FPX = 64, FCX = 10, FZ = 16;
-template<int FPY>   // tile height (32; 16 and 64 measured the same or slower)
+template<int FPY, int ZP>   // tile height (32; 16 and 64 measured the same or slower); z pitch of the LDS tiles (>= g.ZD)
 __global__ __launch_bounds__(256) void bg_blur_slice(const float *__restrict__ in, long in_sy, BGeom g, const float2 *__restrict__ bz,
                                                     float *__restrict__ out, long out_sy, int ox0, int oy0, int ow, int oh) {
     constexpr int FCY = FPY / S + 2;
-    __shared__ float2 s_bz[FZ][FCY + 4][FCX + 4], s_bx[FZ][FCY + 4][FCX], s_by[FZ][FCY][FCX];
+    constexpr int NBZ = (FCY + 4) * (FCX + 4) * ZP, NBX = (FCY + 4) * FCX * ZP, NBY = FCY * FCX * ZP;
+    __shared__ float2 s_bz[NBZ], s_bx[NBX], s_by[NBY];
     const int t = threadIdx.x;
     const int x0 = blockIdx.x * FPX, y0 = blockIdx.y * FPY;
     const int cxa = dev::fdiv8(ox0 + x0) - g.gx0, cya = dev::fdiv8(oy0 + y0) - g.gy0;   // first blury cell of the tile
+    // lane -> pixel: a wave covers 32 columns x 2 rows per step (each 32-lane half: 16 columns x 2 rows), the four waves are the
+    // two column halves of the tile x two row pairs, a step advances by four rows
+    const int wave = t >> 6, lane = t & 63;
+    const int pcol = (wave & 1) * 32 + ((lane >> 5) << 4) + (lane & 15);
+    const int prow = ((wave >> 1) << 1) + ((lane >> 4) & 1);
     // the thread's own pixels first: their latency hides behind the three grid phases (a load cannot move above a barrier
     // by itself); rows / columns past the output re-read its last row / column and are never stored
     float pix[FPY / 4];
     {
-        const int axc = ox0 + min(x0 + (t & 63), ow - 1);
+        const int axc = ox0 + min(x0 + pcol, ow - 1);
 #pragma unroll
         for (int k = 0; k < FPY / 4; k++) {
-            const int ayc = oy0 + min(y0 + (t >> 6) + 4 * k, oh - 1);
+            const int ayc = oy0 + min(y0 + prow + 4 * k, oh - 1);
             pix[k] = in[(long)(ayc - g.iy0) * in_sy + (axc - g.ix0)];
         }
     }
     {
         // all of the thread's cells are requested before the first one is waited for (a loop with a run-time trip count
         // pays the round trip per iteration: 7 x ~0.7 us was most of this kernel)
-        constexpr int PLANE = (FCY + 4) * (FCX + 4), N1 = (FZ * PLANE + 255) / 256;
-        const int total = g.ZD * PLANE;
+        constexpr int N1 = (NBZ + 255) / 256;
         float2 v[N1];
 #pragma unroll
         for (int k = 0; k < N1; k++) {
-            const int e = min(t + 256 * k, total - 1);
-            const int z = e / PLANE, rem = e - z * PLANE, j = rem / (FCX + 4), i = rem - j * (FCX + 4);
+            const int e = min(t + 256 * k, NBZ - 1);
+            const int z = e % ZP, c = e / ZP, j = c / (FCX + 4), i = c - j * (FCX + 4);
             const int hx = min(cxa + i, g.HX - 1), hy = min(cya + j, g.HY - 1);     // cells past the grid are never interpolated
-            v[k] = bz[((size_t)z * g.HY + hy) * g.HX + hx];
+            v[k] = bz[((size_t)hy * g.HX + hx) * g.ZD + min(z, g.ZD - 1)];          // planes past the grid likewise
         }
 #pragma unroll
         for (int k = 0; k < N1; k++) {
             const int e = t + 256 * k;
-            if (e < total) (&s_bz[0][0][0])[e] = v[k];
+            if (e < NBZ) s_bz[e] = v[k];
         }
     }
     __syncthreads();
-    for (int e = t; e < g.ZD * (FCY + 4) * FCX; e += 256) {
-        const int z = e / ((FCY + 4) * FCX), rem = e - z * ((FCY + 4) * FCX), j = rem / FCX, i = rem - j * FCX;
-        const float2 a = s_bz[z][j][i], b = s_bz[z][j][i + 1], c = s_bz[z][j][i + 2], d = s_bz[z][j][i + 3], q = s_bz[z][j][i + 4];
-        s_bx[z][j][i] = make_float2(blur5(a.x, b.x, c.x, d.x, q.x), blur5(a.y, b.y, c.y, d.y, q.y));
+    for (int e = t; e < NBX; e += 256) {
+        const int z = e % ZP, c = e / ZP, j = c / FCX, i = c - j * FCX;
+        const float2 *sp = s_bz + ((j * (FCX + 4) + i) * ZP + z);
+        const float2 a = sp[0], b = sp[ZP], c2 = sp[2 * ZP], d = sp[3 * ZP], q = sp[4 * ZP];
+        s_bx[e] = make_float2(blur5(a.x, b.x, c2.x, d.x, q.x), blur5(a.y, b.y, c2.y, d.y, q.y));
     }
     __syncthreads();
-    for (int e = t; e < g.ZD * FCY * FCX; e += 256) {
-        const int z = e / (FCY * FCX), rem = e - z * (FCY * FCX), j = rem / FCX, i = rem - j * FCX;
-        const float2 a = s_bx[z][j][i], b = s_bx[z][j + 1][i], c = s_bx[z][j + 2][i], d = s_bx[z][j + 3][i], q = s_bx[z][j + 4][i];
-        s_by[z][j][i] = make_float2(blur5(a.x, b.x, c.x, d.x, q.x), blur5(a.y, b.y, c.y, d.y, q.y));
+    for (int e = t; e < NBY; e += 256) {   // (row j + d, cell i, plane z) of s_bx is element e + d FCX ZP
+        const float2 *sp = s_bx + e;
+        const float2 a = sp[0], b = sp[FCX * ZP], c2 = sp[2 * FCX * ZP], d = sp[3 * FCX * ZP], q = sp[4 * FCX * ZP];
+        s_by[e] = make_float2(blur5(a.x, b.x, c2.x, d.x, q.x), blur5(a.y, b.y, c2.y, d.y, q.y));
     }
     __syncthreads();
-    const int x = x0 + (t & 63);
+    const int x = x0 + pcol;
     if (x >= ow) return;
     const int ax = ox0 + x;
     const float xf = (float)dev::fmod8(ax) * 0.125f;
     const int xi = dev::fdiv8(ax) - g.gx0 - cxa;
 #pragma unroll
     for (int k = 0; k < FPY / 4; k++) {
-        const int y = y0 + (t >> 6) + 4 * k;
+        const int y = y0 + prow + 4 * k;
         if (y >= oh) break;
         const int ay = oy0 + y;
         const float val = dev::clampf(pix[k], 0.0f, 1.0f);
@@ -274,9 +293,9 @@ __global__ __launch_bounds__(256) void bg_blur_slice(const float *__restrict__ i
         const float zf = zv - (float)zi;
         const float yf = (float)dev::fmod8(ay) * 0.125f;
         const int yi = dev::fdiv8(ay) - g.gy0 - cya;
-        const float2 a = lerp2(lerp2(s_by[zi][yi][xi], s_by[zi][yi][xi + 1], xf), lerp2(s_by[zi][yi + 1][xi], s_by[zi][yi + 1][xi + 1], xf), yf);
-        const float2 b = lerp2(lerp2(s_by[zi + 1][yi][xi], s_by[zi + 1][yi][xi + 1], xf),
-                               lerp2(s_by[zi + 1][yi + 1][xi], s_by[zi + 1][yi + 1][xi + 1], xf), yf);
+        const float2 *p0 = s_by + ((yi * FCX + xi) * ZP + zi), *p1 = p0 + FCX * ZP;   // rows yi, yi + 1; cell xi + 1 is ZP further, plane zi + 1 one
+        const float2 a = lerp2(lerp2(p0[0], p0[ZP], xf), lerp2(p1[0], p1[ZP], xf), yf);
+        const float2 b = lerp2(lerp2(p0[1], p0[ZP + 1], xf), lerp2(p1[1], p1[ZP + 1], xf), yf);
         const float2 r = lerp2(a, b, zf);
         out[(long)y * out_sy + x] = r.x / r.y;
     }
@@ -364,8 +383,13 @@ extern "C" int bilateral_grid(halide_buffer_t *input, float r_sigma, halide_buff
         HLMI_LAUNCH(uc, "bg_histogram_blurz", st, bg_histogram_blurz, dim3((g.HX + T - 1) / T, g.HY), dim3(T), sh, din, in_sy, g, bz);
     }
     if (g.ZD <= FZ) {   // (grids of more planes — r_sigma < 1/14.5 — take the serial histogram and the three separate launches)
-        HLMI_LAUNCH(uc, "bg_blur_slice", st, bg_blur_slice<32>, dim3((ow + FPX - 1) / FPX, (oh + 31) / 32), dim3(256), 0, din, in_sy, g, bz,
-                    dev_ptr<float>(output), out_sy, ox0, oy0, ow, oh);
+        if (g.ZD <= 12) {
+            HLMI_LAUNCH(uc, "bg_blur_slice", st, (bg_blur_slice<32, 12>), dim3((ow + FPX - 1) / FPX, (oh + 31) / 32), dim3(256), 0, din, in_sy, g,
+                        bz, dev_ptr<float>(output), out_sy, ox0, oy0, ow, oh);
+        } else {
+            HLMI_LAUNCH(uc, "bg_blur_slice", st, (bg_blur_slice<32, 16>), dim3((ow + FPX - 1) / FPX, (oh + 31) / 32), dim3(256), 0, din, in_sy, g,
+                        bz, dev_ptr<float>(output), out_sy, ox0, oy0, ow, oh);
+        }
     } else {
         HLMI_LAUNCH(uc, "bg_blurx", st, bg_blurx, dim3((g.GX + 63) / 64, g.HY, g.ZD), dim3(64), 0, bz, g, bx);
         HLMI_LAUNCH(uc, "bg_blury", st, bg_blury, dim3((g.GX + 63) / 64, g.GY, g.ZD), dim3(64), 0, bx, g, by);

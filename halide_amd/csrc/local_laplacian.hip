@@ -799,7 +799,6 @@ struct D01EArgs {
     // xcd_block() hands an XCD holds horizontal AND vertical neighbours: a strip's 512-byte row pieces start 16 bytes before a
     // 128-byte line, which its left neighbour reads too — from the same L2 then (68.8 -> 58.8 MB fetched per 4K frame)
     unsigned nsx_magic;        // floor(2^32 / nsx) + 1, 0 when nsx == 1
-    unsigned *ctl;             // 16 control words of the ll_coarse launch that follows on this stream: zeroed here (nullptr: none follows)
 };
 // Packed arithmetic: at two waves per SIMD this kernel is bound by how often ONE wave can issue (a wave issues an
 // independent VALU instruction every ~2.1 ns whatever it is, scripts/ubench/valu_pk.hip: v_pk_add / mul / fma_f32 2.4 ns for
@@ -815,7 +814,6 @@ template<bool ODD0, bool ODD1, bool B1, bool EXCH, bool NT>
 __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometry gm, Levels lev) {
     const D01Args &p = pe.d;
     extern __shared__ float slut[];
-    if (pe.ctl && blockIdx.x == 0 && threadIdx.x < 16) pe.ctl[threadIdx.x] = 0u;
     for (int i = threadIdx.x; i <= 2 * gm.half; i += D0_THREADS) slut[i] = p.lut_g[i];
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1247,40 +1245,6 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
 }
 
 // ---------------------------------------------------------------------------------------------------
-// ---- accesses that are coherent across the device WITHOUT cache maintenance.  The eight XCDs' L2s are not coherent with each
-// other for ordinary loads and stores; a kernel whose workgroups exchange data through memory (ll_coarse) either brackets every
-// exchange with an agent-scope release / acquire — a write-back and an invalidate of a whole L2 each time: measured 300-600 us
-// for ll_coarse's ~2000 work items — or makes the exchanged accesses themselves agent-coherent: relaxed agent-scope atomics are
-// ordinary global_load / global_store instructions with the sc1 bit, which write through to / re-validate at the memory side,
-// 4 or 8 bytes at a time.  COH selects them at compile time; the stand-alone kernels instantiate the plain flavour.
-template<bool COH>
-__device__ __forceinline__ float ldc(const float *p) {
-    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
-}
-template<bool COH>
-__device__ __forceinline__ void stc(float *p, float v) {
-    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-template<bool COH>
-__device__ __forceinline__ float2 ldc2(const float *p) {   // 8-byte aligned
-    if (COH) {
-        const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return make_float2(__uint_as_float((unsigned)w), __uint_as_float((unsigned)(w >> 32)));
-    }
-    return *reinterpret_cast<const float2 *>(p);
-}
-template<bool COH>
-__device__ __forceinline__ void stc2(float *p, float2 v) {   // 8-byte aligned
-    if (COH) {
-        const unsigned long long w = (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        *reinterpret_cast<float2 *>(p) = v;
-    }
-}
-
 // level j -> j+1 (j >= 1): one wave = (strip of 126 destination columns, TY rows, one plane)
 struct StripArgs {
     const float *src;        // level j: (K+1) planes
@@ -1292,7 +1256,7 @@ struct StripArgs {
     int nsx, nsy, nunits;
 };
 // one unit; the whole wave is active (DPP exchanges, wave-uniform control flow)
-template<bool ODD, bool CL = false, bool CS = false>
+template<bool ODD>
 __device__ __forceinline__ void down_strip_unit(const StripArgs &a, int unit, int lane) {
     const int sy = unit % a.nsy, rest = unit / a.nsy, sx = rest % a.nsx, plane = rest / a.nsx;
     const int off = STRIP * sx + 2 * lane;
@@ -1304,14 +1268,7 @@ __device__ __forceinline__ void down_strip_unit(const StripArgs &a, int unit, in
     const float *sp = a.src + (size_t)plane * a.sps + qs.oq;
     float *dp = a.dst + (size_t)plane * a.dps + off;
     auto row = [&](int y_abs) -> float4 {
-        const float *rp = sp + (size_t)dev::clampi(y_abs - a.sloy, 0, a.sh - 1) * a.sws;
-        float4 v;
-        if (CL) {
-            const float2 lo = ldc2<true>(rp), hi = ldc2<true>(rp + 2);
-            v = make_float4(lo.x, lo.y, hi.x, hi.y);
-        } else {
-            v = *reinterpret_cast<const float4 *>(rp);
-        }
+        float4 v = *reinterpret_cast<const float4 *>(sp + (size_t)dev::clampi(y_abs - a.sloy, 0, a.sh - 1) * a.sws);
         if (edge_wave) {
             v = make_float4(pick4(v.x, v.y, v.z, v.w, qs.sel[0]), pick4(v.x, v.y, v.z, v.w, qs.sel[1]),
                             pick4(v.x, v.y, v.z, v.w, qs.sel[2]), pick4(v.x, v.y, v.z, v.w, qs.sel[3]));
@@ -1330,7 +1287,7 @@ __device__ __forceinline__ void down_strip_unit(const StripArgs &a, int unit, in
         float dy[4] = {down4_raw(ra.x, rb.x, rc.x, rd.x), down4_raw(ra.y, rb.y, rc.y, rd.y), down4_raw(ra.z, rb.z, rc.z, rd.z),
                        down4_raw(ra.w, rb.w, rc.w, rd.w)};
         float2 o = hpair<ODD>(dy);
-        if (store_ok) stc2<CS>(dp + (size_t)t * a.dws, o);
+        if (store_ok) *reinterpret_cast<float2 *>(dp + (size_t)t * a.dws) = o;
         ra = rc, rb = rd, rc = nc, rd = nd;
     }
 }
@@ -1344,38 +1301,35 @@ __global__ __launch_bounds__(256) void ll_down_strip(StripArgs a) {
 
 // ---------------------------------------------------------------------------------------------------
 // upsample(f)(X,Y) (:276-282) of a stored level plane `f` (origin lox/loy, row stride ws)
-template<bool COH = false>
-__device__ __forceinline__ float up_at(const float *f, int lox, int loy, int ws, int X, int Y) {
+__device__ __forceinline__ float up_at(const float *__restrict__ f, int lox, int loy, int ws, int X, int Y) {
     int xa = dev::fdiv2(X + 1) - lox, xb = dev::fdiv2(X - 1) - lox;
     int ya = dev::fdiv2(Y + 1) - loy, yb = dev::fdiv2(Y - 1) - loy;
     float wx = (float)(dev::fmod2(X) * 2 + 1) * 0.25f, wy = (float)(dev::fmod2(Y) * 2 + 1) * 0.25f;
-    float ua = dev::lerpf(ldc<COH>(f + (size_t)ya * ws + xa), ldc<COH>(f + (size_t)ya * ws + xb), wx);
-    float ub = dev::lerpf(ldc<COH>(f + (size_t)yb * ws + xa), ldc<COH>(f + (size_t)yb * ws + xb), wx);
+    float ua = dev::lerpf(f[(size_t)ya * ws + xa], f[(size_t)ya * ws + xb], wx);
+    float ub = dev::lerpf(f[(size_t)yb * ws + xa], f[(size_t)yb * ws + xb], wx);
     return dev::lerpf(ua, ub, wy);
 }
 
 // outGPyramid[J-1] = outLPyramid[J-1] (:76, :63-72 with lPyramid[J-1] = gPyramid[J-1], :51); o = element offset
-template<bool COH = false>
-__device__ __forceinline__ float top_value(const float *g, size_t ps, size_t o, int K, float Km1) {
-    float level = ldc<COH>(g + (size_t)K * ps + o) * Km1;
+__device__ __forceinline__ float top_value(const float *__restrict__ g, size_t ps, size_t o, int K, float Km1) {
+    float level = g[(size_t)K * ps + o] * Km1;
     int li = dev::clampi((int)level, 0, K - 2);
     float lf = level - (float)li;
-    return (1.0f - lf) * ldc<COH>(g + (size_t)li * ps + o) + lf * ldc<COH>(g + (size_t)(li + 1) * ps + o);
+    return (1.0f - lf) * g[(size_t)li * ps + o] + lf * g[(size_t)(li + 1) * ps + o];
 }
 // outLPyramid[j](X,Y), 0 < j < J-1 (:50-54, :63-72): g = level j (origin lox/loy), gc = level j+1
 // SEL: level j was stored by ll_down01e — plane 0 = gPyramid[j](., ., li), plane 1 = gPyramid[j](., ., li + 1) for the pixel's own
 // li (the only two values of level j this function reads), plane K = inGPyramid[j]
-// CG / CC: level j / level j+1 were written by other workgroups of THIS launch (ll_coarse): agent-coherent loads
-template<bool SEL = false, bool CG = false, bool CC = false>
-__device__ __forceinline__ float outl_value(const float *g, int ws, size_t ps, int lox, int loy,
-                                            const float *gc, int cws, size_t cps, int clox, int cloy,
+template<bool SEL = false>
+__device__ __forceinline__ float outl_value(const float *__restrict__ g, int ws, size_t ps, int lox, int loy,
+                                            const float *__restrict__ gc, int cws, size_t cps, int clox, int cloy,
                                             int X, int Y, int K, float Km1) {
     size_t o = (size_t)(Y - loy) * ws + (X - lox);
-    float level = ldc<CG>(g + (size_t)K * ps + o) * Km1;
+    float level = g[(size_t)K * ps + o] * Km1;
     int li = dev::clampi((int)level, 0, K - 2);
     float lf = level - (float)li;
-    float l0 = ldc<CG>(g + (SEL ? 0 : (size_t)li * ps) + o) - up_at<CC>(gc + (size_t)li * cps, clox, cloy, cws, X, Y);
-    float l1 = ldc<CG>(g + (SEL ? ps : (size_t)(li + 1) * ps) + o) - up_at<CC>(gc + (size_t)(li + 1) * cps, clox, cloy, cws, X, Y);
+    float l0 = g[(SEL ? 0 : (size_t)li * ps) + o] - up_at(gc + (size_t)li * cps, clox, cloy, cws, X, Y);
+    float l1 = g[(SEL ? ps : (size_t)(li + 1) * ps) + o] - up_at(gc + (size_t)(li + 1) * cps, clox, cloy, cws, X, Y);
     return (1.0f - lf) * l0 + lf * l1;
 }
 
@@ -1400,13 +1354,13 @@ struct UpArgs {
     float Km1;
     float *out;              // outGPyramid[j]
 };
-template<bool SEL, bool CC = false>
+template<bool SEL>
 __device__ __forceinline__ void up_pixel(const UpArgs &a, int x, int y) {   // (x, y) relative to R_j
     if (x >= a.rw || y >= a.rh) return;
     int X = a.rx0 + x, Y = a.ry0 + y;
     size_t o = (size_t)(Y - a.loy) * a.ws + (X - a.lox);
-    float outL = outl_value<SEL, false, CC>(a.g, a.ws, a.ps, a.lox, a.loy, a.gc, a.cws, a.cps, a.clox, a.cloy, X, Y, a.K, a.Km1);
-    a.out[o] = up_at<CC>(a.outc, a.clox, a.cloy, a.cws, X, Y) + outL;
+    float outL = outl_value<SEL>(a.g, a.ws, a.ps, a.lox, a.loy, a.gc, a.cws, a.cps, a.clox, a.cloy, X, Y, a.K, a.Km1);
+    a.out[o] = up_at(a.outc, a.clox, a.cloy, a.cws, X, Y) + outL;
 }
 template<bool SEL = false>
 __global__ __launch_bounds__(256) void ll_up(UpArgs a) {
@@ -1450,7 +1404,7 @@ __device__ __forceinline__ Range2 clamp_to_box(const DevLevel &L, int x0, int x1
     r.y0 = dev::clampi(y0, L.loy, L.loy + L.h - 1), r.y1 = dev::clampi(y1, L.loy, L.loy + L.h - 1);
     return r;
 }
-template<int DEPTH, bool COH = false>
+template<int DEPTH>
 __device__ __forceinline__ void down_multi_tile(const CoarseArgs &a, int ntx, int nty, int b) {   // b = tile x + ntx (tile y + nty plane)
     constexpr int W1 = dm_win(DEPTH - 1), W2 = DEPTH >= 2 ? dm_win(DEPTH - 2) : 1, W3 = DEPTH >= 3 ? dm_win(DEPTH - 3) : 1,
                   W4 = DEPTH >= 4 ? dm_win(DEPTH - 4) : 1;
@@ -1491,7 +1445,7 @@ __device__ __forceinline__ void down_multi_tile(const CoarseArgs &a, int ntx, in
                 for (int k = 0; k < 4; k++) {
                     const int qx = dev::clampi(2 * X - 1 + i, Sx.lox, Sx.lox + Sx.w - 1);
                     const int qy = dev::clampi(2 * Y - 1 + k, Sx.loy, Sx.loy + Sx.h - 1);
-                    r[k] = (d == 1) ? ldc<COH>(src_g + (size_t)(qy - Sx.loy) * Sx.ws + (qx - Sx.lox))
+                    r[k] = (d == 1) ? src_g[(size_t)(qy - Sx.loy) * Sx.ws + (qx - Sx.lox)]
                                     : src_t[(qy - pw.y0) * pnx + (qx - pw.x0)];
                 }
                 v[i] = down4_raw(r[0], r[1], r[2], r[3]);
@@ -1499,7 +1453,7 @@ __device__ __forceinline__ void down_multi_tile(const CoarseArgs &a, int ntx, in
             const float val = down4_tail(v[0], v[1], v[2], v[3]);
             dst[yy * ws_[d] + (X - w.x0)] = val;
             if (X >= o.x0 && X <= o.x1 && Y >= o.y0 && Y <= o.y1) {
-                stc<COH>(L.g + (size_t)plane * L.ps + (size_t)(Y - L.loy) * L.ws + (X - L.lox), val);
+                L.g[(size_t)plane * L.ps + (size_t)(Y - L.loy) * L.ws + (X - L.lox)] = val;
             }
         }
         if (d < DEPTH) __syncthreads();
@@ -1526,7 +1480,7 @@ __host__ __device__ constexpr int um_off(int d) {  // offset of level S+d's regi
     for (int i = 0; i < d; i++) o += um_win(i) * um_win(i);
     return o;
 }
-template<int TOP, bool COH = false>
+template<int TOP>
 __device__ __forceinline__ void up_multi_tile(const CoarseArgs &a, int ntx, int b) {
     __shared__ float tl[um_off(TOP + 1)];
     const int tx = b % ntx, ty = b / ntx;
@@ -1554,10 +1508,10 @@ __device__ __forceinline__ void up_multi_tile(const CoarseArgs &a, int ntx, int 
             const int yy = e / nx, X = r.x0 + (e - yy * nx), Y = r.y0 + yy;
             float v;
             if (d == TOP) {
-                v = top_value<COH>(L.g, L.ps, (size_t)(Y - L.loy) * L.ws + (X - L.lox), a.K, a.Km1);
+                v = top_value(L.g, L.ps, (size_t)(Y - L.loy) * L.ws + (X - L.lox), a.K, a.Km1);
             } else {
                 const DevLevel &C = a.lv[d + 1];
-                v = outl_value<false, COH, COH>(L.g, L.ws, L.ps, L.lox, L.loy, C.g, C.ws, C.ps, C.lox, C.loy, X, Y, a.K, a.Km1);
+                v = outl_value(L.g, L.ws, L.ps, L.lox, L.loy, C.g, C.ws, C.ps, C.lox, C.loy, X, Y, a.K, a.Km1);
             }
             tile[yy * tw + (X - r.x0)] = v;
         }
@@ -1581,7 +1535,7 @@ __device__ __forceinline__ void up_multi_tile(const CoarseArgs &a, int ntx, int 
             const float v = dev::lerpf(ua, ub, wy) + tile[yy * tw + (X - r.x0)];
             if (d == 0) {
                 const DevLevel &L = a.lv[0];
-                stc<COH>(L.out + (size_t)(Y - L.loy) * L.ws + (X - L.lox), v);
+                L.out[(size_t)(Y - L.loy) * L.ws + (X - L.lox)] = v;
             } else {
                 tile[yy * tw + (X - r.x0)] = v;
             }
@@ -1594,115 +1548,12 @@ __global__ __launch_bounds__(256) void ll_up_multi(CoarseArgs a, int ntx) {
     up_multi_tile<TOP>(a, ntx, (int)blockIdx.x);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// ll_coarse: everything between the two big kernels of the common geometry in ONE launch — levels 3 and 4 (down_strip_unit),
-// levels 5..7 (down_multi_tile<3>), outGPyramid[3] from levels 3..7 (up_multi_tile<4>) and, where ll_up0h does not collapse level 2
-// itself, outGPyramid[2] (up_pixel).  The reference treats this end of the pyramid the same way: levels >= 5 are serial
-// compute_roots it calls negligible, levels 1..4 of the up pass live inside the output loop (local_laplacian_generator.cpp:164-198).
-// As separate launches the five stages cost a dependent-launch gap each (~4.5 us: end-of-kernel write-back, completion signal,
-// dispatch), 33 of the 112 us of a frame on one stream.
-//
-// Scheduling.  The stages depend on each other through whole levels, so the launch needs device-wide ordering, and a grid barrier
-// would deadlock whenever the launch's workgroups are not all resident (a CU-partitioned stream, other streams' kernels holding
-// the slots).  Instead the work of all stages is ONE queue of tickets in stage order (ChainArgs::base): a workgroup takes the next
-// ticket with an atomic counter, waits until the previous stage's completion counter is full, runs the item (the very device
-// functions of the stand-alone kernels: bit-identical), bumps its stage's counter.  A ticket only ever waits for LOWER tickets, and
-// the lowest unfinished ticket is always held by a running workgroup — progress does not depend on how many workgroups are
-// resident.  The next ticket is requested before the current item runs (its round trip to the L2 passes under the item).
-// Visibility: everything one stage writes for another (levels 3..7, outGPyramid[3]) moves with agent-coherent accesses (ldc / stc
-// above: sc1 loads and stores, no cache maintenance); an item's stores have completed when its waves pass `s_waitcnt vmcnt(0)` + the
-// workgroup barrier, and only then is its completion counted.  (The first build used agent-scope release / acquire fences around
-// plain accesses instead: every item then wrote back and invalidated a whole L2 — 300-600 us for the launch.)
-// The control words are zeroed by ll_down01e, the launch before this one on the same stream.
-struct ChainCtl {
-    unsigned next, bailed, done[6], pad[8];   // 16 words
-};
-constexpr int CHAIN_STAGES = 5;    // 0: level 2 -> 3, 1: level 3 -> 4, 2: levels 5..7, 3: outGPyramid[3], 4: outGPyramid[2] (may be empty)
-constexpr int CHAIN_UP_ROWS = 4;   // rows of outGPyramid[2] per stage-4 item (256 columns wide)
-struct ChainArgs {
-    StripArgs s0, s1;
-    int odd0, odd1;
-    CoarseArgs dm;                 // lv[0] = level 4
-    int dm_ntx, dm_nty;
-    CoarseArgs um;                 // lv[0] = level 3
-    int um_ntx;
-    UpArgs u2;
-    int u2_nbx;
-    unsigned base[CHAIN_STAGES + 1];   // first ticket of each stage; base[CHAIN_STAGES] = number of tickets
-    ChainCtl *ctl;
-};
-__global__ __launch_bounds__(256) void ll_coarse(ChainArgs a) {
-    __shared__ unsigned s_ticket;
-    __shared__ int s_ok;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    unsigned nxt = 0;
-    int known = 0;     // stages below this one are known to be complete (wave-uniform)
-    if (threadIdx.x == 0) nxt = __hip_atomic_fetch_add(&a.ctl->next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (;;) {
-        if (threadIdx.x == 0) s_ticket = nxt;
-        __syncthreads();
-        const unsigned t = s_ticket;
-        if (t >= a.base[CHAIN_STAGES]) break;
-        if (threadIdx.x == 0) nxt = __hip_atomic_fetch_add(&a.ctl->next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int st = 0;
-#pragma unroll
-        for (int q = 1; q < CHAIN_STAGES; q++) st += (t >= a.base[q]) ? 1 : 0;
-        const int item = (int)(t - a.base[st]);
-        if (st > known) {
-            // every ticket of the previous stage finished (the stages before it finished before any of ITS tickets ran)
-            if (threadIdx.x == 0) {
-                const unsigned need = a.base[st] - a.base[st - 1];
-                int ok = 1;
-                unsigned spins = 0;
-                while (__hip_atomic_load(&a.ctl->done[st - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-                    __builtin_amdgcn_s_sleep(1);
-                    // a bug must not hang the device: give up after ~1 s (the frame is then wrong, and the tests say so)
-                    if ((++spins & 1023u) == 0 &&
-                        (spins > (1u << 21) || __hip_atomic_load(&a.ctl->bailed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                        __hip_atomic_store(&a.ctl->bailed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = 0;
-                        break;
-                    }
-                }
-                s_ok = ok;
-            }
-            __syncthreads();
-            if (!s_ok) break;
-            known = st;
-        }
-        asm volatile("" ::: "memory");   // the item's loads stay below the wait
-        switch (st) {
-            case 0: {   // level 2 (the previous launch's) -> level 3
-                const int unit = item * 4 + wave;
-                if (unit < a.s0.nunits) {
-                    if (a.odd0) down_strip_unit<true, false, true>(a.s0, unit, lane);
-                    else down_strip_unit<false, false, true>(a.s0, unit, lane);
-                }
-                break;
-            }
-            case 1: {   // level 3 -> level 4
-                const int unit = item * 4 + wave;
-                if (unit < a.s1.nunits) {
-                    if (a.odd1) down_strip_unit<true, true, true>(a.s1, unit, lane);
-                    else down_strip_unit<false, true, true>(a.s1, unit, lane);
-                }
-                break;
-            }
-            case 2: down_multi_tile<3, true>(a.dm, a.dm_ntx, a.dm_nty, item); break;
-            case 3: up_multi_tile<4, true>(a.um, a.um_ntx, item); break;
-            default: {  // outGPyramid[2]: level 2 is the previous launch's, level 3 and outGPyramid[3] are this launch's
-                const int bx = item % a.u2_nbx, by = item / a.u2_nbx;
-#pragma unroll
-                for (int r = 0; r < CHAIN_UP_ROWS; r++) up_pixel<false, true>(a.u2, bx * 256 + (int)threadIdx.x, by * CHAIN_UP_ROWS + r);
-                break;
-            }
-        }
-        // the item's (write-through) stores have been acknowledged, in every wave, before the item counts as done
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();   // ... and its LDS tiles are free for the next item
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(&a.ctl->done[st], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
+// Measured and not kept (round 5, git 5e5e508, profiles/r05_ll_coarse_*.txt, profiles/NOTES.md): the five launches between the two big
+// kernels as ONE launch (`ll_coarse`: the stages' work items as a ticket queue in stage order — deadlock-free for any number of resident
+// workgroups — running these same device functions; bit-exact on the whole suite).  With agent-scope release / acquire fences around
+// plain accesses every item wrote back and invalidated a whole L2: 300-600 us for the launch; with agent-coherent (sc1) loads and
+// stores and no cache maintenance 125-270 us, growing with the number of workgroups — against 43 us for the five launches: the
+// command processor hands a dependent launch to the CUs (~4.5 us) faster than ~2000 same-address atomics and memory-side round trips do.
 
 // ---------------------------------------------------------------------------------------------------
 // level 0: outGPyramid[0], colour, u16 (:63-87).  gray / gPyramid[0] recomputed pointwise.
@@ -2256,7 +2107,7 @@ uint64_t g_graph_clock = 0;
 uint64_t ll_env_signature() {
     static const char *const names[] = {"HLMI_LL_NO_LUT_CACHE", "HLMI_LL_UNITS0", "HLMI_LL_NO_VEC",
                                         "HLMI_LL_D01_EXCH", "HLMI_LL_FUSE_FROM", "HLMI_LL_UPCHAIN_FROM", "HLMI_LL_RU", "HLMI_LL_EMIT", "HLMI_LL_NT",
-                                        "HLMI_LL_FUSE_UP2", "HLMI_LL_COARSE", "HLMI_LL_COARSE_WGS"};
+                                        "HLMI_LL_FUSE_UP2"};
     uint64_t h = 1469598103934665603ull;
     for (const char *n : names) {
         const char *e = getenv(n);
@@ -2427,20 +2278,15 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     // (on CU partitions, where every dependent launch of the chain idles the partition: 79.4 -> 76.4 us per frame; on a stream that
     // owns the device the tile redundancy costs what the launch saved: 109 -> 111 us)
     const bool fuse2 = emit && SU >= 3 && SU < J && env_int("HLMI_LL_FUSE_UP2", partitioned ? 1 : 0);
-    // everything between ll_down01e and ll_up0h in one launch (ll_coarse); HLMI_LL_COARSE=0: the five stand-alone launches
-    const bool coarse = emit && S == 4 && SU == 3 && env_int("HLMI_LL_COARSE", 1);
 
-    // ---- workspace: the levels, outLPyramid[0] of the re-cut dataflow (input width x output rows) and ll_coarse's control words
+    // ---- workspace: the levels and outLPyramid[0] of the re-cut dataflow (input width x output rows)
     const size_t off_l0 = ws_floats;
     if (emit) ws_floats += ((size_t)(gm.ix1 - gm.ix0 + 1) * (size_t)oh + 63) & ~(size_t)63;
-    const size_t off_ctl = ws_floats;
-    ws_floats += 64;
     void *ws = nullptr;
     if ((r = get_workspace(uc, ctx, ws_floats * sizeof(float), &ws))) return r;
     float *wsf = (float *)ws;
     float *lut = wsf;
     float *outl0 = wsf + off_l0;
-    ChainCtl *chain_ctl = reinterpret_cast<ChainCtl *>(wsf + off_ctl);
     for (int j = 1; j < J; j++) lv[j].g = wsf + off_g[j], lv[j].out = wsf + off_out[j];
     lv[0].g = lv[0].out = nullptr;
     for (int j = 0; j < J; j++) t_dbg_lv[j] = lv[j];
@@ -2487,7 +2333,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         p.g2 = lv[2].g, p.out2 = lv[2].out, p.lox2 = lv[2].lox, p.loy2 = lv[2].loy, p.ws2 = lv[2].ws, p.ps2 = lv[2].ps;
         p.rx1_1 = c.rx1, p.rx0_1 = c.rx0, p.ry0_1 = c.ry0, p.ry1_1 = c.ry1;
     }
-    // the stages of the chain between the two big kernels, as the stand-alone launches and ll_coarse take them
+    // the stages of the chain between the two big kernels
     auto strip_args = [&](int j, int target_units) {   // level j -> j + 1
         const Level &sl = lv[j], &d = lv[j + 1];
         const int cols = d.nsx * (levels + 1);
@@ -2599,7 +2445,6 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
                 D01EArgs ae;
                 ae.d = a, ae.outl0 = outl0, ae.oy0 = output->dim[1].min, ae.oh = oh;
                 ae.nsx_magic = a.nsx == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)a.nsx + 1ull);
-                ae.ctl = coarse ? &chain_ctl->next : nullptr;
 #define LL_D01E(O0, O1, B)                                                                                                    \
     do {                                                                                                                      \
         if (exch && nt) HLMI_LAUNCH(uc, "ll_down01", st, (ll_down01e<O0, O1, B, true, true>), grid2, block, sh2, ae, gm, lev);  \
@@ -2651,38 +2496,6 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         if (r) return r;
     }
     fuse2_out = fuse2;
-    if (coarse) {
-        // ---- one launch for levels 3..7 and the collapse down to outGPyramid[3] (or [2]): the stages' work items as one ticket queue
-        ChainArgs ch;
-        // enough workgroups to run the widest stage in one round; a ticket holder never depends on a workgroup that is not running, so
-        // the count is a matter of speed only
-        const int nwg_env = env_int("HLMI_LL_COARSE_WGS", 0);   // tests: any count must do, down to one workgroup
-        const int nwg = nwg_env > 0 ? nwg_env : max(64, (partitioned ? 4 : 2) * stream_cus);
-        ch.s0 = strip_args(2, 4 * nwg), ch.odd0 = lv[3].odd ? 1 : 0;
-        ch.s1 = strip_args(3, 4 * nwg), ch.odd1 = lv[4].odd ? 1 : 0;
-        ch.dm = coarse_args(4);
-        ch.dm_ntx = (lv[J - 1].w + DM_T - 1) / DM_T, ch.dm_nty = (lv[J - 1].h + DM_T - 1) / DM_T;
-        ch.um = coarse_args(3);
-        ch.um_ntx = (ch.um.lv[0].rw + UM_T - 1) / UM_T;
-        const int um_nty = (ch.um.lv[0].rh + UM_T - 1) / UM_T;
-        ch.u2 = up_args(2);
-        ch.u2_nbx = (ch.u2.rw + 255) / 256;
-        const unsigned items[CHAIN_STAGES] = {(unsigned)(ch.s0.nunits + 3) / 4, (unsigned)(ch.s1.nunits + 3) / 4,
-                                              (unsigned)(ch.dm_ntx * ch.dm_nty * (levels + 1)), (unsigned)(ch.um_ntx * um_nty),
-                                              fuse2 ? 0u : (unsigned)(ch.u2_nbx * ((ch.u2.rh + CHAIN_UP_ROWS - 1) / CHAIN_UP_ROWS))};
-        ch.base[0] = 0;
-        for (int q = 0; q < CHAIN_STAGES; q++) ch.base[q + 1] = ch.base[q] + items[q];
-        ch.ctl = chain_ctl;
-        {   // algorithmic bytes: levels 2..6 read and 3..7 written once by the down stages (K + 1 planes), then what ll_up_multi:3 and
-            // ll_up:2 declare
-            double b = 0;
-            for (int j = 2; j + 1 < J; j++) b += 4.0 * (levels + 1) * ((double)lv[j].w * lv[j].h + (double)lv[j + 1].w * lv[j + 1].h);
-            b += 4.0 * 4.0 * (double)ch.um.lv[0].rw * ch.um.lv[0].rh * (4.0 / 3.0);
-            if (!fuse2) b += 4.0 * (4.0 * ch.u2.rw * ch.u2.rh + 3.0 * (double)ch.um.lv[0].rw * ch.um.lv[0].rh);
-            timing_note_bytes(b);
-        }
-        HLMI_LAUNCH(uc, "ll_coarse", st, ll_coarse, dim3((unsigned)min((unsigned)nwg, ch.base[CHAIN_STAGES])), dim3(256), 0, ch);
-    } else {
     for (int j = 1; j + 1 < J; j++) {
         if (j == S) {
             const CoarseArgs ca = coarse_args(S);
@@ -2737,7 +2550,6 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         // per output: 2 planes of g_j + inG_j read, outG_j written; per coarse pixel: 2 planes of g_{j+1} + outG_{j+1}
         timing_note_bytes(4.0 * (4.0 * ua.rw * ua.rh + 3.0 * (lv[j + 1].rx1 - lv[j + 1].rx0 + 1) * (lv[j + 1].ry1 - lv[j + 1].ry0 + 1)));
         HLMI_LAUNCH(uc, nm, st, ll_up<false>, dim3((ua.rw + 255) / 256, ua.rh), dim3(256), 0, ua);
-    }
     }
     fuse1_out = fuse1;
     {

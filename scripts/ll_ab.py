@@ -1,7 +1,7 @@
 """A/B timing of local_laplacian launch-chain switches in ONE process (the library reads its HLMI_LL_* switches per call):
 for every configuration, (a) one call + device sync, the reference's protocol (tools/halide_benchmark.h: min over samples),
 (b) frames back to back on one stream, (c) frames spread over four CU-partitioned streams.  us per 3840x2160 frame.
-    python scripts/ll_ab.py "HLMI_LL_COARSE=0" "HLMI_LL_COARSE=1" "HLMI_LL_COARSE=1,HLMI_LL_FUSE_UP2=1" ...
+    python scripts/ll_ab.py "HLMI_LL_FUSE_UP2=0" "HLMI_LL_FUSE_UP2=1" "HLMI_LL_NT=1,HLMI_LL_RU=16" ...
 """
 import os
 import sys

@@ -496,42 +496,12 @@ def test_hip_emit_launch_geometries_match_oracle(hl, oracle, monkeypatch, units,
         assert np.array_equal(o.numpy(), oracle.local_laplacian(inp, 8, 1.0 / 7, 1.0, origin=origin))
 
 
-# ---- round 5: ll_coarse — levels 3..7 and the collapse down to outGPyramid[3] (or [2]) as ONE launch whose work items are a
-# ticket queue in stage order (HLMI_LL_COARSE=0: the five stand-alone launches)
+# ---- round 5
 @pytest.mark.gpu
-@pytest.mark.parametrize("coarse,fuse2,wgs", [("1", "0", 0), ("1", "1", 0), ("1", "0", 1), ("1", "1", 3), ("1", "0", 5000), ("0", "0", 0), ("0", "1", 0)])
-@pytest.mark.parametrize("w,h,origin", [(640, 480, (0, 0)), (1000, 300, (2, -5)), (256, 64, (-4, 3)), (2048, 1100, (0, 0))])
-def test_hip_coarse_chain_in_one_launch_matches_oracle(hl, oracle, monkeypatch, w, h, origin, coarse, fuse2, wgs):
-    """The ticket queue must give the stand-alone launches' bits whatever number of workgroups drains it (one workgroup walks
-    all stages by itself; 5000 mostly find the queue empty) and whether or not ll_up0h collapses level 2 itself.  Two different
-    frames alternate through the SAME workspace: a stage that read a level before the stage before it had finished — or found
-    the other frame's lines in its L2 — would show the other frame's values."""
-    monkeypatch.setenv("HLMI_LL_COARSE", coarse)
-    monkeypatch.setenv("HLMI_LL_FUSE_UP2", fuse2)
-    if wgs:
-        monkeypatch.setenv("HLMI_LL_COARSE_WGS", str(wgs))
-    imgs = [_rand_image(w, h, seed=w + h + 11, kind="smooth"), _rand_image(w, h, seed=w + 5 * h, kind="uniform")]
-    want = [oracle.local_laplacian(im, 8, 1.0 / 7, 1.0, origin=origin) for im in imgs]
-    bufs = [(hl.Buffer(im).set_min(origin[0], origin[1], 0), hl.Buffer(np.zeros_like(im)).set_min(origin[0], origin[1], 0)) for im in imgs]
-    for rnd in range(3):
-        for k, (a, o) in enumerate(bufs):
-            hl.local_laplacian(a, 8, 1.0 / 7, 1.0, o)
-            if rnd == 2 and k == 1 and w * h < 1 << 20:
-                for level in range(3, 0, -1):
-                    got = hl.debug_local_laplacian_outg(level)
-                    ref = oracle.local_laplacian_outg(imgs[k], 8, 1.0 / 7, 1.0, level, origin=origin)
-                    assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"level {level}"
-        for k, (a, o) in enumerate(bufs):
-            assert np.array_equal(o.numpy(), want[k]), f"round {rnd} frame {k}: {np.count_nonzero(o.numpy() != want[k])} differ"
-    for a, o in bufs:
-        a.device_free()
-        o.device_free()
-
-
-@pytest.mark.gpu
-def test_hip_coarse_chain_on_concurrent_streams_4k(hl, oracle):
+def test_hip_eight_4k_frames_in_flight_on_partitioned_and_plain_streams(hl, oracle):
     """Eight 4K frames in flight on four CU-partitioned streams and four plain streams at once (every stream has its own
-    workspace and control words; the launches' workgroups compete for the same slots): every frame equals the oracle's."""
+    workspace; the launches' workgroups compete for the same compute units): every frame equals the oracle's, or — for the five
+    frames the oracle is not run on — the same call alone on the device's own stream."""
     hip = hl.hip_runtime()
     import ctypes as C
     plain = []
