@@ -207,6 +207,14 @@ __global__ __launch_bounds__(64 * TH / ROWS) void nlm_7x7w(const float *__restri
     }
 }
 
+// Measured and not kept (round 5, profiles/r05_nlm_shared_d.txt): `nlm_7x7s`, this kernel with every row of d computed ONCE per
+// workgroup and offset — a wave owns the eight rows whose shifted operand it needs anyway plus at most two of the tile's six
+// border rows (10 rows of d per wave instead of 14) and takes the three rows above and below from its neighbours through a
+// double-buffered LDS exchange, one workgroup barrier per offset.  Bit-exact; 0.215 ms per call against 0.154-0.165 for this kernel
+// on the same box, SQ_INSTS_VALU 99.36 M for both: the compiler only holds the exchange version in registers with the seven
+// column offsets NOT unrolled (unrolled: 560 scratch accesses), and the loop and address arithmetic that costs eats the saved
+// d rows, while the 49 barriers put the waves of a workgroup back in lock step (SQ_BUSY_CYCLES 10.5 M -> 15.7 M).
+
 // generic (patch, search): one thread per pixel, everything from (L2-resident) global memory, same sum orders
 __global__ __launch_bounds__(256) void nlm_generic(const float *__restrict__ in, long in_sy, long in_sc, NGeom g, int patch,
                                                   int search, float *__restrict__ out, long out_sy, long out_sc) {

@@ -13,5 +13,16 @@ while IFS= read -r cmd; do
   echo "RUN      $cmd"
   eval "$cmd" || { echo "FAILED   $exe"; fail=1; }
 done < <(HALIDE_RUNGEN_DIR="$HALIDE_RUNGEN_DIR" python3 "$ROOT/scripts/pin_against_halide.py" commands | sed "s|\$HALIDE_RUNGEN_DIR|$HALIDE_RUNGEN_DIR|")
+# harris, lens_blur, bgu: the apps' own drivers (the manifest's "driver_cases"); optional — without HALIDE_DRIVER_DIR they stay unpinned
+if [ -n "${HALIDE_DRIVER_DIR:-}" ]; then
+  while IFS= read -r cmd; do
+    exe=${cmd%% *}
+    if [ ! -x "$exe" ]; then echo "MISSING  $exe"; fail=1; continue; fi
+    echo "RUN      $cmd"
+    eval "$cmd" > /dev/null || { echo "FAILED   $exe"; fail=1; }
+  done < <(python3 "$ROOT/scripts/pin_against_halide.py" driver_commands | sed "s|\$HALIDE_DRIVER_DIR|$HALIDE_DRIVER_DIR|")
+else
+  echo "NOTE     HALIDE_DRIVER_DIR is not set: harris / lens_blur / bgu (driver cases) not run"
+fi
 ls -la "$ROOT/tests/golden/halide" | head -40
 exit $fail
