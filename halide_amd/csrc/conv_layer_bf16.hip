@@ -538,6 +538,13 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_p(const float *__restrict__ 
         }
 }
 
+// Measured and not kept (round 5, profiles/r05_conv_bf16_rows.txt): `conv3x3_bf16_g`, this kernel with ONE barrier per filter row —
+// the B slot holds a row's three taps (24 KB, two slots), the waves meet 12 times instead of 36 and run 24 MFMAs each in between,
+// the fragments of k-step s + 1 requested under the MFMAs of k-step s.  Bit-identical, 0.0262 against 0.0257 ms per call: the
+// barriers are not what the K loop waits for.  What the counters say: 486 144 MFMAs x 32 cycles = 18.4 k cycles per SIMD of a busy
+// CU, and SQ_BUSY_CU_CYCLES / 211 busy CUs = 47 k cycles in 25.8 us — the shader clock under this kernel is ~1.8 GHz, not the
+// 2.4 GHz the 2.5 PFLOP/s peak is quoted at; at that clock the matrix pipe is busy 10.1 us, 58 % of the K loop.
+
 const halide_type_t ty_f32 = {(decltype(halide_type_t::code))2, 32, 0};
 // estimates: BASELINE.json configs[4] (N=16, 56x56 output, 128 -> 128 channels)
 const int64_t e0 = 0, e128 = 128, e3 = 3, e58 = 58, e56 = 56, e16 = 16;

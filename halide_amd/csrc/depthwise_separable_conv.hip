@@ -93,37 +93,69 @@ __global__ __launch_bounds__(256) void dsc_fused_t(const float *__restrict__ in,
     __shared__ float s_mid[TPX * IC], s_dw[FH * FW * IC], s_pw[IC * CO];
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * TPX, y = blockIdx.y, n = blockIdx.z;
-    for (int i = tid; i < FH * FW * IC; i += 256) {
-        const int d = i % IC, rx = (i / IC) % FW, ry = i / (IC * FW);
-        s_dw[i] = dw[d * g.d_s1 + rx * g.d_sx + ry * g.d_sy];
-    }
-    for (int i = tid; i < IC * CO; i += 256) s_pw[i] = pw[(i % CO) + (long)(i / CO) * g.p_s1];
-    __syncthreads();
     constexpr int padw = FW / 2, padh = FH / 2;
     const int Y = g.oy0 + y;
     // ---- phase 1: thread <-> (pixels px0 + k * (256 / IC), channel d)
+    // Round 5: ONE memory round trip before the arithmetic instead of two.  The filters' elements and then every input value the
+    // thread will multiply (FH FW N1 of them) are REQUESTED first; the filters go to LDS when they arrive (the inputs, requested
+    // after them, are still in flight: a wave's loads return in order), the barrier follows, and the fma chains start on inputs that
+    // arrived meanwhile.  Before, a workgroup waited for its filter elements, passed the barrier and only then asked for its pixels.
     constexpr int PPT = 256 / IC, N1 = (TPX + PPT - 1) / PPT;   // pixels per pass, passes
+    constexpr int NDW = (FH * FW * IC + 255) / 256, NPW = (IC * CO + 255) / 256;
+    float fdw[NDW], fpw[NPW];
+#pragma unroll
+    for (int j = 0; j < NDW; j++) {
+        const int i = min(tid + 256 * j, FH * FW * IC - 1);
+        const int d = i % IC, rx = (i / IC) % FW, ry = i / (IC * FW);
+        fdw[j] = dw[d * g.d_s1 + rx * g.d_sx + ry * g.d_sy];
+    }
+#pragma unroll
+    for (int j = 0; j < NPW; j++) {
+        const int i = min(tid + 256 * j, IC * CO - 1);
+        fpw[j] = pw[(i % CO) + (long)(i / CO) * g.p_s1];
+    }
+    const int d = tid % IC, pxo = tid / IC;
+    float v[FH][FW][N1];
+#pragma unroll
+    for (int ry = 0; ry < FH; ry++) {
+        const int yy = Y + ry - padh;
+        const bool yin = yy >= 0 && yy < g.H;
+        const float *rowp = in + (long)n * g.in_sn + (long)(min(max(yy, 0), g.iy0 + g.H - 1) - g.iy0) * g.in_sy + d;
+#pragma unroll
+        for (int rx = 0; rx < FW; rx++) {
+#pragma unroll
+            for (int k = 0; k < N1; k++) {
+                const int px = pxo + k * PPT;
+                const int xx = g.ox0 + x0 + px + rx - padw;
+                const bool inb = yin && xx >= 0 && xx < g.W;                      // (:36-43): zero padding by the EXTENTS
+                const int cx = min(max(xx, 0), g.ix0 + g.W - 1) - g.ix0;           // the read itself is clamped
+                v[ry][rx][k] = inb ? rowp[(long)cx * g.in_sx] : 0.0f;
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NDW; j++) {
+        if (tid + 256 * j < FH * FW * IC) s_dw[tid + 256 * j] = fdw[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NPW; j++) {
+        if (tid + 256 * j < IC * CO) s_pw[tid + 256 * j] = fpw[j];
+    }
+    __syncthreads();
     {
-        const int d = tid % IC, pxo = tid / IC;
         float acc[N1];
 #pragma unroll
         for (int k = 0; k < N1; k++) acc[k] = 0.0f;
 #pragma unroll
         for (int ry = 0; ry < FH; ry++) {
-            const int yy = Y + ry - padh;
-            const bool yin = yy >= 0 && yy < g.H;
-            const float *rowp = in + (long)n * g.in_sn + (long)(min(max(yy, 0), g.iy0 + g.H - 1) - g.iy0) * g.in_sy + d;
 #pragma unroll
             for (int rx = 0; rx < FW; rx++) {
                 const float f = s_dw[(ry * FW + rx) * IC + d];
 #pragma unroll
                 for (int k = 0; k < N1; k++) {
                     const int px = pxo + k * PPT;
-                    const int xx = g.ox0 + x0 + px + rx - padw;
-                    const bool inb = yin && xx >= 0 && xx < g.W;                      // (:36-43): zero padding by the EXTENTS
-                    const int cx = min(max(xx, 0), g.ix0 + g.W - 1) - g.ix0;           // the read itself is clamped
-                    const float v = inb ? rowp[(long)cx * g.in_sx] : 0.0f;
-                    if (px < TPX && x0 + px < g.ow) acc[k] = __builtin_fmaf(f, v, acc[k]);
+                    if (px < TPX && x0 + px < g.ow) acc[k] = __builtin_fmaf(f, v[ry][rx][k], acc[k]);
                 }
             }
         }
