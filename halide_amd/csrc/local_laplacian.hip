@@ -22,7 +22,7 @@
 //   ll_remap_lut    remap LUT (generator :23-25); cached per (device, levels, alpha)
 //   ll_down01e      levels 0 -> 1 -> 2 of all K+1 planes in ONE walk; emits outLPyramid[0] (one plane) and three planes of level 1
 //                   instead of the K+1-plane level-1 pyramid (round 4's dataflow; ll_down01f = round 3's, which stores them all)
-//   ll_down_strip   level j -> j+1 (j = 2, 3): wave-strip scheme, one plane per wave, float4 loads
+//   ll_down_strip2  levels 3 and 4 from level 2 in one launch (round 5; ll_down_strip = one level per launch, other chains)
 //   ll_down_multi   levels 5..7 from level 4 in one launch;  ll_up_multi: outGPyramid[3] from levels 3..7 in one launch
 //   ll_up           outGPyramid[2] (only on a stream that owns the device: on CU partitions ll_up0h collapses level 2 itself)
 //   ll_up0h         outGPyramid[1] (LDS tile) -> outGPyramid[0] = upsample + outLPyramid[0] -> recolour -> u16 store
@@ -1299,6 +1299,92 @@ __global__ __launch_bounds__(256) void ll_down_strip(StripArgs a) {
     down_strip_unit<ODD>(a, unit, threadIdx.x & 63);
 }
 
+// ---- ll_down_strip2: levels j+1 AND j+2 of the stored planes of level j in one launch (round 5; j = 2 in the default chain:
+// ll_down_strip:2 and ll_down_strip:3 become one launch — one dependent-launch gap of the chain between the two big kernels less).
+// ll_down01f's scheme on stored planes: a wave owns RPU rows [A, B] of level j+2 of ONE plane and a strip of S2 of its columns,
+// walks the level-(j+1) rows 2A-1 .. 2B+2 under them (stores 2A .. 2B+1: the two outer rows are the neighbours' — recomputed,
+// identical operations, identical bits), lane = 4 adjacent level-j columns -> 2 level-(j+1) columns (ll_down_strip's hpair),
+// and carries the level-(j+1) -> (j+2) vertical window of its column pair in REGISTERS (one plane per wave: two raw rows and the
+// partial sum), the horizontal pass by DPP as in ll_down01f.  Every source row of the unit (2 NT + 2 float4 per lane) is REQUESTED
+// before the first is used: the launch is one memory round trip, not one per row — these levels are latency, not bandwidth.
+// Rows / columns of level j+1 outside its box are computed from the clamped level-j reads: level j+1 is constant beyond its box,
+// which is what a clamped read of the stored plane returns (see ll_down01f).
+constexpr int S2_RPU = 2;                 // level-(j+2) rows per unit
+constexpr int S2_NT = 2 * S2_RPU + 2;     // level-(j+1) rows a unit walks
+constexpr int S2_NSRC = 2 * S2_NT + 2;    // level-j rows it reads
+struct Strip2Args {
+    const float *src;        // level j, (K+1) planes
+    int slox, sloy, sw, sh, sws;
+    size_t sps;
+    float *g1;               // level j+1
+    int so1, loy1, w1, h1, ws1;
+    size_t ps1;
+    float *g2;               // level j+2
+    int so2, loy2, w2, h2, ws2;
+    size_t ps2;
+    int Pbase, S2, nsx, nsy, nunits;   // nunits = planes * nsx * nsy
+};
+template<bool ODD0, bool ODD1>
+__global__ __launch_bounds__(256) void ll_down_strip2(Strip2Args p) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int unit = xcd_block() * 4 + wave;
+    if (unit >= p.nunits) return;
+    const int lane = threadIdx.x & 63;
+    const int sy = unit % p.nsy, rest = unit / p.nsy, sx = rest % p.nsx, plane = rest / p.nsx;   // sy fastest: vertical neighbours share an L2
+    const int A = p.loy2 + sy * S2_RPU, B = min(A + S2_RPU - 1, p.loy2 + p.h2 - 1);
+    const int P = p.Pbase + 2 * p.S2 * sx + 2 * lane;   // absolute level-(j+1) column of the lane's pair
+    const QuadSel qs = quad_sel((ODD0 ? 2 * P - 1 : 2 * P - 2) - p.slox, p.sw);
+    const bool edge_wave = __any(!qs.plain);
+    const int T0 = 2 * A - 1;                            // first level-(j+1) row walked; the walk always has S2_NT steps
+    const int Ts0 = max(2 * A, p.loy1), Ts1 = min(2 * B + 1, p.loy1 + p.h1 - 1);
+    const int off1 = P - p.so1;
+    const bool st1_ok = lane < p.S2 && off1 >= 0 && off1 < p.w1;
+    const int X2 = ODD1 ? (P + 1) >> 1 : P >> 1;
+    const int off2 = X2 - p.so2;
+    const bool st2_ok = (ODD1 ? lane < p.S2 : (lane >= 1 && lane <= p.S2)) && off2 >= 0 && off2 < p.w2;
+    const float *sp = p.src + (size_t)plane * p.sps + qs.oq;
+    float4 r[S2_NSRC];                                   // level-j rows 2 T0 - 1 .. 2 T0 + 2 NT (clamped to the level's box)
+#pragma unroll
+    for (int i = 0; i < S2_NSRC; i++) r[i] = *reinterpret_cast<const float4 *>(sp + (size_t)dev::clampi(2 * T0 - 1 + i - p.sloy, 0, p.sh - 1) * p.sws);
+    if (edge_wave) {
+#pragma unroll
+        for (int i = 0; i < S2_NSRC; i++) {
+            const float4 v = r[i];
+            r[i] = make_float4(pick4(v.x, v.y, v.z, v.w, qs.sel[0]), pick4(v.x, v.y, v.z, v.w, qs.sel[1]),
+                               pick4(v.x, v.y, v.z, v.w, qs.sel[2]), pick4(v.x, v.y, v.z, v.w, qs.sel[3]));
+        }
+    }
+    float *d1 = p.g1 + (size_t)plane * p.ps1 + off1, *d2 = p.g2 + (size_t)plane * p.ps2 + off2;
+    float2 s0 = make_float2(0.0f, 0.0f), s1 = s0, pc = s0;   // raw level-(j+1) rows T - 2 / T - 1 of the window; a + 3 (b + c)
+#pragma unroll
+    for (int t = 0; t < S2_NT; t++) {
+        const int T = T0 + t;
+        const float4 a = r[2 * t], b = r[2 * t + 1], c = r[2 * t + 2], d = r[2 * t + 3];
+        const float dy[4] = {down4_raw(a.x, b.x, c.x, d.x), down4_raw(a.y, b.y, c.y, d.y), down4_raw(a.z, b.z, c.z, d.z),
+                             down4_raw(a.w, b.w, c.w, d.w)};
+        const float2 res = hpair<ODD0>(dy);
+        if (T >= Ts0 && T <= Ts1 && st1_ok) *reinterpret_cast<float2 *>(d1 + (size_t)(T - p.loy1) * p.ws1) = res;
+        if ((t & 1) == 0) {      // third row of a level-(j+2) window (the first step's window is incomplete: its result is dropped)
+            pc.x = s0.x + 3.0f * (s1.x + res.x);
+            pc.y = s0.y + 3.0f * (s1.y + res.y);
+            s0 = res;
+        } else {                 // fourth row: completes level-(j+2) row (T - 2) / 2
+            const float rx = pc.x + res.x, ry = pc.y + res.y;   // down4_raw of the lane's two level-(j+1) columns
+            float o;
+            if (ODD1) {
+                const float nx = lane_next(rx), ny = lane_next(ry);
+                o = down4_tail(rx, ry, nx, ny);
+            } else {
+                const float py = lane_prev(ry), nx = lane_next(rx);
+                o = down4_tail(py, rx, ry, nx);
+            }
+            const int Y = (T - 2) >> 1;
+            if (T >= 2 * A + 2 && Y <= B && st2_ok) d2[(size_t)(Y - p.loy2) * p.ws2] = o;
+            s1 = res;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // upsample(f)(X,Y) (:276-282) of a stored level plane `f` (origin lox/loy, row stride ws)
 __device__ __forceinline__ float up_at(const float *__restrict__ f, int lox, int loy, int ws, int X, int Y) {
@@ -2496,7 +2582,35 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         if (r) return r;
     }
     fuse2_out = fuse2;
+    // levels 3 and 4 from level 2 in one launch (ll_down_strip2) when the chain below would run ll_down_strip:2 and :3
+    // (one stream: 111.6 -> 105.1 us per frame back to back, 123 -> 116.6 for one call + sync; four partitions 75-77 -> 72-76)
+    const bool strip2 = fuse_d2 && S == 4;
+    if (strip2) {
+        const Level &sl = lv[2], &d = lv[3], &e = lv[4];
+        Strip2Args a;
+        a.src = sl.g, a.slox = sl.lox, a.sloy = sl.loy, a.sw = sl.w, a.sh = sl.h, a.sws = sl.ws, a.sps = sl.ps;
+        a.g1 = d.g, a.so1 = d.lox, a.loy1 = d.loy, a.w1 = d.w, a.h1 = d.h, a.ws1 = d.ws, a.ps1 = d.ps;
+        a.g2 = e.g, a.so2 = e.lox, a.loy2 = e.loy, a.w2 = e.w, a.h2 = e.h, a.ws2 = e.ws, a.ps2 = e.ps;
+        const bool odd0 = d.odd, odd1 = e.odd;                  // as for ll_down01f: e.odd == (d.lox & 1)
+        a.S2 = (odd0 || odd1) ? 62 : 61;
+        const int lim = odd1 ? 2 * e.lox - 1 : 2 * e.lox - 2;   // leftmost pair must reach level-(j+2) column so2
+        a.Pbase = min(d.lox, lim);
+        const int hi1 = d.lox + d.w - 1, hi2 = e.lox + e.w - 1;
+        const int x2_first = odd1 ? (a.Pbase + 1) / 2 + 0 : a.Pbase / 2 + 1;
+        a.nsx = max((hi2 - x2_first + a.S2) / a.S2, (hi1 - a.Pbase + 2 * a.S2) / (2 * a.S2));
+        a.nsy = (e.h + S2_RPU - 1) / S2_RPU;
+        a.nunits = (levels + 1) * a.nsx * a.nsy;
+        timing_note_bytes(4.0 * (levels + 1) * ((double)sl.w * sl.h + (double)d.w * d.h + (double)e.w * e.h));
+        dim3 grid((a.nunits + 3) / 4), block(256);
+        switch ((odd0 ? 2 : 0) | (odd1 ? 1 : 0)) {
+            case 0: HLMI_LAUNCH(uc, "ll_down_strip2:2", st, (ll_down_strip2<false, false>), grid, block, 0, a); break;
+            case 1: HLMI_LAUNCH(uc, "ll_down_strip2:2", st, (ll_down_strip2<false, true>), grid, block, 0, a); break;
+            case 2: HLMI_LAUNCH(uc, "ll_down_strip2:2", st, (ll_down_strip2<true, false>), grid, block, 0, a); break;
+            default: HLMI_LAUNCH(uc, "ll_down_strip2:2", st, (ll_down_strip2<true, true>), grid, block, 0, a); break;
+        }
+    }
     for (int j = 1; j + 1 < J; j++) {
+        if (strip2 && (j == 2 || j == 3)) continue;
         if (j == S) {
             const CoarseArgs ca = coarse_args(S);
             long total = 0;
