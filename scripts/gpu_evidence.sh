@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round evidence: gpu_full (tests, smoke, bench lines, kernel stats, PMC traffic) + apps profile + ceiling sweep; `python scripts/make_profiles.py <tag> <round>`
 # turns the directory into the tracked summaries under profiles/ (and stamps profiles/traffic.json with the kernel source's hash)
-TAG=${1:-r04a}
+TAG=${1:-r05a}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 bash scripts/gpu_full.sh $TAG
@@ -9,8 +9,8 @@ cd $R
 echo "== apps: kernel stats + counters"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_apps -o kt -- bash -c "cd $R && python bench_apps.py --samples 1 --no-batched" > $OUT/kt_apps.log 2>&1)
 find $OUT -name "*kernel_trace.csv" -delete
-PMC_CMD="python bench_apps.py --only nl_means,bilateral_grid,conv_layer_bf16,stencil_chain --samples 1 --no-batched" bash scripts/gpu_pmc_cmd.sh $TAG/pmc_apps \
-  "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" \
+PMC_CMD="python bench_apps.py --only nl_means,bilateral_grid,conv_layer_bf16,stencil_chain,camera_pipe --samples 1 --no-batched" bash scripts/gpu_pmc_cmd.sh $TAG/pmc_apps \
+  "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
   "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES" "FETCH_SIZE" "WRITE_SIZE" 2>&1 | grep -E "^\(" | tee $OUT/apps_pmc.txt | cut -c1-200
 echo "== HBM ceiling sweep + access-width calibration"
 timeout 600 python - <<PY 2>&1 | tee $OUT/membench.log

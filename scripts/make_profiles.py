@@ -75,7 +75,10 @@ if rows:
     per = {}
     # level 1 -> 2 comes out of ll_down01f when that kernel ran (then the strips start at level 2); the level-1 collapse
     # is part of ll_up0f when only two ll_up launches ran (levels 3 and 2)
-    strips = sorted([r for r in rows if r[0].startswith("ll_down_strip")], key=lambda r: -r[5])
+    for r in rows:   # round 5: levels 3 and 4 from level 2 in one launch, reported as ll_down_strip2:2
+        if r[0].startswith("ll_down_strip2"):
+            per["ll_down_strip2:2"] = r[5]
+    strips = sorted([r for r in rows if r[0].startswith("ll_down_strip") and not r[0].startswith("ll_down_strip2")], key=lambda r: -r[5])
     first_strip = 2 if any(r[0].startswith("ll_down01") for r in rows) else 1
     for i, r in enumerate(strips):
         per[f"ll_down_strip:{i + first_strip}"] = r[5]
