@@ -194,8 +194,8 @@ constexpr int TQX = 32;                               // quad columns of output 
 // boundary guarantees ([-6, W+5] x [-6, H+5] around the output) are read as 0; they only feed pixels that are not stored.
 constexpr int FTY = 20;                                                      // quad rows of OUTPUT per tile: 64 x 40 pixels
 constexpr int FQX = TQX + 2, FQY = FTY + 2;                                  // quads made per tile: 34 x 22 = 748 on 256 threads, three passes
-constexpr int FRWD = (2 * FQX + 8) / 2, FRH = 2 * FQY + 8, FRPD = FRWD + 1;  // raw window: 38 dwords x 28 rows
-constexpr int FDQX = FQX + 2, FDQY = FQY + 2, FDPD = FDQX + 1;               // clamped quads 36 x 12
+constexpr int FRWD = (2 * FQX + 8) / 2, FRH = 2 * FQY + 8, FRPD = FRWD + 1;  // raw window: 38 dwords (76 pixels) x 52 rows, pitch 39
+constexpr int FDQX = FQX + 2, FDQY = FQY + 2, FDPD = FDQX + 1;               // clamped quads 36 x 24, pitch 37
 constexpr int FOP = 72;                                                      // staged row pitch in bytes (column k at byte k + 3)
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void cp_fused_tile(const uint16_t *__restrict__ raw, long in_sy, const CPSetup *__restrict__ s,
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void cp_fused_tile(const uint16_t *__restrict_
             const int i = min(tid + 256 * k, FRH * FRWD - 1), r = i / FRWD, cdw = i - r * FRWD;
             const int x = rx0 + 2 * cdw, y = ry0 + r;
             ok[k] = x >= -6 && x + 1 <= W + 5 && y >= -6 && y <= H + 5;
-                        v[k] = *reinterpret_cast<const uint32_t *>(raw + (ok[k] ? (long)y * in_sy + x : 0l));
+            v[k] = *reinterpret_cast<const uint32_t *>(raw + (ok[k] ? (long)y * in_sy + x : 0l));
         }
 #pragma unroll
         for (int k = 0; k < N1; k++) {
@@ -326,8 +326,9 @@ __global__ __launch_bounds__(256) void cp_fused_tile(const uint16_t *__restrict_
     }
     }
     __syncthreads();
-    // sharpen (:398-404) from the staged planes: staged row r = curved row 24 by - 1 + r, staged column k (at byte k + 3) = curved
-    // column 64 bx - 1 + k; output pixel (64 bx + j, 24 by + i) reads rows i + 1 .. i + 3, columns j + 1 .. j + 3.  A thread owns
+    // sharpen (:398-404) from the staged planes: staged row r = curved row 40 by - 2 + r (2 FTY = 40 output rows per tile, quads
+    // start one quad above), the pixel of curved column 64 bx - 2 + k sits at byte k + 3 of its row; output pixel (64 bx + j, 40 by + i)
+    // reads staged rows i + 1 .. i + 3 and the bytes j + 4 .. j + 6 (its own value at byte j + 5).  A thread owns
     // four adjacent pixels of one row, as cp_sharpen4 does: two aligned dwords per row, v_lerp_u8 rounding averages, packed i16.
     const short st = (short)s->strength_x32;
     const i16x2 strength = {st, st}, zero = {0, 0}, top = {255, 255};
