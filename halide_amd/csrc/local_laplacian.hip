@@ -18,7 +18,7 @@
 //   4-column groups the down-sampling waves load and the 2-column groups they store are naturally aligned.
 //
 // Kernels (DESIGN.md §4 has the measurements).  The common geometry — levels == 8, 8-byte-aligned u16 planes whose width is a
-// multiple of 4, three channels, even output origin and width — runs 6 launches per frame (7 on a stream that owns the device):
+// multiple of 4, three channels, even output origin and width — runs 5 launches per frame (6 on a stream that owns the device):
 //   ll_remap_lut    remap LUT (generator :23-25); cached per (device, levels, alpha)
 //   ll_down01e      levels 0 -> 1 -> 2 of all K+1 planes in ONE walk; emits outLPyramid[0] (one plane) and three planes of level 1
 //                   instead of the K+1-plane level-1 pyramid (round 4's dataflow; ll_down01f = round 3's, which stores them all)
