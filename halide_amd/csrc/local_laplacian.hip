@@ -1387,13 +1387,27 @@ __global__ __launch_bounds__(256) void ll_down_strip2(Strip2Args p) {
 
 // ---------------------------------------------------------------------------------------------------
 // upsample(f)(X,Y) (:276-282) of a stored level plane `f` (origin lox/loy, row stride ws)
-__device__ __forceinline__ float up_at(const float *__restrict__ f, int lox, int loy, int ws, int X, int Y) {
-    int xa = dev::fdiv2(X + 1) - lox, xb = dev::fdiv2(X - 1) - lox;
-    int ya = dev::fdiv2(Y + 1) - loy, yb = dev::fdiv2(Y - 1) - loy;
-    float wx = (float)(dev::fmod2(X) * 2 + 1) * 0.25f, wy = (float)(dev::fmod2(Y) * 2 + 1) * 0.25f;
-    float ua = dev::lerpf(f[(size_t)ya * ws + xa], f[(size_t)ya * ws + xb], wx);
-    float ub = dev::lerpf(f[(size_t)yb * ws + xa], f[(size_t)yb * ws + xb], wx);
+// The four taps of the bilinear footprint and the lerps on them are separate steps so that a caller can REQUEST the taps of many
+// values before it combines the first (ll_up_multi); up_at = both steps, the same operations in the same order.
+struct UpTaps {
+    float aa, ab, ba, bb;    // f(ya, xa), f(ya, xb), f(yb, xa), f(yb, xb)
+};
+__device__ __forceinline__ UpTaps up_taps(const float *__restrict__ f, int lox, int loy, int ws, int X, int Y) {
+    const int xa = dev::fdiv2(X + 1) - lox, xb = dev::fdiv2(X - 1) - lox;
+    const int ya = dev::fdiv2(Y + 1) - loy, yb = dev::fdiv2(Y - 1) - loy;
+    UpTaps t;
+    t.aa = f[(size_t)ya * ws + xa], t.ab = f[(size_t)ya * ws + xb];
+    t.ba = f[(size_t)yb * ws + xa], t.bb = f[(size_t)yb * ws + xb];
+    return t;
+}
+__device__ __forceinline__ float up_from(const UpTaps &t, int X, int Y) {
+    const float wx = (float)(dev::fmod2(X) * 2 + 1) * 0.25f, wy = (float)(dev::fmod2(Y) * 2 + 1) * 0.25f;
+    const float ua = dev::lerpf(t.aa, t.ab, wx);
+    const float ub = dev::lerpf(t.ba, t.bb, wx);
     return dev::lerpf(ua, ub, wy);
+}
+__device__ __forceinline__ float up_at(const float *__restrict__ f, int lox, int loy, int ws, int X, int Y) {
+    return up_from(up_taps(f, lox, loy, ws, X, Y), X, Y);
 }
 
 // outGPyramid[J-1] = outLPyramid[J-1] (:76, :63-72 with lPyramid[J-1] = gPyramid[J-1], :51); o = element offset
@@ -1581,26 +1595,54 @@ __device__ __forceinline__ void up_multi_tile(const CoarseArgs &a, int ntx, int 
             reg[d].y0 = dev::fdiv2(reg[d - 1].y0 - 1), reg[d].y1 = dev::fdiv2(reg[d - 1].y1 + 1);
         }
     }
-    // 1. outLPyramid of every level (memory-bound part, all of it independent), finest level first so that its
-    //    loads (the bulk of the traffic) are in flight while the coarse ones are computed
+    // 1. outLPyramid of every level (memory-bound part, all of it independent of the recursion).  A level's region has at most
+    //    UM_T x UM_T = 256 elements, one per thread; a value needs its level's inGPyramid first (which planes?) and then ten
+    //    gathers — two dependent round trips.  Round 5: THREE passes over all levels — request every inGPyramid value, then every
+    //    gather, then combine — so that the tile pays the two round trips once, not once per level (the per-level loops this
+    //    replaces ran them level after level: ten dependent trips).  outl_value's / top_value's operations in their order.
+    int eX[TOP + 1], eY[TOP + 1];
+    bool act[TOP + 1];
+    size_t eo[TOP + 1];
+    float lvl[TOP + 1];
 #pragma unroll
     for (int d = 0; d <= TOP; d++) {
         const DevLevel &L = a.lv[d];
         const Range2 r = reg[d];
-        float *const tile = tl + um_off(d);
-        const int tw = um_win(d);
         const int nx = r.x1 - r.x0 + 1, n = nx * (r.y1 - r.y0 + 1);
-        for (int e = threadIdx.x; e < n; e += 256) {
-            const int yy = e / nx, X = r.x0 + (e - yy * nx), Y = r.y0 + yy;
-            float v;
-            if (d == TOP) {
-                v = top_value(L.g, L.ps, (size_t)(Y - L.loy) * L.ws + (X - L.lox), a.K, a.Km1);
-            } else {
-                const DevLevel &C = a.lv[d + 1];
-                v = outl_value(L.g, L.ws, L.ps, L.lox, L.loy, C.g, C.ws, C.ps, C.lox, C.loy, X, Y, a.K, a.Km1);
-            }
-            tile[yy * tw + (X - r.x0)] = v;
+        act[d] = (int)threadIdx.x < n;
+        const int e = act[d] ? (int)threadIdx.x : 0, yy = e / nx;   // idle threads re-read element 0 and store nothing
+        eX[d] = r.x0 + (e - yy * nx), eY[d] = r.y0 + yy;
+        eo[d] = (size_t)(eY[d] - L.loy) * L.ws + (eX[d] - L.lox);
+        lvl[d] = L.g[(size_t)a.K * L.ps + eo[d]];
+    }
+    __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler starts a level's gathers as soon as its first load is back)
+    float lf[TOP + 1], g0[TOP + 1], g1[TOP + 1];
+    UpTaps t0[TOP + 1], t1[TOP + 1];
+#pragma unroll
+    for (int d = 0; d <= TOP; d++) {
+        const DevLevel &L = a.lv[d];
+        const float level = lvl[d] * a.Km1;
+        const int li = dev::clampi((int)level, 0, a.K - 2);
+        lf[d] = level - (float)li;
+        g0[d] = L.g[(size_t)li * L.ps + eo[d]], g1[d] = L.g[(size_t)(li + 1) * L.ps + eo[d]];
+        if (d < TOP) {
+            const DevLevel &C = a.lv[d + 1];
+            t0[d] = up_taps(C.g + (size_t)li * C.ps, C.lox, C.loy, C.ws, eX[d], eY[d]);
+            t1[d] = up_taps(C.g + (size_t)(li + 1) * C.ps, C.lox, C.loy, C.ws, eX[d], eY[d]);
         }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d <= TOP; d++) {
+        float v;
+        if (d == TOP) {
+            v = (1.0f - lf[d]) * g0[d] + lf[d] * g1[d];
+        } else {
+            const float l0 = g0[d] - up_from(t0[d], eX[d], eY[d]);
+            const float l1 = g1[d] - up_from(t1[d], eX[d], eY[d]);
+            v = (1.0f - lf[d]) * l0 + lf[d] * l1;
+        }
+        if (act[d]) (tl + um_off(d))[(eY[d] - reg[d].y0) * um_win(d) + (eX[d] - reg[d].x0)] = v;
     }
     __syncthreads();
     // 2. collapse: level S+d from level S+d+1 (both in LDS), operation order of up_at
