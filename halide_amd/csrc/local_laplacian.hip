@@ -2029,7 +2029,8 @@ struct Up0HArgs {
 };
 constexpr int U0H_PF = 4;      // rows in flight per wave
 constexpr int U0H_T2 = 68;     // row stride of the level-2 tile
-template<bool NT>
+template<bool NT, int CH = 2>  // CH: tile values a thread requests at a time in the two tile phases (1: 102.0, 2: 101.1, 4: 102.4 us per
+                               // frame on one stream — 4 costs occupancy: 124 VGPRs against 66)
 __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
     const Up0Args &p = ph.u;
     extern __shared__ float s_out1[];
@@ -2051,35 +2052,97 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
     float *const s_out2 = s_out1 + U0_TS * (p.RU + 2);
     const int cx1 = min(cx0 + U0_TW - 1, p.rx1_1);                               // last level-1 column of the tile
     const int c2x0 = dev::fdiv2(cx0 - 1), c2y0 = dev::fdiv2(cy0 - 1);             // level-2 window the level-1 tile's upsampling reads
+    // The two tile phases below are each a handful of values per thread, and a value takes two DEPENDENT memory round trips
+    // (inGPyramid -> which planes -> their bilinear taps).  As per-element loops they ran those trips element after element — and
+    // every workgroup of the launch (one round of resident workgroups) sat in that prologue at the same time, the memory system idle.
+    // Round 5: CH elements per thread at a time, all first loads, then all gathers, then the arithmetic (outl_value's and up_at's
+    // operations in their order): two trips per chunk.  Worth ~1 % of the frame: the resident workgroups of a CU already interleave
+    // their prologues.
     if (ph.fuse2) {
-        const int n2x = dev::fdiv2(cx1 + 1) - c2x0 + 1, n2y = dev::fdiv2(cy0 + th) - c2y0 + 1;
-        for (int e = threadIdx.x; e < n2x * n2y; e += 256) {
-            const int ty = e / n2x, tx = e - ty * n2x;
-            const int X2 = c2x0 + tx, Y2 = c2y0 + ty;
-            // outGPyramid[2] = upsample(outGPyramid[3]) + outLPyramid[2]   (:76-79), exactly as ll_up computes it
-            const float outL = outl_value<false>(p.g2, p.ws2, p.ps2, p.lox2, p.loy2, ph.g3, ph.ws3, ph.ps3, ph.lox3, ph.loy3, X2, Y2, gm.K, gm.Km1);
-            s_out2[ty * U0H_T2 + tx] = up_at(ph.out3, ph.lox3, ph.loy3, ph.ws3, X2, Y2) + outL;
+        const int n2x = dev::fdiv2(cx1 + 1) - c2x0 + 1, n2y = dev::fdiv2(cy0 + th) - c2y0 + 1, n2 = n2x * n2y;
+        for (int e0 = threadIdx.x; e0 < n2; e0 += 256 * CH) {
+            int X2[CH], Y2[CH], ti[CH];
+            bool ok[CH];
+            size_t o[CH];
+            float inG[CH], lf[CH], ga[CH], gb[CH];
+            UpTaps o3[CH], t0[CH], t1[CH];
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                const int e = e0 + 256 * i, ec = min(e, n2 - 1), ty = ec / n2x, tx = ec - ty * n2x;
+                ok[i] = e < n2, ti[i] = ty * U0H_T2 + tx;
+                X2[i] = c2x0 + tx, Y2[i] = c2y0 + ty;
+                o[i] = (size_t)(Y2[i] - p.loy2) * p.ws2 + (X2[i] - p.lox2);
+                inG[i] = p.g2[(size_t)gm.K * p.ps2 + o[i]];
+                o3[i] = up_taps(ph.out3, ph.lox3, ph.loy3, ph.ws3, X2[i], Y2[i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                const float level = inG[i] * gm.Km1;
+                const int li = dev::clampi((int)level, 0, gm.K - 2);
+                lf[i] = level - (float)li;
+                ga[i] = p.g2[(size_t)li * p.ps2 + o[i]], gb[i] = p.g2[(size_t)(li + 1) * p.ps2 + o[i]];
+                t0[i] = up_taps(ph.g3 + (size_t)li * ph.ps3, ph.lox3, ph.loy3, ph.ws3, X2[i], Y2[i]);
+                t1[i] = up_taps(ph.g3 + (size_t)(li + 1) * ph.ps3, ph.lox3, ph.loy3, ph.ws3, X2[i], Y2[i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                // outGPyramid[2] = upsample(outGPyramid[3]) + outLPyramid[2]   (:76-79), exactly as ll_up computes it
+                const float l0 = ga[i] - up_from(t0[i], X2[i], Y2[i]), l1 = gb[i] - up_from(t1[i], X2[i], Y2[i]);
+                const float outL = (1.0f - lf[i]) * l0 + lf[i] * l1;
+                if (ok[i]) s_out2[ti[i]] = up_from(o3[i], X2[i], Y2[i]) + outL;
+            }
         }
         __syncthreads();
     }
-    for (int e = threadIdx.x; e < U0_TW * th; e += 256) {
-        const int ty = e / U0_TW, tx = e - ty * U0_TW;
-        const int cx = cx0 + tx, cy = cy0 + ty;
-        if (cx > p.rx1_1) continue;
-        // outGPyramid[1] = upsample(outGPyramid[2]) + outLPyramid[1]   (:76-79), exactly as ll_up computes it
-        const float outL = outl_value<true>(p.g1, p.ws1, p.ps1, p.lox1, p.loy1, p.g2, p.ws2, p.ps2, p.lox2, p.loy2, cx, cy, gm.K, gm.Km1);
-        float up2;
-        if (ph.fuse2) {   // up_at on the LDS tile: the same taps, weights and lerps
-            const int xa = dev::fdiv2(cx + 1) - c2x0, xb = dev::fdiv2(cx - 1) - c2x0;
-            const int ya = dev::fdiv2(cy + 1) - c2y0, yb = dev::fdiv2(cy - 1) - c2y0;
-            const float wx = (float)(dev::fmod2(cx) * 2 + 1) * 0.25f, wy = (float)(dev::fmod2(cy) * 2 + 1) * 0.25f;
-            const float ua = dev::lerpf(s_out2[ya * U0H_T2 + xa], s_out2[ya * U0H_T2 + xb], wx);
-            const float ub = dev::lerpf(s_out2[yb * U0H_T2 + xa], s_out2[yb * U0H_T2 + xb], wx);
-            up2 = dev::lerpf(ua, ub, wy);
-        } else {
-            up2 = up_at(p.out2, p.lox2, p.loy2, p.ws2, cx, cy);
+    {
+        const int n1 = U0_TW * th;
+        for (int e0 = threadIdx.x; e0 < n1; e0 += 256 * CH) {
+            int cx[CH], cy[CH], ti[CH];
+            bool ok[CH];
+            size_t o[CH];
+            float inG[CH], lf[CH], ga[CH], gb[CH];
+            UpTaps o2[CH], t0[CH], t1[CH];
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                const int e = e0 + 256 * i, ec = min(e, n1 - 1), ty = ec / U0_TW, tx = ec - ty * U0_TW;
+                ok[i] = e < n1 && cx0 + tx <= p.rx1_1, ti[i] = ty * U0_TS + tx;
+                cx[i] = min(cx0 + tx, p.rx1_1), cy[i] = cy0 + ty;      // columns right of R_1 are not tile values: their threads re-read its last one
+                o[i] = (size_t)(cy[i] - p.loy1) * p.ws1 + (cx[i] - p.lox1);
+                // level 1 as ll_down01e stored it: plane 0 / 1 = gPyramid[1](., ., li / li + 1) of the pixel's own li, plane K = inGPyramid[1]
+                inG[i] = p.g1[(size_t)gm.K * p.ps1 + o[i]], ga[i] = p.g1[o[i]], gb[i] = p.g1[p.ps1 + o[i]];
+                if (!ph.fuse2) o2[i] = up_taps(p.out2, p.lox2, p.loy2, p.ws2, cx[i], cy[i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                const float level = inG[i] * gm.Km1;
+                const int li = dev::clampi((int)level, 0, gm.K - 2);
+                lf[i] = level - (float)li;
+                t0[i] = up_taps(p.g2 + (size_t)li * p.ps2, p.lox2, p.loy2, p.ws2, cx[i], cy[i]);
+                t1[i] = up_taps(p.g2 + (size_t)(li + 1) * p.ps2, p.lox2, p.loy2, p.ws2, cx[i], cy[i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                // outGPyramid[1] = upsample(outGPyramid[2]) + outLPyramid[1]   (:76-79), exactly as ll_up computes it
+                const float l0 = ga[i] - up_from(t0[i], cx[i], cy[i]), l1 = gb[i] - up_from(t1[i], cx[i], cy[i]);
+                const float outL = (1.0f - lf[i]) * l0 + lf[i] * l1;
+                float up2;
+                if (ph.fuse2) {   // up_at on the LDS tile: the same taps, weights and lerps
+                    const int xa = dev::fdiv2(cx[i] + 1) - c2x0, xb = dev::fdiv2(cx[i] - 1) - c2x0;
+                    const int ya = dev::fdiv2(cy[i] + 1) - c2y0, yb = dev::fdiv2(cy[i] - 1) - c2y0;
+                    UpTaps t;
+                    t.aa = s_out2[ya * U0H_T2 + xa], t.ab = s_out2[ya * U0H_T2 + xb];
+                    t.ba = s_out2[yb * U0H_T2 + xa], t.bb = s_out2[yb * U0H_T2 + xb];
+                    up2 = up_from(t, cx[i], cy[i]);
+                } else {
+                    up2 = up_from(o2[i], cx[i], cy[i]);
+                }
+                if (ok[i]) s_out1[ti[i]] = up2 + outL;
+            }
         }
-        s_out1[ty * U0_TS + tx] = up2 + outL;
     }
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
