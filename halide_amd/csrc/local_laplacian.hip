@@ -18,14 +18,14 @@
 //   4-column groups the down-sampling waves load and the 2-column groups they store are naturally aligned.
 //
 // Kernels (DESIGN.md §4 has the measurements).  The common geometry — levels == 8, 8-byte-aligned u16 planes whose width is a
-// multiple of 4, three channels, even output origin and width — runs 5 launches per frame (6 on a stream that owns the device):
+// multiple of 4, three channels, even output origin and width — runs 5 launches per frame:
 //   ll_remap_lut    remap LUT (generator :23-25); cached per (device, levels, alpha)
 //   ll_down01e      levels 0 -> 1 -> 2 of all K+1 planes in ONE walk; emits outLPyramid[0] (one plane) and three planes of level 1
 //                   instead of the K+1-plane level-1 pyramid (round 4's dataflow; ll_down01f = round 3's, which stores them all)
 //   ll_down_strip2  levels 3 and 4 from level 2 in one launch (round 5; ll_down_strip = one level per launch, other chains)
 //   ll_down_multi   levels 5..7 from level 4 in one launch;  ll_up_multi: outGPyramid[3] from levels 3..7 in one launch
-//   ll_up           outGPyramid[2] (only on a stream that owns the device: on CU partitions ll_up0h collapses level 2 itself)
-//   ll_up0h         outGPyramid[1] (LDS tile) -> outGPyramid[0] = upsample + outLPyramid[0] -> recolour -> u16 store
+//   ll_up0h         outGPyramid[2] and outGPyramid[1] (LDS tiles) -> outGPyramid[0] = upsample + outLPyramid[0] -> recolour -> u16 store
+//                   (HLMI_LL_FUSE_UP2=0: outGPyramid[2] by an ll_up launch of its own)
 // Everything else (other `levels`, odd widths or strides, fewer channels, odd output origins) takes the general kernels:
 //   ll_down0        level 0 -> 1, any K (chunks of 8 planes), vector or element-wise loads;  ll_down_strip:1
 //   ll_top, ll_up   outGPyramid[J-1], outGPyramid[j]: pointwise, data-dependent plane gathers
@@ -2480,10 +2480,11 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     if (emit) p.RU = max(1, env_int("HLMI_LL_RU", partitioned ? 16 : 8));
     // non-temporal frame / outLPyramid[0] accesses: +6-7 % frames per second on CU partitions, -2-3 % on a stream that owns the device
     const bool nt = env_int("HLMI_LL_NT", partitioned ? 1 : 0) != 0;
-    // ll_up0h also collapses level 2 (into an LDS tile) when level 3 is a stored level of its own
+    // ll_up0h also collapses level 2 (into an LDS tile) when level 3 is a stored level of its own: the ll_up:2 launch goes
     // (on CU partitions, where every dependent launch of the chain idles the partition: 79.4 -> 76.4 us per frame; on a stream that
-    // owns the device the tile redundancy costs what the launch saved: 109 -> 111 us)
-    const bool fuse2 = emit && SU >= 3 && SU < J && env_int("HLMI_LL_FUSE_UP2", partitioned ? 1 : 0);
+    // owns the device the tile redundancy used to cost what the launch saved — 109 -> 111 us in round 4 — until round 5's batched
+    // tile phases: 104.1 -> 98.7 us per frame, 115 -> 110.6 for one call + sync)
+    const bool fuse2 = emit && SU >= 3 && SU < J && env_int("HLMI_LL_FUSE_UP2", 1);
 
     // ---- workspace: the levels and outLPyramid[0] of the re-cut dataflow (input width x output rows)
     const size_t off_l0 = ws_floats;
