@@ -2072,13 +2072,33 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
     // every workgroup of the launch (one round of resident workgroups) sat in that prologue at the same time, the memory system idle.
     // Round 5: CH elements per thread at a time, all first loads, then all gathers, then the arithmetic (outl_value's and up_at's
     // operations in their order): two trips per chunk.  Worth ~1 % of the frame: the resident workgroups of a CU already interleave
-    // their prologues.
+    // their prologues.  Every load is `uniform base + 32-bit byte offset` (the workspace offsets of this path are < 4 GB): as
+    // 64-bit element indices the address arithmetic was 60 % of the 148 VALU instructions a tile value cost, and the tile values
+    // 45 % of the launch's instructions.
+    struct Taps32 {
+        uint32_t aa, ab, ba, bb;   // byte offsets of f(ya, xa), f(ya, xb), f(yb, xa), f(yb, xb) inside a plane
+    };
+    auto tap_bytes = [](int lox, int loy, int ws, int X, int Y) {
+        const int xa = dev::fdiv2(X + 1) - lox, xb = dev::fdiv2(X - 1) - lox;
+        const uint32_t ra = (uint32_t)((dev::fdiv2(Y + 1) - loy) * ws), rb = (uint32_t)((dev::fdiv2(Y - 1) - loy) * ws);
+        Taps32 t;
+        t.aa = (ra + (uint32_t)xa) << 2, t.ab = (ra + (uint32_t)xb) << 2, t.ba = (rb + (uint32_t)xa) << 2, t.bb = (rb + (uint32_t)xb) << 2;
+        return t;
+    };
+    auto taps_at = [](const float *base, uint32_t plane_bytes, const Taps32 &t) {
+        UpTaps r;
+        r.aa = ld_su<float>(base, plane_bytes + t.aa), r.ab = ld_su<float>(base, plane_bytes + t.ab);
+        r.ba = ld_su<float>(base, plane_bytes + t.ba), r.bb = ld_su<float>(base, plane_bytes + t.bb);
+        return r;
+    };
+    const uint32_t ps1b = (uint32_t)p.ps1 * 4u, ps2b = (uint32_t)p.ps2 * 4u, ps3b = (uint32_t)ph.ps3 * 4u;
     if (ph.fuse2) {
         const int n2x = dev::fdiv2(cx1 + 1) - c2x0 + 1, n2y = dev::fdiv2(cy0 + th) - c2y0 + 1, n2 = n2x * n2y;
         for (int e0 = threadIdx.x; e0 < n2; e0 += 256 * CH) {
             int X2[CH], Y2[CH], ti[CH];
             bool ok[CH];
-            size_t o[CH];
+            uint32_t ob[CH];
+            Taps32 t3[CH];
             float inG[CH], lf[CH], ga[CH], gb[CH];
             UpTaps o3[CH], t0[CH], t1[CH];
 #pragma unroll
@@ -2086,9 +2106,10 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
                 const int e = e0 + 256 * i, ec = min(e, n2 - 1), ty = ec / n2x, tx = ec - ty * n2x;
                 ok[i] = e < n2, ti[i] = ty * U0H_T2 + tx;
                 X2[i] = c2x0 + tx, Y2[i] = c2y0 + ty;
-                o[i] = (size_t)(Y2[i] - p.loy2) * p.ws2 + (X2[i] - p.lox2);
-                inG[i] = p.g2[(size_t)gm.K * p.ps2 + o[i]];
-                o3[i] = up_taps(ph.out3, ph.lox3, ph.loy3, ph.ws3, X2[i], Y2[i]);
+                ob[i] = (uint32_t)((Y2[i] - p.loy2) * p.ws2 + (X2[i] - p.lox2)) << 2;
+                inG[i] = ld_su<float>(p.g2, (uint32_t)gm.K * ps2b + ob[i]);
+                t3[i] = tap_bytes(ph.lox3, ph.loy3, ph.ws3, X2[i], Y2[i]);
+                o3[i] = taps_at(ph.out3, 0u, t3[i]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -2096,9 +2117,9 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
                 const float level = inG[i] * gm.Km1;
                 const int li = dev::clampi((int)level, 0, gm.K - 2);
                 lf[i] = level - (float)li;
-                ga[i] = p.g2[(size_t)li * p.ps2 + o[i]], gb[i] = p.g2[(size_t)(li + 1) * p.ps2 + o[i]];
-                t0[i] = up_taps(ph.g3 + (size_t)li * ph.ps3, ph.lox3, ph.loy3, ph.ws3, X2[i], Y2[i]);
-                t1[i] = up_taps(ph.g3 + (size_t)(li + 1) * ph.ps3, ph.lox3, ph.loy3, ph.ws3, X2[i], Y2[i]);
+                ga[i] = ld_su<float>(p.g2, (uint32_t)li * ps2b + ob[i]), gb[i] = ld_su<float>(p.g2, (uint32_t)(li + 1) * ps2b + ob[i]);
+                t0[i] = taps_at(ph.g3, (uint32_t)li * ps3b, t3[i]);
+                t1[i] = taps_at(ph.g3, (uint32_t)(li + 1) * ps3b, t3[i]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -2116,7 +2137,7 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
         for (int e0 = threadIdx.x; e0 < n1; e0 += 256 * CH) {
             int cx[CH], cy[CH], ti[CH];
             bool ok[CH];
-            size_t o[CH];
+            Taps32 t2[CH];
             float inG[CH], lf[CH], ga[CH], gb[CH];
             UpTaps o2[CH], t0[CH], t1[CH];
 #pragma unroll
@@ -2124,10 +2145,11 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
                 const int e = e0 + 256 * i, ec = min(e, n1 - 1), ty = ec / U0_TW, tx = ec - ty * U0_TW;
                 ok[i] = e < n1 && cx0 + tx <= p.rx1_1, ti[i] = ty * U0_TS + tx;
                 cx[i] = min(cx0 + tx, p.rx1_1), cy[i] = cy0 + ty;      // columns right of R_1 are not tile values: their threads re-read its last one
-                o[i] = (size_t)(cy[i] - p.loy1) * p.ws1 + (cx[i] - p.lox1);
+                const uint32_t ob = (uint32_t)((cy[i] - p.loy1) * p.ws1 + (cx[i] - p.lox1)) << 2;
                 // level 1 as ll_down01e stored it: plane 0 / 1 = gPyramid[1](., ., li / li + 1) of the pixel's own li, plane K = inGPyramid[1]
-                inG[i] = p.g1[(size_t)gm.K * p.ps1 + o[i]], ga[i] = p.g1[o[i]], gb[i] = p.g1[p.ps1 + o[i]];
-                if (!ph.fuse2) o2[i] = up_taps(p.out2, p.lox2, p.loy2, p.ws2, cx[i], cy[i]);
+                inG[i] = ld_su<float>(p.g1, (uint32_t)gm.K * ps1b + ob), ga[i] = ld_su<float>(p.g1, ob), gb[i] = ld_su<float>(p.g1, ps1b + ob);
+                t2[i] = tap_bytes(p.lox2, p.loy2, p.ws2, cx[i], cy[i]);
+                if (!ph.fuse2) o2[i] = taps_at(p.out2, 0u, t2[i]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -2135,8 +2157,8 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
                 const float level = inG[i] * gm.Km1;
                 const int li = dev::clampi((int)level, 0, gm.K - 2);
                 lf[i] = level - (float)li;
-                t0[i] = up_taps(p.g2 + (size_t)li * p.ps2, p.lox2, p.loy2, p.ws2, cx[i], cy[i]);
-                t1[i] = up_taps(p.g2 + (size_t)(li + 1) * p.ps2, p.lox2, p.loy2, p.ws2, cx[i], cy[i]);
+                t0[i] = taps_at(p.g2, (uint32_t)li * ps2b, t2[i]);
+                t1[i] = taps_at(p.g2, (uint32_t)(li + 1) * ps2b, t2[i]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
