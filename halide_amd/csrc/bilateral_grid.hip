@@ -220,7 +220,27 @@ __global__ __launch_bounds__(256) void bg_slice(const float *__restrict__ in, lo
 //   * staging copies contiguous runs of the z-innermost blurz grid (a tile row = 14 cells x ZD planes) to contiguous LDS.
 // (scripts/model/lds_banks.py models the three stages: 1684 -> 946 LDS cycles per workgroup on a noise image.)
 constexpr int FPX = 64, FCX = 10, FZ = 16;
-template<int FPY, int ZP>   // tile height (32; 16 and 64 measured the same or slower); z pitch of the LDS tiles (>= g.ZD)
+// e / D for 0 <= e <= MAXE as one full-rate 24-bit multiply and a shift (v_mul_hi_u32, what `/` by a constant compiles to, issues
+// at a quarter of the rate): exact while e (M D - 2^16) < 2^16 with M = ceil(2^16 / D)
+template<int D, int MAXE>
+__device__ __forceinline__ uint32_t divc(uint32_t e) {
+    if ((D & (D - 1)) == 0) return e / (uint32_t)D;
+    constexpr uint32_t M = (65536u + D - 1) / D;
+    static_assert((unsigned long long)(M * D - 65536u) * MAXE < 65536ull && (unsigned long long)M * MAXE < (1ull << 32), "divc: range");
+    return __umul24(e, M) >> 16;
+}
+// a x b of two values below 2^24 as v_mul_u32_u24, kept apart from a following add (the compiler folds `mul24 + c` into
+// v_mad_u64_u32: a quarter-rate instruction again)
+__device__ __forceinline__ uint32_t mul24o(uint32_t a, uint32_t b) {
+    uint32_t r = __umul24(a, b);
+    asm("" : "+v"(r));
+    return r;
+}
+// A32: every byte offset into the input, the output and the blurz grid fits 31 bits and every row number / row stride 23 (the
+// host checks): addresses are `uniform base + 32-bit byte offset` built from full-rate 24-bit multiplies.  As 64-bit element
+// indices the address arithmetic of this kernel was 92 quarter-rate instructions (v_mul_lo_u32, v_mul_hi_u32, v_mad_u64_u32) of
+// 958: 30 % of its issue time.
+template<int FPY, int ZP, bool A32>   // tile height (32; 16 and 64 measured the same or slower); z pitch of the LDS tiles (>= g.ZD)
 __global__ __launch_bounds__(256) void bg_blur_slice(const float *__restrict__ in, long in_sy, BGeom g, const float2 *__restrict__ bz,
                                                     float *__restrict__ out, long out_sy, int ox0, int oy0, int ow, int oh) {
     constexpr int FCY = FPY / S + 2;
@@ -242,7 +262,12 @@ __global__ __launch_bounds__(256) void bg_blur_slice(const float *__restrict__ i
 #pragma unroll
         for (int k = 0; k < FPY / 4; k++) {
             const int ayc = oy0 + min(y0 + prow + 4 * k, oh - 1);
-            pix[k] = in[(long)(ayc - g.iy0) * in_sy + (axc - g.ix0)];
+            if (A32) {
+                const uint32_t ob = (mul24o((uint32_t)(ayc - g.iy0), (uint32_t)in_sy) + (uint32_t)(axc - g.ix0)) << 2;
+                pix[k] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(in) + ob);
+            } else {
+                pix[k] = in[(long)(ayc - g.iy0) * in_sy + (axc - g.ix0)];
+            }
         }
     }
     {
@@ -253,9 +278,14 @@ __global__ __launch_bounds__(256) void bg_blur_slice(const float *__restrict__ i
 #pragma unroll
         for (int k = 0; k < N1; k++) {
             const int e = min(t + 256 * k, NBZ - 1);
-            const int z = e % ZP, c = e / ZP, j = c / (FCX + 4), i = c - j * (FCX + 4);
+            const int c = (int)divc<ZP, NBZ>((uint32_t)e), z = e - c * ZP, j = (int)divc<FCX + 4, NBZ / ZP>((uint32_t)c), i = c - j * (FCX + 4);
             const int hx = min(cxa + i, g.HX - 1), hy = min(cya + j, g.HY - 1);     // cells past the grid are never interpolated
-            v[k] = bz[((size_t)hy * g.HX + hx) * g.ZD + min(z, g.ZD - 1)];          // planes past the grid likewise
+            if (A32) {                                                              // planes past the grid likewise
+                const uint32_t ob = (mul24o(mul24o((uint32_t)hy, (uint32_t)g.HX) + (uint32_t)hx, (uint32_t)g.ZD) + (uint32_t)min(z, g.ZD - 1)) << 3;
+                v[k] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(bz) + ob);
+            } else {
+                v[k] = bz[((size_t)hy * g.HX + hx) * g.ZD + min(z, g.ZD - 1)];
+            }
         }
 #pragma unroll
         for (int k = 0; k < N1; k++) {
@@ -265,7 +295,7 @@ __global__ __launch_bounds__(256) void bg_blur_slice(const float *__restrict__ i
     }
     __syncthreads();
     for (int e = t; e < NBX; e += 256) {
-        const int z = e % ZP, c = e / ZP, j = c / FCX, i = c - j * FCX;
+        const int c = (int)divc<ZP, NBX + 256>((uint32_t)e), z = e - c * ZP, j = (int)divc<FCX, (NBX + 256) / ZP + 1>((uint32_t)c), i = c - j * FCX;
         const float2 *sp = s_bz + ((j * (FCX + 4) + i) * ZP + z);
         const float2 a = sp[0], b = sp[ZP], c2 = sp[2 * ZP], d = sp[3 * ZP], q = sp[4 * ZP];
         s_bx[e] = make_float2(blur5(a.x, b.x, c2.x, d.x, q.x), blur5(a.y, b.y, c2.y, d.y, q.y));
@@ -293,11 +323,17 @@ __global__ __launch_bounds__(256) void bg_blur_slice(const float *__restrict__ i
         const float zf = zv - (float)zi;
         const float yf = (float)dev::fmod8(ay) * 0.125f;
         const int yi = dev::fdiv8(ay) - g.gy0 - cya;
-        const float2 *p0 = s_by + ((yi * FCX + xi) * ZP + zi), *p1 = p0 + FCX * ZP;   // rows yi, yi + 1; cell xi + 1 is ZP further, plane zi + 1 one
+        // rows yi, yi + 1; cell xi + 1 is ZP further, plane zi + 1 one (all indices are small: 24-bit multiplies)
+        const float2 *p0 = s_by + (mul24o(mul24o((uint32_t)yi, FCX) + (uint32_t)xi, ZP) + (uint32_t)zi), *p1 = p0 + FCX * ZP;
         const float2 a = lerp2(lerp2(p0[0], p0[ZP], xf), lerp2(p1[0], p1[ZP], xf), yf);
         const float2 b = lerp2(lerp2(p0[1], p0[ZP + 1], xf), lerp2(p1[1], p1[ZP + 1], xf), yf);
         const float2 r = lerp2(a, b, zf);
-        out[(long)y * out_sy + x] = r.x / r.y;
+        if (A32) {
+            const uint32_t ob = (mul24o((uint32_t)y, (uint32_t)out_sy) + (uint32_t)x) << 2;
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(out) + ob) = r.x / r.y;
+        } else {
+            out[(long)y * out_sy + x] = r.x / r.y;
+        }
     }
 }
 
@@ -383,13 +419,22 @@ extern "C" int bilateral_grid(halide_buffer_t *input, float r_sigma, halide_buff
         HLMI_LAUNCH(uc, "bg_histogram_blurz", st, bg_histogram_blurz, dim3((g.HX + T - 1) / T, g.HY), dim3(T), sh, din, in_sy, g, bz);
     }
     if (g.ZD <= FZ) {   // (grids of more planes — r_sigma < 1/14.5 — take the serial histogram and the three separate launches)
+        // 32-bit addressing (see bg_blur_slice): strides and row counts below 2^23, every buffer's byte span below 2^31
+        const long lim = 1L << 23, span = 1L << 29;
+        const bool a32 = in_sy >= 0 && out_sy >= 0 && in_sy < lim && out_sy < lim && input->dim[1].extent < lim && oh < lim &&
+                         in_sy * (long)input->dim[1].extent < span && out_sy * (long)oh < span && (long)g.HX * g.HY < (1L << 24) &&
+                         (long)g.HX * g.HY * g.ZD < (span >> 1) && !getenv("HLMI_BG_NO_A32");
+#define HLMI_BG_FUSED(ZP_, A32_)                                                                                                     \
+    HLMI_LAUNCH(uc, "bg_blur_slice", st, (bg_blur_slice<32, ZP_, A32_>), dim3((ow + FPX - 1) / FPX, (oh + 31) / 32), dim3(256), 0, din, \
+                in_sy, g, bz, dev_ptr<float>(output), out_sy, ox0, oy0, ow, oh)
         if (g.ZD <= 12) {
-            HLMI_LAUNCH(uc, "bg_blur_slice", st, (bg_blur_slice<32, 12>), dim3((ow + FPX - 1) / FPX, (oh + 31) / 32), dim3(256), 0, din, in_sy, g,
-                        bz, dev_ptr<float>(output), out_sy, ox0, oy0, ow, oh);
+            if (a32) HLMI_BG_FUSED(12, true);
+            else HLMI_BG_FUSED(12, false);
         } else {
-            HLMI_LAUNCH(uc, "bg_blur_slice", st, (bg_blur_slice<32, 16>), dim3((ow + FPX - 1) / FPX, (oh + 31) / 32), dim3(256), 0, din, in_sy, g,
-                        bz, dev_ptr<float>(output), out_sy, ox0, oy0, ow, oh);
+            if (a32) HLMI_BG_FUSED(16, true);
+            else HLMI_BG_FUSED(16, false);
         }
+#undef HLMI_BG_FUSED
     } else {
         HLMI_LAUNCH(uc, "bg_blurx", st, bg_blurx, dim3((g.GX + 63) / 64, g.HY, g.ZD), dim3(64), 0, bz, g, bx);
         HLMI_LAUNCH(uc, "bg_blury", st, bg_blury, dim3((g.GX + 63) / 64, g.GY, g.ZD), dim3(64), 0, bx, g, by);

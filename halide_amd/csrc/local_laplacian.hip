@@ -2075,27 +2075,35 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
     // their prologues.  Every load is `uniform base + 32-bit byte offset` (the workspace offsets of this path are < 4 GB): as
     // 64-bit element indices the address arithmetic was 60 % of the 148 VALU instructions a tile value cost, and the tile values
     // 45 % of the launch's instructions.
+    // The four taps of an upsampled value are f(yb, xb), f(yb, xb + 1) and the same pair one row on (fdiv2(v + 1) = fdiv2(v - 1) + 1):
+    // two unaligned 8-byte loads from two byte offsets.  Rows are numbered from the tile's first one, so every row x stride product
+    // is (small) x (stride < 2^24, the host checks) = one full-rate v_mul_u32_u24 on top of a scalar base; e / tile width is a
+    // multiplication by ceil(2^22 / width), exact while e x width < 2^22 (130 x 302 rows x 130 at the largest tile LDS can hold).
     struct Taps32 {
-        uint32_t aa, ab, ba, bb;   // byte offsets of f(ya, xa), f(ya, xb), f(yb, xa), f(yb, xb) inside a plane
+        uint32_t b, a;             // byte offsets of f(yb, xb) and f(yb + 1, xb) inside a plane
     };
-    auto tap_bytes = [](int lox, int loy, int ws, int X, int Y) {
-        const int xa = dev::fdiv2(X + 1) - lox, xb = dev::fdiv2(X - 1) - lox;
-        const uint32_t ra = (uint32_t)((dev::fdiv2(Y + 1) - loy) * ws), rb = (uint32_t)((dev::fdiv2(Y - 1) - loy) * ws);
+    auto mul24 = [](uint32_t a, uint32_t b) { return (uint32_t)__umul24(a, b); };
+    auto tap_bytes = [&](uint32_t row0, int y0, int lox, int ws, int X, int Y) {   // row0 = (y0 - loy) * ws (uniform), y0 <= fdiv2(Y - 1)
         Taps32 t;
-        t.aa = (ra + (uint32_t)xa) << 2, t.ab = (ra + (uint32_t)xb) << 2, t.ba = (rb + (uint32_t)xa) << 2, t.bb = (rb + (uint32_t)xb) << 2;
+        t.b = (row0 + mul24((uint32_t)(dev::fdiv2(Y - 1) - y0), (uint32_t)ws) + (uint32_t)(dev::fdiv2(X - 1) - lox)) << 2;
+        t.a = t.b + ((uint32_t)ws << 2);
         return t;
     };
     auto taps_at = [](const float *base, uint32_t plane_bytes, const Taps32 &t) {
+        const F2U lo = ld_su<F2U>(base, plane_bytes + t.b), hi = ld_su<F2U>(base, plane_bytes + t.a);
         UpTaps r;
-        r.aa = ld_su<float>(base, plane_bytes + t.aa), r.ab = ld_su<float>(base, plane_bytes + t.ab);
-        r.ba = ld_su<float>(base, plane_bytes + t.ba), r.bb = ld_su<float>(base, plane_bytes + t.bb);
+        r.bb = lo.x, r.ba = lo.y, r.ab = hi.x, r.aa = hi.y;
         return r;
     };
     const uint32_t ps1b = (uint32_t)p.ps1 * 4u, ps2b = (uint32_t)p.ps2 * 4u, ps3b = (uint32_t)ph.ps3 * 4u;
     if (ph.fuse2) {
         const int n2x = dev::fdiv2(cx1 + 1) - c2x0 + 1, n2y = dev::fdiv2(cy0 + th) - c2y0 + 1, n2 = n2x * n2y;
+        const uint32_t m2 = (4194304u + (uint32_t)n2x - 1u) / (uint32_t)n2x;
+        const int c3y0 = dev::fdiv2(c2y0 - 1);
+        const uint32_t row2 = (uint32_t)((c2y0 - p.loy2) * p.ws2), row3 = (uint32_t)((c3y0 - ph.loy3) * ph.ws3);
         for (int e0 = threadIdx.x; e0 < n2; e0 += 256 * CH) {
-            int X2[CH], Y2[CH], ti[CH];
+            int X2[CH], Y2[CH];
+            uint32_t ti[CH];
             bool ok[CH];
             uint32_t ob[CH];
             Taps32 t3[CH];
@@ -2103,12 +2111,13 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
             UpTaps o3[CH], t0[CH], t1[CH];
 #pragma unroll
             for (int i = 0; i < CH; i++) {
-                const int e = e0 + 256 * i, ec = min(e, n2 - 1), ty = ec / n2x, tx = ec - ty * n2x;
-                ok[i] = e < n2, ti[i] = ty * U0H_T2 + tx;
-                X2[i] = c2x0 + tx, Y2[i] = c2y0 + ty;
-                ob[i] = (uint32_t)((Y2[i] - p.loy2) * p.ws2 + (X2[i] - p.lox2)) << 2;
+                const int e = e0 + 256 * i;
+                const uint32_t ec = (uint32_t)min(e, n2 - 1), ty = mul24(ec, m2) >> 22, tx = ec - mul24(ty, (uint32_t)n2x);
+                ok[i] = e < n2, ti[i] = mul24(ty, U0H_T2) + tx;
+                X2[i] = c2x0 + (int)tx, Y2[i] = c2y0 + (int)ty;
+                ob[i] = (row2 + mul24(ty, (uint32_t)p.ws2) + (uint32_t)(X2[i] - p.lox2)) << 2;
                 inG[i] = ld_su<float>(p.g2, (uint32_t)gm.K * ps2b + ob[i]);
-                t3[i] = tap_bytes(ph.lox3, ph.loy3, ph.ws3, X2[i], Y2[i]);
+                t3[i] = tap_bytes(row3, c3y0, ph.lox3, ph.ws3, X2[i], Y2[i]);
                 o3[i] = taps_at(ph.out3, 0u, t3[i]);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -2134,21 +2143,25 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
     }
     {
         const int n1 = U0_TW * th;
+        constexpr uint32_t M1 = (4194304u + U0_TW - 1) / U0_TW;
+        const uint32_t row1 = (uint32_t)((cy0 - p.loy1) * p.ws1), row2 = (uint32_t)((c2y0 - p.loy2) * p.ws2);
         for (int e0 = threadIdx.x; e0 < n1; e0 += 256 * CH) {
-            int cx[CH], cy[CH], ti[CH];
+            int cx[CH], cy[CH];
+            uint32_t ti[CH];
             bool ok[CH];
             Taps32 t2[CH];
             float inG[CH], lf[CH], ga[CH], gb[CH];
             UpTaps o2[CH], t0[CH], t1[CH];
 #pragma unroll
             for (int i = 0; i < CH; i++) {
-                const int e = e0 + 256 * i, ec = min(e, n1 - 1), ty = ec / U0_TW, tx = ec - ty * U0_TW;
-                ok[i] = e < n1 && cx0 + tx <= p.rx1_1, ti[i] = ty * U0_TS + tx;
-                cx[i] = min(cx0 + tx, p.rx1_1), cy[i] = cy0 + ty;      // columns right of R_1 are not tile values: their threads re-read its last one
-                const uint32_t ob = (uint32_t)((cy[i] - p.loy1) * p.ws1 + (cx[i] - p.lox1)) << 2;
+                const int e = e0 + 256 * i;
+                const uint32_t ec = (uint32_t)min(e, n1 - 1), ty = mul24(ec, M1) >> 22, tx = ec - mul24(ty, U0_TW);
+                ok[i] = e < n1 && cx0 + (int)tx <= p.rx1_1, ti[i] = mul24(ty, U0_TS) + tx;
+                cx[i] = min(cx0 + (int)tx, p.rx1_1), cy[i] = cy0 + (int)ty;      // columns right of R_1 are not tile values: their threads re-read its last one
+                const uint32_t ob = (row1 + mul24(ty, (uint32_t)p.ws1) + (uint32_t)(cx[i] - p.lox1)) << 2;
                 // level 1 as ll_down01e stored it: plane 0 / 1 = gPyramid[1](., ., li / li + 1) of the pixel's own li, plane K = inGPyramid[1]
                 inG[i] = ld_su<float>(p.g1, (uint32_t)gm.K * ps1b + ob), ga[i] = ld_su<float>(p.g1, ob), gb[i] = ld_su<float>(p.g1, ps1b + ob);
-                t2[i] = tap_bytes(p.lox2, p.loy2, p.ws2, cx[i], cy[i]);
+                t2[i] = tap_bytes(row2, c2y0, p.lox2, p.ws2, cx[i], cy[i]);
                 if (!ph.fuse2) o2[i] = taps_at(p.out2, 0u, t2[i]);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -2168,11 +2181,9 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
                 const float outL = (1.0f - lf[i]) * l0 + lf[i] * l1;
                 float up2;
                 if (ph.fuse2) {   // up_at on the LDS tile: the same taps, weights and lerps
-                    const int xa = dev::fdiv2(cx[i] + 1) - c2x0, xb = dev::fdiv2(cx[i] - 1) - c2x0;
-                    const int ya = dev::fdiv2(cy[i] + 1) - c2y0, yb = dev::fdiv2(cy[i] - 1) - c2y0;
+                    const float *q = s_out2 + mul24((uint32_t)(dev::fdiv2(cy[i] - 1) - c2y0), U0H_T2) + (uint32_t)(dev::fdiv2(cx[i] - 1) - c2x0);
                     UpTaps t;
-                    t.aa = s_out2[ya * U0H_T2 + xa], t.ab = s_out2[ya * U0H_T2 + xb];
-                    t.ba = s_out2[yb * U0H_T2 + xa], t.bb = s_out2[yb * U0H_T2 + xb];
+                    t.bb = q[0], t.ba = q[1], t.ab = q[U0H_T2], t.aa = q[U0H_T2 + 1];
                     up2 = up_from(t, cx[i], cy[i]);
                 } else {
                     up2 = up_from(o2[i], cx[i], cy[i]);
@@ -2188,7 +2199,7 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
     if (y0 >= p.oh || x >= p.ow) return;
     const int y1 = min(y0 + p.RU, p.oh);
     const int X = p.ox0 + x;                                              // even
-    const uint32_t inb = (uint32_t)(X - gm.ix0) * 2u, outb = (uint32_t)x * 2u, l0b = (uint32_t)(X - gm.ix0) * 4u;
+    uint32_t inb = (uint32_t)(X - gm.ix0) * 2u, outb = (uint32_t)x * 2u, l0b = (uint32_t)(X - gm.ix0) * 4u;
     auto hl0 = [](float rm, float r0) { return __builtin_fmaf(rm, 0.25f, r0 * 0.75f); };  // lerp(f[c], f[c-1], 1/4): X even
     auto hl1 = [](float r0, float rp) { return __builtin_fmaf(rp, 0.25f, r0 * 0.75f); };  // lerp(f[c+1], f[c], 3/4): X odd
     auto vl = [](float uq, float ut) { return __builtin_fmaf(uq, 0.25f, ut * 0.75f); };
@@ -2196,12 +2207,20 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
         ushort2 c0, c1, c2;
         float2 l0;
     };
+    // The lane's byte offsets are loop invariants: hoisted out of the row loop as 64-bit values they cost a v_lshl_add_u64 per load
+    // and store (7 per row); redefined in place per use (an empty asm) they stay 32-bit and every access is `row base in SGPRs +
+    // VGPR offset`.
+    auto fresh = [](uint32_t &v) {
+        asm volatile("" : "+v"(v));
+        return v;
+    };
     auto load_frame = [&](int y, Frame &f) {
         const int yc = min(y, y1 - 1);
         const uint16_t *irow = p.in + (long)(p.oy0 + yc - gm.iy0) * p.in_sy;
-        f.c0 = ld_frame2<NT>(irow + p.gco[0], inb), f.c1 = ld_frame2<NT>(irow + p.gco[1], inb), f.c2 = ld_frame2<NT>(irow + p.gco[2], inb);
+        const uint32_t ib = fresh(inb);
+        f.c0 = ld_frame2<NT>(irow + p.gco[0], ib), f.c1 = ld_frame2<NT>(irow + p.gco[1], ib), f.c2 = ld_frame2<NT>(irow + p.gco[2], ib);
         {
-            const f2 *const lp = reinterpret_cast<const f2 *>(reinterpret_cast<const char *>(ph.outl0 + (size_t)yc * ph.l0_ws) + l0b);
+            const f2 *const lp = reinterpret_cast<const f2 *>(reinterpret_cast<const char *>(ph.outl0 + (size_t)yc * ph.l0_ws) + fresh(l0b));
             const f2 v = NT ? __builtin_nontemporal_load(lp) : *lp;
             f.l0 = make_float2(v.x, v.y);
         }
@@ -2232,7 +2251,7 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
         if (y < y1) {
             uint16_t *orow = p.out + (long)y * p.out_sy;
 #pragma unroll
-            for (int c = 0; c < 3; c++) st_frame2<NT>(reinterpret_cast<char *>(orow + (long)c * p.out_sc) + outb, res[c][0], res[c][1]);
+            for (int c = 0; c < 3; c++) st_frame2<NT>(reinterpret_cast<char *>(orow + (long)c * p.out_sc) + fresh(outb), res[c][0], res[c][1]);
         }
     };
     Frame f[U0H_PF];
@@ -2496,7 +2515,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
                               (gm.ix1 - gm.ix0 + 1) % 4 == 0 && !env_int("HLMI_LL_NO_VEC", 0);
     // The default for the common geometry: ll_down01e emits outLPyramid[0] and three planes of level 1, ll_up0h collapses
     // (HLMI_LL_EMIT=0: the round-3 pair ll_down01f / ll_up0f with the materialised K + 1 level-1 planes)
-    const bool emit = d01_possible && fast && fuse1 && env_int("HLMI_LL_EMIT", 1);
+    const bool emit = d01_possible && fast && fuse1 && lv[1].ws < (1 << 24) && env_int("HLMI_LL_EMIT", 1);   // ws: ll_up0h's 24-bit row products
     // ll_up0h has no data-dependent gathers to amortise over a tall tile: short tiles (more, smaller workgroups) are faster on a
     // stream that owns the device (31.7 us at 8 rows per wave against 33.5 / 38.4 at 16 / 32); on CU partitions 8..32 measure the same
     if (emit) p.RU = max(1, env_int("HLMI_LL_RU", partitioned ? 16 : 8));
