@@ -139,6 +139,23 @@ __device__ __forceinline__ float src_at(const float *__restrict__ s, const Box &
     return s[((size_t)zc * b.h + (y - b.y0)) * b.w + (x - b.x0)];
 }
 
+// ---- 32-bit index helpers of the *32 kernels (planes below 2^29 elements, boxes below 2^23 wide / high: the host checks)
+template<int D, int MAXE>
+__device__ __forceinline__ uint32_t lb_divc(uint32_t e) {   // e / D for 0 <= e <= MAXE
+    constexpr uint32_t M = (65536u + D - 1) / D;
+    static_assert((unsigned long long)(M * D - 65536u) * MAXE < 65536ull, "lb_divc: range");
+    return __umul24(e, M) >> 16;
+}
+__device__ __forceinline__ uint32_t lb_mul24(uint32_t a, uint32_t b) {   // kept apart from a following add (else: v_mad_u64_u32, quarter rate)
+    uint32_t r = __umul24(a, b);
+    asm("" : "+v"(r));
+    return r;
+}
+__device__ __forceinline__ uint32_t lb_clamped_off(const Box &b, int x, int y) {   // element offset of (x, y) clamped to the box, in its plane
+    const int cx = dev::clampi(x, b.x0, b.x0 + b.w - 1) - b.x0, cy = dev::clampi(y, b.y0, b.y0 + b.h - 1) - b.y0;
+    return lb_mul24((uint32_t)cy, (uint32_t)b.w) + (uint32_t)cx;
+}
+
 // A workgroup makes a 64 x 16 tile of one plane of the next level: its 130 x 34 source window goes through LDS once (every
 // source value is a tap of four outputs), the 1-3-3-1 pass in x over the 34 rows, then in y — the generator's expressions
 // (:279-285), operand for operand.  Source coordinates are clamped to the source box when staging: that IS the function for
@@ -167,6 +184,51 @@ __global__ __launch_bounds__(256) void lb_down(const float *__restrict__ src, Bo
         const int xi = blockIdx.x * DTW + xo, yi = blockIdx.y * DTH + yo;
         if (xi < db.w && yi < db.h)
             dst[((size_t)zc * db.h + yi) * db.w + xi] = (s_dx[2 * yo][xo] + 3.0f * (s_dx[2 * yo + 1][xo] + s_dx[2 * yo + 2][xo]) + s_dx[2 * yo + 3][xo]) * 0.125f;
+    }
+}
+
+// lb_down32: lb_down with a thread owning ONE source column (its clamped offset computed once) and a row pair per step: all 17 + 1
+// loads of a thread are requested before the first is written to LDS, a load costs five full-rate integer instructions (lb_down:
+// a division by 130, two clamps and a 64-bit index per element — the launch was bound by that arithmetic, not by its 10 MB).
+template<bool SRC_CLAMP>
+__global__ __launch_bounds__(256) void lb_down32(const float *__restrict__ src, Box sb, float *__restrict__ dst, Box db) {
+    __shared__ float s_in[2 * DTH + 2][2 * DTW + 3];
+    __shared__ float s_dx[2 * DTH + 2][DTW + 1];
+    static_assert(2 * DTW == 128 && (2 * DTH + 2) % 2 == 0 && 2 * (2 * DTH + 2) <= 256, "lb_down32: thread layout");
+    const int tid = threadIdx.x, zc = blockIdx.z;
+    const int tx0 = db.x0 + blockIdx.x * DTW, ty0 = db.y0 + blockIdx.y * DTH;
+    const int ix0 = 2 * tx0 - 1, iy0 = 2 * ty0 - 1;
+    const float *const f = src + (size_t)zc * sb.h * sb.w;
+    {
+        constexpr int NR = (2 * DTH + 2) / 2;
+        const int cl = tid & 127, rh = tid >> 7;
+        const uint32_t cxo = (uint32_t)(dev::clampi(ix0 + cl, sb.x0, sb.x0 + sb.w - 1) - sb.x0);
+        float v[NR];
+#pragma unroll
+        for (int it = 0; it < NR; it++) {
+            const int cy = dev::clampi(iy0 + 2 * it + rh, sb.y0, sb.y0 + sb.h - 1) - sb.y0;
+            v[it] = f[lb_mul24((uint32_t)cy, (uint32_t)sb.w) + cxo];
+        }
+        // columns 128, 129 of the window: one element each for the first 2 (2 DTH + 2) threads
+        const int er = min(tid >> 1, 2 * DTH + 1), ec = 2 * DTW + (tid & 1);
+        const float ve = f[lb_clamped_off(sb, ix0 + ec, iy0 + er)];
+#pragma unroll
+        for (int it = 0; it < NR; it++) s_in[2 * it + rh][cl] = v[it];
+        if (tid < 2 * (2 * DTH + 2)) s_in[er][ec] = ve;
+    }
+    __syncthreads();
+    for (int i = tid; i < (2 * DTH + 2) * DTW; i += 256) {
+        const int r = i / DTW, xo = i - r * DTW;
+        const float *q = &s_in[r][2 * xo];
+        s_dx[r][xo] = (q[0] + 3.0f * (q[1] + q[2]) + q[3]) * 0.125f;
+    }
+    __syncthreads();
+    float *const o = dst + (size_t)zc * db.h * db.w;
+    for (int i = tid; i < DTH * DTW; i += 256) {
+        const int yo = i / DTW, xo = i - yo * DTW;
+        const int xi = blockIdx.x * DTW + xo, yi = blockIdx.y * DTH + yo;
+        if (xi < db.w && yi < db.h)
+            o[lb_mul24((uint32_t)yi, (uint32_t)db.w) + (uint32_t)xi] = (s_dx[2 * yo][xo] + 3.0f * (s_dx[2 * yo + 1][xo] + s_dx[2 * yo + 2][xo]) + s_dx[2 * yo + 3][xo]) * 0.125f;
     }
 }
 
@@ -246,6 +308,87 @@ __global__ __launch_bounds__(256) void lb_pull_multi(const float *__restrict__ p
         const int y = y0 + (tid >> 6) + 4 * k;
         if (y > y1) break;
         pull1[((size_t)zc * p1.h + (y - p1.y0)) * p1.w + (x - p1.x0)] = dev::lerpf(up_lds(s2, PM2W, ax0, ay0, x, y), q1[k], 0.5f);
+    }
+}
+
+// lb_pull_multi32: the same launch with the index arithmetic it takes to get there cut down.  lb_pull_multi is 659 VALU
+// instructions per thread of which 99 are the float operations of the algorithm; 108 of the rest are quarter-rate 32 / 64-bit integer
+// multiplies (element indices as size_t, divisions by the run-time tile widths).  Here: the plane's base pointer is uniform and every
+// access is base + 32-bit element offset built from 24-bit multiplies (the host checks that every level's plane is below 2^29
+// elements and 2^23 wide / high); cells are numbered on the FIXED pitches PM2W / PM3W (division by a constant = one 24-bit multiply,
+// cells past the tile's own w2 x h2 / w3 x h3 idle); the four taps of an upsample are one offset and two +-1 / +-pitch steps
+// (xa = xb +- 1 by the parity of x, :288-294).  Same float expressions in the same order as lb_pull_multi (= lb_pull's).
+struct LbUp {   // the four taps of upsample(f)(x, y): offsets of f(yb, xb) and the steps to xa / ya
+    uint32_t o;
+    int dx, dy;
+};
+__device__ __forceinline__ LbUp lb_up_taps(int x, int y, int x0, int y0, int pitch) {
+    LbUp t;
+    t.o = lb_mul24((uint32_t)((y >> 1) - y0), (uint32_t)pitch) + (uint32_t)((x >> 1) - x0);
+    t.dx = (x & 1) ? 1 : -1, t.dy = (y & 1) ? pitch : -pitch;
+    return t;
+}
+template<typename F>
+__device__ __forceinline__ float lb_up_from(const LbUp &t, F f) {   // f(offset) -> value; the operation order of up_at / up_lds
+    const uint32_t oa = t.o + (uint32_t)t.dy;
+    const float ua = 0.25f * f(oa + (uint32_t)t.dx) + 0.75f * f(oa);
+    const float ub = 0.25f * f(t.o + (uint32_t)t.dx) + 0.75f * f(t.o);
+    return 0.25f * ua + 0.75f * ub;
+}
+__global__ __launch_bounds__(256) void lb_pull_multi32(const float *__restrict__ push1, Box pb1, const float *__restrict__ push2, Box pb2,
+                                                      const float *__restrict__ push3, Box pb3, const float *__restrict__ pull4, Box p4,
+                                                      float *__restrict__ pull1, Box p1) {
+    __shared__ float s2[PM2H * PM2W], s3[PM3H * PM3W];
+    const int tid = threadIdx.x, zc = blockIdx.z;
+    const int x0 = p1.x0 + blockIdx.x * PMW, x1 = min(x0 + PMW, p1.x0 + p1.w) - 1;
+    const int y0 = p1.y0 + blockIdx.y * PMH, y1 = min(y0 + PMH, p1.y0 + p1.h) - 1;
+    const int ax0 = (x0 >> 1) - 1, ay0 = (y0 >> 1) - 1, w2 = (x1 >> 1) + 1 - ax0 + 1, h2 = (y1 >> 1) + 1 - ay0 + 1;                     // pull[2] cells read
+    const int bx0 = (ax0 >> 1) - 1, by0 = (ay0 >> 1) - 1, w3 = ((ax0 + w2 - 1) >> 1) + 1 - bx0 + 1, h3 = ((ay0 + h2 - 1) >> 1) + 1 - by0 + 1;   // pull[3]
+    // the planes of this workgroup (uniform pointers)
+    const float *const f1 = push1 + (size_t)zc * pb1.h * pb1.w, *const f2 = push2 + (size_t)zc * pb2.h * pb2.w;
+    const float *const f3 = push3 + (size_t)zc * pb3.h * pb3.w, *const f4 = pull4 + (size_t)zc * p4.h * p4.w;
+    float *const o1 = pull1 + (size_t)zc * p1.h * p1.w;
+    constexpr int N2 = (PM2H * PM2W + 255) / 256, N1 = PMH / 4;
+    float q2[N2], q1[N1];
+    int c2x[N2], c2y[N2];
+    bool on2[N2];
+#pragma unroll
+    for (int k = 0; k < N2; k++) {
+        const uint32_t i = (uint32_t)min(tid + 256 * k, PM2H * PM2W - 1), yy = lb_divc<PM2W, PM2H * PM2W>(i), xx = i - yy * PM2W;
+        on2[k] = tid + 256 * k < PM2H * PM2W && (int)xx < w2 && (int)yy < h2;
+        c2x[k] = (int)xx, c2y[k] = (int)yy;
+        q2[k] = f2[lb_clamped_off(pb2, ax0 + (int)xx, ay0 + (int)yy)];
+    }
+    const int x = min(x0 + (tid & 63), x1);
+#pragma unroll
+    for (int k = 0; k < N1; k++) q1[k] = f1[lb_clamped_off(pb1, x, min(y0 + (tid >> 6) + 4 * k, y1))];
+    {
+        const uint32_t i = (uint32_t)min(tid, PM3H * PM3W - 1), yy = lb_divc<PM3W, PM3H * PM3W>(i), xx = i - yy * PM3W;
+        const int x3 = bx0 + (int)xx, y3 = by0 + (int)yy;
+        if (tid < PM3H * PM3W && (int)xx < w3 && (int)yy < h3) {
+            const LbUp t = lb_up_taps(x3, y3, p4.x0, p4.y0, p4.w);
+            const float up = lb_up_from(t, [&](uint32_t o) { return f4[o]; });
+            s3[yy * PM3W + xx] = dev::lerpf(up, f3[lb_clamped_off(pb3, x3, y3)], 0.5f);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N2; k++) {
+        if (on2[k]) {
+            const LbUp t = lb_up_taps(ax0 + c2x[k], ay0 + c2y[k], bx0, by0, PM3W);
+            const float up = lb_up_from(t, [&](uint32_t o) { return s3[o]; });
+            s2[c2y[k] * PM2W + c2x[k]] = dev::lerpf(up, q2[k], 0.5f);
+        }
+    }
+    __syncthreads();
+    if (x0 + (tid & 63) > x1) return;
+#pragma unroll
+    for (int k = 0; k < N1; k++) {
+        const int y = y0 + (tid >> 6) + 4 * k;
+        if (y > y1) break;
+        const LbUp t = lb_up_taps(x, y, ax0, ay0, PM2W);
+        const float up = lb_up_from(t, [&](uint32_t o) { return s2[o]; });
+        o1[lb_mul24((uint32_t)(y - p1.y0), (uint32_t)p1.w) + (uint32_t)(x - p1.x0)] = dev::lerpf(up, q1[k], 0.5f);
     }
 }
 
@@ -897,6 +1040,9 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
     } else {
         LB_DISPATCH(lb_cost, dim3((E.w + 255) / 256, E.h), dim3(256), 0, dl, dr, g, E, push[0]);
     }
+    // the *32 kernels (32-bit plane offsets from 24-bit multiplies) take boxes that are small enough for them; HLMI_LB_NO_A32=1: never (A/B)
+    const bool a32 = !getenv("HLMI_LB_NO_A32");
+    auto box_small = [&](const Box &b) { return a32 && b.w < (1 << 23) && b.h < (1 << 23) && (long)b.w * b.h < (1L << 29); };
     // levels below `tail` (at most 128 x 128 elements per plane) go down and up in ONE launch, a workgroup per plane
     int tail = LV;
     for (int i = LV - 1; i >= 2; i--) {
@@ -907,6 +1053,8 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
         char nm[24];
         snprintf(nm, sizeof nm, "lb_down:%d", i);
         if (i == 1) HLMI_LAUNCH(uc, nm, st, lb_down<false>, dim3((PB[i].w + DTW - 1) / DTW, (PB[i].h + DTH - 1) / DTH, zc), dim3(256), 0, push[0], PB[0], push[i], PB[i]);
+        else if (box_small(PB[i - 1]) && box_small(PB[i]))
+            HLMI_LAUNCH(uc, nm, st, lb_down32<true>, dim3((PB[i].w + DTW - 1) / DTW, (PB[i].h + DTH - 1) / DTH, zc), dim3(256), 0, push[i - 1], PB[i - 1], push[i], PB[i]);
         else HLMI_LAUNCH(uc, nm, st, lb_down<true>, dim3((PB[i].w + DTW - 1) / DTW, (PB[i].h + DTH - 1) / DTH, zc), dim3(256), 0, push[i - 1], PB[i - 1], push[i], PB[i]);
     }
     if (tail < LV) {
@@ -929,8 +1077,15 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
             if (i == LV - 1) HLMI_LAUNCH(uc, nm, st, lb_pull<true>, dim3((P[i].w + 63) / 64, (P[i].h + 3) / 4, zc), dim3(256), 0, push[i], PB[i], (const float *)nullptr, P[i], pull[i], P[i]);
             else HLMI_LAUNCH(uc, nm, st, lb_pull<false>, dim3((P[i].w + 63) / 64, (P[i].h + 3) / 4, zc), dim3(256), 0, push[i], PB[i], pull[i + 1], P[i + 1], pull[i], P[i]);
         }
-        HLMI_LAUNCH(uc, "lb_pull_multi:1", st, lb_pull_multi, dim3((P[1].w + PMW - 1) / PMW, (P[1].h + PMH - 1) / PMH, zc), dim3(256), 0, push[1], PB[1],
-                    push[2], PB[2], push[3], PB[3], pull[4], P[4], pull[1], P[1]);
+        // 32-bit plane offsets from 24-bit multiplies (lb_pull_multi32) when every plane involved is small enough for them
+        bool small = true;
+        for (const Box *b : {&PB[1], &PB[2], &PB[3], &P[4], &P[1]}) small = small && box_small(*b);
+        if (small)
+            HLMI_LAUNCH(uc, "lb_pull_multi:1", st, lb_pull_multi32, dim3((P[1].w + PMW - 1) / PMW, (P[1].h + PMH - 1) / PMH, zc), dim3(256), 0, push[1],
+                        PB[1], push[2], PB[2], push[3], PB[3], pull[4], P[4], pull[1], P[1]);
+        else
+            HLMI_LAUNCH(uc, "lb_pull_multi:1", st, lb_pull_multi, dim3((P[1].w + PMW - 1) / PMW, (P[1].h + PMH - 1) / PMH, zc), dim3(256), 0, push[1], PB[1],
+                        push[2], PB[2], push[3], PB[3], pull[4], P[4], pull[1], P[1]);
     }
     for (int i = pull_multi ? 0 : min(LV - 1, tail - 1); i >= 1; i--) {
         char nm[24];
