@@ -777,6 +777,11 @@ __device__ __forceinline__ float rand_float_x(uint32_t ry, int x) {
     return dev::clampf(__uint_as_float((127u << 23) | (r >> 9)) - 1.0f, 0.0f, 1.0f);
 }
 
+// WCY: `wcy` is the bokeh-radius plane itself and the workgroup makes the 256 + 2 R column maxima over rows y - R .. y + R that
+// its pixels' windows read (lb_wcy's values — a maximum has no rounding and no order) in LDS instead of reading them from a plane an
+// lb_wcy launch wrote: 2 R + 1 loads per column from a 4 MB plane that sits in L2 against a launch of its own in the chain.
+constexpr int LB_MAXR = 64;   // generator :14-19: (slices - focus or focus) x scale <= 64
+template<bool WCY>
 __global__ __launch_bounds__(256) void lb_final(LBGeom g, const uint32_t *__restrict__ rec, const float *__restrict__ wcy, Box D, int ox0, int oy0,
                                                int ow, int nc, float *__restrict__ out, long out_sy, long out_sc) {
     // the hash consumes (id, tag, sample, y, x) in that order: everything up to the row is the same for the whole workgroup
@@ -800,10 +805,28 @@ __global__ __launch_bounds__(256) void lb_final(LBGeom g, const uint32_t *__rest
         r = r ^ (r >> 16);
         return dev::clampf(__uint_as_float((127u << 23) | (r >> 9)) - 1.0f, 0.0f, 1.0f);
     };
+    __shared__ float s_w[WCY ? 256 + 2 * LB_MAXR : 1];
+    if (WCY) {
+        const int c0 = ox0 + (int)blockIdx.x * 256 - g.R - D.x0;   // first column of the workgroup's windows, relative to D
+        for (int c = threadIdx.x; c < 256 + 2 * g.R; c += 256) {
+            const float *col = wcy + (size_t)(y - g.R - D.y0) * D.w + min(c0 + c, D.w - 1);   // columns past D feed pixels past the output only
+            float m = -INFINITY;
+            for (int r0 = 0; r0 <= 2 * g.R; r0 += 8) {   // batched as in lb_wcy; rows past the window repeat its last row
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = col[(size_t)min(r0 + j, 2 * g.R) * D.w];
+#pragma unroll
+                for (int j = 0; j < 8; j++) m = fmaxf(m, v[j]);
+            }
+            s_w[c] = m;
+        }
+    }
     __syncthreads();
     if (xo >= ow) return;
     float worst = -INFINITY;
-    {
+    if (WCY) {
+        for (int j = 0; j <= 2 * g.R; j++) worst = fmaxf(worst, s_w[threadIdx.x + j]);
+    } else {
         const float *wrow = wcy + (size_t)yo * D.w + (x - g.R - D.x0);
         for (int r0 = 0; r0 <= 2 * g.R; r0 += 8) {   // batched as in lb_wcy
             float v[8];
@@ -1096,9 +1119,14 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
     if (!fused) HLMI_LAUNCH(uc, "lb_depth", st, lb_depth, dim3((D.w + 255) / 256, D.h), dim3(256), 0, push[0], E, pull[1], P[1], dl, g, D, depth, br);
     else LB_DISPATCH(lb_depth_rc, dim3((D.w + 63) / 64, (D.h + 3) / 4), dim3(256), 0, dl, dr, pull[1], P[1], g, D, depth, br);
 #undef LB_DISPATCH
-    HLMI_LAUNCH(uc, "lb_wcy", st, lb_wcy, dim3((D.w + 255) / 256, oh), dim3(256), 0, br, D, g.R, oy0, oh, wcy);
-    HLMI_LAUNCH(uc, "lb_final", st, lb_final, dim3((ow + 255) / 256, oh), dim3(256), 0, g, depth, wcy, D, ox0, oy0, ow, nc,
-                dev_ptr<float>(final_), (long)final_->dim[1].stride, (long)final_->dim[2].stride);
+    if (!fused || getenv("HLMI_LB_WCY_LAUNCH")) {
+        HLMI_LAUNCH(uc, "lb_wcy", st, lb_wcy, dim3((D.w + 255) / 256, oh), dim3(256), 0, br, D, g.R, oy0, oh, wcy);
+        HLMI_LAUNCH(uc, "lb_final", st, lb_final<false>, dim3((ow + 255) / 256, oh), dim3(256), 0, g, depth, wcy, D, ox0, oy0, ow, nc,
+                    dev_ptr<float>(final_), (long)final_->dim[1].stride, (long)final_->dim[2].stride);
+    } else {
+        HLMI_LAUNCH(uc, "lb_final", st, lb_final<true>, dim3((ow + 255) / 256, oh), dim3(256), 0, g, depth, br, D, ox0, oy0, ow, nc,
+                    dev_ptr<float>(final_), (long)final_->dim[1].stride, (long)final_->dim[2].stride);
+    }
     mark_output_written(final_);
     return 0;
 }
