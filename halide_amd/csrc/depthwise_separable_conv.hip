@@ -87,7 +87,18 @@ __global__ __launch_bounds__(256) void dsc_fused(const float *__restrict__ in, c
 // address chains) and in two LATENCY-bound fma chains per thread; here every index folds, a thread owns TPX IC / 256
 // depthwise values and TPX CO / 256 outputs and walks their fma chains interleaved (independent accumulators), so that the
 // dependent-issue latency of one chain hides behind the others.  Same operations in the same order: bit-identical.
-template<int FW, int FH, int IC, int CO, int TPX>
+// A32 (round 5, second pass): 32-bit addressing.  With `long` strides every one of the 63 input loads of a thread carried a
+// 64-bit multiply-add chain (213 quarter-rate integer instructions + 82 64-bit adds of 890 VALU: 40 % of the launch's issue
+// slots, and the launch was issue-bound: 3.5 waves per SIMD x ~1500 slots).  Here the 21 distinct column offsets of a thread
+// (clamped column x pixel stride + channel, one 24-bit multiply each) are computed once and shared by the three rows, whose bases
+// are scalar: a load is `row base (SGPRs) + lane byte offset`, no vector arithmetic; likewise filters and stores.  The host checks
+// that strides are non-negative and below 2^23 and that every buffer spans less than 2^31 bytes.  Same fma chains, same bits.
+__device__ __forceinline__ uint32_t dsc_mul24(uint32_t a, uint32_t b) {   // kept apart from a following add (else v_mad_u64_u32)
+    uint32_t r = __umul24(a, b);
+    asm("" : "+v"(r));
+    return r;
+}
+template<int FW, int FH, int IC, int CO, int TPX, bool A32>
 __global__ __launch_bounds__(256) void dsc_fused_t(const float *__restrict__ in, const float *__restrict__ dw, const float *__restrict__ pw,
                                                   const float *__restrict__ bias, float *__restrict__ out, DGeom g) {
     __shared__ float s_mid[TPX * IC], s_dw[FH * FW * IC], s_pw[IC * CO];
@@ -106,18 +117,55 @@ __global__ __launch_bounds__(256) void dsc_fused_t(const float *__restrict__ in,
 #pragma unroll
     for (int j = 0; j < NDW; j++) {
         const int i = min(tid + 256 * j, FH * FW * IC - 1);
-        const int d = i % IC, rx = (i / IC) % FW, ry = i / (IC * FW);
-        fdw[j] = dw[d * g.d_s1 + rx * g.d_sx + ry * g.d_sy];
+        if (A32) {   // i < 2^16: i / (IC FW) and i / IC as 24-bit multiplies by ceil(2^16 / n) would need a range proof per shape; IC is a power of two
+            static_assert((IC & (IC - 1)) == 0 && FH * FW * IC < 4096, "dsc_fused_t<A32>: filter indexing");
+            const uint32_t q = (uint32_t)i / IC, d = (uint32_t)i % IC, ry = (q * ((65536u + FW - 1) / FW)) >> 16, rx = q - ry * FW;   // q < 128: exact
+            fdw[j] = dw[dsc_mul24(d, (uint32_t)g.d_s1) + dsc_mul24(rx, (uint32_t)g.d_sx) + dsc_mul24(ry, (uint32_t)g.d_sy)];
+        } else {
+            const int d = i % IC, rx = (i / IC) % FW, ry = i / (IC * FW);
+            fdw[j] = dw[d * g.d_s1 + rx * g.d_sx + ry * g.d_sy];
+        }
     }
 #pragma unroll
     for (int j = 0; j < NPW; j++) {
         const int i = min(tid + 256 * j, IC * CO - 1);
-        fpw[j] = pw[(i % CO) + (long)(i / CO) * g.p_s1];
+        if (A32) fpw[j] = pw[(uint32_t)(i % CO) + dsc_mul24((uint32_t)(i / CO), (uint32_t)g.p_s1)];
+        else fpw[j] = pw[(i % CO) + (long)(i / CO) * g.p_s1];
     }
     const int d = tid % IC, pxo = tid / IC;
     float v[FH][FW][N1];
+    bool vin[FH][FW][N1];
+    if (A32) {
+        uint32_t xob[FW][N1];     // byte offset of (clamped column, channel d) in a row, per tap column and pass
+        bool xin[FW][N1];
+        const int xx0 = g.ox0 + x0 + pxo - padw;
 #pragma unroll
-    for (int ry = 0; ry < FH; ry++) {
+        for (int rx = 0; rx < FW; rx++) {
+#pragma unroll
+            for (int k = 0; k < N1; k++) {
+                const int xx = xx0 + rx + k * PPT;
+                xin[rx][k] = xx >= 0 && xx < g.W;                                  // (:36-43): zero padding by the EXTENTS
+                const int cx = min(max(xx, 0), g.ix0 + g.W - 1) - g.ix0;           // the read itself is clamped
+                xob[rx][k] = (dsc_mul24((uint32_t)cx, (uint32_t)g.in_sx) + (uint32_t)d) << 2;
+            }
+        }
+#pragma unroll
+        for (int ry = 0; ry < FH; ry++) {
+            const int yy = Y + ry - padh;
+            const bool yin = yy >= 0 && yy < g.H;
+            const char *rowp = reinterpret_cast<const char *>(in + (long)n * g.in_sn + (long)(min(max(yy, 0), g.iy0 + g.H - 1) - g.iy0) * g.in_sy);   // uniform
+#pragma unroll
+            for (int rx = 0; rx < FW; rx++) {
+#pragma unroll
+                for (int k = 0; k < N1; k++) {
+                    v[ry][rx][k] = *reinterpret_cast<const float *>(rowp + xob[rx][k]);   // unconditional (the address is clamped); masked below
+                    vin[ry][rx][k] = yin && xin[rx][k];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ry = 0; ry < (A32 ? 0 : FH); ry++) {
         const int yy = Y + ry - padh;
         const bool yin = yy >= 0 && yy < g.H;
         const float *rowp = in + (long)n * g.in_sn + (long)(min(max(yy, 0), g.iy0 + g.H - 1) - g.iy0) * g.in_sy + d;
@@ -143,6 +191,22 @@ __global__ __launch_bounds__(256) void dsc_fused_t(const float *__restrict__ in,
         if (tid + 256 * j < IC * CO) s_pw[tid + 256 * j] = fpw[j];
     }
     __syncthreads();
+    if (A32) {
+        // every loaded value is USED here, in one place (an empty asm): left to itself the compiler turns `in bounds ? load : 0` into
+        // a branch around each load with a wait behind it — 63 round trips in a row
+#pragma unroll
+        for (int ry = 0; ry < FH; ry++)
+#pragma unroll
+            for (int rx = 0; rx < FW; rx++)
+#pragma unroll
+                for (int k = 0; k < N1; k++) asm volatile("" : "+v"(v[ry][rx][k]));
+#pragma unroll
+        for (int ry = 0; ry < FH; ry++)
+#pragma unroll
+            for (int rx = 0; rx < FW; rx++)
+#pragma unroll
+                for (int k = 0; k < N1; k++) v[ry][rx][k] = vin[ry][rx][k] ? v[ry][rx][k] : 0.0f;
+    }
     {
         float acc[N1];
 #pragma unroll
@@ -153,10 +217,7 @@ __global__ __launch_bounds__(256) void dsc_fused_t(const float *__restrict__ in,
             for (int rx = 0; rx < FW; rx++) {
                 const float f = s_dw[(ry * FW + rx) * IC + d];
 #pragma unroll
-                for (int k = 0; k < N1; k++) {
-                    const int px = pxo + k * PPT;
-                    if (px < TPX && x0 + px < g.ow) acc[k] = __builtin_fmaf(f, v[ry][rx][k], acc[k]);
-                }
+                for (int k = 0; k < N1; k++) acc[k] = __builtin_fmaf(f, v[ry][rx][k], acc[k]);   // pixels past the tile / the row: finite values nobody stores
             }
         }
 #pragma unroll
@@ -187,7 +248,13 @@ __global__ __launch_bounds__(256) void dsc_fused_t(const float *__restrict__ in,
         for (int k = 0; k < N2; k++) {
             const int px = pxo + k * QPT;
             if (px < TPX && x0 + px < g.ow) {
-                out[(long)n * g.out_sn + (long)y * g.out_sy + (long)(x0 + px) * g.out_sx + c] = acc[k] > 0.0f ? acc[k] : 0.0f;
+                const float rv = acc[k] > 0.0f ? acc[k] : 0.0f;
+                if (A32) {
+                    char *orow = reinterpret_cast<char *>(out + (long)n * g.out_sn + (long)y * g.out_sy);   // uniform
+                    *reinterpret_cast<float *>(orow + ((dsc_mul24((uint32_t)(x0 + px), (uint32_t)g.out_sx) + (uint32_t)c) << 2)) = rv;
+                } else {
+                    out[(long)n * g.out_sn + (long)y * g.out_sy + (long)(x0 + px) * g.out_sx + c] = rv;
+                }
             }
         }
     }
@@ -297,8 +364,19 @@ extern "C" int depthwise_separable_conv(halide_buffer_t *input, halide_buffer_t 
         timing_note_bytes(4.0 * ((double)g.CI * g.W * g.H * g.N + (double)g.CO * g.ow * g.oh * g.N));
         if (g.FW == 3 && g.FH == 3 && g.IC == 32 && g.CO == 16 && g.CM == 1) {
             constexpr int TPX = 56;   // the driver's MobileNet-v2 layer (process.cpp:13): two tiles per 112-pixel row
-            HLMI_LAUNCH(uc, "dsc_fused", ctx.stream, (dsc_fused_t<3, 3, 32, 16, TPX>), dim3((g.ow + TPX - 1) / TPX, g.oh, g.N), dim3(256), 0,
-                        d_in, d_dw, d_pw, d_b, dev_ptr<float>(output), g);
+            // 32-bit addressing (see the kernel): small non-negative strides, every row / filter spanning less than 2^31 bytes
+            const long lim = 1L << 23;
+            auto ok = [&](long st) { return st >= 0 && st < lim; };
+            const bool a32 = ok(g.in_sx) && ok(g.out_sx) && ok(g.d_s1) && ok(g.d_sx) && ok(g.d_sy) && ok(g.p_s1) && g.W < lim && g.ow < lim &&
+                             (long)g.W * g.in_sx + g.IC < (1L << 29) && (long)g.ow * g.out_sx + g.CO < (1L << 29) &&
+                             (long)g.IC * g.d_s1 + g.FW * g.d_sx + g.FH * g.d_sy < (1L << 29) && (long)g.IC * g.p_s1 + g.CO < (1L << 29) &&
+                             !getenv("HLMI_DSC_NO_A32");
+            if (a32)
+                HLMI_LAUNCH(uc, "dsc_fused", ctx.stream, (dsc_fused_t<3, 3, 32, 16, TPX, true>), dim3((g.ow + TPX - 1) / TPX, g.oh, g.N), dim3(256),
+                            0, d_in, d_dw, d_pw, d_b, dev_ptr<float>(output), g);
+            else
+                HLMI_LAUNCH(uc, "dsc_fused", ctx.stream, (dsc_fused_t<3, 3, 32, 16, TPX, false>), dim3((g.ow + TPX - 1) / TPX, g.oh, g.N), dim3(256),
+                            0, d_in, d_dw, d_pw, d_b, dev_ptr<float>(output), g);
         } else {
             dim3 grid((g.ow + TP - 1) / TP, g.oh, g.N);
             HLMI_LAUNCH(uc, "dsc_fused", ctx.stream, dsc_fused, grid, dim3(256), sh, d_in, d_dw, d_pw, d_b, dev_ptr<float>(output), g);
