@@ -12,6 +12,7 @@
 #include "hlmi_internal.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 using namespace hlmi;
 
@@ -87,6 +88,101 @@ __global__ __launch_bounds__(256) void unsharp_tile(const float *__restrict__ in
     }
 }
 
+// unsharp_tile2 (round 5): the same tile, the same expressions, without the index arithmetic.  unsharp_tile is 1587 VALU
+// instructions per thread of which 156 are quarter-rate integer multiplies and 178 64-bit adds (flat element numbers divided by
+// the window width, `long` row products per element): ~2300 issue slots, in a launch whose workgroups all run in one round — load,
+// compute, store in lock step — so the issue time adds to the memory time.  Here a thread owns a COLUMN: its clamped x offset is
+// computed once, row numbers are wave-uniform (128 threads per row), so every global access is `scalar row pointer + lane byte
+// offset` and LDS addresses are `lane base + constant`; the vertical 7-tap pass walks 16 rows of its column with a sliding window
+// (22 LDS reads for 16 outputs instead of 112).  Rows narrower than 2^29 floats (the host checks; else unsharp_tile).
+__global__ __launch_bounds__(256) void unsharp_tile2(const float *__restrict__ in, float *__restrict__ out, UGeom g) {
+    static_assert(TW == 128 && TH == 32 && 2 * R <= 128, "unsharp_tile2: thread layout");
+    __shared__ float s_gray[GH * GP];
+    __shared__ float s_by[TH * GP];
+    const int tid = threadIdx.x, cl = tid & 127;
+    const int rh = __builtin_amdgcn_readfirstlane(tid >> 7);                // 0 / 1: wave-uniform
+    const int X0 = g.ox0 + blockIdx.x * TW, Y0 = g.oy0 + blockIdx.y * TH;   // absolute origin of the tile
+    auto gray_of = [](float r, float gg, float b) { return (0.299f * r + 0.587f * gg) + 0.114f * b; };
+    auto ld = [](const float *rowp, uint32_t byte_off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(rowp) + byte_off); };
+    {
+        // window column cl (0..127) of rows rh, rh + 2, ...: all 3 x 19 loads requested before the first gray; columns 128..133 below
+        constexpr int NR = GH / 2;
+        static_assert(GH % 2 == 0, "row pairs");
+        const uint32_t xb = (uint32_t)(min(max(X0 - R + cl, g.ix0), g.ix0 + g.W - 1) - g.ix0) << 2;
+        float v[NR][3];
+#pragma unroll
+        for (int it = 0; it < NR; it++) {
+            const int y = min(max(Y0 - R + 2 * it + rh, g.iy0), g.iy0 + g.H - 1) - g.iy0;   // scalar
+            const float *rowp = in + (long)y * g.in_sy;
+            v[it][0] = ld(rowp, xb), v[it][1] = ld(rowp + g.in_sc, xb), v[it][2] = ld(rowp + 2 * g.in_sc, xb);
+        }
+        // the six columns right of them: 6 x 38 elements, one per thread
+        constexpr int NE = (GW - 128) * GH;
+        static_assert(NE <= 256 && GW - 128 == 6, "edge columns");
+        const int ei = min(tid, NE - 1), er = (ei * 10923) >> 16, ec = 128 + (ei - 6 * er);   // ei / 6 for ei < 228
+        float ve[3];
+        {
+            const int x = min(max(X0 - R + ec, g.ix0), g.ix0 + g.W - 1) - g.ix0, y = min(max(Y0 - R + er, g.iy0), g.iy0 + g.H - 1) - g.iy0;
+            const float *p = in + (long)y * g.in_sy + x;
+            ve[0] = p[0], ve[1] = p[g.in_sc], ve[2] = p[2 * g.in_sc];
+        }
+#pragma unroll
+        for (int it = 0; it < NR; it++) s_gray[(2 * it + rh) * GP + cl] = gray_of(v[it][0], v[it][1], v[it][2]);
+        if (tid < NE) s_gray[er * GP + ec] = gray_of(ve[0], ve[1], ve[2]);
+    }
+    __syncthreads();
+    {
+        // blur_y: column cl, rows 16 rh .. 16 rh + 15 from gray rows 16 rh .. 16 rh + 21 of the column; then the six edge columns
+        auto by_of = [&](float m3, float m2, float m1, float c0, float p1, float p2, float p3) {
+            return ((g.k[0] * c0 + g.k[1] * (m1 + p1)) + g.k[2] * (m2 + p2)) + g.k[3] * (m3 + p3);
+        };
+        const float *q = s_gray + (16 * rh) * GP + cl;
+        float w[22];
+#pragma unroll
+        for (int j = 0; j < 22; j++) w[j] = q[j * GP];
+#pragma unroll
+        for (int j = 0; j < 16; j++) s_by[(16 * rh + j) * GP + cl] = by_of(w[j], w[j + 1], w[j + 2], w[j + 3], w[j + 4], w[j + 5], w[j + 6]);
+        constexpr int NE = (GW - 128) * TH;   // 192
+        if (tid < NE) {
+            const int er = (tid * 10923) >> 16, ec = 128 + (tid - 6 * er);
+            const float *e = s_gray + (er + R) * GP + ec;
+            s_by[er * GP + ec] = by_of(e[-3 * GP], e[-2 * GP], e[-GP], e[0], e[GP], e[2 * GP], e[3 * GP]);
+        }
+    }
+    __syncthreads();
+    constexpr int N3 = TW * TH / 256;   // 16 rows per thread: rh, rh + 2, ...
+    const int xo = (int)blockIdx.x * TW + cl;
+    uint32_t xib = (uint32_t)(g.ox0 + min(xo, g.ow - 1) - g.ix0) << 2, xob = (uint32_t)xo << 2;
+    // (a lane offset defined in another basic block reaches the loads as a zero-extended 64-bit value and costs a 64-bit add per
+    // access; redefined in place by an empty asm it stays 32-bit: scalar base + lane offset, no vector arithmetic)
+    auto fresh = [](uint32_t &v) {
+        asm volatile("" : "+v"(v));
+        return v;
+    };
+    float px[N3][3];
+#pragma unroll
+    for (int k = 0; k < N3; k++) {   // the pixels themselves, all requested first (pixels past the region re-read its last one)
+        const int y = min((int)blockIdx.y * TH + 2 * k + rh, g.oh - 1);   // scalar
+        const float *rowp = in + (long)(g.oy0 + y - g.iy0) * g.in_sy;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) px[k][ch] = ld(rowp + ch * g.in_sc, fresh(xib));
+    }
+#pragma unroll
+    for (int k = 0; k < N3; k++) {
+        const int r = 2 * k + rh, y = (int)blockIdx.y * TH + r;
+        if (y >= g.oh) break;             // scalar
+        const float *q = s_by + r * GP + cl + R;
+        const float bx = ((g.k[0] * q[0] + g.k[1] * (q[-1] + q[1])) + g.k[2] * (q[-2] + q[2])) + g.k[3] * (q[-3] + q[3]);
+        const float gr = s_gray[(r + R) * GP + cl + R];
+        const float ratio = (2.0f * gr - bx) / gr;
+        if (xo < g.ow) {
+            float *orow = out + (long)y * g.out_sy;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) *reinterpret_cast<float *>(reinterpret_cast<char *>(orow + ch * g.out_sc) + fresh(xob)) = ratio * px[k][ch];
+        }
+    }
+}
+
 const int64_t e0 = 0, ew = 1536, eh = 2560, ec = 3;
 const int64_t *const est[6] = {&e0, &ew, &e0, &eh, &e0, &ec};
 const halide_type_t ty_f32 = {(decltype(halide_type_t::code))2, 32, 0};
@@ -142,8 +238,13 @@ extern "C" int unsharp(halide_buffer_t *input, halide_buffer_t *output) {
         }
         const float *din = dev_ptr<float>(input) + (long)(0 - input->dim[2].min) * g.in_sc;
         timing_note_bytes(24.0 * ow * oh);
-        HLMI_LAUNCH(uc, "unsharp_tile", ctx.stream, unsharp_tile, dim3((ow + TW - 1) / TW, (oh + TH - 1) / TH), dim3(256), 0, din,
-                    dev_ptr<float>(output), g);
+        const bool narrow = g.W < (1 << 29) && ow < (1 << 29) && !getenv("HLMI_UNSHARP_REF");   // 32-bit lane byte offsets inside a row
+        if (narrow)
+            HLMI_LAUNCH(uc, "unsharp_tile", ctx.stream, unsharp_tile2, dim3((ow + TW - 1) / TW, (oh + TH - 1) / TH), dim3(256), 0, din,
+                        dev_ptr<float>(output), g);
+        else
+            HLMI_LAUNCH(uc, "unsharp_tile", ctx.stream, unsharp_tile, dim3((ow + TW - 1) / TW, (oh + TH - 1) / TH), dim3(256), 0, din,
+                        dev_ptr<float>(output), g);
     }
     mark_output_written(output);
     return 0;
