@@ -545,6 +545,11 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_p(const float *__restrict__ 
 // CU, and SQ_BUSY_CU_CYCLES / 211 busy CUs = 47 k cycles in 25.8 us — the shader clock under this kernel is ~1.8 GHz, not the
 // 2.4 GHz the 2.5 PFLOP/s peak is quoted at; at that clock the matrix pipe is busy 10.1 us, 58 % of the K loop.
 
+// Also measured and not kept (round 5, profiles/NOTES.md): `conv3x3_bf16_w`, the verdict's loader-wave split — twelve waves, eight that
+// run only fragment reads, MFMAs and the tap's barrier and four loaders (one per SIMD) that request, convert and write A and B.
+// Bit-identical (15 tests), 0.0275-0.0279 against 0.0261-0.0262 ms per call: taking the staging out of the MFMA waves' instruction
+// streams does not put the matrix pipe under it either.
+
 const halide_type_t ty_f32 = {(decltype(halide_type_t::code))2, 32, 0};
 // estimates: BASELINE.json configs[4] (N=16, 56x56 output, 128 -> 128 channels)
 const int64_t e0 = 0, e128 = 128, e3 = 3, e58 = 58, e56 = 56, e16 = 16;
