@@ -125,6 +125,18 @@ def test_hip_matches_oracle(hl, oracle, w, h, r_sigma, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("w,h,r_sigma", [(1920, 1080, 0.1), (333, 129, 0.07)])
+def test_hip_64_bit_addressing_path_matches_oracle(hl, oracle, monkeypatch, w, h, r_sigma):
+    """Images / grids beyond the 32-bit bounds the host checks take bg_blur_slice<.., A32 = false>; HLMI_BG_NO_A32=1 selects it at
+    any size (12- and 16-plane grids)."""
+    monkeypatch.setenv("HLMI_BG_NO_A32", "1")
+    inp = _img(w, h, seed=w + h, kind="uniform")
+    got = _run(hl, inp, r_sigma)
+    want = oracle.bilateral_grid(inp, r_sigma)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"{np.count_nonzero(got.view(np.uint32) != want.view(np.uint32))} differ"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mx,my", [(8, 16), (3, -5), (-17, 29)])
 def test_hip_nonzero_min(hl, oracle, mx, my):
     inp = _img(150, 70, seed=9, kind="smooth")

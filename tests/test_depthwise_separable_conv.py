@@ -65,6 +65,17 @@ def test_hip_matches_oracle_bit_for_bit(hl, oracle, n, h, w, ci, co, cm, fw, fh)
 
 
 @pytest.mark.gpu
+def test_hip_64_bit_addressing_path_matches_oracle(hl, oracle, monkeypatch):
+    """Buffers too large for 32-bit offsets take dsc_fused_t<.., A32 = false> (long strides, 64-bit index chains): the same kernel
+    body selected by HLMI_DSC_NO_A32=1 at the driver's MobileNet shape, bit for bit against the oracle like the default path."""
+    monkeypatch.setenv("HLMI_DSC_NO_A32", "1")
+    inp, dw, pw, bias = _data(4, 112, 112, 32, 16, 1, 3, 3, seed=11)
+    got = _run(hl, inp, dw, pw, bias)
+    want = oracle.depthwise_separable_conv(inp, dw, pw, bias)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"{np.count_nonzero(got != want)} of {got.size} differ"
+
+
+@pytest.mark.gpu
 def test_hip_channel_multiplier_two(hl, oracle):
     """CM = 2: depthwise_filter's second dimension is indexed by the INTERMEDIATE channel (generator :57-62), so it
     has IC = 2 CI entries and stride CM."""

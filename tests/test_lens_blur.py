@@ -193,6 +193,18 @@ def test_hip_matches_oracle(hl, oracle, w, h, slices, focus, scale, samples):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("switch", ["HLMI_LB_NO_A32", "HLMI_LB_WCY_LAUNCH"])
+def test_hip_64_bit_pyramid_kernels_and_the_separate_maximum_launch_match_the_oracle(hl, oracle, monkeypatch, switch):
+    """HLMI_LB_NO_A32=1: lb_pull_multi / lb_down with size_t indices (what planes of 2^29 elements and more take);
+    HLMI_LB_WCY_LAUNCH=1: the vertical maximum of the bokeh radius as its own launch (lb_wcy + lb_final<false>)."""
+    monkeypatch.setenv(switch, "1")
+    left, right = _pair(200, 130, seed=77, shift=3)
+    got = _run(hl, left, right, 32, 13, 0.5, 32)
+    want = oracle.lens_blur(left, right, 32, 13, 0.5, 32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"{np.count_nonzero(got != want)} of {got.size} differ"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("unfused", [False, True])
 @pytest.mark.parametrize("w,h,slices,samples", [(530, 70, 32, 8), (300, 41, 33, 5), (258, 36, 64, 4), (515, 19, 31, 3)])
 def test_hip_front_ends_agree_with_the_oracle(hl, oracle, monkeypatch, unfused, w, h, slices, samples):

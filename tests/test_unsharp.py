@@ -76,6 +76,16 @@ def test_hip_matches_oracle_bit_for_bit(hl, oracle, w, h):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("w,h", [(1536, 2560), (333, 201)])
+def test_hip_64_bit_kernel_matches_oracle_bit_for_bit(hl, oracle, monkeypatch, w, h):
+    """Rows of 2^29 floats and more take unsharp_tile (flat element numbers, long row products); HLMI_UNSHARP_REF=1 selects it."""
+    monkeypatch.setenv("HLMI_UNSHARP_REF", "1")
+    inp = _img(w, h, seed=w + h)
+    got, want = _run(hl, inp), oracle.unsharp(inp)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"{np.count_nonzero(got != want)} of {got.size} differ"
+
+
+@pytest.mark.gpu
 def test_hip_crop_with_nonzero_mins(hl, oracle):
     inp = _img(120, 90, seed=3)
     got = _run(hl, inp, out_min=(17, 9), out_size=(64, 40), in_min=(5, 2))
