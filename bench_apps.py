@@ -277,16 +277,17 @@ def run(only=(), samples=5, sink=None, cpu=False, batched=True):
         emit("unsharp", "apps/unsharp sigma=1.5, f32 1536x2560x3", t, W * H, "hbm", 24.0 * W * H / t / 1e9, HBM_PEAK_GBS, "GB/s",
              {"alg_bytes": 24 * W * H, "kernels_ms": kernels(call, o)})
 
-    # ---- max_filter f32 1536x2560x3 (generator estimates).  LDS-bandwidth bound: every output folds 55 footprint rows x 2
-    # ds_read_b32 samples (440 B), and building the doubling slices of a 64x64 tile's 120 staged rows costs another
-    # 15 chunks x 1024 words x 60 B / 4096 outputs = 225 B; ds_read_b32 moves 128 B/clk/CU (MI355X_MICROARCH.md, LDS table).
+    # ---- max_filter f32 1536x2560x3 (generator estimates).  LDS bound: every output folds 55 footprint rows x 2 four-byte
+    # samples (440 B), and the four doubling slices of a 64x64 tile's 120 staged rows are written once each: 15 chunks x 4 x 1024
+    # words x 4 B / 4096 outputs = 60 B (round 5: built in registers; they were read back 2.5 times before: 225 B); priced at
+    # the ds_read_b32 rate of 128 B/clk/CU (MI355X_MICROARCH.md, LDS table).
     if not only or "max_filter" in only:
         W, H = 1536, 2560
         a = hl.Buffer(rng.random((3, H, W), dtype=np.float32))
         o = hl.Buffer(np.zeros((3, H, W), np.float32))
         call = lambda: hl.max_filter(a, o)
         t = timed(call, o, 20)
-        lds_bytes = (440.0 + 225.0) * 3 * W * H
+        lds_bytes = (440.0 + 60.0) * 3 * W * H
         emit("max_filter", "apps/max_filter radius 26, f32 1536x2560x3", t, W * H, "lds", lds_bytes / t / 1e9, 256 * 128 * 2.4, "GB/s",
              {"alg_bytes": 24 * W * H, "hbm_gbs": 24.0 * W * H / t / 1e9, "lds_bytes": lds_bytes, "kernels_ms": kernels(call, o)})
 

@@ -16,7 +16,8 @@
 // The footprint is transposed here — rows of a 55-row window, each a horizontal max of half-width w(|dy|) = max{dx :
 // h(dx) >= |dy|} — so that lanes read consecutive LDS words: a workgroup owns a 64 x 64 output tile, walks the 118 input
 // rows it depends on in chunks of 8, builds the horizontal doubling slices R_s[i] = max of 2^s consecutive pixels in LDS
-// (5 steps), and every thread folds max(R_s[x - w], R_s[x + w + 1 - 2^s]) into its 8 outputs.  110 LDS reads per output;
+// (5 steps; since round 5 in registers, see the kernel), and every thread folds max(R_s[x - w], R_s[x + w + 1 - 2^s]) into its 8
+// outputs.  110 sample reads per output (about 70 LDS instructions after the outputs of a lane share them);
 // HBM: 4 B/px/channel read (+ the tile halo from L2) and 4 written.
 #include "hlmi_internal.h"
 
@@ -111,7 +112,7 @@ __device__ __forceinline__ void mf_fold(float (&acc)[CH], const float *base) {
 }
 
 __global__ __launch_bounds__(NT) void max_filter_tile(const float *__restrict__ in, float *__restrict__ out, MFGeom g) {
-    __shared__ float s_r[NSLOT * CH * SP + SP];      // + one row: the slice builds read up to 16 words past a row's end
+    __shared__ __attribute__((aligned(16))) float s_r[NSLOT * CH * SP];   // slices R_2 .. R_5 in slots 1 .. 4 (slot 0, R_0, stays in registers)
     const int tid = threadIdx.x, cx = tid & 63;
     const float *base = s_r + cx;
     const int rg = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,42 +122,56 @@ __global__ __launch_bounds__(NT) void max_filter_tile(const float *__restrict__ 
 #pragma unroll
     for (int k = 0; k < CH; k++) acc[k] = -INFINITY;
 
-    // slice 0 of a chunk: CH clamped input rows, columns X0 - 26 .. X0 + 101 (116 used); fetched one chunk ahead into
-    // registers so the HBM/L2 latency hides behind the previous chunk's LDS work
-    constexpr int PER = CH * SP / NT;
-    float nxt[PER];
+    // The slices of a chunk are built in REGISTERS (round 5): threads 0..255 each own four adjacent staged pixels of one of the
+    // chunk's CH rows (fetched one chunk ahead, straight from memory: R_0 never goes to LDS), the neighbours' pixels a window needs
+    // come by DPP wave shifts — lane l + 1 holds the next four pixels, and lane 32 the first four of the next row, exactly the
+    // words that follow in the LDS rows the per-entry builds read — and every slice is written once, 16 bytes per lane.  Entries
+    // whose window runs past column 115 (or off the end of a wave) are garbage as before; no fold sample reads them (the samples end
+    // at x + w <= column 115).  One LDS write per entry and slice instead of 4 + 3 x 2 reads and 5 writes per entry: the launch
+    // is bound by LDS instructions, and the builds were 43 % of them; two workgroup barriers per chunk instead of six.
+    static_assert(CH * SP / 4 == 256 && SP == 128, "one quad per thread of the first four waves");
+    const int qr = tid >> 5, qc = tid & 31;            // the thread's row of the chunk and quad of the row (threads 0..255)
+    int qx[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) qx[j] = min(max(X0 - RAD + 4 * qc + j, g.ix0), g.ix0 + g.W - 1) - g.ix0;
+    float nxt[4];
     auto fetch = [&](int chunk) {
+        const int y = min(max(Y0 - VR + chunk * CH + qr, g.iy0), g.iy0 + g.H - 1) - g.iy0;
+        const float *rowp = inc + (long)y * g.in_sy;
 #pragma unroll
-        for (int e = 0; e < PER; e++) {
-            const int i = tid + e * NT, r = i >> 7, c = i & (SP - 1);
-            const int y = min(max(Y0 - VR + chunk * CH + r, g.iy0), g.iy0 + g.H - 1) - g.iy0;
-            const int x = min(max(X0 - RAD + c, g.ix0), g.ix0 + g.W - 1) - g.ix0;
-            nxt[e] = inc[(long)y * g.in_sy + x];
-        }
+        for (int j = 0; j < 4; j++) nxt[j] = rowp[qx[j]];
     };
-    fetch(0);
+    auto nextlane = [](float v) {   // the value lane + 1 holds (0 in lane 63)
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+    };
+    typedef float mf_f4 __attribute__((ext_vector_type(4)));
+    if (tid < 256) fetch(0);
     for (int chunk = 0; chunk < NCHUNK; chunk++) {
+        if (chunk > 0) __syncthreads();   // every wave has folded the previous chunk's slices
+        if (tid < 256) {
+            const float r0[4] = {nxt[0], nxt[1], nxt[2], nxt[3]};
+            if (chunk + 1 < NCHUNK) fetch(chunk + 1);
+            float n[4], r2[4], r3[4], r4[4], r5[4];
 #pragma unroll
-        for (int e = 0; e < PER; e++) s_r[tid + e * NT] = nxt[e];
-        __syncthreads();
-        if (chunk + 1 < NCHUNK) fetch(chunk + 1);
-        // R_2 from R_0 (four neighbours), then R_3, R_4, R_5 by doubling.  Entries whose window runs past column 115 pick
-        // up words of the next row; no fold sample ever reads them (the samples end at x + w <= column 115).
-#pragma unroll
-        for (int e = 0; e < PER; e++) {
-            const float *p = s_r + tid + e * NT;
-            s_r[CH * SP + tid + e * NT] = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3]));
-        }
-        __syncthreads();
-#pragma unroll
-        for (int slot = 2; slot < NSLOT; slot++) {
-#pragma unroll
-            for (int e = 0; e < PER; e++) {
-                const float *p = s_r + (slot - 1) * CH * SP + tid + e * NT;
-                s_r[slot * CH * SP + tid + e * NT] = fmaxf(p[0], p[2 << (slot - 1)]);
+            for (int j = 0; j < 3; j++) n[j] = nextlane(r0[j]);
+            {
+                const float m01 = fmaxf(r0[0], r0[1]), m23 = fmaxf(r0[2], r0[3]), n01 = fmaxf(n[0], n[1]);
+                r2[0] = fmaxf(m01, m23), r2[1] = fmaxf(fmaxf(r0[1], r0[2]), fmaxf(r0[3], n[0]));
+                r2[2] = fmaxf(m23, n01), r2[3] = fmaxf(fmaxf(r0[3], n[0]), fmaxf(n[1], n[2]));
             }
-            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; j++) r3[j] = fmaxf(r2[j], nextlane(r2[j]));                                   // + 4 words
+#pragma unroll
+            for (int j = 0; j < 4; j++) r4[j] = fmaxf(r3[j], nextlane(nextlane(r3[j])));                         // + 8
+#pragma unroll
+            for (int j = 0; j < 4; j++) r5[j] = fmaxf(r4[j], nextlane(nextlane(nextlane(nextlane(r4[j])))));    // + 16
+            float *w = s_r + qr * SP + 4 * qc;
+            *reinterpret_cast<mf_f4 *>(w + 1 * CH * SP) = mf_f4{r2[0], r2[1], r2[2], r2[3]};
+            *reinterpret_cast<mf_f4 *>(w + 2 * CH * SP) = mf_f4{r3[0], r3[1], r3[2], r3[3]};
+            *reinterpret_cast<mf_f4 *>(w + 3 * CH * SP) = mf_f4{r4[0], r4[1], r4[2], r4[3]};
+            *reinterpret_cast<mf_f4 *>(w + 4 * CH * SP) = mf_f4{r5[0], r5[1], r5[2], r5[3]};
         }
+        __syncthreads();   // the slices of the chunk are complete
         switch (chunk - rg) {   // wave-uniform
         case 0: mf_fold<0>(acc, base); break;
         case 1: mf_fold<1>(acc, base); break;
@@ -169,7 +184,6 @@ __global__ __launch_bounds__(NT) void max_filter_tile(const float *__restrict__ 
         default: break;
         }
         static_assert(NFOLD == 8, "one case per chunk of a wave's window");
-        // no barrier here: the next chunk's first write goes to slice 0, which the folds do not read
     }
     const int x = blockIdx.x * TW + cx;
     if (x < g.ow) {
