@@ -28,14 +28,15 @@ using namespace hlmi;
 namespace {
 
 constexpr int RAD = 26, VR = RAD + 1;          // horizontal radius; largest vertical half-height (filter_height(0) = 27)
-constexpr int TW = 64, TY = 64, NT = 512;      // output tile, threads (one wave per 8 output rows)
-constexpr int CH = 8;                          // input rows per chunk = output rows per wave
+constexpr int TW = 64, TY = 64, NT = 256;      // output tile, threads (four waves)
+constexpr int CH = 8;                          // input rows per chunk
+constexpr int ORW = TY / (NT / 64);            // output rows per wave (16: a lane's outputs share more of their sample reads than with 8)
 constexpr int SW = TW + 2 * RAD;               // 116 staged pixels per row
 constexpr int SP = 128;                        // LDS row pitch
 static_assert(SW <= SP, "a staged row fits its pitch");
 constexpr int NSLOT = 5;                       // LDS slices: R_0, R_2, R_3, R_4, R_5 (R_s = max of 2^s consecutive pixels)
 constexpr int NCHUNK = (TY + 2 * VR + CH - 1) / CH;
-constexpr int NFOLD = (CH - 1 + 2 * VR) / CH + 1;   // chunks that hold rows of one wave's 8 + 54 row window
+constexpr int NFOLD = (ORW - 1 + 2 * VR) / CH + 1;  // chunks that hold rows of one wave's 16 + 54 row window
 
 // filter_height(dx) clamped to [0, 27] (generator :47-53)
 constexpr int mf_height(int dx) {
@@ -103,9 +104,9 @@ __device__ __forceinline__ void mf_max3(float &acc, float a, float b) { asm("v_m
 // meets output row k at dy = 8M + r - k - 27.  Everything but the lane's column is a compile-time constant, so each pair
 // is two ds_read_b32 with immediate offsets and one v_max3; pairs outside the footprint do not exist.
 template <int M, int I = 0>
-__device__ __forceinline__ void mf_fold(float (&acc)[CH], const float *base) {
-    if constexpr (I < CH * CH) {
-        constexpr int r = I / CH, k = I % CH, dy = M * CH + r - k - VR, ady = dy < 0 ? -dy : dy;
+__device__ __forceinline__ void mf_fold(float (&acc)[ORW], const float *base) {
+    if constexpr (I < CH * ORW) {
+        constexpr int r = I / ORW, k = I % ORW, dy = M * CH + r - k - VR, ady = dy < 0 ? -dy : dy;
         if constexpr (ady <= VR) mf_max3(acc[k], base[r * SP + mf_offA(ady)], base[r * SP + mf_offB(ady)]);
         mf_fold<M, I + 1>(acc, base);
     }
@@ -118,9 +119,9 @@ __global__ __launch_bounds__(NT) void max_filter_tile(const float *__restrict__ 
     const int rg = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int X0 = g.ox0 + blockIdx.x * TW, Y0 = g.oy0 + g.lit_rows + blockIdx.y * TY;
     const float *inc = in + (long)blockIdx.z * g.in_sc;
-    float acc[CH];
+    float acc[ORW];
 #pragma unroll
-    for (int k = 0; k < CH; k++) acc[k] = -INFINITY;
+    for (int k = 0; k < ORW; k++) acc[k] = -INFINITY;
 
     // The slices of a chunk are built in REGISTERS (round 5): threads 0..255 each own four adjacent staged pixels of one of the
     // chunk's CH rows (fetched one chunk ahead, straight from memory: R_0 never goes to LDS), the neighbours' pixels a window needs
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(NT) void max_filter_tile(const float *__restrict__ 
     // whose window runs past column 115 (or off the end of a wave) are garbage as before; no fold sample reads them (the samples end
     // at x + w <= column 115).  One LDS write per entry and slice instead of 4 + 3 x 2 reads and 5 writes per entry: the launch
     // is bound by LDS instructions, and the builds were 43 % of them; two workgroup barriers per chunk instead of six.
-    static_assert(CH * SP / 4 == 256 && SP == 128, "one quad per thread of the first four waves");
+    static_assert(CH * SP / 4 == NT && SP == 128, "one quad per thread");
     const int qr = tid >> 5, qc = tid & 31;            // the thread's row of the chunk and quad of the row (threads 0..255)
     int qx[4];
 #pragma unroll
@@ -145,10 +146,10 @@ __global__ __launch_bounds__(NT) void max_filter_tile(const float *__restrict__ 
         return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
     };
     typedef float mf_f4 __attribute__((ext_vector_type(4)));
-    if (tid < 256) fetch(0);
+    fetch(0);
     for (int chunk = 0; chunk < NCHUNK; chunk++) {
         if (chunk > 0) __syncthreads();   // every wave has folded the previous chunk's slices
-        if (tid < 256) {
+        {
             const float r0[4] = {nxt[0], nxt[1], nxt[2], nxt[3]};
             if (chunk + 1 < NCHUNK) fetch(chunk + 1);
             float n[4], r2[4], r3[4], r4[4], r5[4];
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(NT) void max_filter_tile(const float *__restrict__ 
             *reinterpret_cast<mf_f4 *>(w + 4 * CH * SP) = mf_f4{r5[0], r5[1], r5[2], r5[3]};
         }
         __syncthreads();   // the slices of the chunk are complete
-        switch (chunk - rg) {   // wave-uniform
+        switch (chunk - rg * (ORW / CH)) {   // wave-uniform
         case 0: mf_fold<0>(acc, base); break;
         case 1: mf_fold<1>(acc, base); break;
         case 2: mf_fold<2>(acc, base); break;
@@ -181,16 +182,17 @@ __global__ __launch_bounds__(NT) void max_filter_tile(const float *__restrict__ 
         case 5: mf_fold<5>(acc, base); break;
         case 6: mf_fold<6>(acc, base); break;
         case 7: mf_fold<7>(acc, base); break;
+        case 8: mf_fold<8>(acc, base); break;
         default: break;
         }
-        static_assert(NFOLD == 8, "one case per chunk of a wave's window");
+        static_assert(NFOLD == 9, "one case per chunk of a wave's window");
     }
     const int x = blockIdx.x * TW + cx;
     if (x < g.ow) {
         float *o = out + (long)blockIdx.z * g.out_sc + x;
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
-            const int y = g.lit_rows + blockIdx.y * TY + rg * CH + k;
+        for (int k = 0; k < ORW; k++) {
+            const int y = g.lit_rows + blockIdx.y * TY + rg * ORW + k;
             if (y < g.oh) o[(long)y * g.out_sy] = acc[k];
         }
     }
