@@ -222,6 +222,7 @@ lib.hlmi_kernel_timing_enable.argtypes = [C.c_int]
 lib.hlmi_kernel_timing_report.argtypes = [C.c_char_p, C.c_size_t]
 lib.hlmi_kernel_timing_report.restype = C.c_size_t
 lib.hlmi_version.restype = C.c_char_p
+lib.hlmi_canon_fma.restype = C.c_int
 
 
 def hip_device_interface() -> int:
@@ -625,3 +626,8 @@ def metadata(name: str) -> halide_filter_metadata_t:
 
 def version() -> str:
     return lib.hlmi_version().decode()
+
+
+def canon_fma() -> int:
+    """1: the library's float kernels contract mul+add pairs into fma (the default build), 0: one rounding per operator."""
+    return int(lib.hlmi_canon_fma())

@@ -34,7 +34,7 @@ struct BGeom {
 };
 
 __device__ __forceinline__ float blur5(float a, float b, float c, float d, float e) {
-    return (((a + b * 4.0f) + c * 6.0f) + d * 4.0f) + e;
+    return dev::mad(d, 4.0f, dev::mad(c, 6.0f, dev::mad(b, 4.0f, a))) + e;   // (((a + b 4) + c 6) + d 4) + e; the products have one use each
 }
 
 __global__ void bg_histogram_blurz(const float *__restrict__ in, long in_sy, BGeom g, float2 *__restrict__ bz) {
@@ -64,7 +64,7 @@ __global__ void bg_histogram_blurz(const float *__restrict__ in, long in_sy, BGe
 #pragma unroll
             for (int rx = 0; rx < S; rx++) {
                 float val = dev::clampf(v[ry][rx], 0.0f, 1.0f);
-                int zi = (int)(val * g.inv_r + 0.5f);
+                int zi = (int)dev::mad(val, g.inv_r, 0.5f);
                 float *h = &hist[(zi * 2) * T + t];
                 h[0] = h[0] + val;
                 h[T] = h[T] + 1.0f;
@@ -123,8 +123,8 @@ __global__ __launch_bounds__(HTH) void bg_histogram_blurz_par(const float *__res
             cv.x = dev::clampf(v.x, 0.0f, 1.0f), cv.y = dev::clampf(v.y, 0.0f, 1.0f);
             cv.z = dev::clampf(v.z, 0.0f, 1.0f), cv.w = dev::clampf(v.w, 0.0f, 1.0f);
             int4 zi;
-            zi.x = (int)(cv.x * g.inv_r + 0.5f), zi.y = (int)(cv.y * g.inv_r + 0.5f);
-            zi.z = (int)(cv.z * g.inv_r + 0.5f), zi.w = (int)(cv.w * g.inv_r + 0.5f);
+            zi.x = (int)dev::mad(cv.x, g.inv_r, 0.5f), zi.y = (int)dev::mad(cv.y, g.inv_r, 0.5f);
+            zi.z = (int)dev::mad(cv.z, g.inv_r, 0.5f), zi.w = (int)dev::mad(cv.w, g.inv_r, 0.5f);
             *reinterpret_cast<float4 *>(&s_val[cc][o]) = cv;
             *reinterpret_cast<int4 *>(&s_zi[cc][o]) = zi;
         }
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(HTH) void bg_histogram_blurz_par(const float *__res
             const int px = dev::clampi(xlo + xx, g.ix0, g.ix1) - g.ix0;
             const float val = dev::clampf(in[(long)py * in_sy + px], 0.0f, 1.0f);
             s_val[cc][ry * S + rx] = val;
-            s_zi[cc][ry * S + rx] = (int)(val * g.inv_r + 0.5f);
+            s_zi[cc][ry * S + rx] = (int)dev::mad(val, g.inv_r, 0.5f);
         }
     }
     for (int i = t; i < HC * (HZ + 4); i += NT) s_h[i / (HZ + 4)][i % (HZ + 4)] = make_float2(0.0f, 0.0f);

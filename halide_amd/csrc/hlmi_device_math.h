@@ -3,7 +3,13 @@
 // These restate, for the GPU, the scalar semantics the reference's code generator gives the same
 // operators on its CPU targets (paths relative to /root/reference); the kernels must be compiled with
 // -ffp-contract=off and without fast-math so that every expression below rounds exactly once per
-// operator, IEEE binary32 (division is the correctly-rounded `/`).
+// operator, IEEE binary32 (division is the correctly-rounded `/`).  A fused multiply-add is issued ONLY where the
+// canonical form asks for one, through the helpers below:
+//   HLMI_CANON_FMA = 1 (default)  a multiply with one use that feeds an add or a subtract is contracted with it, the way LLVM's
+//                                 DAG combiner contracts it under the `contract` flag the reference sets on every float operation
+//                                 (src/CodeGen_LLVM.cpp:483-500, src/CodeGen_Internal.cpp:614): mad / mad2 / msub / mulsub
+//   HLMI_CANON_FMA = 0            no contraction: one rounding per operator (`make VARIANT=_nofma EXTRA=-DHLMI_CANON_FMA=0`)
+// oracle/oracle_common.h defines the two forms for the checker; hlmi_canon_fma() reports which one a library was built for.
 //   integer division / modulo by a positive constant round toward -inf       src/IR.h:145-166
 //   clamp(a, lo, hi) = max(min(a, hi), lo)                                    src/IROperator.h
 //   float lerp(zero, one, w) = zero*(1-w) + one*w                             src/Lerp.cpp:82-83,127-128
@@ -16,8 +22,22 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef HLMI_CANON_FMA
+#define HLMI_CANON_FMA 1
+#endif
+
 namespace hlmi {
 namespace dev {
+
+constexpr bool CANON_FMA = HLMI_CANON_FMA != 0;
+// a * b + c  (fadd(fmul(a, b), c) and fadd(c, fmul(a, b)))
+__device__ __forceinline__ float mad(float a, float b, float c) { return CANON_FMA ? __builtin_fmaf(a, b, c) : a * b + c; }
+// a * b + c * d: the first product is the one contracted
+__device__ __forceinline__ float mad2(float a, float b, float c, float d) { return CANON_FMA ? __builtin_fmaf(a, b, c * d) : a * b + c * d; }
+// c - a * b
+__device__ __forceinline__ float msub(float c, float a, float b) { return CANON_FMA ? __builtin_fmaf(-a, b, c) : c - a * b; }
+// a * b - c
+__device__ __forceinline__ float mulsub(float a, float b, float c) { return CANON_FMA ? __builtin_fmaf(a, b, -c) : a * b - c; }
 
 __device__ __forceinline__ int fdiv2(int a) { return a >> 1; }           // floor(a / 2)
 __device__ __forceinline__ int fmod2(int a) { return a & 1; }            // a mod 2, always in {0,1}
@@ -28,7 +48,7 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) {
     float m = v < hi ? v : hi;
     return m > lo ? m : lo;
 }
-__device__ __forceinline__ float lerpf(float zero, float one, float w) { return zero * (1.0f - w) + one * w; }
+__device__ __forceinline__ float lerpf(float zero, float one, float w) { return mad2(zero, 1.0f - w, one, w); }
 
 template<int N>
 __device__ __forceinline__ float poly(float x, const float (&c)[N]) {
@@ -37,12 +57,12 @@ __device__ __forceinline__ float poly(float x, const float (&c)[N]) {
 #pragma unroll
     for (int i = 2; i < N; i++) {
         if ((i & 1) == 0) {
-            even = (c[i] == 0.0f) ? even * x2 : even * x2 + c[i];
+            even = (c[i] == 0.0f) ? even * x2 : mad(even, x2, c[i]);
         } else {
-            odd = (c[i] == 0.0f) ? odd * x2 : odd * x2 + c[i];
+            odd = (c[i] == 0.0f) ? odd * x2 : mad(odd, x2, c[i]);
         }
     }
-    return ((N & 1) == 0) ? even * x + odd : odd * x + even;
+    return ((N & 1) == 0) ? mad(even, x, odd) : mad(odd, x, even);
 }
 
 __device__ __forceinline__ float halide_exp(float x_full) {
@@ -54,8 +74,8 @@ __device__ __forceinline__ float halide_exp(float x_full) {
     float scaled = x_full * one_over_ln2;
     float k_real = floorf(scaled);
     int k = (int)k_real;
-    float x = x_full - k_real * ln2_part1;
-    x = x - k_real * ln2_part2;
+    float x = msub(x_full, k_real, ln2_part1);
+    x = msub(x, k_real, ln2_part2);
     float result = poly<8>(x, coeff);
     int biased = k + 127;
     result = result * __uint_as_float((uint32_t)biased << 23);
@@ -76,7 +96,7 @@ __device__ __forceinline__ float halide_log(float x_full) {
     int32_t exponent = (iv >> 23) - new_biased;
     float reduced = __uint_as_float((uint32_t)(no_exponent | (new_biased << 23)));
     float result = poly<10>(reduced - 1.0f, coeff);
-    result = result + (float)exponent * __uint_as_float(0x3f317218u);  // logf(2.0)
+    result = mad((float)exponent, __uint_as_float(0x3f317218u) /* logf(2.0) */, result);
     if (use_nan) return __uint_as_float(0x7fc00000u);
     if (use_neg_inf) return __uint_as_float(0xff800000u);
     return result;
@@ -99,7 +119,7 @@ __device__ __forceinline__ float fast_exp(float x_full) {
     const float coeff[6] = {0.01314350012789660196f, 0.03668965196652099192f, 0.16873890085469545053f,
                             0.49970514590562437052f, 1.0f, 1.0f};
     float k_real = floorf(x_full * inv_ln2);
-    float x = x_full - k_real * ln2;
+    float x = msub(x_full, k_real, ln2);
     float result = poly<6>(x, coeff);
     int biased = clampi((int)k_real + 127, 0, 255);
     return result * __uint_as_float((uint32_t)biased << 23);

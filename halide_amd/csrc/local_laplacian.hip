@@ -101,15 +101,16 @@ __device__ __forceinline__ int xcd_block() {
     return (b < (nb8 << 3)) ? (b & 7) * nb8 + (b >> 3) : b;
 }
 
+// `3.0f * (b + c)` has one use and feeds the add: dev::mad contracts the pair under the fma canon (hlmi_device_math.h)
 __device__ __forceinline__ float down4(float a, float b, float c, float d) {
-    return ((a + 3.0f * (b + c)) + d) * 0.125f;  // (:270-271), "/ 8.0f" == "* 0.125f"
+    return (dev::mad(3.0f, b + c, a) + d) * 0.125f;  // (:270-271), "/ 8.0f" == "* 0.125f"
 }
 // The two passes of one level, with the vertical pass's "* 0.125f" deferred: scaling by a power of two commutes
 // with every rounding of the chain (no operand is anywhere near the subnormal range), so
 //   down4(down4(..), ..) == down4_tail(down4_raw(..), ..)   bit for bit, one multiply less per vertical result.
-__device__ __forceinline__ float down4_raw(float a, float b, float c, float d) { return (a + 3.0f * (b + c)) + d; }
+__device__ __forceinline__ float down4_raw(float a, float b, float c, float d) { return dev::mad(3.0f, b + c, a) + d; }
 __device__ __forceinline__ float down4_tail(float a, float b, float c, float d) {
-    return ((a + 3.0f * (b + c)) + d) * 0.015625f;
+    return (dev::mad(3.0f, b + c, a) + d) * 0.015625f;
 }
 
 // gray = 0.299f * floating(0) + 0.587f * floating(1) + 0.114f * floating(2), floating = u16 / 65535.0f (:32, :36), in the
@@ -121,7 +122,7 @@ __device__ __forceinline__ float gray_from(uint16_t r, uint16_t g, uint16_t b) {
     constexpr float s = (float)(1.0 / 65535.0);
     constexpr float C0 = (float)((double)s * (double)0.299f), C1 = (float)((double)s * (double)0.587f),
                     C2 = (float)((double)s * (double)0.114f);
-    return ((float)r * C0 + (float)g * C1) + (float)b * C2;
+    return dev::mad((float)b, C2, dev::mad2((float)r, C0, (float)g, C1));   // (r C0 + g C1) + b C2
 }
 __device__ __forceinline__ int idx_of(float gray, float Km1, int half) {
     return dev::clampi((int)((gray * Km1) * 256.0f), 0, half);  // (:42-43)
@@ -130,7 +131,7 @@ __device__ __forceinline__ int idx_of(float gray, float Km1, int half) {
 // B1: beta == 1.0f exactly, and 1.0f * x == x bit for bit, so the multiply is skipped
 template<bool B1 = false>
 __device__ __forceinline__ float g0_val(float gray, float level, float beta, float l) {
-    return B1 ? ((gray - level) + level) + l : (beta * (gray - level) + level) + l;
+    return B1 ? ((gray - level) + level) + l : dev::mad(beta, gray - level, level) + l;
 }
 
 // ---- lane <-> lane exchange: DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1; gfx9-family only,
@@ -597,12 +598,12 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry 
             float t[8];
 #pragma unroll
             for (int i = 0; i < 4; i++) t[i] = r0.g[i] - L, t[4 + i] = r1.g[i] - L;
-            if (!B1) {
+            if (!B1 && !dev::CANON_FMA) {
 #pragma unroll
                 for (int i = 0; i < 8; i++) t[i] = p.beta * t[i];
             }
 #pragma unroll
-            for (int i = 0; i < 8; i++) t[i] = t[i] + L;
+            for (int i = 0; i < 8; i++) t[i] = (!B1 && dev::CANON_FMA) ? __builtin_fmaf(p.beta, t[i], L) : t[i] + L;
 #pragma unroll
             for (int i = 0; i < 4; i++) v0[i] = t[i] + lv[i], v1[i] = t[4 + i] + lv[4 + i];
         } else {
@@ -614,10 +615,12 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry 
         float t[4];   // down4_raw, column-parallel
 #pragma unroll
         for (int i = 0; i < 4; i++) t[i] = ib[i] + c[i];
+        if (!dev::CANON_FMA) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) t[i] = 3.0f * t[i];
+            for (int i = 0; i < 4; i++) t[i] = 3.0f * t[i];
+        }
 #pragma unroll
-        for (int i = 0; i < 4; i++) t[i] = ia[i] + t[i];
+        for (int i = 0; i < 4; i++) t[i] = dev::CANON_FMA ? __builtin_fmaf(3.0f, t[i], ia[i]) : ia[i] + t[i];
 #pragma unroll
         for (int i = 0; i < 4; i++) o[i] = t[i] + d[i];
     };
@@ -665,8 +668,8 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry 
             const float2 c = res[k];
             if (PH == 0) {
                 float2 pc;
-                pc.x = sa.x + 3.0f * (sb.x + c.x);
-                pc.y = sa.y + 3.0f * (sb.y + c.y);
+                pc.x = dev::mad(3.0f, sb.x + c.x, sa.x);
+                pc.y = dev::mad(3.0f, sb.y + c.y, sa.y);
                 st2[(2 * k + 1) * 64] = pc;
                 st2[(2 * k) * 64] = c;
             } else {
@@ -754,7 +757,7 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01f(D01Args p, Geometry 
         for (int k = 0; k <= KCH; k++) {
             const float2 sa = st2[(2 * k) * 64], sb = st2[(2 * k + 1) * 64];
             const float2 c = pub_next[k * 64], d = pub_next[(KCH + 1 + k) * 64];
-            const float rx = (sa.x + 3.0f * (sb.x + c.x)) + d.x, ry = (sa.y + 3.0f * (sb.y + c.y)) + d.y;
+            const float rx = dev::mad(3.0f, sb.x + c.x, sa.x) + d.x, ry = dev::mad(3.0f, sb.y + c.y, sa.y) + d.y;
             float o;
             if (ODD1) {
                 const float nx = lane_next(rx), ny = lane_next(ry);
@@ -809,6 +812,9 @@ struct D01EArgs {
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 f2s(float v) { return f2{v, v}; }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+// dev::mad / dev::mad2 on column pairs: a * b + c and a * b + c * d in the canonical form the library is built for
+__device__ __forceinline__ f2 mad_2(f2 a, f2 b, f2 c) { return dev::CANON_FMA ? fma2(a, b, c) : a * b + c; }
+__device__ __forceinline__ f2 mad2_2(f2 a, f2 b, f2 c, f2 d) { return dev::CANON_FMA ? fma2(a, b, c * d) : a * b + c * d; }
 
 template<bool ODD0, bool ODD1, bool B1, bool EXCH, bool NT>
 __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometry gm, Levels lev) {
@@ -897,7 +903,7 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const f2 fr = {(float)rr[h], (float)rr[h + 2]}, fg = {(float)gg[h], (float)gg[h + 2]}, fb = {(float)bb[h], (float)bb[h + 2]};
-            o.g[h] = (fr * C0 + fg * C1) + fb * C2;
+            o.g[h] = mad_2(fb, f2s(C2), mad2_2(fr, f2s(C0), fg, f2s(C1)));   // gray_from, column pairs
         }
         if (EDGE) {
             const float g0 = o.g[0].x, g1v = o.g[1].x, g2v = o.g[0].y, g3 = o.g[1].y;
@@ -925,12 +931,12 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         if (kk < KCH) {
             const f2 L = f2s(level[kk < KCH ? kk : 0]);
             f2 t[4] = {r0.g[0] - L, r0.g[1] - L, r1.g[0] - L, r1.g[1] - L};
-            if (!B1) {
+            if (!B1 && !dev::CANON_FMA) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) t[i] = p.beta * t[i];
             }
 #pragma unroll
-            for (int i = 0; i < 4; i++) t[i] = t[i] + L;
+            for (int i = 0; i < 4; i++) t[i] = (!B1 && dev::CANON_FMA) ? fma2(f2s(p.beta), t[i], L) : t[i] + L;
             v0[0] = t[0] + lv[0], v0[1] = t[1] + lv[1], v1[0] = t[2] + lv[2], v1[1] = t[3] + lv[3];
         } else {
             v0[0] = r0.g[0], v0[1] = r0.g[1], v1[0] = r1.g[0], v1[1] = r1.g[1];
@@ -938,8 +944,12 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
     };
     auto vpass = [&](const f2 (&ia)[2], const f2 (&ib)[2], const f2 (&c)[2], const f2 (&d)[2], f2 (&o)[2]) {
         f2 t[2] = {ib[0] + c[0], ib[1] + c[1]};   // down4_raw, column-parallel
-        t[0] = 3.0f * t[0], t[1] = 3.0f * t[1];
-        t[0] = ia[0] + t[0], t[1] = ia[1] + t[1];
+        if (dev::CANON_FMA) {
+            t[0] = fma2(f2s(3.0f), t[0], ia[0]), t[1] = fma2(f2s(3.0f), t[1], ia[1]);
+        } else {
+            t[0] = 3.0f * t[0], t[1] = 3.0f * t[1];
+            t[0] = ia[0] + t[0], t[1] = ia[1] + t[1];
+        }
         o[0] = t[0] + d[0], o[1] = t[1] + d[1];
     };
     // horizontal 1-3-3-1 (hpair<ODD0>) on the paired layout: dy[0] = columns (0, 2), dy[1] = columns (1, 3)
@@ -987,33 +997,46 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         if (AFTER == 2) asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(g.lut), "+v"(g.qa), "+v"(g.qb), "+v"(g.ta), "+v"(g.tb));
         if (AFTER == 3) asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(g.lut), "+v"(g.qa), "+v"(g.qb), "+v"(g.ta), "+v"(g.tb));
     };
-    auto em_arith = [&](const Row &n, int i, const EmPix &g) {
+    // YODD: the level-0 row is odd (2T - 1) — its `zero` operand of the vertical lerp is the row weighted 1/4.
+    auto em_arith = [&](const Row &n, int i, const EmPix &g, auto yodd_tag) {
+        constexpr bool YODD = decltype(yodd_tag)::value;
         const bool xodd = ODD0 ? (i & 1) == 0 : (i & 1) == 1;
-        // even x: lerp(f[c], f[c-1], 1/4) = f[c-1]/4 + 3 f[c]/4; odd x: lerp(f[c+1], f[c], 3/4) = f[c+1]/4 + 3 f[c]/4
-        auto hl = [&](f2 fa, f2 fb) { return xodd ? fma2(fb, f2s(0.25f), fa * 0.75f) : fma2(fa, f2s(0.25f), fb * 0.75f); };
-        auto vl = [](f2 uq, f2 ut) { return fma2(uq, f2s(0.25f), ut * 0.75f); };
+        // even x: lerp(f[c], f[c-1], 1/4) = f[c-1]/4 + 3 f[c]/4; odd x: lerp(f[c+1], f[c], 3/4) = f[c+1]/4 + 3 f[c]/4.  lerp(zero, one, w) =
+        // zero (1 - w) + one w (:276-282, src/Lerp.cpp:127-128).  Canon 0: the exact quarter product folded into an fma changes
+        // nothing; fma canon: the product with `zero` is the contracted one — the 3/4 one at an even coordinate, where the quarter
+        // product of `one` is exact anyway, the 1/4 one at an odd coordinate (same instruction as canon 0 there).
+        auto hl = [&](f2 fa, f2 fb) {
+            if (xodd) return fma2(fb, f2s(0.25f), fa * 0.75f);
+            return dev::CANON_FMA ? fma2(fb, f2s(0.75f), fa * 0.25f) : fma2(fa, f2s(0.25f), fb * 0.75f);
+        };
+        auto vl = [](f2 uq, f2 ut) {
+            return (dev::CANON_FMA && !YODD) ? fma2(ut, f2s(0.75f), uq * 0.25f) : fma2(uq, f2s(0.25f), ut * 0.75f);
+        };
         const float gr = n.g[i & 1][i >> 1];
-        const float lf = gr * gm.Km1 - g.lif;
+        const float lf = gr * gm.Km1 - g.lif;   // `level` has two uses (:64-66): not contracted in either form
         const f2 lev = f2{g.lif, g.lif + 1.0f} * gm.inv_Km1;
         const f2 u = vl(hl(g.qa, g.qb), hl(g.ta, g.tb));
         const f2 g2 = f2s(gr);
-        const f2 l = (B1 ? ((g2 - lev) + lev) + g.lut : (p.beta * (g2 - lev) + lev) + g.lut) - u;   // g0_val of planes li, li + 1
+        const f2 l = (B1 ? ((g2 - lev) + lev) + g.lut : mad_2(f2s(p.beta), g2 - lev, lev) + g.lut) - u;   // g0_val of planes li, li + 1
+        if (dev::CANON_FMA) return __builtin_fmaf(1.0f - lf, l.x, lf * l.y);
         const f2 m = f2{1.0f - lf, lf} * l;
         return m.x + m.y;
     };
+    constexpr std::true_type row_odd{};
+    constexpr std::false_type row_even{};
     constexpr std::integral_constant<int, 0> after0{};
     constexpr std::integral_constant<int, 1> after1{};
     constexpr std::integral_constant<int, 2> after2{};
     constexpr std::integral_constant<int, 3> after3{};
     // one row on its own (the seam pair after the walk): all four pixels requested, then finished in order
-    auto emit_row = [&](const Row &n, const f2 *rq, const f2 *rt, float (&r)[4]) {
+    auto emit_row = [&](const Row &n, const f2 *rq, const f2 *rt, float (&r)[4], auto yodd_tag) {
         EmPix g[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) em_gather(n, i, rq, rt, g[i]);
-        em_wait(g[0], after3), r[0] = em_arith(n, 0, g[0]);
-        em_wait(g[1], after2), r[1] = em_arith(n, 1, g[1]);
-        em_wait(g[2], after1), r[2] = em_arith(n, 2, g[2]);
-        em_wait(g[3], after0), r[3] = em_arith(n, 3, g[3]);
+        em_wait(g[0], after3), r[0] = em_arith(n, 0, g[0], yodd_tag);
+        em_wait(g[1], after2), r[1] = em_arith(n, 1, g[1], yodd_tag);
+        em_wait(g[2], after1), r[2] = em_arith(n, 2, g[2], yodd_tag);
+        em_wait(g[3], after0), r[3] = em_arith(n, 3, g[3], yodd_tag);
     };
     auto emit_store = [&](int y, const float (&r)[4]) {
         if (em_ok && y >= pe.oy0 && y < pe.oy0 + pe.oh) {
@@ -1065,7 +1088,7 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         auto level2 = [&](int k) {
             const f2 c = res[k];
             if (PH == 0) {
-                pcr[k] = sa + 3.0f * (sb + c);
+                pcr[k] = mad_2(f2s(3.0f), sb + c, sa);
                 st2[(2 * k) * 64] = c;
             } else {
                 const f2 r = pcr[k] + c;   // down4_raw of the lane's two level-1 columns
@@ -1141,26 +1164,26 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
             // row 2T - 1's pixels are finished one by one while row 2T's are requested into the registers they free: twenty
             // gathers stay in flight from the first request to the last pixel
             EmPix fg[4];
-            em_wait(eg[0], after3), eo[0] = em_arith(n0, 0, eg[0]);
+            em_wait(eg[0], after3), eo[0] = em_arith(n0, 0, eg[0], row_odd);
             __builtin_amdgcn_sched_barrier(0);
             em_gather(n1, 0, rowP, rowT, fg[0]);   // even row 2T
             __builtin_amdgcn_sched_barrier(0);
-            em_wait(eg[1], after3), eo[1] = em_arith(n0, 1, eg[1]);
+            em_wait(eg[1], after3), eo[1] = em_arith(n0, 1, eg[1], row_odd);
             __builtin_amdgcn_sched_barrier(0);
             em_gather(n1, 1, rowP, rowT, fg[1]);
             __builtin_amdgcn_sched_barrier(0);
-            em_wait(eg[2], after3), eo[2] = em_arith(n0, 2, eg[2]);
+            em_wait(eg[2], after3), eo[2] = em_arith(n0, 2, eg[2], row_odd);
             __builtin_amdgcn_sched_barrier(0);
             em_gather(n1, 2, rowP, rowT, fg[2]);
             __builtin_amdgcn_sched_barrier(0);
-            em_wait(eg[3], after3), eo[3] = em_arith(n0, 3, eg[3]);
+            em_wait(eg[3], after3), eo[3] = em_arith(n0, 3, eg[3], row_odd);
             __builtin_amdgcn_sched_barrier(0);
             em_gather(n1, 3, rowP, rowT, fg[3]);
             __builtin_amdgcn_sched_barrier(0);
-            em_wait(fg[0], after3), ee[0] = em_arith(n1, 0, fg[0]);
-            em_wait(fg[1], after2), ee[1] = em_arith(n1, 1, fg[1]);
-            em_wait(fg[2], after1), ee[2] = em_arith(n1, 2, fg[2]);
-            em_wait(fg[3], after0), ee[3] = em_arith(n1, 3, fg[3]);
+            em_wait(fg[0], after3), ee[0] = em_arith(n1, 0, fg[0], row_even);
+            em_wait(fg[1], after2), ee[1] = em_arith(n1, 1, fg[1], row_even);
+            em_wait(fg[2], after1), ee[2] = em_arith(n1, 2, fg[2], row_even);
+            em_wait(fg[3], after0), ee[3] = em_arith(n1, 3, fg[3], row_even);
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -1211,7 +1234,7 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         for (int k = 0; k <= KCH; k++) {
             const f2 sa = st2[(2 * k) * 64], sb = st2[(2 * k + 1) * 64];
             const f2 c = pub_next[(2 * k) * 64], d = pub_next[(2 * k + 1) * 64];
-            const f2 r = (sa + 3.0f * (sb + c)) + d;
+            const f2 r = mad_2(f2s(3.0f), sb + c, sa) + d;
             float o;
             if (ODD1) {
                 const float nx = lane_next(r.x), ny = lane_next(r.y);
@@ -1226,8 +1249,8 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         // (published)
         {
             float eo[4], ee[4];
-            emit_row(p2, pub_next, st2 + 64, eo);
-            emit_row(p3, st2 + 64, pub_next, ee);
+            emit_row(p2, pub_next, st2 + 64, eo, row_odd);
+            emit_row(p3, st2 + 64, pub_next, ee, row_even);
             emit_store(4 * B + 1, eo);
             emit_store(4 * B + 2, ee);
         }
@@ -1365,8 +1388,8 @@ __global__ __launch_bounds__(256) void ll_down_strip2(Strip2Args p) {
         const float2 res = hpair<ODD0>(dy);
         if (T >= Ts0 && T <= Ts1 && st1_ok) *reinterpret_cast<float2 *>(d1 + (size_t)(T - p.loy1) * p.ws1) = res;
         if ((t & 1) == 0) {      // third row of a level-(j+2) window (the first step's window is incomplete: its result is dropped)
-            pc.x = s0.x + 3.0f * (s1.x + res.x);
-            pc.y = s0.y + 3.0f * (s1.y + res.y);
+            pc.x = dev::mad(3.0f, s1.x + res.x, s0.x);
+            pc.y = dev::mad(3.0f, s1.y + res.y, s0.y);
             s0 = res;
         } else {                 // fourth row: completes level-(j+2) row (T - 2) / 2
             const float rx = pc.x + res.x, ry = pc.y + res.y;   // down4_raw of the lane's two level-(j+1) columns
@@ -1415,7 +1438,7 @@ __device__ __forceinline__ float top_value(const float *__restrict__ g, size_t p
     float level = g[(size_t)K * ps + o] * Km1;
     int li = dev::clampi((int)level, 0, K - 2);
     float lf = level - (float)li;
-    return (1.0f - lf) * g[(size_t)li * ps + o] + lf * g[(size_t)(li + 1) * ps + o];
+    return dev::mad2(1.0f - lf, g[(size_t)li * ps + o], lf, g[(size_t)(li + 1) * ps + o]);
 }
 // outLPyramid[j](X,Y), 0 < j < J-1 (:50-54, :63-72): g = level j (origin lox/loy), gc = level j+1
 // SEL: level j was stored by ll_down01e — plane 0 = gPyramid[j](., ., li), plane 1 = gPyramid[j](., ., li + 1) for the pixel's own
@@ -1430,7 +1453,7 @@ __device__ __forceinline__ float outl_value(const float *__restrict__ g, int ws,
     float lf = level - (float)li;
     float l0 = g[(SEL ? 0 : (size_t)li * ps) + o] - up_at(gc + (size_t)li * cps, clox, cloy, cws, X, Y);
     float l1 = g[(SEL ? ps : (size_t)(li + 1) * ps) + o] - up_at(gc + (size_t)(li + 1) * cps, clox, cloy, cws, X, Y);
-    return (1.0f - lf) * l0 + lf * l1;
+    return dev::mad2(1.0f - lf, l0, lf, l1);
 }
 
 __global__ void ll_top(const float *__restrict__ g, int ws, size_t ps, int lox, int loy, int rx0, int ry0, int rw,
@@ -1651,11 +1674,11 @@ __device__ __forceinline__ void up_multi_tile(const CoarseArgs &a, int ntx, int 
     for (int d = 0; d <= TOP; d++) {
         float v;
         if (d == TOP) {
-            v = (1.0f - lf[d]) * g0[d] + lf[d] * g1[d];
+            v = dev::mad2(1.0f - lf[d], g0[d], lf[d], g1[d]);
         } else {
             const float l0 = g0[d] - up_from(t0[d], eX[d], eY[d]);
             const float l1 = g1[d] - up_from(t1[d], eX[d], eY[d]);
-            v = (1.0f - lf[d]) * l0 + lf[d] * l1;
+            v = dev::mad2(1.0f - lf[d], l0, lf[d], l1);
         }
         if (act[d]) (tl + um_off(d))[(eY[d] - reg[d].y0) * um_win(d) + (eX[d] - reg[d].x0)] = v;
     }
@@ -1785,7 +1808,7 @@ __global__ __launch_bounds__(256) void ll_up0(Up0Args p, Geometry gm) {
             const float *gp = p.g1 + (size_t)li * p.ps1;
             float l0 = g0_val(gray, lev0, p.beta, lp[0]) - up_at(gp, p.lox1, p.loy1, p.ws1, Xi, Y);
             float l1 = g0_val(gray, lev1, p.beta, lp[-256]) - up_at(gp + p.ps1, p.lox1, p.loy1, p.ws1, Xi, Y);
-            float outL = (1.0f - lf) * l0 + lf * l1;
+            float outL = dev::mad2(1.0f - lf, l0, lf, l1);
             float og = (up_at(p.out1, p.lox1, p.loy1, p.ws1, Xi, Y) + outL) + 0.01f;
             float gr = gray + 0.01f;
 #pragma unroll
@@ -1907,7 +1930,10 @@ __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
     const uint32_t psb = (uint32_t)p.ps1 * 4u;
     // lerp(zero, one, w) = zero*(1-w) + one*w with w in {1/4, 3/4}: the product by 1/4 is exact, so adding it with
     // an fma rounds exactly like the separate multiply and add of the definition (one instruction less per lerp)
-    auto hl0 = [](float rm, float r0) { return __builtin_fmaf(rm, 0.25f, r0 * 0.75f); };  // lerp(f[c], f[c-1], 1/4): X even
+    // fma canon: the contracted product is the one with `zero` (dev::mad2) — f[c] * 3/4 for even X, f[c+1] * 1/4 for odd X
+    auto hl0 = [](float rm, float r0) {   // lerp(f[c], f[c-1], 1/4): X even
+        return dev::CANON_FMA ? __builtin_fmaf(r0, 0.75f, rm * 0.25f) : __builtin_fmaf(rm, 0.25f, r0 * 0.75f);
+    };
     auto hl1 = [](float r0, float rp) { return __builtin_fmaf(rp, 0.25f, r0 * 0.75f); };  // lerp(f[c+1], f[c], 3/4): X odd
     // The row loop is software-pipelined over three rows: a row needs two dependent round trips to memory (its pixels
     // -> which planes to gather from -> the gathers), ~2 us per row if taken one after the other, and a wave walks RU
@@ -1923,6 +1949,7 @@ __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
         float gray[2], lf[2], lev0[2], lev1[2];
         float lut0[2], lut1[2];   // remap values of the two planes
         F3U OA, OB;               // outGPyramid[1] rows (q: weight 1/4, t: weight 3/4), columns c-1, c, c+1
+        float wq, wt;             // fma canon: OA / A* are row ya (`zero`), OB / B* row yb (`one`); their weights
     };
     struct Gath {
         F2U A0[2], B0[2], A1[2], Bp[2];
@@ -1931,14 +1958,19 @@ __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
         const uint16_t *irow = p.in + (long)(p.oy0 + min(y, y1 - 1) - gm.iy0) * p.in_sy;
         f.c0 = ld_frame2(irow + p.gco[0], inb), f.c1 = ld_frame2(irow + p.gco[1], inb), f.c2 = ld_frame2(irow + p.gco[2], inb);
     };
-    auto vl = [](float uq, float ut) { return __builtin_fmaf(uq, 0.25f, ut * 0.75f); };
+    // canon 0: (uq, ut) = the rows weighted 1/4 and 3/4; fma canon: (uq, ut) = (`zero` = row ya, `one` = row yb) with the row's weights
+    // wq = 1 - wy, wt = wy (wave-uniform): lerp(ua, ub, wy) = fma(ua, 1 - wy, ub * wy)
+    auto vl = [](float uq, float ut, float wq, float wt) {
+        return dev::CANON_FMA ? __builtin_fmaf(uq, wq, ut * wt) : __builtin_fmaf(uq, 0.25f, ut * 0.75f);
+    };
     auto stage1 = [&](int yy, const Frame &f, Prep &s, Gath &g) {
         const int Y = p.oy0 + min(yy, y1 - 1);
         const int ya = dev::fdiv2(Y + 1) - p.loy1, yb = dev::fdiv2(Y - 1) - p.loy1;
         const bool yodd = dev::fmod2(Y) != 0;  // wave-uniform
         // lerp(ua, ub, wy) (:280), ua from coarse row ya, ub from yb: wy = 3/4 for odd Y, 1/4 for even Y.  The row
         // whose weight is 1/4 (an exact product) is called q, the other t — a scalar choice of row pointers.
-        const int yq = yodd ? ya : yb, yt = yodd ? yb : ya;
+        const int yq = (dev::CANON_FMA || yodd) ? ya : yb, yt = (dev::CANON_FMA || yodd) ? yb : ya;
+        s.wq = yodd ? 0.25f : 0.75f, s.wt = yodd ? 0.75f : 0.25f;
         const float *ga = p.g1 + (size_t)yq * p.ws1, *gb = p.g1 + (size_t)yt * p.ws1;
         const uint16_t ch[3][2] = {{f.c0.x, f.c0.y}, {f.c1.x, f.c1.y}, {f.c2.x, f.c2.y}};
 #pragma unroll
@@ -1970,19 +2002,19 @@ __global__ __launch_bounds__(256) void ll_up0f(Up0Args p, Geometry gm) {
         }
     };
     auto stage2 = [&](int y, const Prep &s, const Gath &g) {
-        const float uo[2] = {vl(hl0(s.OA.x, s.OA.y), hl0(s.OB.x, s.OB.y)), vl(hl1(s.OA.y, s.OA.z), hl1(s.OB.y, s.OB.z))};
+        const float uo[2] = {vl(hl0(s.OA.x, s.OA.y), hl0(s.OB.x, s.OB.y), s.wq, s.wt), vl(hl1(s.OA.y, s.OA.z), hl1(s.OB.y, s.OB.z), s.wq, s.wt)};
         uint16_t res[3][2];
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             float u0, u1;
             if (i == 0) {
-                u0 = vl(hl0(g.A0[i].x, g.A0[i].y), hl0(g.B0[i].x, g.B0[i].y)), u1 = vl(hl0(g.A1[i].x, g.A1[i].y), hl0(g.Bp[i].x, g.Bp[i].y));
+                u0 = vl(hl0(g.A0[i].x, g.A0[i].y), hl0(g.B0[i].x, g.B0[i].y), s.wq, s.wt), u1 = vl(hl0(g.A1[i].x, g.A1[i].y), hl0(g.Bp[i].x, g.Bp[i].y), s.wq, s.wt);
             } else {
-                u0 = vl(hl1(g.A0[i].x, g.A0[i].y), hl1(g.B0[i].x, g.B0[i].y)), u1 = vl(hl1(g.A1[i].x, g.A1[i].y), hl1(g.Bp[i].x, g.Bp[i].y));
+                u0 = vl(hl1(g.A0[i].x, g.A0[i].y), hl1(g.B0[i].x, g.B0[i].y), s.wq, s.wt), u1 = vl(hl1(g.A1[i].x, g.A1[i].y), hl1(g.Bp[i].x, g.Bp[i].y), s.wq, s.wt);
             }
             const float l0 = g0_val<B1>(s.gray[i], s.lev0[i], p.beta, s.lut0[i]) - u0;
             const float l1 = g0_val<B1>(s.gray[i], s.lev1[i], p.beta, s.lut1[i]) - u1;
-            const float outL = (1.0f - s.lf[i]) * l0 + s.lf[i] * l1;
+            const float outL = dev::mad2(1.0f - s.lf[i], l0, s.lf[i], l1);
             const float og = (uo[i] + outL) + 0.01f;
             const float gr = s.gray[i] + 0.01f;
             const float n[3] = {s.chf[0][i] * og, s.chf[1][i] * og, s.chf[2][i] * og};
@@ -2135,7 +2167,7 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
             for (int i = 0; i < CH; i++) {
                 // outGPyramid[2] = upsample(outGPyramid[3]) + outLPyramid[2]   (:76-79), exactly as ll_up computes it
                 const float l0 = ga[i] - up_from(t0[i], X2[i], Y2[i]), l1 = gb[i] - up_from(t1[i], X2[i], Y2[i]);
-                const float outL = (1.0f - lf[i]) * l0 + lf[i] * l1;
+                const float outL = dev::mad2(1.0f - lf[i], l0, lf[i], l1);
                 if (ok[i]) s_out2[ti[i]] = up_from(o3[i], X2[i], Y2[i]) + outL;
             }
         }
@@ -2178,7 +2210,7 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
             for (int i = 0; i < CH; i++) {
                 // outGPyramid[1] = upsample(outGPyramid[2]) + outLPyramid[1]   (:76-79), exactly as ll_up computes it
                 const float l0 = ga[i] - up_from(t0[i], cx[i], cy[i]), l1 = gb[i] - up_from(t1[i], cx[i], cy[i]);
-                const float outL = (1.0f - lf[i]) * l0 + lf[i] * l1;
+                const float outL = dev::mad2(1.0f - lf[i], l0, lf[i], l1);
                 float up2;
                 if (ph.fuse2) {   // up_at on the LDS tile: the same taps, weights and lerps
                     const float *q = s_out2 + mul24((uint32_t)(dev::fdiv2(cy[i] - 1) - c2y0), U0H_T2) + (uint32_t)(dev::fdiv2(cx[i] - 1) - c2x0);
@@ -2200,9 +2232,14 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
     const int y1 = min(y0 + p.RU, p.oh);
     const int X = p.ox0 + x;                                              // even
     uint32_t inb = (uint32_t)(X - gm.ix0) * 2u, outb = (uint32_t)x * 2u, l0b = (uint32_t)(X - gm.ix0) * 4u;
-    auto hl0 = [](float rm, float r0) { return __builtin_fmaf(rm, 0.25f, r0 * 0.75f); };  // lerp(f[c], f[c-1], 1/4): X even
+    // fma canon: the contracted product is the one with `zero` (dev::mad2) — f[c] * 3/4 for even X, f[c+1] * 1/4 for odd X
+    auto hl0 = [](float rm, float r0) {   // lerp(f[c], f[c-1], 1/4): X even
+        return dev::CANON_FMA ? __builtin_fmaf(r0, 0.75f, rm * 0.25f) : __builtin_fmaf(rm, 0.25f, r0 * 0.75f);
+    };
     auto hl1 = [](float r0, float rp) { return __builtin_fmaf(rp, 0.25f, r0 * 0.75f); };  // lerp(f[c+1], f[c], 3/4): X odd
-    auto vl = [](float uq, float ut) { return __builtin_fmaf(uq, 0.25f, ut * 0.75f); };
+    auto vl = [](float uq, float ut, float wq, float wt) {   // as in ll_up0f
+        return dev::CANON_FMA ? __builtin_fmaf(uq, wq, ut * wt) : __builtin_fmaf(uq, 0.25f, ut * 0.75f);
+    };
     struct Frame {
         ushort2 c0, c1, c2;
         float2 l0;
@@ -2229,11 +2266,13 @@ __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
         const int Y = p.oy0 + min(y, y1 - 1);
         const int ya = dev::fdiv2(Y + 1), yb = dev::fdiv2(Y - 1);
         const bool yodd = dev::fmod2(Y) != 0;  // wave-uniform
-        const int yq = yodd ? ya : yb, yt = yodd ? yb : ya;   // q: the coarse row whose weight is 1/4 (see ll_up0f)
+        // q: the coarse row whose weight is 1/4; fma canon: q = row ya (`zero`), t = row yb (`one`) with weights wq, wt (see ll_up0f)
+        const int yq = (dev::CANON_FMA || yodd) ? ya : yb, yt = (dev::CANON_FMA || yodd) ? yb : ya;
+        const float wq = yodd ? 0.25f : 0.75f, wt = yodd ? 0.75f : 0.25f;
         const float *oa = s_out1 + (yq - cy0) * U0_TS + (wave & 1) * 64 + lane;
         const float *ob = s_out1 + (yt - cy0) * U0_TS + (wave & 1) * 64 + lane;
         const float ax = oa[0], ay = oa[1], az = oa[2], bx = ob[0], by = ob[1], bz = ob[2];
-        const float uo[2] = {vl(hl0(ax, ay), hl0(bx, by)), vl(hl1(ay, az), hl1(by, bz))};
+        const float uo[2] = {vl(hl0(ax, ay), hl0(bx, by), wq, wt), vl(hl1(ay, az), hl1(by, bz), wq, wt)};
         const float outL[2] = {f.l0.x, f.l0.y};
         const uint16_t ch[3][2] = {{f.c0.x, f.c0.y}, {f.c1.x, f.c1.y}, {f.c2.x, f.c2.y}};
         uint16_t res[3][2];

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64 * TH / ROWS) void nlm_7x7w(const float *__restri
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     const float t = u[i][c] - sh[i][c];
-                    dd = c == 0 ? t * t : dd + t * t;
+                    dd = c == 0 ? t * t : dev::mad(t, t, dd);   // 0 + t t == t t in either form
                 }
                 d[i] = dd;
             }
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64 * TH / ROWS) void nlm_7x7w(const float *__restri
                 const float sum = (((((r3 + r2) + r1) + bdy[o]) + l1) + l2) + l3;
                 const float w = dev::fast_exp(sum * g.inv);
 #pragma unroll
-                for (int c = 0; c < 3; c++) acc[o][c] = acc[o][c] + w * sh[o + HALF][c];
+                for (int c = 0; c < 3; c++) acc[o][c] = dev::mad(w, sh[o + HALF][c], acc[o][c]);
                 acc[o][3] = acc[o][3] + w * 1.0f;
             }
             if (XL) {   // the next offset's stores stay behind these loads
@@ -237,14 +237,14 @@ __global__ __launch_bounds__(256) void nlm_generic(const float *__restrict__ in,
                     float d = 0.0f;
                     for (int c = 0; c < 3; c++) {
                         float t = IN(X + px, Y + py, c) - IN(X + px + sx, Y + py + sy, c);
-                        d = d + t * t;
+                        d = dev::mad(t, t, d);
                     }
                     bdy = bdy + d;
                 }
                 bd = bd + bdy;
             }
             float w = dev::fast_exp(bd * g.inv);
-            for (int c = 0; c < 3; c++) acc[c] = acc[c] + w * IN(X + sx, Y + sy, c);
+            for (int c = 0; c < 3; c++) acc[c] = dev::mad(w, IN(X + sx, Y + sy, c), acc[c]);
             acc[3] = acc[3] + w * 1.0f;
         }
     }

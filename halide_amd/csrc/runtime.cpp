@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "hlmi_internal.h"
+#include "hlmi_device_math.h"   // HLMI_CANON_FMA
 
 namespace hlmi {
 
@@ -1405,5 +1406,6 @@ size_t hlmi_kernel_timing_report(char *out, size_t cap) {
 }
 
 const char *hlmi_version(void) { return "hlmi 0.1 gfx950"; }
+int hlmi_canon_fma(void) { return HLMI_CANON_FMA; }
 
 }  // extern "C"

@@ -153,6 +153,10 @@ size_t hlmi_kernel_timing_report(char *out, size_t cap);
  * experiment is closed are deleted together with their kernels (round 4: ten of local_laplacian's and conv_layer_bf16's). */
 /* Library identification: returns e.g. "hlmi 0.1 gfx950". */
 const char *hlmi_version(void);
+/* Which of the two canonical float forms the kernels were built for (halide_amd/csrc/hlmi_device_math.h): 1 = a multiply with
+ * one use that feeds an add / subtract is fused with it, as LLVM contracts the reference's float operations
+ * (/root/reference/src/CodeGen_LLVM.cpp:483-500); 0 = one rounding per operator (a `-DHLMI_CANON_FMA=0` build). */
+int hlmi_canon_fma(void);
 
 #ifdef __cplusplus
 }

@@ -8,15 +8,19 @@
  *   - lerp(a,b,w) = a*(1-w) + b*w nested x -> y -> z (:58-64), out = interp0 / interp1 (:67)
  *   - 1.0f / r_sigma is one float division, shared by both uses (:25, :52)
  *   - x / s_sigma, x % s_sigma are floor division / non-negative modulo (src/IR.h:145-166)
+ * Canon 1 (oracle_common.h): val * (1 / r_sigma) + 0.5f is one fma (both uses of 1 / r_sigma are separate multiplies);
+ * each `tap * 4` / `tap * 6` of the blurs is contracted with the add it feeds (B5 below); lerp = fma(a, 1 - w, b * w).
  */
 #include "oracle_common.h"
 
 #define S_SIGMA 8
+/* (((a + b * 4) + c * 6) + d * 4) + e */
+static inline float B5(float a, float b, float c, float d, float e) { return o_mad(d, 4.0f, o_mad(c, 6.0f, o_mad(b, 4.0f, a))) + e; }
 
 int oracle_bilateral_grid(const float *in, int W, int H, int in_sy, int X0, int Y0, float r_sigma, float *out, int out_sy) {
     if (W < 1 || H < 1) return -1;
     const float inv_r = 1.0f / r_sigma;
-    const int zmax = (int)(1.0f * inv_r + 0.5f); /* largest bin a clamped value can hit */
+    const int zmax = (int)o_mad(1.0f, inv_r, 0.5f); /* largest bin a clamped value can hit */
     const int ZH = zmax + 1;                     /* histogram bins 0..zmax */
     const int ZD = zmax + 2;                     /* blurred planes 0..zmax+1 */
     const int gx0 = o_fdiv(X0, S_SIGMA), gx1 = o_fdiv(X0 + W - 1, S_SIGMA) + 1;
@@ -34,7 +38,7 @@ int oracle_bilateral_grid(const float *in, int W, int H, int in_sy, int X0, int 
                     int px = o_clampi(gx * S_SIGMA + rx - S_SIGMA / 2, X0, X0 + W - 1) - X0;
                     int py = o_clampi(gy * S_SIGMA + ry - S_SIGMA / 2, Y0, Y0 + H - 1) - Y0;
                     float val = o_clampf(in[(size_t)py * in_sy + px], 0.0f, 1.0f);
-                    int zi = (int)(val * inv_r + 0.5f);
+                    int zi = (int)o_mad(val, inv_r, 0.5f);
                     HIST(cx, cy, zi, 0) += val;
                     HIST(cx, cy, zi, 1) += 1.0f;
                 }
@@ -50,8 +54,7 @@ int oracle_bilateral_grid(const float *in, int W, int H, int in_sy, int X0, int 
         for (int y = 0; y < HY; y++)
             for (int x = 0; x < HX; x++)
                 for (int c = 0; c < 2; c++)
-                    BZ(x, y, z, c) = (((HZ(x, y, z - 2, c) + HZ(x, y, z - 1, c) * 4.0f) + HZ(x, y, z, c) * 6.0f) +
-                                      HZ(x, y, z + 1, c) * 4.0f) + HZ(x, y, z + 2, c);
+                    BZ(x, y, z, c) = B5(HZ(x, y, z - 2, c), HZ(x, y, z - 1, c), HZ(x, y, z, c), HZ(x, y, z + 1, c), HZ(x, y, z + 2, c));
     /* blurx on x in [gx0, gx1] (GX), y still HY */
     float *bx = (float *)malloc(sizeof(float) * (size_t)GX * HY * ZD * 2);
 #define BX(x, y, z, c) bx[((((size_t)(z)) * HY + (y)) * GX + (x)) * 2 + (c)]
@@ -60,8 +63,7 @@ int oracle_bilateral_grid(const float *in, int W, int H, int in_sy, int X0, int 
         for (int y = 0; y < HY; y++)
             for (int x = 0; x < GX; x++)
                 for (int c = 0; c < 2; c++)
-                    BX(x, y, z, c) = (((BZ(x, y, z, c) + BZ(x + 1, y, z, c) * 4.0f) + BZ(x + 2, y, z, c) * 6.0f) +
-                                      BZ(x + 3, y, z, c) * 4.0f) + BZ(x + 4, y, z, c);
+                    BX(x, y, z, c) = B5(BZ(x, y, z, c), BZ(x + 1, y, z, c), BZ(x + 2, y, z, c), BZ(x + 3, y, z, c), BZ(x + 4, y, z, c));
     /* blury on y in [gy0, gy1] (GY) */
     float *by = (float *)malloc(sizeof(float) * (size_t)GX * GY * ZD * 2);
 #define BY(x, y, z, c) by[((((size_t)(z)) * GY + (y)) * GX + (x)) * 2 + (c)]
@@ -70,8 +72,7 @@ int oracle_bilateral_grid(const float *in, int W, int H, int in_sy, int X0, int 
         for (int y = 0; y < GY; y++)
             for (int x = 0; x < GX; x++)
                 for (int c = 0; c < 2; c++)
-                    BY(x, y, z, c) = (((BX(x, y, z, c) + BX(x, y + 1, z, c) * 4.0f) + BX(x, y + 2, z, c) * 6.0f) +
-                                      BX(x, y + 3, z, c) * 4.0f) + BX(x, y + 4, z, c);
+                    BY(x, y, z, c) = B5(BX(x, y, z, c), BX(x, y + 1, z, c), BX(x, y + 2, z, c), BX(x, y + 3, z, c), BX(x, y + 4, z, c));
     /* trilinear slice + normalise */
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < H; y++) {

@@ -11,6 +11,7 @@
  *   - one arena, kept between calls (the first oracle pays a page fault per 4 KB of every plane, every call);
  *   - every loop nest is one flat OpenMP loop over (plane, row) so that the small levels still feed all threads.
  * It is NOT Halide's autoscheduled x86 code (that needs the Halide compiler), hence cpu_baseline.kind stays "port". */
+#ifndef FCANON
 #include "oracle_common.h"
 
 #include <omp.h>
@@ -25,23 +26,6 @@ typedef struct {
 static inline float FP(const fpl_t *pl, int x, int y) { return pl->p[(size_t)(y - pl->y0) * (size_t)pl->w + (size_t)(x - pl->x0)]; }
 static inline float *FPP(fpl_t *pl, int x, int y) { return &pl->p[(size_t)(y - pl->y0) * (size_t)pl->w + (size_t)(x - pl->x0)]; }
 
-/* the canonical forms of local_laplacian_oracle.c (variant 0) */
-static inline float f_gray(float u0, float u1, float u2) {
-    const float r = (float)(1.0 / 65535.0);
-    const float C0 = (float)((double)r * (double)0.299f), C1 = (float)((double)r * (double)0.587f), C2 = (float)((double)r * (double)0.114f);
-    return u2 * C2 + (u0 * C0 + u1 * C1);
-}
-static inline float f_lerp(float zero, float one, float w) { return zero * (1.0f - w) + one * w; }
-static inline float f_upx(const fpl_t *f, int x, int y) {
-    float w = (float)(o_fmod(x, 2) * 2 + 1) * 0.25f;
-    return f_lerp(FP(f, o_fdiv(x + 1, 2), y), FP(f, o_fdiv(x - 1, 2), y), w);
-}
-static inline float f_up(const fpl_t *f, int x, int y) {
-    float w = (float)(o_fmod(y, 2) * 2 + 1) * 0.25f;
-    return f_lerp(f_upx(f, x, o_fdiv(y + 1, 2)), f_upx(f, x, o_fdiv(y - 1, 2)), w);
-}
-static inline float f_down4(float a, float b, float c, float d) { return ((3.0f * (b + c) + a) + d) * 0.125f; }
-
 /* cpu_baseline picks the thread count that runs fastest (on a 256-thread host the small levels make 16-32 threads faster
  * than all of them); n <= 0 restores the OpenMP default */
 void oracle_set_threads(int n) { omp_set_num_threads(n > 0 ? n : omp_get_num_procs()); }
@@ -54,8 +38,53 @@ static void set_box(fpl_t *pl, int x0, int x1, int y0, int y1) {
 }
 static size_t box_floats(const fpl_t *pl) { return ((size_t)pl->w * (size_t)pl->h + 15) & ~(size_t)15; }
 
+
+/* The evaluation itself is compiled twice — once per canonical form, the contraction decided at compile time so that the
+ * timed loops carry no test of the switch — by including this file in itself. */
+#define FN2(n, c) n##_c##c
+#define FN1(n, c) FN2(n, c)
+#define FN(n) FN1(n, FCANON)
+#define FCANON 0
+#define F_MAD(a, b, c) ((a) * (b) + (c))
+#define F_MAD2(a, b, c, d) ((a) * (b) + (c) * (d))
+#include "local_laplacian_fast_oracle.c"
+#undef FCANON
+#undef F_MAD
+#undef F_MAD2
+#define FCANON 1
+#define F_MAD(a, b, c) fmaf((a), (b), (c))
+#define F_MAD2(a, b, c, d) fmaf((a), (b), (c) * (d))
+#include "local_laplacian_fast_oracle.c"
+#undef FCANON
+#undef F_MAD
+#undef F_MAD2
+
+int oracle_local_laplacian_fast(const uint16_t *in, int W, int H, int in_sy, int in_sc, int X0, int Y0, int J, int levels,
+                                float alpha, float beta, uint16_t *out, int out_sy, int out_sc) {
+    return o_canon_fma ? ll_fast_c1(in, W, H, in_sy, in_sc, X0, Y0, J, levels, alpha, beta, out, out_sy, out_sc)
+                       : ll_fast_c0(in, W, H, in_sy, in_sc, X0, Y0, J, levels, alpha, beta, out, out_sy, out_sc);
+}
+#else  /* ---- the body, for canon FCANON ---- */
+/* the canonical forms of local_laplacian_oracle.c (variant 0), for canon FCANON (oracle_common.h): 0 = one rounding per
+ * operator, 1 = contracted (v_mad / v_mad2 there) */
+static inline float FN(f_gray)(float u0, float u1, float u2) {
+    const float r = (float)(1.0 / 65535.0);
+    const float C0 = (float)((double)r * (double)0.299f), C1 = (float)((double)r * (double)0.587f), C2 = (float)((double)r * (double)0.114f);
+    return F_MAD(u2, C2, F_MAD2(u0, C0, u1, C1));
+}
+static inline float FN(f_lerp)(float zero, float one, float w) { return F_MAD2(zero, 1.0f - w, one, w); }
+static inline float FN(f_upx)(const fpl_t *f, int x, int y) {
+    float w = (float)(o_fmod(x, 2) * 2 + 1) * 0.25f;
+    return FN(f_lerp)(FP(f, o_fdiv(x + 1, 2), y), FP(f, o_fdiv(x - 1, 2), y), w);
+}
+static inline float FN(f_up)(const fpl_t *f, int x, int y) {
+    float w = (float)(o_fmod(y, 2) * 2 + 1) * 0.25f;
+    return FN(f_lerp)(FN(f_upx)(f, x, o_fdiv(y + 1, 2)), FN(f_upx)(f, x, o_fdiv(y - 1, 2)), w);
+}
+static inline float FN(f_down4)(float a, float b, float c, float d) { return (F_MAD(3.0f, b + c, a) + d) * 0.125f; }
+
 /* one level of one or several planes: dy then dx, flat loops over (plane, row); tmp: the planes' dy images */
-static void down_planes(const fpl_t *src, fpl_t *dst, fpl_t *tmp, int np) {
+static void FN(down_planes)(const fpl_t *src, fpl_t *dst, fpl_t *tmp, int np) {
     const int th = tmp[0].h, dh = dst[0].h;
 #pragma omp parallel for schedule(static)
     for (int t = 0; t < np * th; t++) {
@@ -63,7 +92,7 @@ static void down_planes(const fpl_t *src, fpl_t *dst, fpl_t *tmp, int np) {
         float *o = FPP(&tmp[k], tmp[k].x0, y);
         const fpl_t *f = &src[k];
         for (int x = tmp[k].x0; x <= tmp[k].x1; x++)
-            *o++ = f_down4(FP(f, x, 2 * y - 1), FP(f, x, 2 * y), FP(f, x, 2 * y + 1), FP(f, x, 2 * y + 2));
+            *o++ = FN(f_down4)(FP(f, x, 2 * y - 1), FP(f, x, 2 * y), FP(f, x, 2 * y + 1), FP(f, x, 2 * y + 2));
     }
 #pragma omp parallel for schedule(static)
     for (int t = 0; t < np * dh; t++) {
@@ -71,11 +100,11 @@ static void down_planes(const fpl_t *src, fpl_t *dst, fpl_t *tmp, int np) {
         float *o = FPP(&dst[k], dst[k].x0, y);
         const fpl_t *f = &tmp[k];
         for (int x = dst[k].x0; x <= dst[k].x1; x++)
-            *o++ = f_down4(FP(f, 2 * x - 1, y), FP(f, 2 * x, y), FP(f, 2 * x + 1, y), FP(f, 2 * x + 2, y));
+            *o++ = FN(f_down4)(FP(f, 2 * x - 1, y), FP(f, 2 * x, y), FP(f, 2 * x + 1, y), FP(f, 2 * x + 2, y));
     }
 }
 
-int oracle_local_laplacian_fast(const uint16_t *in, int W, int H, int in_sy, int in_sc, int X0, int Y0, int J, int levels,
+static int FN(ll_fast)(const uint16_t *in, int W, int H, int in_sy, int in_sc, int X0, int Y0, int J, int levels,
                                 float alpha, float beta, uint16_t *out, int out_sy, int out_sc) {
     if (J < 2 || J > FJ || levels < 2 || W < 1 || H < 1) return -1;
     const int K = levels;
@@ -154,12 +183,12 @@ int oracle_local_laplacian_fast(const uint16_t *in, int W, int H, int in_sy, int
         for (int x = gray.x0; x <= gray.x1; x++) {
             const int xc = o_clampi(x, X0, X0 + W - 1) - X0;
             const size_t i = (size_t)yc * (size_t)in_sy + (size_t)xc;
-            *o++ = f_gray((float)in[i], (float)in[i + (size_t)in_sc], (float)in[i + 2 * (size_t)in_sc]);
+            *o++ = FN(f_gray)((float)in[i], (float)in[i + (size_t)in_sc], (float)in[i + 2 * (size_t)in_sc]);
         }
     }
     const float Km1 = (float)(K - 1), inv_Km1 = 1.0f / Km1;
 #define F_G0(gr, k) \
-    ((beta * ((gr) - (float)(k) * inv_Km1) + (float)(k) * inv_Km1) + lut[o_clampi((int)(((gr) * Km1) * 256.0f), 0, half) - 256 * (k) + half])
+    (F_MAD(beta, (gr) - (float)(k) * inv_Km1, (float)(k) * inv_Km1) + lut[o_clampi((int)(((gr) * Km1) * 256.0f), 0, half) - 256 * (k) + half])
 
     /* ---- level 1 of the K processed planes straight from gray: tasks = (plane, band of level-1 rows) */
     {
@@ -191,11 +220,11 @@ int oracle_local_laplacian_fast(const uint16_t *in, int W, int H, int in_sy, int
                             o[x] = F_G0(gr, k);
                         }
                     }
-                    for (int x = 0; x < dw; x++) dyr[x] = f_down4(r[0][x], r[1][x], r[2][x], r[3][x]);
+                    for (int x = 0; x < dw; x++) dyr[x] = FN(f_down4)(r[0][x], r[1][x], r[2][x], r[3][x]);
                     float *o = FPP(dst, dst->x0, y);
                     for (int x = dst->x0; x <= dst->x1; x++) {
                         const float *d = dyr + (2 * x - 1 - dx0);
-                        *o++ = f_down4(d[0], d[1], d[2], d[3]);
+                        *o++ = FN(f_down4)(d[0], d[1], d[2], d[3]);
                     }
                 }
             }
@@ -209,7 +238,7 @@ int oracle_local_laplacian_fast(const uint16_t *in, int W, int H, int in_sy, int
             for (int k = 0; k < K; k++) {
                 set_box(&tmp[0], 2 * Gx0[j] - 1, 2 * Gx1[j] + 2, Gy0[j], Gy1[j]);
                 tmp[0].p = tmp_base;
-                down_planes(&g[k * FJ + j - 1], &g[k * FJ + j], tmp, 1);
+                FN(down_planes)(&g[k * FJ + j - 1], &g[k * FJ + j], tmp, 1);
             }
             continue;
         }
@@ -219,7 +248,7 @@ int oracle_local_laplacian_fast(const uint16_t *in, int W, int H, int in_sy, int
             set_box(&tmp[k], 2 * Gx0[j] - 1, 2 * Gx1[j] + 2, Gy0[j], Gy1[j]);
             tmp[k].p = tp, tp += box_floats(&tmp[k]);
         }
-        down_planes(src, dst, tmp, K);
+        FN(down_planes)(src, dst, tmp, K);
         for (int k = 0; k < K; k++) g[k * FJ + j].p = dst[k].p;
     }
     /* ---- Gaussian pyramid of the input */
@@ -227,7 +256,7 @@ int oracle_local_laplacian_fast(const uint16_t *in, int W, int H, int in_sy, int
     for (int j = 1; j < J; j++) {
         set_box(&tmp[0], 2 * Gx0[j] - 1, 2 * Gx1[j] + 2, Gy0[j], Gy1[j]);
         tmp[0].p = tmp_base;
-        down_planes(&inG[j - 1], &inG[j], tmp, 1);
+        FN(down_planes)(&inG[j - 1], &inG[j], tmp, 1);
     }
     /* ---- output pyramids, coarse to fine; level 0 goes straight into the colour stage */
     for (int j = J - 1; j >= 1; j--) {
@@ -240,11 +269,11 @@ int oracle_local_laplacian_fast(const uint16_t *in, int W, int H, int in_sy, int
                 const float lf = level - (float)li;
                 float l0 = FP(&g[li * FJ + j], x, y), l1 = FP(&g[(li + 1) * FJ + j], x, y);
                 if (j < J - 1) {
-                    l0 = l0 - f_up(&g[li * FJ + j + 1], x, y);
-                    l1 = l1 - f_up(&g[(li + 1) * FJ + j + 1], x, y);
+                    l0 = l0 - FN(f_up)(&g[li * FJ + j + 1], x, y);
+                    l1 = l1 - FN(f_up)(&g[(li + 1) * FJ + j + 1], x, y);
                 }
-                const float outL = (1.0f - lf) * l0 + lf * l1;
-                *o++ = (j == J - 1) ? outL : f_up(&outG[j + 1], x, y) + outL;
+                const float outL = F_MAD2(1.0f - lf, l0, lf, l1);
+                *o++ = (j == J - 1) ? outL : FN(f_up)(&outG[j + 1], x, y) + outL;
             }
         }
     }
@@ -258,10 +287,10 @@ int oracle_local_laplacian_fast(const uint16_t *in, int W, int H, int in_sy, int
             const int li = o_clampi((int)level, 0, K - 2);
             const float lf = level - (float)li;
             float l0 = F_G0(gr, li), l1 = F_G0(gr, li + 1);
-            l0 = l0 - f_up(&g[li * FJ + 1], X, Y);
-            l1 = l1 - f_up(&g[(li + 1) * FJ + 1], X, Y);
-            const float outL = (1.0f - lf) * l0 + lf * l1;
-            const float og = (f_up(&outG[1], X, Y) + outL) + eps, gre = gr + eps;
+            l0 = l0 - FN(f_up)(&g[li * FJ + 1], X, Y);
+            l1 = l1 - FN(f_up)(&g[(li + 1) * FJ + 1], X, Y);
+            const float outL = F_MAD2(1.0f - lf, l0, lf, l1);
+            const float og = (FN(f_up)(&outG[1], X, Y) + outL) + eps, gre = gr + eps;
             for (int c = 0; c < 3; c++) {
                 const float v = ((float)in[(size_t)y * (size_t)in_sy + (size_t)x + (size_t)c * (size_t)in_sc] * og) / gre;
                 out[(size_t)y * (size_t)out_sy + (size_t)x + (size_t)c * (size_t)out_sc] = (uint16_t)o_clampf(v, 0.0f, 65535.0f);
@@ -272,3 +301,4 @@ int oracle_local_laplacian_fast(const uint16_t *in, int W, int H, int in_sy, int
     free(g), free(tmp);
     return 0;
 }
+#endif

@@ -39,10 +39,13 @@ static int ll_var = 0;
 void oracle_ll_set_variant(int v) { ll_var = v; }
 int oracle_ll_get_variant(void) { return ll_var; }
 
+/* contraction is in force under canon 1 (oracle_common.h) or when the variant asks for it on top of canon 0 (the Python
+ * side sets canon 1 for the call then, so that halide_exp's polynomial is contracted with the rest) */
+static inline int ll_fma(void) { return (ll_var & LL_VAR_FMA) || o_canon_fma; }
 /* a * b + c, contracted or not */
-static inline float v_mad(float a, float b, float c) { return (ll_var & LL_VAR_FMA) ? fmaf(a, b, c) : a * b + c; }
+static inline float v_mad(float a, float b, float c) { return ll_fma() ? fmaf(a, b, c) : a * b + c; }
 /* a * b + c * d: the DAG combiner contracts the first multiply and keeps the second */
-static inline float v_mad2(float a, float b, float c, float d) { return (ll_var & LL_VAR_FMA) ? fmaf(a, b, c * d) : a * b + c * d; }
+static inline float v_mad2(float a, float b, float c, float d) { return ll_fma() ? fmaf(a, b, c * d) : a * b + c * d; }
 static inline float v_lerp(float zero, float one, float w) { return v_mad2(zero, 1.0f - w, one, w); }
 
 static inline float ll_gray(float u0, float u1, float u2) {

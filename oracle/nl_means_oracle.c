@@ -10,6 +10,8 @@
  *   S(x,y,c) = sum over s_dom (x fastest, then y) of w * clamped_with_alpha(x+sx, y+sy, c), alpha = 1.0f (:52-59)
  *   out = clamp(S_c / S_3, 0, 1)                                                               (:61-62)
  * Every tap goes through repeat_edge(input) (:27), channel index included.
+ * Canon 1 (oracle_common.h) contracts the two multiply-adds of the update definitions: d += dc * dc and S += w * in
+ * (the alpha lane's w * 1.0f is folded to w by the simplifier in either form).
  */
 #include "oracle_common.h"
 
@@ -34,7 +36,7 @@ int oracle_nl_means(const float *in, int W, int H, int in_sy, int in_sc, int pat
                     float acc = 0.0f;
                     for (int c = 0; c < 3; c++) {
                         float t = IN(ax, ay, c) - IN(ax + sx, ay + sy, c);
-                        acc = acc + t * t;
+                        acc = o_mad(t, t, acc);   /* d += (a - b)^2: the square has one use */
                     }
                     d[(size_t)y * DW + x] = acc;
                 }
@@ -54,7 +56,7 @@ int oracle_nl_means(const float *in, int W, int H, int in_sy, int in_sc, int pat
                     for (int p = 0; p < patch; p++) acc = acc + bdy[(size_t)y * DW + x + p];
                     float w = o_fast_exp(acc * inv);
                     float *s = &sum[((size_t)y * W + x) * 4];
-                    for (int c = 0; c < 3; c++) s[c] = s[c] + w * IN(x + sx, y + sy, c);
+                    for (int c = 0; c < 3; c++) s[c] = o_mad(w, IN(x + sx, y + sy, c), s[c]);
                     s[3] = s[3] + w * 1.0f;
                 }
             }

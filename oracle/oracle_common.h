@@ -5,10 +5,24 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may call it, and only as the checker /
  * the timed CPU baseline.
  *
- * All paths below are relative to /root/reference.  Build with -ffp-contract=off: the canonical
- * evaluation order is "expression order as written in the generator, IEEE binary32, round to nearest
- * even, no FMA contraction", with the simplifier's deterministic float rewrite
- * x / c -> x * (1/c) (src/Simplify_Div.cpp:204) applied.
+ * All paths below are relative to /root/reference.  Build with -ffp-contract=off: every rounding below is
+ * written out.  The evaluation order is "expression order as written in the generator, IEEE binary32, round
+ * to nearest even", with the simplifier's deterministic float rewrite x / c -> x * (1/c)
+ * (src/Simplify_Div.cpp:204) applied, in one of TWO canonical forms selected at run time
+ * (oracle_set_canon, canon_oracle.c):
+ *   canon 0  no contraction: one rounding per operator of the expression.
+ *   canon 1  FMA contraction, modelled on what LLVM's DAG combiner does with the `contract` flag the
+ *            reference sets on every float operation (src/CodeGen_LLVM.cpp:483-500 setAllowContract,
+ *            src/CodeGen_Internal.cpp:614 AllowFPOpFusion = Fast), non-aggressive fusion (x86):
+ *              fadd(fmul(a, b), c)          -> fma(a, b, c)        o_mad
+ *              fadd(c, fmul(a, b))          -> fma(a, b, c)        o_mad
+ *              fadd(fmul(a, b), fmul(c, d)) -> fma(a, b, c * d)    o_mad2 (the first product is the one fused)
+ *              fsub(fmul(a, b), c)          -> fma(a, b, -c)       o_mulsub
+ *              fsub(c, fmul(a, b))          -> fma(-a, b, c)       o_msub
+ *            for multiplies with ONE use; a product that is used twice stays a multiply.  Reassociation
+ *            (the `reassoc` flag) is not part of either form: scripts/oracle_variants.py bounds it.
+ * The library is built for one of the two (halide_amd/csrc/hlmi_device_math.h, HLMI_CANON_FMA; it reports which
+ * through hlmi_canon_fma()) and the parity tests select the matching form here.
  */
 #ifndef ORACLE_COMMON_H
 #define ORACLE_COMMON_H
@@ -17,6 +31,20 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+
+/* the canonical form in force (canon_oracle.c); read by every helper below */
+extern int o_canon_fma;
+void oracle_set_canon(int fma);
+int oracle_get_canon(void);
+
+/* a * b + c */
+static inline float o_mad(float a, float b, float c) { return o_canon_fma ? fmaf(a, b, c) : a * b + c; }
+/* a * b + c * d: the first product is contracted, the second stays a multiply */
+static inline float o_mad2(float a, float b, float c, float d) { return o_canon_fma ? fmaf(a, b, c * d) : a * b + c * d; }
+/* c - a * b */
+static inline float o_msub(float c, float a, float b) { return o_canon_fma ? fmaf(-a, b, c) : c - a * b; }
+/* a * b - c */
+static inline float o_mulsub(float a, float b, float c) { return o_canon_fma ? fmaf(a, b, -c) : a * b - c; }
 
 /* Halide integer division / modulo round toward -inf for positive divisors (src/IR.h:145-166). */
 static inline int o_fdiv(int a, int b) {
@@ -45,7 +73,7 @@ static inline uint32_t o_f2bits(float f) {
 }
 
 /* lerp(zero, one, w) for floats = zero*(1-w) + one*w  (src/Lerp.cpp:82-83,127-128) */
-static inline float o_lerp(float zero, float one, float w) { return zero * (1.0f - w) + one * w; }
+static inline float o_lerp(float zero, float one, float w) { return o_mad2(zero, 1.0f - w, one, w); }
 
 /* evaluate_polynomial (src/IROperator.cpp:33-65): even/odd Horner split on x^2, high order first.
  * A zero coefficient multiplies by x2 without the add. */
@@ -54,12 +82,12 @@ static inline float o_poly(float x, const float *c, int n) {
     float even = c[0], odd = c[1];
     for (int i = 2; i < n; i++) {
         if ((i & 1) == 0) {
-            even = (c[i] == 0.0f) ? even * x2 : even * x2 + c[i];
+            even = (c[i] == 0.0f) ? even * x2 : o_mad(even, x2, c[i]);
         } else {
-            odd = (c[i] == 0.0f) ? odd * x2 : odd * x2 + c[i];
+            odd = (c[i] == 0.0f) ? odd * x2 : o_mad(odd, x2, c[i]);
         }
     }
-    return ((n & 1) == 0) ? even * x + odd : odd * x + even;
+    return ((n & 1) == 0) ? o_mad(even, x, odd) : o_mad(odd, x, even);
 }
 
 /* halide_exp (src/IROperator.cpp:921-966).  one_over_ln2 = 1.0f / logf(2.0f) evaluated in float when
@@ -73,8 +101,8 @@ static inline float o_halide_exp(float x_full) {
     float scaled = x_full * one_over_ln2;
     float k_real = floorf(scaled);
     int k = (int)k_real;
-    float x = x_full - k_real * ln2_part1;
-    x = x - k_real * ln2_part2;
+    float x = o_msub(x_full, k_real, ln2_part1);
+    x = o_msub(x, k_real, ln2_part2);
     float result = o_poly(x, coeff, 8);
     int biased = k + 127;
     float two_to_the_n = o_bits2f((uint32_t)biased << 23);
@@ -100,7 +128,7 @@ static inline float o_halide_log(float x_full) {
     float reduced = o_bits2f((uint32_t)(no_exponent | (new_biased << 23)));
     float x1 = reduced - 1.0f;
     float result = o_poly(x1, coeff, 10);
-    result = result + (float)exponent * 0.693147182464599609375f; /* logf(2.0) */
+    result = o_mad((float)exponent, 0.693147182464599609375f /* logf(2.0) */, result);
     if (use_nan) return NAN;
     if (use_neg_inf) return -INFINITY;
     return result;
@@ -128,7 +156,7 @@ static inline float o_fast_exp(float x_full) {
                                    0.49970514590562437052f, 1.0f, 1.0f};
     float scaled = x_full * (1.0f / ln2); /* x / logf(2) -> x * fold(1/c) */
     float k_real = floorf(scaled);
-    float x = x_full - k_real * ln2;
+    float x = o_msub(x_full, k_real, ln2);
     float result = o_poly(x, coeff, 6);
     int k = (int)k_real;
     int biased = o_clampi(k + 127, 0, 255);

@@ -111,7 +111,11 @@ if __name__ == "__main__":
         sys.exit(0)
     d = {"_comment": "Regression digests of the canonical CPU oracle (sha256 of the output bytes on fixed seeded inputs, "
                      "scripts/make_golden.py). NOT reference-derived: the reference ships no golden outputs for these pipelines."}
-    d.update(digests())
+    import oracle_lib
+    with oracle_lib.canon(0):
+        d.update(digests())
+    with oracle_lib.canon(1):   # the contracted canonical form (oracle/oracle_common.h)
+        d["_canon1"] = digests()
     with open(os.path.join(ROOT, "tests", "golden", "oracle_digests.json"), "w") as f:
         json.dump(d, f, indent=1)
     print(json.dumps(d, indent=1))

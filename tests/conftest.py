@@ -12,6 +12,43 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_canon_follows_the_library():
+    """The oracle has two canonical float forms (oracle/oracle_common.h); the parity tests compare a library with the form it
+    was built for (hlmi_canon_fma(): 1 = contracted, the default build; 0 = a -DHLMI_CANON_FMA=0 build loaded through
+    HLMI_LIB).  The library loads — and answers this — without a GPU."""
+    import halide_amd
+    import oracle_lib
+    oracle_lib.set_canon(halide_amd.canon_fma())
+    yield
+
+
+@pytest.fixture
+def linked_library_canon(oracle):
+    """The binaries under oracle/_ref (the reference's drivers, its RunGen, the Buffer consumer test) are LINKED against
+    halide_amd/lib/libhlmi.so, whatever HLMI_LIB makes the Python caller load: their outputs face the oracle in that
+    library's canonical form."""
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, "halide_amd", "lib", "libhlmi.so"))
+    lib.hlmi_canon_fma.restype = ctypes.c_int
+    with oracle.canon(lib.hlmi_canon_fma()):
+        yield
+
+
+@pytest.fixture
+def canon0(oracle):
+    """For the tests that hold an oracle to an independent evaluator written without fused operations: canon 0."""
+    with oracle.canon(0):
+        yield
+
+
+@pytest.fixture(params=[0, 1], ids=["canon0", "canon1"])
+def each_canon(request, oracle):
+    """CPU tests of oracle-internal consistency run in both canonical forms."""
+    with oracle.canon(request.param):
+        yield request.param
+
+
 @pytest.fixture(scope="session")
 def hl():
     """The product library (fails loudly if libhlmi.so was not built)."""

@@ -51,6 +51,37 @@ _lib.oracle_set_threads.argtypes = [C.c_int]
 _lib.oracle_set_threads.restype = None
 
 
+_lib.oracle_set_canon.argtypes = [C.c_int]
+_lib.oracle_get_canon.restype = C.c_int
+
+
+def set_canon(fma: int) -> None:
+    """Selects the oracle's canonical form (oracle/oracle_common.h): 0 = one rounding per operator, 1 = mul+add pairs
+    contracted into fma as LLVM contracts the reference's float operations.  tests/conftest.py sets it to the form the
+    loaded libhlmi.so was built for (hlmi_canon_fma())."""
+    _lib.oracle_set_canon(int(fma))
+
+
+def get_canon() -> int:
+    return int(_lib.oracle_get_canon())
+
+
+class canon:
+    """with oracle_lib.canon(0): ...   — evaluates the oracle in the given form, then restores the one in force."""
+
+    def __init__(self, fma: int):
+        self.fma = int(fma)
+
+    def __enter__(self):
+        self.prev = get_canon()
+        set_canon(self.fma)
+        return self
+
+    def __exit__(self, *exc):
+        set_canon(self.prev)
+        return False
+
+
 def halide_exp(x: float) -> float:
     return _lib.oracle_halide_exp(x)
 
@@ -98,12 +129,16 @@ def local_laplacian(inp: np.ndarray, levels: int, alpha: float, beta: float, J: 
     c, h, w = inp.shape
     assert c == 3
     out = np.zeros_like(inp)
+    prev = get_canon()
+    if variant & LL_VAR_FMA:   # the fma variant IS canon 1 (halide_exp's polynomial is contracted with the rest)
+        set_canon(1)
     _lib.oracle_ll_set_variant(int(variant))
     try:
         r = _lib.oracle_local_laplacian(inp, w, h, w, w * h, int(origin[0]), int(origin[1]), J, levels, alpha, beta, out,
                                         w, w * h, -1, None)
     finally:
         _lib.oracle_ll_set_variant(0)
+        set_canon(prev)
     assert r == 0
     return out
 

@@ -162,7 +162,7 @@ def naive_bgu(r_sigma, s_sigma, splat, values, slice_loc, region):
     (20, 14, 1, 3, 0.125, (3, 2, 11, 9)),       # no upsampling, odd cell size, a crop of the output
     (18, 12, 3, 2, 0.3, None),                   # 1 / r_sigma not an integer: nb = 3, samples land in bins 0..3
 ])
-def test_oracle_matches_naive_pure_function_evaluator(oracle, W, H, factor, s_sigma, r_sigma, region):
+def test_oracle_matches_naive_pure_function_evaluator(oracle, canon0, W, H, factor, s_sigma, r_sigma, region):
     hi, lo, val = _scene(W, H, seed=W + H, factor=factor)
     reg = region or (0, 0, W, H)
     with np.errstate(all="ignore"):

@@ -85,7 +85,7 @@ def _img(w, h, seed, kind="uniform"):
 
 
 @pytest.mark.parametrize("w,h,r_sigma", [(11, 9, 0.1), (20, 13, 0.25), (1, 1, 0.1)])
-def test_oracle_matches_naive_restatement(oracle, w, h, r_sigma):
+def test_oracle_matches_naive_restatement(oracle, canon0, w, h, r_sigma):
     inp = _img(w, h, seed=w + h, kind="smooth")
     got = oracle.bilateral_grid(inp, r_sigma)
     want = naive_bilateral_grid(inp, r_sigma)

@@ -13,6 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_BIN = os.path.join(ROOT, "oracle", "_ref")
 
 
+@pytest.fixture(autouse=True)
+def _oracle_in_the_form_of_the_library_the_binaries_link(linked_library_canon):
+    yield
+
+
+
 def _exe(name):
     p = os.path.join(REF_BIN, name)
     assert os.path.exists(p), (f"oracle/_ref/{name} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` where "

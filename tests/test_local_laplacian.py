@@ -120,7 +120,7 @@ def _rand_image(w, h, seed, kind="uniform"):
 
 # ---------------------------------------------------------------------------------------------------- CPU
 @pytest.mark.parametrize("w,h,levels", [(1, 1, 8), (5, 3, 8), (9, 7, 4), (12, 10, 2)])
-def test_oracle_matches_naive_pure_function_evaluator(oracle, w, h, levels):
+def test_oracle_matches_naive_pure_function_evaluator(oracle, canon0, w, h, levels):
     inp = _rand_image(w, h, seed=w * 100 + h)
     want = naive_local_laplacian(inp, levels, 1.0 / (levels - 1), 1.0)
     got = oracle.local_laplacian(inp, levels, 1.0 / (levels - 1), 1.0)
@@ -150,8 +150,8 @@ def test_oracle_alpha0_beta1_is_identity_within_one_lsb(oracle):
     assert np.max(np.abs(out.astype(np.int64) - inp.astype(np.int64))) <= 1
 
 
-def test_oracle_regression_digest(oracle):
-    """Regression pin of the canonical oracle (NOT a reference-derived vector: none exists, see module doc)."""
+def test_oracle_regression_digest(oracle, each_canon):
+    """Regression pin of the oracle in both canonical forms (NOT a reference-derived vector: none exists, see module doc)."""
     import hashlib
     import json
     import os
@@ -160,7 +160,8 @@ def test_oracle_regression_digest(oracle):
     digest = hashlib.sha256(out.tobytes()).hexdigest()
     path = os.path.join(os.path.dirname(__file__), "golden", "oracle_digests.json")
     with open(path) as f:
-        assert json.load(f)["local_laplacian_64x48_seed11_K8"] == digest
+        d = json.load(f)
+    assert (d["_canon1"] if each_canon else d)["local_laplacian_64x48_seed11_K8"] == digest
 
 
 # ---------------------------------------------------------------------------------------------------- GPU

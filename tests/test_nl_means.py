@@ -65,7 +65,7 @@ def _img(w, h, seed, kind="uniform"):
 
 
 @pytest.mark.parametrize("w,h,patch,search", [(6, 5, 7, 7), (7, 4, 3, 5), (5, 5, 4, 2)])
-def test_oracle_matches_naive_restatement(oracle, w, h, patch, search):
+def test_oracle_matches_naive_restatement(oracle, canon0, w, h, patch, search):
     inp = _img(w, h, seed=w * h, kind="smooth")
     got = oracle.nl_means(inp, patch, search, 0.12)
     want = naive_nl_means(inp, patch, search, 0.12)

@@ -21,6 +21,12 @@ CASES = pin.cases()
 DRIVER_CASES = pin.driver_cases()   # harris, lens_blur, bgu: through the apps' own drivers (RunGen cannot drive them)
 
 
+@pytest.fixture(autouse=True)
+def _oracle_in_the_form_of_the_library_the_binaries_link(linked_library_canon):
+    yield
+
+
+
 def _ulp_diff(a, b):
     """distance in float32 representable values"""
     ia, ib = a.view(np.int32).astype(np.int64), b.view(np.int32).astype(np.int64)
