@@ -57,7 +57,7 @@ __device__ const unsigned char IB[NC] = {0, 1, 2, 6, 1, 2, 6, 2, 6, 6, 0, 1, 2, 
 // the seven-tap filter (:333-359), in the generator's order; the centre weight is 1
 __device__ __forceinline__ float tap7(float a, float b, float c, float d, float e, float f, float h) {
     const float t0 = 1.0f / 64, t1 = 1.0f / 27, t2 = 1.0f / 8;
-    return a * t0 + b * t1 + c * t2 + d + e * t2 + f * t1 + h * t0;
+    return dev::mad(h, t0, dev::mad(f, t1, dev::mad(e, t2, dev::mad(c, t2, dev::mad2(a, t0, b, t1)) + d)));   // left to right (:333-359)
 }
 
 // bz: [nhy][nhx][nz][22] = blurz on the histogram's box.  The cell's histogram [nhz][22] never leaves LDS (hb, dynamic).
@@ -145,21 +145,21 @@ __device__ __forceinline__ void solve_column(const float *b, int k, float (&x)[4
 #pragma unroll
             for (int kk = j + 1; kk < 4; kk++) {
                 if (kk < i) A[i][kk] = A[kk][i];
-                else A[i][kk] = A[i][kk] - A[kk][j] * A[j][i];
+                else A[i][kk] = dev::msub(A[i][kk], A[kk][j], A[j][i]);
             }
         }
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
 #pragma unroll
-        for (int i = 0; i < j; i++) x[j] = x[j] - A[j][i] * x[i];
+        for (int i = 0; i < j; i++) x[j] = dev::msub(x[j], A[j][i], x[i]);
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) x[j] = x[j] * A[j][j];
 #pragma unroll
     for (int j = 3; j >= 0; j--) {
 #pragma unroll
-        for (int i = j + 1; i < 4; i++) x[j] = x[j] - A[i][j] * x[i];
+        for (int i = j + 1; i < 4; i++) x[j] = dev::msub(x[j], A[i][j], x[i]);
     }
 }
 
@@ -200,7 +200,9 @@ struct SGeom {
 
 typedef float f2 __attribute__((ext_vector_type(2)));   // v_pk_mul_f32 / v_pk_add_f32: two lerps per instruction, each lane
                                                          // rounding exactly as the scalar operation does
-__device__ __forceinline__ f2 lerp2(f2 zero, f2 one, float w, float iw) { return zero * iw + one * w; }
+__device__ __forceinline__ f2 lerp2(f2 zero, f2 one, float w, float iw) {   // dev::lerpf on a pair
+    return dev::CANON_FMA ? __builtin_elementwise_fma(zero, f2{iw, iw}, one * w) : zero * iw + one * w;
+}
 
 __device__ __forceinline__ void slice_pixel(const float *__restrict__ tab, int xs, int xl, float xf, float s0, float s1, float s2, int nb,
                                             float (&o)[3]) {
@@ -226,8 +228,12 @@ __device__ __forceinline__ void slice_pixel(const float *__restrict__ tab, int x
     const f2 s01 = f2{s0, s1}, s2one = f2{s2, 1.0f};
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        const f2 p = m[2 * c] * s01, q = m[2 * c + 1] * s2one;               // :473-477; m * 1 is m
-        o[c] = clampf(p.x + p.y + q.x + q.y, 0.0f, 1.0f);
+        if (dev::CANON_FMA) {   // ((m0 s0 + m1 s1) + m2 s2) + m3 (:473-477): the first and the third product fused
+            o[c] = clampf(dev::mad(m[2 * c + 1].x, s2, dev::mad2(m[2 * c].x, s0, m[2 * c].y, s1)) + m[2 * c + 1].y, 0.0f, 1.0f);
+        } else {
+            const f2 p = m[2 * c] * s01, q = m[2 * c + 1] * s2one;           // :473-477; m * 1 is m
+            o[c] = clampf(p.x + p.y + q.x + q.y, 0.0f, 1.0f);
+        }
     }
 }
 
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(TW) void bgu_slice(const float *__restrict__ line, 
         float *tb = tab + ((y - ya) & 1) * tsz;
         for (int it = tid; it < tsz / 4; it += TW) {             // interpolated_matrix_y for this image row (:444-447)
             const float4 u = l0[it], w = l1[it];
-            reinterpret_cast<float4 *>(tb)[it] = float4{u.x * iyf + w.x * yf, u.y * iyf + w.y * yf, u.z * iyf + w.z * yf, u.w * iyf + w.w * yf};
+            reinterpret_cast<float4 *>(tb)[it] = float4{dev::mad2(u.x, iyf, w.x, yf), dev::mad2(u.y, iyf, w.y, yf), dev::mad2(u.z, iyf, w.z, yf), dev::mad2(u.w, iyf, w.w, yf)};
         }
         float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;                   // next row's pixel, in flight across the barrier
         if (live && y + 1 < yb) n0 = sp[q.s_sy], n1 = sp[q.s_sy + q.s_sc], n2 = sp[q.s_sy + 2 * q.s_sc];
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(256) void bgu_slice_direct(const float *__restrict_
         m[c] = lerpf(mz[0], mz[1], zf);
     }
     float *op = out + (long)yo * q.o_sy + xo;
-    for (int c = 0; c < 3; c++) op[c * q.o_sc] = clampf(m[4 * c] * s0 + m[4 * c + 1] * s1 + m[4 * c + 2] * s2 + m[4 * c + 3], 0.0f, 1.0f);
+    for (int c = 0; c < 3; c++) op[c * q.o_sc] = clampf(dev::mad(m[4 * c + 2], s2, dev::mad2(m[4 * c], s0, m[4 * c + 1], s1)) + m[4 * c + 3], 0.0f, 1.0f);
 }
 
 const int64_t e0 = 0, e3 = 3, e192 = 192, e320 = 320, e1536 = 1536, e2560 = 2560;

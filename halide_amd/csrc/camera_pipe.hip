@@ -41,7 +41,7 @@ __global__ void cp_setup(const float *__restrict__ m3200, long m3_sy, const floa
         const float inv_den = 1.0f / (k2 - k1);
         float alpha = (1.0f / color_temp - k1) * inv_den;
         int c = t / 4, j = t - 4 * c;
-        float val = m3200[c * m3_sy + j] * alpha + m7000[c * m7_sy + j] * (1.0f - alpha);
+        float val = dev::mad2(m3200[c * m3_sy + j], alpha, m7000[c * m7_sy + j], 1.0f - alpha);
         s->matrix[t] = (int16_t)(val * 256.0f);
     }
     if (t == 12) s->strength_x32 = (uint8_t)dev::clampf(sharpen_strength * 32.0f, 0.0f, 255.0f);
@@ -52,8 +52,8 @@ __global__ void cp_setup(const float *__restrict__ m3200, long m3_sy, const floa
         float a = 2.0f - 2.0f * b;
         float xf = dev::clampf((float)(t - minRaw) * invRange, 0.0f, 1.0f);
         float g = dev::halide_pow(xf, 1.0f / gamma);
-        float z = g > 0.5f ? 1.0f - ((a * (1.0f - g)) * (1.0f - g) + b * (1.0f - g)) : (a * g) * g + b * g;
-        uint8_t val = (uint8_t)dev::clampf(z * 255.0f + 0.5f, 0.0f, 255.0f);
+        float z = g > 0.5f ? 1.0f - dev::mad2(a * (1.0f - g), 1.0f - g, b, 1.0f - g) : dev::mad2(a * g, g, b, g);
+        uint8_t val = (uint8_t)dev::clampf(dev::mad(z, 255.0f, 0.5f), 0.0f, 255.0f);
         s->curve[t] = t <= minRaw ? (uint8_t)0 : (t > maxRaw ? (uint8_t)255 : val);
     }
 }

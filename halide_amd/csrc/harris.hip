@@ -6,6 +6,7 @@
 // One workgroup = a 64 x 16 output tile: gray of the tile + 2 (LDS), the three gradient products of the tile + 1 (LDS),
 // then the 3x3 sums and the response per pixel.  Sums are left to right as written in the generator, one rounding per
 // operator (oracle/harris_oracle.c).  HBM: 12 B/px read, 4 B/px written.
+#include "hlmi_device_math.h"
 #include "hlmi_internal.h"
 
 using namespace hlmi;
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void harris_tile(const float *__restrict__ in,
             const int i = tid + 256 * k;
             if (i < GW * GH) {
                 const int r = i / GW, c = i - r * GW;
-                s_g[r * GP + c] = (0.299f * v[k][0] + 0.587f * v[k][1]) + 0.114f * v[k][2];
+                s_g[r * GP + c] = dev::mad(0.114f, v[k][2], dev::mad2(0.299f, v[k][0], 0.587f, v[k][1]));
             }
         }
     }
@@ -55,9 +56,19 @@ __global__ __launch_bounds__(256) void harris_tile(const float *__restrict__ in,
     for (int i = tid; i < DW * DH; i += 256) {
         const int r = i / DW, c = i - r * DW;
         const float *q = s_g + (r + 1) * GP + (c + 1);   // gray at (x, y) of this gradient sample
-        const float iy = ((((q[-GP - 1] * a + q[GP - 1] * b) + q[-GP] * c2) + q[GP] * d) + q[-GP + 1] * a) + q[GP + 1] * b;
-        const float ix = ((((q[-GP - 1] * a + q[-GP + 1] * b) + q[-1] * c2) + q[1] * d) + q[GP - 1] * a) + q[GP + 1] * b;
-        s_xx[r * DP + c] = ix * ix, s_yy[r * DP + c] = iy * iy, s_xy[r * DP + c] = ix * iy;
+        // ((((g0 k0 + g1 k1) + g2 k2) + g3 k3) + g4 k4) + g5 k5
+        auto d6 = [](float g0, float k0, float g1, float k1, float g2, float k2, float g3, float k3, float g4, float k4, float g5, float k5) {
+            return dev::mad(g5, k5, dev::mad(g4, k4, dev::mad(g3, k3, dev::mad(g2, k2, dev::mad2(g0, k0, g1, k1)))));
+        };
+        const float iy = d6(q[-GP - 1], a, q[GP - 1], b, q[-GP], c2, q[GP], d, q[-GP + 1], a, q[GP + 1], b);
+        const float ix = d6(q[-GP - 1], a, q[-GP + 1], b, q[-1], c2, q[1], d, q[GP - 1], a, q[GP + 1], b);
+        if (dev::CANON_FMA) {
+            // Ixx / Iyy / Ixy are inline in the reference's schedule (:111-123): under the fma canon their products are contracted into
+            // the 3 x 3 sums, so the tile keeps the gradients and the sums multiply (s_xy is unused in this form)
+            s_xx[r * DP + c] = ix, s_yy[r * DP + c] = iy;
+        } else {
+            s_xx[r * DP + c] = ix * ix, s_yy[r * DP + c] = iy * iy, s_xy[r * DP + c] = ix * iy;
+        }
     }
     __syncthreads();
     for (int i = tid; i < TW * TH; i += 256) {
@@ -68,9 +79,17 @@ __global__ __launch_bounds__(256) void harris_tile(const float *__restrict__ in,
             const float *q = f + (r + 1) * DP + (c + 1);
             return (((((((q[-DP - 1] + q[-1]) + q[DP - 1]) + q[-DP]) + q[0]) + q[DP]) + q[-DP + 1]) + q[1]) + q[DP + 1];
         };
-        const float sxx = s3(s_xx), syy = s3(s_yy), sxy = s3(s_xy);
-        const float det = sxx * syy - sxy * sxy, trace = sxx + syy;
-        out[(long)y * g.out_sy + x] = det - (0.04f * trace) * trace;
+        auto s3p = [&](const float *f, const float *h) {   // sum3x3 of the inline product f h, fma canon: the first product is fused
+            const float *q = f + (r + 1) * DP + (c + 1), *w = h + (r + 1) * DP + (c + 1);   // with the second, the others with the sum
+            float acc = dev::mad2(q[-DP - 1], w[-DP - 1], q[-1], w[-1]);
+            acc = dev::mad(q[DP - 1], w[DP - 1], acc), acc = dev::mad(q[-DP], w[-DP], acc), acc = dev::mad(q[0], w[0], acc);
+            acc = dev::mad(q[DP], w[DP], acc), acc = dev::mad(q[-DP + 1], w[-DP + 1], acc), acc = dev::mad(q[1], w[1], acc);
+            return dev::mad(q[DP + 1], w[DP + 1], acc);
+        };
+        const float sxx = dev::CANON_FMA ? s3p(s_xx, s_xx) : s3(s_xx), syy = dev::CANON_FMA ? s3p(s_yy, s_yy) : s3(s_yy);
+        const float sxy = dev::CANON_FMA ? s3p(s_xx, s_yy) : s3(s_xy);
+        const float det = dev::mulsub(sxx, syy, sxy * sxy), trace = sxx + syy;
+        out[(long)y * g.out_sy + x] = dev::msub(det, 0.04f * trace, trace);
     }
 }
 

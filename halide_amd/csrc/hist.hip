@@ -20,7 +20,7 @@ using namespace hlmi;
 namespace {
 
 __device__ __forceinline__ float luma(uint8_t r, uint8_t g, uint8_t b) {
-    return (0.299f * (float)r + 0.587f * (float)g) + 0.114f * (float)b;
+    return dev::mad(0.114f, (float)b, dev::mad2(0.299f, (float)r, 0.587f, (float)g));
 }
 
 // in: channel 0 of the input's element (0, 0); W x H pixels.  VEC: rows start 4-byte aligned and W % 4 == 0
@@ -117,12 +117,12 @@ __global__ __launch_bounds__(256) void hist_apply(const uint8_t *__restrict__ in
     uint8_t *o0 = out + (long)y * g.out_sy, *o1 = o0 + g.out_sc, *o2 = o0 + 2 * g.out_sc;
     auto pixel = [&](uint8_t rr, uint8_t gg, uint8_t bb, uint8_t &red, uint8_t &green, uint8_t &blue) {
         const float Y = luma(rr, gg, bb);
-        const float Cr = ((float)rr - Y) * 0.713f + 128.0f, Cb = ((float)bb - Y) * 0.564f + 128.0f;
+        const float Cr = dev::mad((float)rr - Y, 0.713f, 128.0f), Cb = dev::mad((float)bb - Y, 0.564f, 128.0f);
         const uint8_t bin = (uint8_t)dev::clampf(Y, 0.0f, 255.0f);
         const float eq = dev::clampf((float)s_cdf[bin] * g.scale, 0.0f, 255.0f);
-        red = (uint8_t)dev::clampf(eq + (Cr - 128.0f) * 1.4f, 0.0f, 255.0f);
-        green = (uint8_t)dev::clampf((eq - 0.343f * (Cb - 128.0f)) - 0.711f * (Cr - 128.0f), 0.0f, 255.0f);
-        blue = (uint8_t)dev::clampf(eq + 1.765f * (Cb - 128.0f), 0.0f, 255.0f);
+        red = (uint8_t)dev::clampf(dev::mad(Cr - 128.0f, 1.4f, eq), 0.0f, 255.0f);
+        green = (uint8_t)dev::clampf(dev::msub(dev::msub(eq, 0.343f, Cb - 128.0f), 0.711f, Cr - 128.0f), 0.0f, 255.0f);
+        blue = (uint8_t)dev::clampf(dev::mad(1.765f, Cb - 128.0f, eq), 0.0f, 255.0f);
     };
     if (VEC) {
         const int x = 4 * (blockIdx.x * 256 + threadIdx.x);

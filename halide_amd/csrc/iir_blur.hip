@@ -19,6 +19,7 @@
 //   backward  b = (1-a) b + a scratch(x, y), bottom to top; tiles are written out TRANSPOSED (the generator transposes
 //             after each column blur, :31): lane = y, 64 consecutive floats per store
 // Launched twice (columns of the input, then columns of the transposed intermediate = rows of the input).
+#include "hlmi_device_math.h"
 #include "hlmi_internal.h"
 
 #include <type_traits>
@@ -60,7 +61,8 @@ __global__ __launch_bounds__(64 * (1 + NHELP)) void iir_cols_T(const float *__re
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x0 = blockIdx.x * 64, c = blockIdx.y;
     const int x = min(x0 + lane, Wd - 1);                    // lanes past the edge shadow the last column (never stored)
-    const float c1 = 1.0f - alpha;
+    const float c1 = 1.0f - alpha;   // (1 - alpha) b + alpha in: the first product is the one fused under the fma canon (dev::mad), alpha in
+                                     // stays a multiply — made by the helper waves, off the scanner's dependent chain
     const float *sbase = src + (long)c * s_sc, *tbase = scratch + ((long)c * Hd) * Wd;   // uniform; the loaders add xoff
     const uint32_t xoff = 4u * (uint32_t)x;
     float *t = scratch + ((long)c * Hd) * Wd + x;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(64 * (1 + NHELP)) void iir_cols_T(const float *__re
                     st = 1;
                 }
                 for (; st < n; st++) {
-                    b = c1 * b + tl[at(st, lane)];
+                    b = dev::mad(c1, b, tl[at(st, lane)]);
                     tl[at(st, lane)] = b;
                 }
             };
@@ -132,10 +134,10 @@ __global__ __launch_bounds__(64 * (1 + NHELP)) void iir_cols_T(const float *__re
 #pragma unroll
                 for (int gq = 0; gq < TR / 4; gq++) {
                     float4 r;
-                    b = c1 * b + ucur[gq].x, r.x = b;
-                    b = c1 * b + ucur[gq].y, r.y = b;
-                    b = c1 * b + ucur[gq].z, r.z = b;
-                    b = c1 * b + ucur[gq].w, r.w = b;
+                    b = dev::mad(c1, b, ucur[gq].x), r.x = b;
+                    b = dev::mad(c1, b, ucur[gq].y), r.y = b;
+                    b = dev::mad(c1, b, ucur[gq].z), r.z = b;
+                    b = dev::mad(c1, b, ucur[gq].w), r.w = b;
                     tl[gq * (TG / 4)] = r;
                     unxt[gq] = tn[gq * (TG / 4)];
                 }
@@ -152,11 +154,11 @@ __global__ __launch_bounds__(64 * (1 + NHELP)) void iir_cols_T(const float *__re
                 for (int gq = 0; gq < TR / 4; gq++) {
                     float4 r;
                     if (gq == 0) b = u[0].x;                 // the pass's first row is taken as it is (:21, :26-28)
-                    else b = c1 * b + u[gq].x;
+                    else b = dev::mad(c1, b, u[gq].x);
                     r.x = b;
-                    b = c1 * b + u[gq].y, r.y = b;
-                    b = c1 * b + u[gq].z, r.z = b;
-                    b = c1 * b + u[gq].w, r.w = b;
+                    b = dev::mad(c1, b, u[gq].y), r.y = b;
+                    b = dev::mad(c1, b, u[gq].z), r.z = b;
+                    b = dev::mad(c1, b, u[gq].w), r.w = b;
                     tl[gq * (TG / 4)] = r;
                 }
             };
@@ -165,10 +167,10 @@ __global__ __launch_bounds__(64 * (1 + NHELP)) void iir_cols_T(const float *__re
 #pragma unroll
                 for (int gq = 0; gq < TR / 4; gq++) {
                     float4 r;
-                    b = c1 * b + ucur[gq].x, r.x = b;
-                    b = c1 * b + ucur[gq].y, r.y = b;
-                    b = c1 * b + ucur[gq].z, r.z = b;
-                    b = c1 * b + ucur[gq].w, r.w = b;
+                    b = dev::mad(c1, b, ucur[gq].x), r.x = b;
+                    b = dev::mad(c1, b, ucur[gq].y), r.y = b;
+                    b = dev::mad(c1, b, ucur[gq].z), r.z = b;
+                    b = dev::mad(c1, b, ucur[gq].w), r.w = b;
                     tl[gq * (TG / 4)] = r;
                 }
             };

@@ -114,7 +114,7 @@ __device__ __forceinline__ float4 interp_value(const float4 d, const Lvl &up, in
     const float alpha = 1.0f - d.w;
     auto one = [&](float d_c, float paa, float pba, float pab, float pbb) {
         const float ua = (paa + pba) * 0.5f, ub = (pab + pbb) * 0.5f;
-        return d_c + alpha * ((ua + ub) * 0.5f);
+        return dev::mad(alpha, (ua + ub) * 0.5f, d_c);
     };
     return make_float4(one(d.x, aa.x, ba.x, ab.x, bb.x), one(d.y, aa.y, ba.y, ab.y, bb.y), one(d.z, aa.z, ba.z, ab.z, bb.z),
                        one(d.w, aa.w, ba.w, ab.w, bb.w));
@@ -212,7 +212,7 @@ __device__ __forceinline__ float4 interp_from(const float4 d, const float4 aa, c
     const float alpha = 1.0f - d.w;
     auto one = [&](float d_c, float paa, float pba, float pab, float pbb) {
         const float ua = (paa + pba) * 0.5f, ub = (pab + pbb) * 0.5f;
-        return d_c + alpha * ((ua + ub) * 0.5f);
+        return dev::mad(alpha, (ua + ub) * 0.5f, d_c);
     };
     return make_float4(one(d.x, aa.x, ba.x, ab.x, bb.x), one(d.y, aa.y, ba.y, ab.y, bb.y), one(d.z, aa.z, ba.z, ab.z, bb.z),
                        one(d.w, aa.w, ba.w, ab.w, bb.w));
@@ -305,7 +305,22 @@ __global__ __launch_bounds__(256) void ip_final(InGeom g, Lvl d1, Lvl d2, Lvl up
         const int y = y0 + (tid >> 6) + 4 * k;
         if (y > y1) break;
         const int ya = (y >> 1) - ay0, yb = ((y + 1) >> 1) - ay0;
-        const float4 v = interp_from(ds0(g, x, y), s1[ya * F1W + xa], s1[ya * F1W + xb], s1[yb * F1W + xa], s1[yb * F1W + xb]);
+        // interpolated[0] with downsampled[0] INLINE, as the reference's CPU schedule has it inside `normalize` (:178-188): for the colour
+        // channels the sum is product + product — under the fma canon the first one, input * alpha-channel, is the one fused (dev::mad2)
+        float4 v;
+        {
+            const long off = (long)y * g.sy + x;   // inside the image
+            const float a = g.in[3 * g.sc + off], alpha = 1.0f - a;
+            const float4 aa = s1[ya * F1W + xa], ba = s1[ya * F1W + xb], ab = s1[yb * F1W + xa], bb = s1[yb * F1W + xb];
+            auto up = [](float paa, float pba, float pab, float pbb) {
+                const float ua = (paa + pba) * 0.5f, ub = (pab + pbb) * 0.5f;
+                return (ua + ub) * 0.5f;
+            };
+            v.x = dev::mad2(g.in[off], a, alpha, up(aa.x, ba.x, ab.x, bb.x));
+            v.y = dev::mad2(g.in[g.sc + off], a, alpha, up(aa.y, ba.y, ab.y, bb.y));
+            v.z = dev::mad2(g.in[2 * g.sc + off], a, alpha, up(aa.z, ba.z, ab.z, bb.z));
+            v.w = dev::mad(alpha, up(aa.w, ba.w, ab.w, bb.w), a);
+        }
         float *o = out + (long)y * out_sy + x;
         o[0] = v.x / v.w, o[out_sc] = v.y / v.w, o[2 * out_sc] = v.z / v.w;
     }

@@ -69,6 +69,8 @@ struct CostRow {
     uint32_t l01;   // c0 | c1 << 16 of the left pixel
     int l2;
 };
+// (a + 3 (b + c) + d) / 8 (:282-283); the product has one use: fused with the first add under the fma canon
+__device__ __forceinline__ float lb_down4(float a, float b, float c, float d) { return (dev::mad(3.0f, b + c, a) + d) * 0.125f; }
 __device__ __forceinline__ uint2 lb_pack(int c0, int c1, int c2) { return make_uint2((uint32_t)c0 | (uint32_t)c1 << 16, (uint32_t)c2); }
 __device__ __forceinline__ float lb_cost1(const uint2 A, const uint2 B, const CostRow &c) {
     const lb_s16x2 l = __builtin_bit_cast(lb_s16x2, c.l01), a = __builtin_bit_cast(lb_s16x2, A.x), b = __builtin_bit_cast(lb_s16x2, B.x);
@@ -92,13 +94,12 @@ __device__ __forceinline__ float cost_stack(const uint2 *__restrict__ sr, int ti
     for (int z = 0; z < SB; z++) {
         cz[z] = lb_cost1(sr[tid + 2 * z], sr[tid + 2 * z + 1], c);
         const bool on = FULL || z < g.slices;
-        const float sq = cz[z] * cz[z];
-        sa = sa + (on ? sq : 0.0f);
+        sa = dev::mad(on ? cz[z] : 0.0f, cz[z], sa);   // sum(pow(cost, 2)) (:44); a slice that does not exist adds +0
         const float q0 = cz[z] * rn;                                   // cz / fslices, see above
         const float q = __builtin_fmaf(__builtin_fmaf(-g.fslices, q0, cz[z]), rn, q0);
         sb = sb + (on ? q : 0.0f);
     }
-    return sa / g.fslices - sb * sb;   // the confidence
+    return dev::msub(sa / g.fslices, sb, sb);   // the confidence (:44-46)
 }
 
 // One workgroup = 256 consecutive pixels of a row of E.  Every pixel compares itself with the 2 * slices right-image pixels
@@ -176,14 +177,14 @@ __global__ __launch_bounds__(256) void lb_down(const float *__restrict__ src, Bo
     for (int i = tid; i < (2 * DTH + 2) * DTW; i += 256) {
         const int r = i / DTW, xo = i - r * DTW;
         const float *q = &s_in[r][2 * xo];
-        s_dx[r][xo] = (q[0] + 3.0f * (q[1] + q[2]) + q[3]) * 0.125f;
+        s_dx[r][xo] = lb_down4(q[0], q[1], q[2], q[3]);
     }
     __syncthreads();
     for (int i = tid; i < DTH * DTW; i += 256) {
         const int yo = i / DTW, xo = i - yo * DTW;
         const int xi = blockIdx.x * DTW + xo, yi = blockIdx.y * DTH + yo;
         if (xi < db.w && yi < db.h)
-            dst[((size_t)zc * db.h + yi) * db.w + xi] = (s_dx[2 * yo][xo] + 3.0f * (s_dx[2 * yo + 1][xo] + s_dx[2 * yo + 2][xo]) + s_dx[2 * yo + 3][xo]) * 0.125f;
+            dst[((size_t)zc * db.h + yi) * db.w + xi] = lb_down4(s_dx[2 * yo][xo], s_dx[2 * yo + 1][xo], s_dx[2 * yo + 2][xo], s_dx[2 * yo + 3][xo]);
     }
 }
 
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void lb_down32(const float *__restrict__ src, 
     for (int i = tid; i < (2 * DTH + 2) * DTW; i += 256) {
         const int r = i / DTW, xo = i - r * DTW;
         const float *q = &s_in[r][2 * xo];
-        s_dx[r][xo] = (q[0] + 3.0f * (q[1] + q[2]) + q[3]) * 0.125f;
+        s_dx[r][xo] = lb_down4(q[0], q[1], q[2], q[3]);
     }
     __syncthreads();
     float *const o = dst + (size_t)zc * db.h * db.w;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void lb_down32(const float *__restrict__ src, 
         const int yo = i / DTW, xo = i - yo * DTW;
         const int xi = blockIdx.x * DTW + xo, yi = blockIdx.y * DTH + yo;
         if (xi < db.w && yi < db.h)
-            o[lb_mul24((uint32_t)yi, (uint32_t)db.w) + (uint32_t)xi] = (s_dx[2 * yo][xo] + 3.0f * (s_dx[2 * yo + 1][xo] + s_dx[2 * yo + 2][xo]) + s_dx[2 * yo + 3][xo]) * 0.125f;
+            o[lb_mul24((uint32_t)yi, (uint32_t)db.w) + (uint32_t)xi] = lb_down4(s_dx[2 * yo][xo], s_dx[2 * yo + 1][xo], s_dx[2 * yo + 2][xo], s_dx[2 * yo + 3][xo]);
     }
 }
 
@@ -412,10 +413,10 @@ __global__ __launch_bounds__(1024) void lb_tail(TailArgs a) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int yy = 2 * y - 1 + k;
-                dx[k] = (src_at<true>(src, sb, zc, 2 * x - 1, yy) + 3.0f * (src_at<true>(src, sb, zc, 2 * x, yy) + src_at<true>(src, sb, zc, 2 * x + 1, yy)) +
-                         src_at<true>(src, sb, zc, 2 * x + 2, yy)) * 0.125f;
+                dx[k] = lb_down4(src_at<true>(src, sb, zc, 2 * x - 1, yy), src_at<true>(src, sb, zc, 2 * x, yy), src_at<true>(src, sb, zc, 2 * x + 1, yy),
+                                 src_at<true>(src, sb, zc, 2 * x + 2, yy));
             }
-            dst[(size_t)zc * db.h * db.w + i] = (dx[0] + 3.0f * (dx[1] + dx[2]) + dx[3]) * 0.125f;
+            dst[(size_t)zc * db.h * db.w + i] = lb_down4(dx[0], dx[1], dx[2], dx[3]);
         }
         __syncthreads();
     }
@@ -458,9 +459,9 @@ __global__ __launch_bounds__(1024) void lb_tail_lds(TailArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     t[j] = first ? src_at<true>(src, sb, zc, 2 * x - 1 + j, yy) : lds_at(opush[l - 1], sb, 2 * x - 1 + j, yy);
-                dx[k] = (t[0] + 3.0f * (t[1] + t[2]) + t[3]) * 0.125f;
+                dx[k] = lb_down4(t[0], t[1], t[2], t[3]);
             }
-            s_lv[opush[l] + i] = (dx[0] + 3.0f * (dx[1] + dx[2]) + dx[3]) * 0.125f;
+            s_lv[opush[l] + i] = lb_down4(dx[0], dx[1], dx[2], dx[3]);
         }
         __syncthreads();
     }
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(256) void lb_cost_down(const uint8_t *__restrict__ 
 #pragma unroll
             for (int k = 0; k < KPT; k++) {   // slots past the end read LDS offset 0 and store nothing
                 const float2 qa = *(const float2 *)&s_row[qoff[k]], qb = *(const float2 *)&s_row[qoff[k] + 2];
-                const float d = (qa.x + 3.0f * (qa.y + qb.x) + qb.y) * 0.125f;
+                const float d = lb_down4(qa.x, qa.y, qb.x, qb.y);
                 if (emit && doff[k] >= 0) drow[doff[k]] = (p2[k] + d) * 0.125f;
                 p1[k] = d;
             }
@@ -585,8 +586,8 @@ __global__ __launch_bounds__(256) void lb_cost_down(const uint8_t *__restrict__ 
 #pragma unroll
             for (int k = 0; k < KPT; k++) {
                 const float2 qa = *(const float2 *)&s_row[qoff[k]], qb = *(const float2 *)&s_row[qoff[k] + 2];
-                const float d = (qa.x + 3.0f * (qa.y + qb.x) + qb.y) * 0.125f;
-                p2[k] = p0[k] + 3.0f * (p1[k] + d);
+                const float d = lb_down4(qa.x, qa.y, qb.x, qb.y);
+                p2[k] = dev::mad(3.0f, p1[k] + d, p0[k]);
                 p0[k] = d;
             }
         }
@@ -661,9 +662,9 @@ __global__ __launch_bounds__(512) void lb_cost_down2(const uint8_t *__restrict__
             for (int k = 0; k < KPT; k++) {   // slots past the end read LDS offset 0 and store nothing
                 const float2 ea = *(const float2 *)&s_row[qoff[k]], eb = *(const float2 *)&s_row[qoff[k] + 2];
                 const float2 oa = *(const float2 *)&s_row[rowsz + qoff[k]], ob = *(const float2 *)&s_row[rowsz + qoff[k] + 2];
-                const float de = (ea.x + 3.0f * (ea.y + eb.x) + eb.y) * 0.125f;
-                const float dd = (oa.x + 3.0f * (oa.y + ob.x) + ob.y) * 0.125f;
-                p2[k] = p0[k] + 3.0f * (p1[k] + de);
+                const float de = lb_down4(ea.x, ea.y, eb.x, eb.y);
+                const float dd = lb_down4(oa.x, oa.y, ob.x, ob.y);
+                p2[k] = dev::mad(3.0f, p1[k] + de, p0[k]);
                 p0[k] = de;
                 if (emit && doff[k] >= 0) drow[doff[k]] = (p2[k] + dd) * 0.125f;
                 p1[k] = dd;

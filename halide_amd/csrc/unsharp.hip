@@ -9,6 +9,7 @@
 //
 // HBM bound: 12 B/px read + 12 B/px written.  One workgroup = a 64 x 32 output tile: gray of the (64+6) x (32+6) window
 // goes to LDS once (edge-clamped), blur_y of 70 x 32 to LDS, then each thread finishes 8 pixels (64 x 16 tiles: 5 % slower).
+#include "hlmi_device_math.h"
 #include "hlmi_internal.h"
 
 #include <math.h>
@@ -27,6 +28,11 @@ struct UGeom {
     long in_sy, in_sc, out_sy, out_sc;
     float k[4];
 };
+
+// ((k0 c + k1 s1) + k2 s2) + k3 s3 (:35-44): every product feeds an add (dev::mad2 / dev::mad fuse them under the fma canon)
+__device__ __forceinline__ float tap7(const float (&k)[4], float c, float s1, float s2, float s3) {
+    return dev::mad(k[3], s3, dev::mad(k[2], s2, dev::mad2(k[0], c, k[1], s1)));
+}
 
 __global__ __launch_bounds__(256) void unsharp_tile(const float *__restrict__ in, float *__restrict__ out, UGeom g) {
     __shared__ float s_gray[GH * GP];
@@ -51,7 +57,7 @@ __global__ __launch_bounds__(256) void unsharp_tile(const float *__restrict__ in
             const int i = tid + 256 * k;
             if (i < GW * GH) {
                 const int r = i / GW, c = i - r * GW;
-                s_gray[r * GP + c] = (0.299f * v[k][0] + 0.587f * v[k][1]) + 0.114f * v[k][2];
+                s_gray[r * GP + c] = dev::mad(0.114f, v[k][2], dev::mad2(0.299f, v[k][0], 0.587f, v[k][1]));
             }
         }
     }
@@ -59,7 +65,7 @@ __global__ __launch_bounds__(256) void unsharp_tile(const float *__restrict__ in
     for (int i = tid; i < GW * TH; i += 256) {
         const int r = i / GW, c = i - r * GW;
         const float *q = s_gray + (r + R) * GP + c;
-        s_by[r * GP + c] = ((g.k[0] * q[0] + g.k[1] * (q[-GP] + q[GP])) + g.k[2] * (q[-2 * GP] + q[2 * GP])) + g.k[3] * (q[-3 * GP] + q[3 * GP]);
+        s_by[r * GP + c] = tap7(g.k, q[0], q[-GP] + q[GP], q[-2 * GP] + q[2 * GP], q[-3 * GP] + q[3 * GP]);
     }
     __syncthreads();
     static_assert((TW * TH) % 256 == 0, "whole passes");
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(256) void unsharp_tile(const float *__restrict__ in
         const int x = blockIdx.x * TW + c, y = blockIdx.y * TH + r;
         if (x >= g.ow || y >= g.oh) continue;
         const float *q = s_by + r * GP + c + R;
-        const float bx = ((g.k[0] * q[0] + g.k[1] * (q[-1] + q[1])) + g.k[2] * (q[-2] + q[2])) + g.k[3] * (q[-3] + q[3]);
+        const float bx = tap7(g.k, q[0], q[-1] + q[1], q[-2] + q[2], q[-3] + q[3]);
         const float gr = s_gray[(r + R) * GP + c + R];
         const float ratio = (2.0f * gr - bx) / gr;
         float *o = out + (long)y * g.out_sy + x;
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(256) void unsharp_tile2(const float *__restrict__ i
     const int tid = threadIdx.x, cl = tid & 127;
     const int rh = __builtin_amdgcn_readfirstlane(tid >> 7);                // 0 / 1: wave-uniform
     const int X0 = g.ox0 + blockIdx.x * TW, Y0 = g.oy0 + blockIdx.y * TH;   // absolute origin of the tile
-    auto gray_of = [](float r, float gg, float b) { return (0.299f * r + 0.587f * gg) + 0.114f * b; };
+    auto gray_of = [](float r, float gg, float b) { return dev::mad(0.114f, b, dev::mad2(0.299f, r, 0.587f, gg)); };
     auto ld = [](const float *rowp, uint32_t byte_off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(rowp) + byte_off); };
     {
         // window column cl (0..127) of rows rh, rh + 2, ...: all 3 x 19 loads requested before the first gray; columns 128..133 below
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256) void unsharp_tile2(const float *__restrict__ i
     {
         // blur_y: column cl, rows 16 rh .. 16 rh + 15 from gray rows 16 rh .. 16 rh + 21 of the column; then the six edge columns
         auto by_of = [&](float m3, float m2, float m1, float c0, float p1, float p2, float p3) {
-            return ((g.k[0] * c0 + g.k[1] * (m1 + p1)) + g.k[2] * (m2 + p2)) + g.k[3] * (m3 + p3);
+            return tap7(g.k, c0, m1 + p1, m2 + p2, m3 + p3);
         };
         const float *q = s_gray + (16 * rh) * GP + cl;
         float w[22];
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(256) void unsharp_tile2(const float *__restrict__ i
         const int r = 2 * k + rh, y = (int)blockIdx.y * TH + r;
         if (y >= g.oh) break;             // scalar
         const float *q = s_by + r * GP + cl + R;
-        const float bx = ((g.k[0] * q[0] + g.k[1] * (q[-1] + q[1])) + g.k[2] * (q[-2] + q[2])) + g.k[3] * (q[-3] + q[3]);
+        const float bx = tap7(g.k, q[0], q[-1] + q[1], q[-2] + q[2], q[-3] + q[3]);
         const float gr = s_gray[(r + R) * GP + cl + R];
         const float ratio = (2.0f * gr - bx) / gr;
         if (xo < g.ow) {

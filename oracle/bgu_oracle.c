@@ -20,6 +20,9 @@
  * Every Func is a total function on Z^n (histogram is 0 wherever no sample lands), so each stage is evaluated on the
  * box its consumers read: line / blurx on the cells [cx0, cx1] x [cy0, cy1] x [0, nb + 1] the output region touches
  * (:441-476), blury 3 cells wider in x, blurz 3 wider in x and y, histogram 3 wider in z as well.
+ * Canon 1 (oracle_common.h) contracts: the products of the seven-tap filters, the multiply-subtracts of the elimination and the
+ * two substitutions, the three lerps and the affine transform of the slice.  The histogram's update adds one of 22 products
+ * chosen by mux() (:307-315) — a select stands between the product and the add, so those stay two operations in both forms.
  */
 #include "oracle_common.h"
 #include <xmmintrin.h>
@@ -41,23 +44,23 @@ static void bgu_solve(float f[4][7], int variant) {
         for (int i = j + 1; i < M; i++) {                                 /* :178-187 */
             for (int k = j + 1; k < M; k++) {
                 if (k < i) f[i][k] = f[k][i];
-                else f[i][k] = f[i][k] - f[k][j] * f[j][i];
+                else f[i][k] = o_msub(f[i][k], f[k][j], f[j][i]);
             }
         }
     }
     for (int k = 0; k < N; k++) {                                         /* :199-229 */
         for (int j = 0; j < M; j++)
-            for (int i = 0; i < j; i++) f[j][M + k] = f[j][M + k] - f[j][i] * f[i][M + k];
+            for (int i = 0; i < j; i++) f[j][M + k] = o_msub(f[j][M + k], f[j][i], f[i][M + k]);
         for (int j = 0; j < M; j++) f[j][M + k] = f[j][M + k] * f[j][j];
         for (int j = M - 1; j >= 0; j--)
-            for (int i = j + 1; i < M; i++) f[j][M + k] = f[j][M + k] - f[i][j] * f[i][M + k];
+            for (int i = j + 1; i < M; i++) f[j][M + k] = o_msub(f[j][M + k], f[i][j], f[i][M + k]);
     }
 }
 
 /* the seven-tap 1/d^3-like filter (:333-359): ((((((a t0 + b t1) + c t2) + d) + e t2) + f t1) + g t0) */
 static inline float bgu_tap7(float a, float b, float c, float d, float e, float f, float g) {
     const float t0 = 1.0f / 64, t1 = 1.0f / 27, t2 = 1.0f / 8;
-    return a * t0 + b * t1 + c * t2 + d + e * t2 + f * t1 + g * t0;
+    return o_mad(g, t0, o_mad(f, t1, o_mad(e, t2, o_mad(c, t2, o_mad2(a, t0, b, t1)) + d)));
 }
 
 static inline int bgu_cell(int v, int big) { return (int)floorf((float)v / (float)big); }
@@ -195,7 +198,7 @@ int oracle_bgu(float r_sigma, int s_sigma, const float *splat, int lw, int lh, i
                 m[c] = o_lerp(mz[0], mz[1], zf);                                                                /* :467-470 */
             }
             for (int c = 0; c < 3; c++) {
-                const float v = m[4 * c] * s0 + m[4 * c + 1] * s1 + m[4 * c + 2] * s2 + m[4 * c + 3];           /* :473-477 */
+                const float v = o_mad(m[4 * c + 2], s2, o_mad2(m[4 * c], s0, m[4 * c + 1], s1)) + m[4 * c + 3];           /* :473-477 */
                 out[((size_t)c * oh + yo) * ow + xo] = o_clampf(v, 0.0f, 1.0f);                                 /* :482 */
             }
         }

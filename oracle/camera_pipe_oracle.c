@@ -8,6 +8,8 @@
  * construction.  The two float set-up computations (3x4 colour matrix, 1024-entry tone curve) use the canonical
  * float order of oracle_common.h (pow -> halide_exp(halide_log(x)*y), x/c -> x*(1/c)); PARITY UNPINNED for those
  * (no golden output in the reference) — a 1-ulp difference there could move a LUT entry or a matrix coefficient by 1.
+ * Canon 1 (oracle_common.h) contracts the set-up's product sums (the matrix blend, the two branches of the contrast curve,
+ * z * 255 + 0.5) and the polynomials inside pow.
  * Every Func is evaluated as a pure function straight from raw input; no boundary condition exists in the
  * pipeline: the caller's input must cover x in [10, W+21], y in [6, H+17] for a W x H output.
  */
@@ -124,7 +126,7 @@ void oracle_camera_pipe_setup(const float *m3200, const float *m7000 /* [3][4] r
     const float inv_den = 1.0f / (k2 - k1);         /* x / c -> x * fold(1 / c) */
     float alpha = (1.0f / color_temp - k1) * inv_den;
     for (int i = 0; i < 12; i++) {
-        float val = m3200[i] * alpha + m7000[i] * (1.0f - alpha);
+        float val = o_mad2(m3200[i], alpha, m7000[i], 1.0f - alpha);
         matrix[i] = (int16_t)(val * 256.0f);
     }
     int minRaw = 0 + blackLevel, maxRaw = whiteLevel;
@@ -135,8 +137,8 @@ void oracle_camera_pipe_setup(const float *m3200, const float *m7000 /* [3][4] r
     for (int x = 0; x < 1024; x++) {
         float xf = o_clampf((float)(x - minRaw) * invRange, 0.0f, 1.0f);
         float g = o_halide_pow(xf, inv_gamma);
-        float z = g > 0.5f ? 1.0f - ((a * (1.0f - g)) * (1.0f - g) + b * (1.0f - g)) : (a * g) * g + b * g;
-        uint8_t val = (uint8_t)o_clampf(z * 255.0f + 0.5f, 0.0f, 255.0f);
+        float z = g > 0.5f ? 1.0f - o_mad2(a * (1.0f - g), 1.0f - g, b, 1.0f - g) : o_mad2(a * g, g, b, g);
+        uint8_t val = (uint8_t)o_clampf(o_mad(z, 255.0f, 0.5f), 0.0f, 255.0f);
         curve[x] = x <= minRaw ? 0 : (x > maxRaw ? 255 : val);
     }
     float s = o_clampf(sharpen_strength * 32.0f, 0.0f, 255.0f); /* u8_sat */

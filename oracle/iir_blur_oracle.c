@@ -6,7 +6,8 @@
  *   blur(x, y)        = (1 - alpha) blur(x, y-1) + alpha in(x, y)          y = 1 .. H-1        (:22-24)
  *   blur(x, y)        = (1 - alpha) blur(x, y+1) + alpha blur(x, y)        y = H-2 .. 0        (:26-28)
  *   transpose(x, y)   = blur(y, x);  output = the same applied to transpose (height := the input's width)
- * The scans are sequential by definition; one rounding per operator (two products, one sum per step).
+ * The scans are sequential by definition; one rounding per operator (two products, one sum per step); canon 1
+ * (oracle_common.h): product + product, the first — (1 - alpha) blur — is the one fused: fma(1 - alpha, blur, alpha in).
  * The reference pins the shape to 1536 x 2560 x 3 (:158-163); the restatement takes any W, H, C.
  * Planar f32: in[c*in_sc + y*in_sy + x], out likewise.  PARITY UNPINNED.
  */
@@ -19,8 +20,8 @@ static void iir_cols_T(const float *src, long s_sy, int w, int h, float alpha, f
     for (int x = 0; x < w; x++) {
         float *b = (float *)malloc(sizeof(float) * h);
         b[0] = src[x];
-        for (int y = 1; y < h; y++) b[y] = c1 * b[y - 1] + alpha * src[(long)y * s_sy + x];
-        for (int y = h - 2; y >= 0; y--) b[y] = c1 * b[y + 1] + alpha * b[y];
+        for (int y = 1; y < h; y++) b[y] = o_mad2(c1, b[y - 1], alpha, src[(long)y * s_sy + x]);
+        for (int y = h - 2; y >= 0; y--) b[y] = o_mad2(c1, b[y + 1], alpha, b[y]);
         for (int y = 0; y < h; y++) dst[(long)x * d_sy + y] = b[y];
         free(b);
     }

@@ -12,6 +12,9 @@
  *              interpolated[l]    = downsampled[l] + (1 - downsampled[l](.,3)) * upsampled[l]
  *   output(x,y,c)      = interpolated[0](x,y,c) / interpolated[0](x,y,3),  c < 3, over exactly [0,W) x [0,H)   (:83-87)
  * Sums left to right as written, one rounding per operator; "/ 2.0f" == "* 0.5f".  PARITY UNPINNED.
+ * Canon 1 (oracle_common.h): 2 prev is exact, so the taps are the same in both forms; interpolated[l] = fma(alpha, upsampled, downsampled[l])
+ * for l >= 1 (downsampled[l] is stored: compute_root, :150-160); at l = 0 downsampled[0] is INLINE in `normalize` (:178-188), so for a
+ * colour channel the sum is product + product and the first, clamped(c) * clamped(3), is the one fused: fma(in_c, in_3, alpha * up).
  * Every Func is a total function on Z^2; level l is evaluated on the box the levels above and below it read (same
  * recursion as the kernels: I_l for interpolated, D_l for downsampled), stored as float[4] per pixel.
  */
@@ -95,16 +98,20 @@ int oracle_interpolate(const float *in, int W, int H, long in_sy, long in_sc, fl
                     memcpy(o, ilevel_at(&ds[l], x, y), 16);
                     continue;
                 }
-                float d[4];
-                if (l == 0) DS0(x, y, d);
-                else memcpy(d, ilevel_at(&ds[l], x, y), 16);
+                float d[4], a0[4] = {1.0f, 1.0f, 1.0f, 1.0f};   /* l == 0: d[c] = a0[c] * d3 with the product still open */
+                if (l == 0) {
+                    const long off = (long)y * in_sy + x;   /* I_0 is the image itself */
+                    d[3] = in[3 * in_sc + off], a0[0] = in[off], a0[1] = in[in_sc + off], a0[2] = in[2 * in_sc + off];
+                } else {
+                    memcpy(d, ilevel_at(&ds[l], x, y), 16);
+                }
                 const int xa = o_fdiv(x, 2), xb = o_fdiv(x + 1, 2), ya = o_fdiv(y, 2), yb = o_fdiv(y + 1, 2);
                 const float alpha = 1.0f - d[3];
                 for (int c = 0; c < 4; c++) {
                     const float ua = (ilevel_at(&ip[l + 1], xa, ya)[c] + ilevel_at(&ip[l + 1], xb, ya)[c]) * 0.5f;
                     const float ub = (ilevel_at(&ip[l + 1], xa, yb)[c] + ilevel_at(&ip[l + 1], xb, yb)[c]) * 0.5f;
                     const float up = (ua + ub) * 0.5f;
-                    o[c] = d[c] + alpha * up;
+                    o[c] = (l == 0 && c < 3) ? o_mad2(a0[c], d[3], alpha, up) : o_mad(alpha, up, d[c]);
                 }
             }
         }

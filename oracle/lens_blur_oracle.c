@@ -5,7 +5,10 @@
  *
  *   * the float stages (cost confidence, the push-pull pyramids, filtered_cost) have no golden output in the
  *     reference and the compiler cannot be built here; the canonical order is the generator's expression order
- *     (oracle_common.h);
+ *     (oracle_common.h); canon 1 there contracts sum(cost cost) (each square with the running sum), the confidence
+ *     sa / slices - sb sb = fma(-sb, sb, sa / slices), and the 3 (b + c) of the down-sampling taps with the add it feeds.  The
+ *     up-sampling weights 1/4, 3/4 and the lerp weight 1/2 make one exact product per sum (identical in both forms), the bokeh
+ *     weights are 0 or 1, the colour costs are integers below 2^18;
  *   * the sample positions come from Halide's random_float() (:116-117), which is a FIXED hash of
  *     (call id, definition tag, free variables) — src/Random.cpp:20-104, src/IROperator.cpp:2873-2889,
  *     src/Function.cpp:640-648 — but the call ids and the tag are values of two process-global counters of the
@@ -121,13 +124,13 @@ int oracle_lens_blur(const uint8_t *left, int W, int H, const uint8_t *right, in
                     const int r1 = right[((size_t)c * RH + ry) * RW + o_clampi(x + 2 * z + 1, 0, RW - 1)];
                     const int d0 = l > r0 ? l - r0 : r0 - l, d1 = l > r1 ? l - r1 : r1 - l; /* absd :32-33 */
                     const float d = (float)(d0 < d1 ? d0 : d1);
-                    cz = (c == 0) ? d * d : cz + d * d; /* pow(., 2) = e * e (src/IROperator.cpp:1008-1027) */
+                    cz = (c == 0) ? d * d : o_mad(d, d, cz); /* pow(., 2) = e * e (src/IROperator.cpp:1008-1027); integers below 2^18: exact either way */
                 }
                 cost[z] = cz;
-                sa = sa + cz * cz;      /* sum(pow(cost, 2))  :44 */
+                sa = o_mad(cz, cz, sa); /* sum(pow(cost, 2))  :44 */
                 sb = sb + cz / fslices; /* sum(cost / slices) :45 */
             }
-            const float conf = sa / fslices - sb * sb; /* :44-46 */
+            const float conf = o_msub(sa / fslices, sb, sb); /* :44-46 */
             for (int z = 0; z < slices; z++) {
                 PUSH(0, x, y, z, 0) = cost[z] * conf; /* :53-54 */
                 PUSH(0, x, y, z, 1) = conf;
@@ -144,10 +147,10 @@ int oracle_lens_blur(const uint8_t *left, int W, int H, const uint8_t *right, in
                     float dx[4];
                     for (int k = 0; k < 4; k++) {
                         const int yy = 2 * y - 1 + k;
-                        dx[k] = (PUSHF(i - 1, 2 * x - 1, yy, z, c) + 3.0f * (PUSHF(i - 1, 2 * x, yy, z, c) + PUSHF(i - 1, 2 * x + 1, yy, z, c)) +
+                        dx[k] = (o_mad(3.0f, PUSHF(i - 1, 2 * x, yy, z, c) + PUSHF(i - 1, 2 * x + 1, yy, z, c), PUSHF(i - 1, 2 * x - 1, yy, z, c)) +
                                  PUSHF(i - 1, 2 * x + 2, yy, z, c)) * 0.125f;
                     }
-                    PUSH(i, x, y, z, c) = (dx[0] + 3.0f * (dx[1] + dx[2]) + dx[3]) * 0.125f;
+                    PUSH(i, x, y, z, c) = (o_mad(3.0f, dx[1] + dx[2], dx[0]) + dx[3]) * 0.125f;
                 }
             }
         }

@@ -7,7 +7,9 @@
  *   blur_y    = k0 gray(y) + k1 (gray(y-1) + gray(y+1)) + k2 (gray(y-2) + gray(y+2)) + k3 (gray(y-3) + gray(y+3))
  *   blur_x    = the same along x on blur_y
  *   sharpen   = 2 gray - blur_x;  ratio = sharpen / gray;  output(x,y,c) = ratio(x,y) * input(x,y,c)   (input unclamped)
- * Every operator rounds once, left to right as written (no contraction): PARITY UNPINNED, like the other float pipelines.
+ * Canon 0: every operator rounds once, left to right as written; canon 1 (oracle_common.h): every product of gray and of the two
+ * 7-tap sums is fused with the add it feeds (2 gray is exact: sharpen is the same in both).  PARITY UNPINNED, like the other
+ * float pipelines.
  * Planar layout: in[c*in_sc + y*in_sy + x]; (ix0, iy0) = absolute coordinates of the input's first element, (W, H) its
  * extents; the output region starts at (ox0, oy0) and must lie inside the input (the final tap is unclamped).
  */
@@ -38,12 +40,12 @@ int oracle_unsharp(const float *in, int W, int H, long in_sy, long in_sc, int ix
             for (int dx = -3; dx <= 3; dx++) {
                 float g[7];
                 for (int dy = -3; dy <= 3; dy++) {
-                    g[dy + 3] = (0.299f * IN(X + dx, Y + dy, 0) + 0.587f * IN(X + dx, Y + dy, 1)) + 0.114f * IN(X + dx, Y + dy, 2);
+                    g[dy + 3] = o_mad(0.114f, IN(X + dx, Y + dy, 2), o_mad2(0.299f, IN(X + dx, Y + dy, 0), 0.587f, IN(X + dx, Y + dy, 1)));
                 }
-                by[dx + 3] = ((k[0] * g[3] + k[1] * (g[2] + g[4])) + k[2] * (g[1] + g[5])) + k[3] * (g[0] + g[6]);
+                by[dx + 3] = o_mad(k[3], g[0] + g[6], o_mad(k[2], g[1] + g[5], o_mad2(k[0], g[3], k[1], g[2] + g[4])));
                 if (dx == 0) g0 = g[3];
             }
-            const float bx = ((k[0] * by[3] + k[1] * (by[2] + by[4])) + k[2] * (by[1] + by[5])) + k[3] * (by[0] + by[6]);
+            const float bx = o_mad(k[3], by[0] + by[6], o_mad(k[2], by[1] + by[5], o_mad2(k[0], by[3], k[1], by[2] + by[4])));
             const float sharpen = 2.0f * g0 - bx;
             const float ratio = sharpen / g0;
             for (int c = 0; c < 3; c++) {

@@ -26,7 +26,7 @@ def test_oracle_against_float64_reference(oracle):
 
 
 
-def test_oracle_matches_float32_numpy_restatement_bit_for_bit(oracle):
+def test_oracle_matches_float32_numpy_restatement_bit_for_bit(oracle, canon0):
     """Second reading of the generator (:7-62), array at a time in float32: same operator order, one rounding each."""
     f32 = np.float32
     inp = _img(57, 43, 2)

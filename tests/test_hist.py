@@ -49,7 +49,7 @@ def _numpy_hist(inp):
 
 
 @pytest.mark.parametrize("kind,seed", [("scene", 5), ("uniform", 6)])
-def test_oracle_matches_numpy_restatement(oracle, kind, seed):
+def test_oracle_matches_numpy_restatement(oracle, kind, seed, canon0):
     inp = _img(90, 70, seed, kind)
     got, want = oracle.hist(inp), _numpy_hist(inp)
     assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} of {got.size} differ"

@@ -23,7 +23,7 @@ def test_oracle_against_float64_recurrence(oracle):
 
 
 
-def test_oracle_matches_float32_recurrence_bit_for_bit(oracle):
+def test_oracle_matches_float32_recurrence_bit_for_bit(oracle, canon0):
     """The same recurrence (generator :18-31, :146-156) row by row in float32: (1 - alpha) is rounded once, every step is
     one multiply, one multiply, one add."""
     f32 = np.float32

@@ -62,7 +62,7 @@ def naive_interpolate(inp):
 
 
 @pytest.mark.parametrize("w,h", [(13, 9), (1, 1), (24, 17)])
-def test_oracle_matches_naive_pure_function_evaluator(oracle, w, h):
+def test_oracle_matches_naive_pure_function_evaluator(oracle, w, h, canon0):
     inp = _img(w, h, seed=w * 31 + h)
     got, want = oracle.interpolate(inp), naive_interpolate(inp)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"{np.count_nonzero(got != want)} of {got.size} differ"

@@ -21,11 +21,6 @@ CASES = pin.cases()
 DRIVER_CASES = pin.driver_cases()   # harris, lens_blur, bgu: through the apps' own drivers (RunGen cannot drive them)
 
 
-@pytest.fixture(autouse=True)
-def _oracle_in_the_form_of_the_library_the_binaries_link(linked_library_canon):
-    yield
-
-
 
 def _ulp_diff(a, b):
     """distance in float32 representable values"""
@@ -77,6 +72,15 @@ def test_oracle_reproduces_halide(oracle, name):
         d = np.abs(got.astype(np.int64) - want.astype(np.int64))
         unit, bound = "LSB", 0
     print(f"\n{name}: |oracle - Halide| in {unit}: {_histogram(d)}  ({np.count_nonzero(d)} of {d.size} differ, max {int(d.max())})")
+    # the other canonical form (oracle/oracle_common.h) beside the one in force: which of the two is the object Halide built?
+    with oracle.canon(1 - oracle.get_canon()):
+        other = np.asarray(c["oracle"](oracle))
+    if np.dtype(dtype).kind == "f":
+        do = _ulp_diff(np.ascontiguousarray(other, np.float32), np.ascontiguousarray(want, np.float32))
+    else:
+        do = np.abs(other.astype(np.int64) - want.astype(np.int64))
+    print(f"  canon {oracle.get_canon()} (in force): {np.count_nonzero(d)} differ, max {int(d.max())};  canon {1 - oracle.get_canon()}: "
+          f"{np.count_nonzero(do)} differ, max {int(do.max())} {unit}")
     if name.startswith("local_laplacian") and d.max() > 0:
         inp = c["args"][0][1]
         for label, v in (("SOURCE", oracle.LL_VAR_SOURCE), ("FMA", oracle.LL_VAR_FMA), ("SOURCE|FMA", oracle.LL_VAR_SOURCE | oracle.LL_VAR_FMA),
@@ -115,7 +119,7 @@ def test_oracle_reproduces_halide_driver_output(oracle, name):
 
 
 @pytest.mark.gpu
-def test_the_driver_cases_run_end_to_end_with_this_repositorys_driver_builds(oracle, tmp_path):
+def test_the_driver_cases_run_end_to_end_with_this_repositorys_driver_builds(oracle, linked_library_canon, tmp_path):
     """The driver command lines of the recipe, executed with oracle/_ref's builds of the SAME unmodified driver sources (linked
     against libhlmi.so instead of a Halide object) standing in for Halide's: the argument order, the image formats and the output
     shapes of the manifest are what the drivers accept, and what they write (the GPU library's results — scratch files, never pinned)

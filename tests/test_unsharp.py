@@ -36,7 +36,7 @@ def test_oracle_against_float64_reference(oracle):
 
 
 
-def test_oracle_matches_float32_numpy_restatement_bit_for_bit(oracle):
+def test_oracle_matches_float32_numpy_restatement_bit_for_bit(oracle, canon0):
     """Second reading of the generator (:13-52), array at a time in float32, with the folded kernel constants."""
     f32 = np.float32
     inp = _img(45, 37, 4)
