@@ -64,6 +64,8 @@ def run(only=(), samples=5, sink=None, cpu=False, batched=True):
         return {"cpu_baseline": {"value": round(units / sec / 1e6, 3), "unit": unit, "cores": os.cpu_count() or 1, "kind": "port",
                                  "ms_per_call": round(sec * 1e3, 2), "sample": f"{n} calls of {what} (C oracle, OpenMP, all host threads)"}}
 
+    last_clock = [None]
+
     def timed(call, sync_buf, iters):
         call()
         sync_buf.device_sync()
@@ -74,6 +76,16 @@ def run(only=(), samples=5, sink=None, cpu=False, batched=True):
                 call()
             sync_buf.device_sync()
             best = min(best, (time.perf_counter() - t0) / iters)
+        # shader clock / package power under this call pattern (0.25 s of it, untimed): per-call figures of short pipelines move with
+        # the box's clock state (bench.ClockSampler)
+        import bench
+        with bench.ClockSampler(0) as cs:
+            t_end = time.perf_counter() + 0.25
+            while time.perf_counter() < t_end:
+                for _ in range(iters):
+                    call()
+                sync_buf.device_sync()
+        last_clock[0] = cs.summary()
         return best
 
     def timed_batched(make_call, nframes=8, rounds=6):
@@ -130,7 +142,7 @@ def run(only=(), samples=5, sink=None, cpu=False, batched=True):
         sink({"pipeline": name, "workload": workload, "ms_per_call": round(t * 1e3, 4),
               "value": round(mpx / t / 1e6, 1), "unit": "Mpx/s",
               "roofline": {"bound": bound, "achieved": round(achieved, 1), "peak": peak, "unit": unit,
-                           "frac": round(achieved / peak, 4)}, **extra})
+                           "frac": round(achieved / peak, 4)}, "clock_state": last_clock[0], **extra})
 
     # ---- the practical HBM ceiling: copy / read / write kernels over 1 GiB buffers (4x the MALL)
     if not only or "membench" in only:

@@ -220,6 +220,7 @@ lib.halide_device_release.argtypes = [C.c_void_p, C.c_void_p]
 lib.halide_reuse_device_allocations.argtypes = [C.c_void_p, C.c_bool]
 lib.hlmi_kernel_timing_enable.argtypes = [C.c_int]
 lib.hlmi_kernel_timing_report.argtypes = [C.c_char_p, C.c_size_t]
+lib.hlmi_kernel_timing_only.argtypes = [C.c_char_p]
 lib.hlmi_kernel_timing_report.restype = C.c_size_t
 lib.hlmi_version.restype = C.c_char_p
 lib.hlmi_canon_fma.restype = C.c_int
@@ -249,6 +250,11 @@ def partition_stream(part: int, nparts: int, replica: int = 0) -> int | None:
 
 def kernel_timing(enable: bool) -> None:
     lib.hlmi_kernel_timing_enable(1 if enable else 0)
+
+
+def kernel_timing_only(name) -> None:
+    """Measurement only: while `name` is set, every kernel launch with another timing name is skipped (hlmi_runtime.h)."""
+    lib.hlmi_kernel_timing_only(name.encode() if name else None)
 
 
 def kernel_timing_reset() -> None:

@@ -175,8 +175,12 @@ struct ScopedKernelTimer {
 };
 // launch + error check; kernel errors surface as -23 (device_run_failed)
 int launch_failed(void *uc, const char *kernel);
+// measurement only (hlmi_kernel_timing_only): while a launch name is selected every OTHER launch is skipped, so that a
+// caller can run one kernel of a chain back to back (its inputs are whatever earlier, complete calls left in the workspace)
+bool launch_selected(const char *name);
 #define HLMI_LAUNCH(uc, name, stream, kernel, grid, block, shmem, ...)                      \
     do {                                                                                    \
+        if (!::hlmi::launch_selected(name)) break;                                          \
         ::hlmi::ScopedKernelTimer t__(name, stream);                                        \
         hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                \
         if (hipGetLastError() != hipSuccess) return ::hlmi::launch_failed(uc, name);        \

@@ -964,6 +964,14 @@ static thread_local hipEvent_t t_pending_e1;
 
 bool timing_enabled() { return g_timing.load(std::memory_order_relaxed) != 0; }
 
+static std::atomic<int> g_only_active{0};
+static std::string g_only_name;   // written under g_timing_mu, read only while g_only_active != 0
+bool launch_selected(const char *name) {
+    if (g_only_active.load(std::memory_order_acquire) == 0) return true;
+    std::lock_guard<std::mutex> lock(g_timing_mu);
+    return g_only_name == name;
+}
+
 void timing_begin(const char *name, hipStream_t s) {
     TimedLaunch t;
     t.name = name;
@@ -1361,6 +1369,11 @@ void *halide_hip_get_stream(void *uc) {
 }
 
 void hlmi_kernel_timing_enable(int on) { g_timing.store(on ? 1 : 0); }
+void hlmi_kernel_timing_only(const char *name) {
+    std::lock_guard<std::mutex> lock(g_timing_mu);
+    g_only_name = name ? name : "";
+    g_only_active.store(name && *name ? 1 : 0, std::memory_order_release);
+}
 void hlmi_kernel_timing_reset(void) {
     std::lock_guard<std::mutex> lock(g_timing_mu);
     for (auto &t : g_launches) {

@@ -138,6 +138,10 @@ int hlmi_device_count(void);
  * number of bytes needed).  Off by default; never enabled inside a timed throughput region. */
 void hlmi_kernel_timing_enable(int on);
 void hlmi_kernel_timing_reset(void);
+/* Measurement only: while `name` is non-empty, every kernel launch of every pipeline whose timing name differs is SKIPPED, so that
+ * a caller can enqueue one kernel of a launch chain back to back and time it with nothing in between (bench.py's roofline leg;
+ * outputs are meaningless meanwhile).  NULL or "" restores normal operation. */
+void hlmi_kernel_timing_only(const char *name);
 size_t hlmi_kernel_timing_report(char *out, size_t cap);
 /* ---- environment variables -------------------------------------------------------------------------------------------
  * The INTERFACE (what a deployment may set):

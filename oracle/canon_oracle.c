@@ -10,3 +10,6 @@
 int o_canon_fma = 1;
 void oracle_set_canon(int fma) { o_canon_fma = fma ? 1 : 0; }
 int oracle_get_canon(void) { return o_canon_fma; }
+
+int o_reassoc = 0;
+void oracle_set_reassoc(int on) { o_reassoc = on ? 1 : 0; }

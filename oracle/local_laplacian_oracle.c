@@ -46,6 +46,12 @@ static inline int ll_fma(void) { return (ll_var & LL_VAR_FMA) || o_canon_fma; }
 static inline float v_mad(float a, float b, float c) { return ll_fma() ? fmaf(a, b, c) : a * b + c; }
 /* a * b + c * d: the DAG combiner contracts the first multiply and keeps the second */
 static inline float v_mad2(float a, float b, float c, float d) { return ll_fma() ? fmaf(a, b, c * d) : a * b + c * d; }
+/* (a + 3 (b + c) + d) / 8 (:270-271), left to right; under the re-association study (oracle_common.h) as the balanced tree
+ * (a + d) + 3 (b + c) */
+static inline float ll_down4(float a, float b, float c, float d) {
+    if (o_reassoc) return v_mad(3.0f, b + c, a + d) * 0.125f;
+    return (v_mad(3.0f, b + c, a) + d) * 0.125f;
+}
 static inline float v_lerp(float zero, float one, float w) { return v_mad2(zero, 1.0f - w, one, w); }
 
 static inline float ll_gray(float u0, float u1, float u2) {
@@ -96,14 +102,14 @@ static void downsample(const plane_t *f, plane_t *out) {
     for (int y = dy.y0; y <= dy.y1; y++) {
         for (int x = dy.x0; x <= dy.x1; x++) {
             float a = P(f, x, 2 * y - 1), b = P(f, x, 2 * y), c = P(f, x, 2 * y + 1), d = P(f, x, 2 * y + 2);
-            *PP(&dy, x, y) = (v_mad(3.0f, b + c, a) + d) * 0.125f;
+            *PP(&dy, x, y) = ll_down4(a, b, c, d);
         }
     }
 #pragma omp parallel for schedule(static)
     for (int y = out->y0; y <= out->y1; y++) {
         for (int x = out->x0; x <= out->x1; x++) {
             float a = P(&dy, 2 * x - 1, y), b = P(&dy, 2 * x, y), c = P(&dy, 2 * x + 1, y), d = P(&dy, 2 * x + 2, y);
-            *PP(out, x, y) = (v_mad(3.0f, b + c, a) + d) * 0.125f;
+            *PP(out, x, y) = ll_down4(a, b, c, d);
         }
     }
     free(dy.p);

@@ -45,7 +45,12 @@ int oracle_nl_means(const float *in, int W, int H, int in_sy, int in_sc, int pat
             for (int y = 0; y < H; y++) {
                 for (int x = 0; x < DW; x++) {
                     float acc = 0.0f;
-                    for (int p = 0; p < patch; p++) acc = acc + d[(size_t)(y + p) * DW + x]; /* rows y+p0.. in abs coords */
+                    if (o_reassoc && patch == 7) { /* variant study: balanced tree */
+                        const float *q = &d[(size_t)y * DW + x];
+                        acc = ((q[0] + q[DW]) + (q[2 * (size_t)DW] + q[3 * (size_t)DW])) + ((q[4 * (size_t)DW] + q[5 * (size_t)DW]) + q[6 * (size_t)DW]);
+                    } else {
+                        for (int p = 0; p < patch; p++) acc = acc + d[(size_t)(y + p) * DW + x]; /* rows y+p0.. in abs coords */
+                    }
                     bdy[(size_t)y * DW + x] = acc;
                 }
             }
@@ -53,7 +58,12 @@ int oracle_nl_means(const float *in, int W, int H, int in_sy, int in_sc, int pat
             for (int y = 0; y < H; y++) {
                 for (int x = 0; x < W; x++) {
                     float acc = 0.0f;
-                    for (int p = 0; p < patch; p++) acc = acc + bdy[(size_t)y * DW + x + p];
+                    if (o_reassoc && patch == 7) {
+                        const float *q = &bdy[(size_t)y * DW + x];
+                        acc = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + q[6]);
+                    } else {
+                        for (int p = 0; p < patch; p++) acc = acc + bdy[(size_t)y * DW + x + p];
+                    }
                     float w = o_fast_exp(acc * inv);
                     float *s = &sum[((size_t)y * W + x) * 4];
                     for (int c = 0; c < 3; c++) s[c] = o_mad(w, IN(x + sx, y + sy, c), s[c]);

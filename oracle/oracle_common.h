@@ -36,6 +36,11 @@
 extern int o_canon_fma;
 void oracle_set_canon(int fma);
 int oracle_get_canon(void);
+/* Variant study only (scripts/oracle_variants.py): 1 = the sums LLVM may re-associate under the `reassoc` flag
+ * (src/CodeGen_LLVM.cpp:495) are evaluated as balanced trees instead of left to right — the four taps of local_laplacian's
+ * down-sampling, the seven-term patch sums of nl_means.  Never a canonical form: no library build follows it. */
+extern int o_reassoc;
+void oracle_set_reassoc(int on);
 
 /* a * b + c */
 static inline float o_mad(float a, float b, float c) { return o_canon_fma ? fmaf(a, b, c) : a * b + c; }

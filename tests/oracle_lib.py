@@ -66,6 +66,22 @@ def get_canon() -> int:
     return int(_lib.oracle_get_canon())
 
 
+_lib.oracle_set_reassoc.argtypes = [C.c_int]
+
+
+class reassoc:
+    """with oracle_lib.reassoc(): ...   — the re-association study's evaluation (balanced trees for local_laplacian's taps and
+    nl_means' patch sums); never a canonical form."""
+
+    def __enter__(self):
+        _lib.oracle_set_reassoc(1)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.oracle_set_reassoc(0)
+        return False
+
+
 class canon:
     """with oracle_lib.canon(0): ...   — evaluates the oracle in the given form, then restores the one in force."""
 

@@ -37,7 +37,8 @@ def test_spread_between_plausible_canonicalisations_is_small(oracle, kind):
     large differences come from a truncation (`int(gray*(K-1)*256)`, `int(level)`) landing on the other side of an
     integer, which moves the result to a neighbouring LUT entry / pyramid plane."""
     frame = _frames()[kind]
-    base = oracle.local_laplacian(frame, 8, 1.0 / 7.0, 1.0)
+    with oracle.canon(0):
+        base = oracle.local_laplacian(frame, 8, 1.0 / 7.0, 1.0)
     seen_any_difference = False
     for v in (oracle.LL_VAR_SOURCE, oracle.LL_VAR_FMA, oracle.LL_VAR_SOURCE | oracle.LL_VAR_FMA, oracle.LL_VAR_DIV,
               oracle.LL_VAR_DIV | oracle.LL_VAR_FMA):
@@ -51,4 +52,38 @@ def test_spread_between_plausible_canonicalisations_is_small(oracle, kind):
         assert d.max() < 1024, (v, int(d.max()))
     assert seen_any_difference            # the variants are real alternatives, not aliases of the canonical form
     # the variant switch is per call: the canonical result is reproduced afterwards
-    assert np.array_equal(base, oracle.local_laplacian(frame, 8, 1.0 / 7.0, 1.0))
+    with oracle.canon(0):
+        assert np.array_equal(base, oracle.local_laplacian(frame, 8, 1.0 / 7.0, 1.0))
+    # and the fma variant IS canon 1
+    with oracle.canon(1):
+        assert np.array_equal(oracle.local_laplacian(frame, 8, 1.0 / 7.0, 1.0),
+                              oracle.local_laplacian(frame, 8, 1.0 / 7.0, 1.0, variant=oracle.LL_VAR_FMA))
+
+
+def test_distance_between_the_two_canonical_forms_per_pipeline(oracle, capsys):
+    """Round 6: every float pipeline has a contracted canonical form (canon 1) beside the one-rounding-per-operator form
+    (canon 0).  Whichever the reference's object is, the gap is bounded by their distance, printed here per pipeline (the
+    larger table: profiles/r06_oracle_canon_distance.md, scripts/oracle_variants.py --canon) together with the re-association
+    study for the two pipelines with re-associable sums."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("oracle_variants", os.path.join(root, "scripts", "oracle_variants.py"))
+    ov = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ov)
+    rows = ov.canon_table(scale=1)
+    with capsys.disabled():
+        print()
+        for name, what, n, tot, mx, p99, unit, mabs in rows:
+            print(f"  {name:32s} {what:32s} {n:7d} of {tot:7d} differ ({n / tot:7.3%}), max {mx} {unit} (p99 {p99:.0f}), max |diff| {mabs:.3g}")
+    by = {(r[0], r[1]): r for r in rows}
+    moved = 0
+    for (name, what), r in by.items():
+        n, tot, mx, unit, mabs = r[2], r[3], r[4], r[6], r[7]
+        moved += n > 0
+        if unit == "LSB":
+            assert n / tot < 0.02, (name, what, n)          # integer outputs: a fraction of a percent moves
+        else:
+            assert mabs < 2e-3, (name, what, mabs)          # float outputs: far below anything visible (values are O(1))
+    assert moved >= 8                                       # the two forms are real alternatives for most pipelines
+    assert oracle.get_canon() in (0, 1)
