@@ -240,12 +240,20 @@ __device__ __forceinline__ uint32_t mul24o(uint32_t a, uint32_t b) {
 // host checks): addresses are `uniform base + 32-bit byte offset` built from full-rate 24-bit multiplies.  As 64-bit element
 // indices the address arithmetic of this kernel was 92 quarter-rate instructions (v_mul_lo_u32, v_mul_hi_u32, v_mad_u64_u32) of
 // 958: 30 % of its issue time.
-template<int FPY, int ZP, bool A32>   // tile height (32; 16 and 64 measured the same or slower); z pitch of the LDS tiles (>= g.ZD)
+// HIST (round 6): the WHOLE pipeline in one launch.  The blurz cells of the tile are not read from a grid another launch made but
+// built here: the histogram of the tile's 14 x 10 cells from the input (every cell's 64 pixels in RDom order, thread = (cell, bin) as
+// in bg_histogram_blurz_par: per bin exactly the additions of :28-29 in their order) and its z blur, straight into s_bz.  A cell is
+// rebuilt by every tile whose blur footprint holds it (4.4 x the histogram work of the two-launch path, its input re-read from L2)
+// in exchange for one launch, no grid round trip and no dependent launch: the two-launch call is latency, not work (8.9 + 10.4 us
+// of kernels for 16.6 MB).  The tile's 112 x 80 input pixels are requested first, all of them, before anything is waited for.
+template<int FPY, int ZP, bool A32, bool HIST = false>   // tile height (32; 16 and 64 measured the same or slower); z pitch of the LDS tiles (>= g.ZD)
 __global__ __launch_bounds__(256) void bg_blur_slice(const float *__restrict__ in, long in_sy, BGeom g, const float2 *__restrict__ bz,
                                                     float *__restrict__ out, long out_sy, int ox0, int oy0, int ow, int oh) {
     constexpr int FCY = FPY / S + 2;
     constexpr int NBZ = (FCY + 4) * (FCX + 4) * ZP, NBX = (FCY + 4) * FCX * ZP, NBY = FCY * FCX * ZP;
-    __shared__ float2 s_bz[NBZ], s_bx[NBX], s_by[NBY];
+    // one array: the staging of the histogram passes (HIST) lives where s_bx / s_by will be
+    __shared__ __attribute__((aligned(16))) float2 s_all[NBZ + NBX + NBY];
+    float2 *const s_bz = s_all, *const s_bx = s_all + NBZ, *const s_by = s_all + NBZ + NBX;
     const int t = threadIdx.x;
     const int x0 = blockIdx.x * FPX, y0 = blockIdx.y * FPY;
     const int cxa = dev::fdiv8(ox0 + x0) - g.gx0, cya = dev::fdiv8(oy0 + y0) - g.gy0;   // first blury cell of the tile
@@ -270,7 +278,75 @@ __global__ __launch_bounds__(256) void bg_blur_slice(const float *__restrict__ i
             }
         }
     }
-    {
+    if (HIST) {
+        constexpr int CW = FCX + 4, CH = FCY + 4, NCELL = CW * CH;        // the tile's blurz cells: 14 x 10
+        constexpr int RW = CW * S, RH = CH * S, NPX = RW * RH;            // their pixels: 112 x 80
+        constexpr int NLD = (NPX + 255) / 256;                            // loads per thread (35)
+        // idx / RW for idx < NLD * 256 as one 24-bit multiply and a shift: exact while idx (M RW - 2^21) < 2^21
+        constexpr uint32_t RWM = ((1u << 21) + RW - 1) / RW;
+        static_assert((unsigned long long)(RWM * RW - (1u << 21)) * (NLD * 256) < (1ull << 21) && (unsigned long long)RWM * (NLD * 256) < (1ull << 32), "row division");
+        constexpr int HC = 256 / ZP, NTH = HC * ZP;                       // cells per histogram pass, threads that accumulate
+        constexpr int NPASS = (NCELL + HC - 1) / HC;
+        constexpr int SP = 2 * S * S + 8;                                 // staged cell: 64 {value, bin} pairs, pitch padded by 8 words
+        static_assert((size_t)HC * SP * 4 <= (size_t)(NBX + NBY) * 8, "bg_blur_slice<HIST>: staging does not fit under s_bx / s_by");
+        __shared__ float2 s_h[HC][ZP + 4];                                // a pass's histograms, bins -2 .. ZP + 1 (zero padded)
+        float *const s_st = reinterpret_cast<float *>(s_bx);
+        // the region's pixels, row-major over 112 x 80, edge-clamped (:21-23); element idx = t + 256 k
+        const int X0 = (g.gx0 - 2 + cxa) * S - S / 2, Y0 = (g.gy0 - 2 + cya) * S - S / 2;
+        float v[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const uint32_t idx = min((uint32_t)(t + 256 * k), (uint32_t)(NPX - 1));
+            const uint32_t row = __umul24(idx, RWM) >> 21, col = idx - row * RW;
+            const int px = dev::clampi(X0 + (int)col, g.ix0, g.ix1) - g.ix0, py = dev::clampi(Y0 + (int)row, g.iy0, g.iy1) - g.iy0;
+            if (A32) v[k] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(in) + ((mul24o((uint32_t)py, (uint32_t)in_sy) + (uint32_t)px) << 2));
+            else v[k] = in[(long)py * in_sy + px];
+        }
+        for (int i = t; i < HC * (ZP + 4); i += 256) (&s_h[0][0])[i] = make_float2(0.0f, 0.0f);
+        const int hc = t / ZP, hz = t - hc * ZP;                          // this thread's (cell of the pass, bin)
+#pragma unroll
+        for (int p = 0; p < NPASS; p++) {
+            // pass p = cells [p HC, p HC + HC) in row-major order; their pixels are rows [8 jlo, 8 jhi + 7] of the region, i.e. only the
+            // thread's loads klo .. khi can belong to it (compile-time window, run-time test)
+            const int e0 = p * HC, e1 = min(e0 + HC, NCELL) - 1;
+            const int jlo = e0 / CW, jhi = e1 / CW;
+            const int klo = max(0, (jlo * S * RW - 255) / 256), khi = min(NLD - 1, ((jhi * S + S) * RW - 1) / 256);
+#pragma unroll
+            for (int k = 0; k < NLD; k++) {
+                if (k < klo || k > khi) continue;
+                const uint32_t idx = (uint32_t)(t + 256 * k);
+                const uint32_t row = __umul24(idx, RWM) >> 21, col = idx - row * RW;
+                const int e = (int)(row >> 3) * CW + (int)(col >> 3);      // the pixel's cell
+                if (idx < (uint32_t)NPX && e >= e0 && e <= e1) {
+                    const float val = dev::clampf(v[k], 0.0f, 1.0f);
+                    const int zi = (int)dev::mad(val, g.inv_r, 0.5f);       // (:25)
+                    *reinterpret_cast<float2 *>(s_st + (e - e0) * SP + 2 * (int)(((row & 7) << 3) + (col & 7))) = make_float2(val, __int_as_float(zi));
+                }
+            }
+            __syncthreads();
+            if (t < NTH) {
+                // a sum that starts at +0 and only ever adds non-negative terms is never -0: adding +0 for the pixels of other bins leaves it
+                // bit for bit what the selective add gives; the weight channel is a count (sums of 1.0f up to 64 are exact in any order)
+                float hv = 0.0f;
+                int cnt = 0;
+                const float4 *q4 = reinterpret_cast<const float4 *>(s_st + hc * SP);
+#pragma unroll 8
+                for (int q = 0; q < S * S / 2; q++) {
+                    const float4 w = q4[q];                                 // {v0, bin0, v1, bin1}
+                    const int z0 = __float_as_int(w.y), z1 = __float_as_int(w.w);
+                    hv = hv + (z0 == hz ? w.x : 0.0f), cnt += (z0 == hz);
+                    hv = hv + (z1 == hz ? w.z : 0.0f), cnt += (z1 == hz);
+                }
+                s_h[hc][hz + 2] = make_float2(hv, (float)cnt);
+            }
+            __syncthreads();
+            if (t < NTH && e0 + hc <= e1) {
+                const float2 a = s_h[hc][hz], b = s_h[hc][hz + 1], m = s_h[hc][hz + 2], d = s_h[hc][hz + 3], e = s_h[hc][hz + 4];
+                // planes past ZD - 1 are never interpolated; what is computed there is a blur of zeros and in-range bins: harmless
+                s_bz[(e0 + hc) * ZP + hz] = make_float2(blur5(a.x, b.x, m.x, d.x, e.x), blur5(a.y, b.y, m.y, d.y, e.y));
+            }
+        }
+    } else {
         // all of the thread's cells are requested before the first one is waited for (a loop with a run-time trip count
         // pays the round trip per iteration: 7 x ~0.7 us was most of this kernel)
         constexpr int N1 = (NBZ + 255) / 256;
@@ -404,6 +480,29 @@ extern "C" int bilateral_grid(halide_buffer_t *input, float r_sigma, halide_buff
     hipStream_t st = ctx.stream;
     // float4 staging: rows 16-byte aligned at every staged column group (cells start at multiples of 8 minus 4)
     const int vec = ((uintptr_t)din % 16 == 0 && in_sy % 4 == 0 && floor_div(g.ix0, 4) * 4 == g.ix0) ? 1 : 0;
+    // 32-bit addressing (see bg_blur_slice): strides and row counts below 2^23, every buffer's byte span below 2^31
+    const long lim = 1L << 23, span = 1L << 29;
+    const bool a32 = in_sy >= 0 && out_sy >= 0 && in_sy < lim && out_sy < lim && input->dim[1].extent < lim && oh < lim &&
+                     in_sy * (long)input->dim[1].extent < span && out_sy * (long)oh < span && (long)g.HX * g.HY < (1L << 24) &&
+                     (long)g.HX * g.HY * g.ZD < (span >> 1) && !env_flag("HLMI_BG_NO_A32");
+    // round 6: grids of at most 16 planes run as ONE launch (bg_blur_slice<.., HIST = true>); HLMI_BG_TWO_LAUNCH=1 keeps the
+    // histogram + z blur as a launch of its own in front of it (the parity tests run both)
+    const bool one_launch = g.ZD <= FZ && !env_flag("HLMI_BG_TWO_LAUNCH");
+    if (one_launch) {
+#define HLMI_BG_ONE(ZP_, A32_)                                                                                                       \
+    HLMI_LAUNCH(uc, "bg_fused", st, (bg_blur_slice<32, ZP_, A32_, true>), dim3((ow + FPX - 1) / FPX, (oh + 31) / 32), dim3(256), 0, din, \
+                in_sy, g, (const float2 *)nullptr, dev_ptr<float>(output), out_sy, ox0, oy0, ow, oh)
+        if (g.ZD <= 12) {
+            if (a32) HLMI_BG_ONE(12, true);
+            else HLMI_BG_ONE(12, false);
+        } else {
+            if (a32) HLMI_BG_ONE(16, true);
+            else HLMI_BG_ONE(16, false);
+        }
+#undef HLMI_BG_ONE
+        mark_output_written(output);
+        return 0;
+    }
     if (g.ZD <= 12) {
         constexpr int HC = HTH / 12;
         HLMI_LAUNCH(uc, "bg_histogram_blurz", st, bg_histogram_blurz_par<12>, dim3((g.HX + HC - 1) / HC, g.HY), dim3(HC * 12), 0, din,
@@ -419,11 +518,6 @@ extern "C" int bilateral_grid(halide_buffer_t *input, float r_sigma, halide_buff
         HLMI_LAUNCH(uc, "bg_histogram_blurz", st, bg_histogram_blurz, dim3((g.HX + T - 1) / T, g.HY), dim3(T), sh, din, in_sy, g, bz);
     }
     if (g.ZD <= FZ) {   // (grids of more planes — r_sigma < 1/14.5 — take the serial histogram and the three separate launches)
-        // 32-bit addressing (see bg_blur_slice): strides and row counts below 2^23, every buffer's byte span below 2^31
-        const long lim = 1L << 23, span = 1L << 29;
-        const bool a32 = in_sy >= 0 && out_sy >= 0 && in_sy < lim && out_sy < lim && input->dim[1].extent < lim && oh < lim &&
-                         in_sy * (long)input->dim[1].extent < span && out_sy * (long)oh < span && (long)g.HX * g.HY < (1L << 24) &&
-                         (long)g.HX * g.HY * g.ZD < (span >> 1) && !getenv("HLMI_BG_NO_A32");
 #define HLMI_BG_FUSED(ZP_, A32_)                                                                                                     \
     HLMI_LAUNCH(uc, "bg_blur_slice", st, (bg_blur_slice<32, ZP_, A32_>), dim3((ow + FPX - 1) / FPX, (oh + 31) / 32), dim3(256), 0, din, \
                 in_sy, g, bz, dev_ptr<float>(output), out_sy, ox0, oy0, ow, oh)

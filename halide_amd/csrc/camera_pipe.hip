@@ -552,7 +552,7 @@ extern "C" int camera_pipe(halide_buffer_t *input, halide_buffer_t *matrix_3200,
     key.s3 = matrix_3200->dim[1].stride, key.s7 = matrix_7000->dim[1].stride, key.o3 = mo3, key.o7 = mo7;
     key.color_temp = color_temp, key.gamma = gamma, key.contrast = contrast, key.sharpen = sharpen_strength;
     key.black = blackLevel, key.white = whiteLevel;
-    const bool cacheable = key.v3 != 0 && key.v7 != 0 && !getenv("HLMI_CP_NO_SETUP_CACHE");
+    const bool cacheable = key.v3 != 0 && key.v7 != 0 && !env_flag("HLMI_CP_NO_SETUP_CACHE");
     std::unique_lock<std::mutex> si_lock(g_si_mu, std::defer_lock);
     SetupImage *slot = nullptr;
     if (cacheable) {

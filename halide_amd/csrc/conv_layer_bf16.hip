@@ -669,7 +669,7 @@ struct FilterUse {
 
 int filter_image(void *uc, const DeviceCtx &ctx, const halide_buffer_t *filter, size_t bytes, int layout, FilterUse *use) {
     const uint64_t version = buffer_version(filter);
-    if (version == 0 || getenv("HLMI_CONV_NO_FILTER_CACHE")) {
+    if (version == 0 || env_flag("HLMI_CONV_NO_FILTER_CACHE")) {
         void *ws = nullptr;
         int r = get_workspace(uc, ctx, bytes, &ws);
         if (r) return r;

@@ -370,7 +370,7 @@ extern "C" int depthwise_separable_conv(halide_buffer_t *input, halide_buffer_t 
             const bool a32 = ok(g.in_sx) && ok(g.out_sx) && ok(g.d_s1) && ok(g.d_sx) && ok(g.d_sy) && ok(g.p_s1) && g.W < lim && g.ow < lim &&
                              (long)g.W * g.in_sx + g.IC < (1L << 29) && (long)g.ow * g.out_sx + g.CO < (1L << 29) &&
                              (long)g.IC * g.d_s1 + g.FW * g.d_sx + g.FH * g.d_sy < (1L << 29) && (long)g.IC * g.p_s1 + g.CO < (1L << 29) &&
-                             !getenv("HLMI_DSC_NO_A32");
+                             !env_flag("HLMI_DSC_NO_A32");
             if (a32)
                 HLMI_LAUNCH(uc, "dsc_fused", ctx.stream, (dsc_fused_t<3, 3, 32, 16, TPX, true>), dim3((g.ow + TPX - 1) / TPX, g.oh, g.N), dim3(256),
                             0, d_in, d_dw, d_pw, d_b, dev_ptr<float>(output), g);

@@ -173,6 +173,9 @@ struct ScopedKernelTimer {
         if (on) timing_end(s);
     }
 };
+// Run-time switches (HLMI_*): one helper so that every switch reads the same way — set and non-zero = on, unset / empty / "0" = off.
+// Read at every call (a getenv, ~100 ns): the parity tests flip switches inside one process to reach the alternative paths.
+bool env_flag(const char *name);
 // launch + error check; kernel errors surface as -23 (device_run_failed)
 int launch_failed(void *uc, const char *kernel);
 // measurement only (hlmi_kernel_timing_only): while a launch name is selected every OTHER launch is skipped, so that a

@@ -410,7 +410,7 @@ extern "C" int interpolate(halide_buffer_t *input, halide_buffer_t *output) {
         if (T < 3 || T > IL - 2) T = IL;   // (interpolated[2] and [1] are not stored: the tail cannot start below level 3)
         // levels 3, 4, 5 in one launch per direction (ip_down_multi / ip_up_multi) when the tail starts at 6 and every tile's
         // windows fit the kernels' LDS arrays (they do for any image: the check guards the constants, not the input)
-        bool fused = T == 6 && !getenv("HLMI_IP_UNFUSED");
+        bool fused = T == 6 && !env_flag("HLMI_IP_UNFUSED");
         const int ntx5 = (ds[5].w + DM5 - 1) / DM5, nty5 = (ds[5].h + DM5 - 1) / DM5;
         if (fused) {
             auto owned = [](int llo, int lhi, int sh, int tlo, int thi, int a, int b, int &lo, int &hi) {

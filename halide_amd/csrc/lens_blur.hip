@@ -1065,7 +1065,7 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
         LB_DISPATCH(lb_cost, dim3((E.w + 255) / 256, E.h), dim3(256), 0, dl, dr, g, E, push[0]);
     }
     // the *32 kernels (32-bit plane offsets from 24-bit multiplies) take boxes that are small enough for them; HLMI_LB_NO_A32=1: never (A/B)
-    const bool a32 = !getenv("HLMI_LB_NO_A32");
+    const bool a32 = !env_flag("HLMI_LB_NO_A32");
     auto box_small = [&](const Box &b) { return a32 && b.w < (1 << 23) && b.h < (1 << 23) && (long)b.w * b.h < (1L << 29); };
     // levels below `tail` (at most 128 x 128 elements per plane) go down and up in ONE launch, a workgroup per plane
     int tail = LV;
@@ -1120,7 +1120,7 @@ extern "C" int lens_blur(halide_buffer_t *left_im, halide_buffer_t *right_im, in
     if (!fused) HLMI_LAUNCH(uc, "lb_depth", st, lb_depth, dim3((D.w + 255) / 256, D.h), dim3(256), 0, push[0], E, pull[1], P[1], dl, g, D, depth, br);
     else LB_DISPATCH(lb_depth_rc, dim3((D.w + 63) / 64, (D.h + 3) / 4), dim3(256), 0, dl, dr, pull[1], P[1], g, D, depth, br);
 #undef LB_DISPATCH
-    if (!fused || getenv("HLMI_LB_WCY_LAUNCH")) {
+    if (!fused || env_flag("HLMI_LB_WCY_LAUNCH")) {
         HLMI_LAUNCH(uc, "lb_wcy", st, lb_wcy, dim3((D.w + 255) / 256, oh), dim3(256), 0, br, D, g.R, oy0, oh, wcy);
         HLMI_LAUNCH(uc, "lb_final", st, lb_final<false>, dim3((ow + 255) / 256, oh), dim3(256), 0, g, depth, wcy, D, ox0, oy0, ow, nc,
                     dev_ptr<float>(final_), (long)final_->dim[1].stride, (long)final_->dim[2].stride);

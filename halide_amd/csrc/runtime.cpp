@@ -962,6 +962,11 @@ static std::mutex g_timing_mu;
 static std::vector<TimedLaunch> g_launches;
 static thread_local hipEvent_t t_pending_e1;
 
+bool env_flag(const char *name) {
+    const char *e = getenv(name);
+    return e && *e && atoi(e) != 0;
+}
+
 bool timing_enabled() { return g_timing.load(std::memory_order_relaxed) != 0; }
 
 static std::atomic<int> g_only_active{0};

@@ -244,7 +244,7 @@ extern "C" int unsharp(halide_buffer_t *input, halide_buffer_t *output) {
         }
         const float *din = dev_ptr<float>(input) + (long)(0 - input->dim[2].min) * g.in_sc;
         timing_note_bytes(24.0 * ow * oh);
-        const bool narrow = g.W < (1 << 29) && ow < (1 << 29) && !getenv("HLMI_UNSHARP_REF");   // 32-bit lane byte offsets inside a row
+        const bool narrow = g.W < (1 << 29) && ow < (1 << 29) && !env_flag("HLMI_UNSHARP_REF");   // 32-bit lane byte offsets inside a row
         if (narrow)
             HLMI_LAUNCH(uc, "unsharp_tile", ctx.stream, unsharp_tile2, dim3((ow + TW - 1) / TW, (oh + TH - 1) / TH), dim3(256), 0, din,
                         dev_ptr<float>(output), g);

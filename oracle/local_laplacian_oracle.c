@@ -141,6 +141,27 @@ float oracle_halide_exp(float x) { return o_halide_exp(x); }
 float oracle_halide_log(float x) { return o_halide_log(x); }
 float oracle_halide_pow(float x, float y) { return o_halide_pow(x, y); }
 float oracle_fast_exp(float x) { return o_fast_exp(x); }
+/* array forms, for the direct sweeps of the device-side primitives (tests/test_device_math.py) */
+void oracle_halide_exp_v(const float *x, float *out, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) out[i] = o_halide_exp(x[i]);
+}
+void oracle_halide_log_v(const float *x, float *out, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) out[i] = o_halide_log(x[i]);
+}
+void oracle_fast_exp_v(const float *x, float *out, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) out[i] = o_fast_exp(x[i]);
+}
+void oracle_halide_pow_v(const float *x, const float *y, float *out, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) out[i] = o_halide_pow(x[i], y[i]);
+}
+void oracle_lerp_v(const float *a, const float *b, const float *w, float *out, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) out[i] = o_lerp(a[i], b[i], w[i]);
+}
 
 /* Full pipeline.  in/out: planar u16 [3][H][W] with row stride `in_sy`/`out_sy` and plane stride
  * `in_sc`/`out_sc` (elements); (X0, Y0) = dim[0].min, dim[1].min of both buffers, i.e. the absolute

@@ -99,6 +99,15 @@ def test_oracle_preserves_constant_and_smooth_images(oracle):
     assert np.max(np.abs(oracle.bilateral_grid(s, 0.1) - s)) < 0.12
 
 
+@pytest.fixture(params=["one_launch", "two_launches"])
+def bg_path(request, monkeypatch):
+    """Grids of at most 16 planes run as one launch since round 6 (bg_blur_slice<.., HIST = true> builds the tile's blurz cells from the
+    input itself); HLMI_BG_TWO_LAUNCH=1 keeps the histogram + z blur as a launch of its own.  Both face the oracle."""
+    if request.param == "two_launches":
+        monkeypatch.setenv("HLMI_BG_TWO_LAUNCH", "1")
+    return request.param
+
+
 def _run(hl, inp, r_sigma, out=None, in_min=None, out_min=None):
     a = hl.Buffer(inp)
     o = hl.Buffer(np.zeros_like(inp) if out is None else out)
@@ -116,7 +125,7 @@ def _run(hl, inp, r_sigma, out=None, in_min=None, out_min=None):
     (8, 8, 0.1, "smooth"), (333, 129, 0.05, "smooth"), (250, 100, 0.3, "uniform"), (250, 100, 1.0, "smooth"),
     (64, 64, 0.004, "uniform"), (1536, 2560, 0.1, "uniform"),
 ])
-def test_hip_matches_oracle(hl, oracle, w, h, r_sigma, kind):
+def test_hip_matches_oracle(hl, oracle, bg_path, w, h, r_sigma, kind):
     inp = _img(w, h, seed=w + h, kind=kind)
     got = _run(hl, inp, r_sigma)
     want = oracle.bilateral_grid(inp, r_sigma)
@@ -126,7 +135,7 @@ def test_hip_matches_oracle(hl, oracle, w, h, r_sigma, kind):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("w,h,r_sigma", [(1920, 1080, 0.1), (333, 129, 0.07)])
-def test_hip_64_bit_addressing_path_matches_oracle(hl, oracle, monkeypatch, w, h, r_sigma):
+def test_hip_64_bit_addressing_path_matches_oracle(hl, oracle, bg_path, monkeypatch, w, h, r_sigma):
     """Images / grids beyond the 32-bit bounds the host checks take bg_blur_slice<.., A32 = false>; HLMI_BG_NO_A32=1 selects it at
     any size (12- and 16-plane grids)."""
     monkeypatch.setenv("HLMI_BG_NO_A32", "1")
@@ -138,7 +147,7 @@ def test_hip_64_bit_addressing_path_matches_oracle(hl, oracle, monkeypatch, w, h
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mx,my", [(8, 16), (3, -5), (-17, 29)])
-def test_hip_nonzero_min(hl, oracle, mx, my):
+def test_hip_nonzero_min(hl, oracle, bg_path, mx, my):
     inp = _img(150, 70, seed=9, kind="smooth")
     got = _run(hl, inp, 0.1, in_min=(mx, my), out_min=(mx, my))
     want = oracle.bilateral_grid(inp, 0.1, origin=(mx, my))
@@ -146,7 +155,7 @@ def test_hip_nonzero_min(hl, oracle, mx, my):
 
 
 @pytest.mark.gpu
-def test_hip_output_window_inside_larger_input(hl, oracle):
+def test_hip_output_window_inside_larger_input(hl, oracle, bg_path):
     inp = _img(200, 120, seed=4, kind="smooth")
     full = oracle.bilateral_grid(inp, 0.1)
     out = np.zeros((50, 90), np.float32)
@@ -155,7 +164,7 @@ def test_hip_output_window_inside_larger_input(hl, oracle):
 
 
 @pytest.mark.gpu
-def test_hip_special_values(hl, oracle):
+def test_hip_special_values(hl, oracle, bg_path):
     inp = _img(64, 48, seed=1)
     inp[3, 5] = -4.0
     inp[10, 11] = 7.5
