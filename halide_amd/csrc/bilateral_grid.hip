@@ -244,8 +244,8 @@ __device__ __forceinline__ uint32_t mul24o(uint32_t a, uint32_t b) {
 // built here: the histogram of the tile's 14 x 10 cells from the input (every cell's 64 pixels in RDom order, thread = (cell, bin) as
 // in bg_histogram_blurz_par: per bin exactly the additions of :28-29 in their order) and its z blur, straight into s_bz.  A cell is
 // rebuilt by every tile whose blur footprint holds it (4.4 x the histogram work of the two-launch path, its input re-read from L2)
-// in exchange for one launch, no grid round trip and no dependent launch: the two-launch call is latency, not work (8.9 + 10.4 us
-// of kernels for 16.6 MB).  The tile's 112 x 80 input pixels are requested first, all of them, before anything is waited for.
+// in exchange for one launch, no grid round trip and no dependent launch.  Measured: slower (0.0297 vs 0.0180 ms per call), so this
+// mode is opt-in (HLMI_BG_ONE_LAUNCH=1).  The tile's 112 x 80 input pixels are requested first, all of them, before anything is waited for.
 template<int FPY, int ZP, bool A32, bool HIST = false>   // tile height (32; 16 and 64 measured the same or slower); z pitch of the LDS tiles (>= g.ZD)
 __global__ __launch_bounds__(256) void bg_blur_slice(const float *__restrict__ in, long in_sy, BGeom g, const float2 *__restrict__ bz,
                                                     float *__restrict__ out, long out_sy, int ox0, int oy0, int ow, int oh) {
@@ -485,9 +485,11 @@ extern "C" int bilateral_grid(halide_buffer_t *input, float r_sigma, halide_buff
     const bool a32 = in_sy >= 0 && out_sy >= 0 && in_sy < lim && out_sy < lim && input->dim[1].extent < lim && oh < lim &&
                      in_sy * (long)input->dim[1].extent < span && out_sy * (long)oh < span && (long)g.HX * g.HY < (1L << 24) &&
                      (long)g.HX * g.HY * g.ZD < (span >> 1) && !env_flag("HLMI_BG_NO_A32");
-    // round 6: grids of at most 16 planes run as ONE launch (bg_blur_slice<.., HIST = true>); HLMI_BG_TWO_LAUNCH=1 keeps the
-    // histogram + z blur as a launch of its own in front of it (the parity tests run both)
-    const bool one_launch = g.ZD <= FZ && !env_flag("HLMI_BG_TWO_LAUNCH");
+    // round 6: HLMI_BG_ONE_LAUNCH=1 runs grids of at most 16 planes as ONE launch (bg_blur_slice<.., HIST = true>).  Built, bit-exact
+    // (the parity tests run both paths) and NOT the default: 0.0297 against 0.0180 ms per call at 1920x1080 — a cell's histogram is
+    // rebuilt by every tile whose blur footprint holds it (4.4 x the work) and the histogram is work, not latency, at the clock a
+    // call + sync pattern runs at (profiles/r06_bg_one_launch_ab.txt)
+    const bool one_launch = g.ZD <= FZ && env_flag("HLMI_BG_ONE_LAUNCH");
     if (one_launch) {
 #define HLMI_BG_ONE(ZP_, A32_)                                                                                                       \
     HLMI_LAUNCH(uc, "bg_fused", st, (bg_blur_slice<32, ZP_, A32_, true>), dim3((ow + FPX - 1) / FPX, (oh + 31) / 32), dim3(256), 0, din, \

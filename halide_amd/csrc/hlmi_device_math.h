@@ -102,15 +102,18 @@ __device__ __forceinline__ float halide_log(float x_full) {
     return result;
 }
 
+// pow_f32 as the LLVM back ends lower it (src/CodeGen_LLVM.cpp:3925-3941): exp(log(abs(x)) * y) under a select chain; abs clears the
+// sign bit (of a NaN too), `iy % 2` is the float modulo a - b floor(a / b) with a / 2 folded to a * 0.5f
 __device__ __forceinline__ float halide_pow(float x, float y) {
-    float ax = x < 0.0f ? -x : x;
-    float e = halide_exp(halide_log(ax) * y);
-    if (x > 0.0f) return e;
-    if (y == 0.0f) return 1.0f;
-    if (x == 0.0f) return 0.0f;
-    float yi = floorf(y);
-    if (yi != y) return __uint_as_float(0x7fc00000u);
-    return ((((long long)yi) & 1) != 0) ? -e : e;
+    const float ax = __uint_as_float(__float_as_uint(x) & 0x7fffffffu);
+    const float e = halide_exp(halide_log(ax) * y);
+    if (x > 0.0f) return e;                                   // strictly positive x
+    if (y == 0.0f) return 1.0f;                               // x^0 == 1
+    if (x == 0.0f) return 0.0f;                               // 0^y == 0
+    const float iy = floorf(y);
+    if (y != iy) return __uint_as_float(0x7fc00000u);         // negative x to a non-integer power
+    const float r = iy - 2.0f * floorf(iy * 0.5f);            // 2 * floor(..) is exact: the same with or without contraction
+    return (r == 0.0f) ? e : -e;                              // negative x to an even / odd power
 }
 
 __device__ __forceinline__ float fast_exp(float x_full) {

@@ -1618,6 +1618,8 @@ __host__ __device__ constexpr int um_off(int d) {  // offset of level S+d's regi
     for (int i = 0; i < d; i++) o += um_win(i) * um_win(i);
     return o;
 }
+// up_multi_tile handles ONE element per thread and level (act[d] = tid < n): every region of a tile must fit 256 threads
+static_assert(UM_T * UM_T <= 256 && um_win(1) * um_win(1) <= 256, "ll_up_multi: a level's region of a tile exceeds the workgroup");
 template<int TOP>
 __device__ __forceinline__ void up_multi_tile(const CoarseArgs &a, int ntx, int b) {
     __shared__ float tl[um_off(TOP + 1)];
@@ -2330,6 +2332,10 @@ int env_int(const char *name, int dflt) {
     return (e && *e) ? atoi(e) : dflt;
 }
 
+// rows per wave of the up kernels: ll_up0h turns tile element numbers into rows with multiplications that are exact for at most
+// RU + 2 = 302 tile rows (tests/test_index_arithmetic.py), so the switch is clamped to the proven range
+int dev_clamp_ru(int ru) { return ru < 1 ? 1 : (ru > 300 ? 300 : ru); }
+
 // last call's level table, for hlmi_debug_local_laplacian_outg (tests only)
 thread_local Level t_dbg_lv[J];
 thread_local hipStream_t t_dbg_stream = nullptr;
@@ -2546,7 +2552,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         // rows per wave: taller tiles re-read less of level 1 (18 coarse rows per 16 output rows, 34 per 32) but keep a wave
         // busy longer.  On a CU-partitioned stream, where several frames share the memory system and the frame rate is set by
         // bytes, 32 rows measure 2.7 % faster (84.8 vs 82.6 Gpx/s); on a stream that owns the device 16 rows do (72.7 vs 68.2).
-        p.RU = max(1, env_int("HLMI_LL_RU", fuse1 ? (partitioned ? 32 : 16) : 8));
+        p.RU = dev_clamp_ru(env_int("HLMI_LL_RU", fuse1 ? (partitioned ? 32 : 16) : 8));
     }
     // ll_down01f / ll_down01e: levels 1 and 2 from the input in one walk (levels == KCH planes in registers, 8-byte input loads)
     const bool d01_possible = levels == KCH && lut_lds &&
@@ -2557,7 +2563,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     const bool emit = d01_possible && fast && fuse1 && lv[1].ws < (1 << 24) && env_int("HLMI_LL_EMIT", 1);   // ws: ll_up0h's 24-bit row products
     // ll_up0h has no data-dependent gathers to amortise over a tall tile: short tiles (more, smaller workgroups) are faster on a
     // stream that owns the device (31.7 us at 8 rows per wave against 33.5 / 38.4 at 16 / 32); on CU partitions 8..32 measure the same
-    if (emit) p.RU = max(1, env_int("HLMI_LL_RU", partitioned ? 16 : 8));
+    if (emit) p.RU = dev_clamp_ru(env_int("HLMI_LL_RU", partitioned ? 16 : 8));
     // non-temporal frame / outLPyramid[0] accesses: +6-7 % frames per second on CU partitions, -2-3 % on a stream that owns the device
     const bool nt = env_int("HLMI_LL_NT", partitioned ? 1 : 0) != 0;
     // ll_up0h also collapses level 2 (into an LDS tile) when level 3 is a stored level of its own: the ll_up:2 launch goes

@@ -34,7 +34,7 @@ constexpr int ORW = TY / (NT / 64);            // output rows per wave (16: a la
 constexpr int SW = TW + 2 * RAD;               // 116 staged pixels per row
 constexpr int SP = 128;                        // LDS row pitch
 static_assert(SW <= SP, "a staged row fits its pitch");
-constexpr int NSLOT = 5;                       // LDS slices: R_0, R_2, R_3, R_4, R_5 (R_s = max of 2^s consecutive pixels)
+constexpr int NSLOT = 4;                       // LDS slices: R_2, R_3, R_4, R_5 (R_s = max of 2^s consecutive pixels; R_0 and R_1 stay in registers)
 constexpr int NCHUNK = (TY + 2 * VR + CH - 1) / CH;
 constexpr int NFOLD = (ORW - 1 + 2 * VR) / CH + 1;  // chunks that hold rows of one wave's 16 + 54 row window
 
@@ -60,9 +60,9 @@ constexpr int mf_log2(int v) {   // floor(log2(v)), v >= 1: slice_for_radius(t) 
 static_assert(mf_halfwidth(0) == RAD && mf_halfwidth(VR) == 3 && mf_log2(2 * 3 + 1) == 2 && mf_log2(2 * RAD + 1) == 5,
               "every row of the footprint is two samples of a slice R_2 .. R_5");
 // LDS word offsets (relative to row start + own column) of the two samples covering [x - w, x + w]
-constexpr int mf_slot(int ady) { return mf_log2(2 * mf_halfwidth(ady) + 1) - 1; }
+constexpr int mf_slot(int ady) { return mf_log2(2 * mf_halfwidth(ady) + 1) - 2; }   // slice R_s lives in slot s - 2
 constexpr int mf_offA(int ady) { return mf_slot(ady) * CH * SP + RAD - mf_halfwidth(ady); }
-constexpr int mf_offB(int ady) { return mf_slot(ady) * CH * SP + RAD + mf_halfwidth(ady) + 1 - (1 << (mf_slot(ady) + 1)); }
+constexpr int mf_offB(int ady) { return mf_slot(ady) * CH * SP + RAD + mf_halfwidth(ady) + 1 - (1 << (mf_slot(ady) + 2)); }
 
 struct MFGeom {
     int ix0, iy0, W, H;
@@ -113,7 +113,7 @@ __device__ __forceinline__ void mf_fold(float (&acc)[ORW], const float *base) {
 }
 
 __global__ __launch_bounds__(NT) void max_filter_tile(const float *__restrict__ in, float *__restrict__ out, MFGeom g) {
-    __shared__ __attribute__((aligned(16))) float s_r[NSLOT * CH * SP];   // slices R_2 .. R_5 in slots 1 .. 4 (slot 0, R_0, stays in registers)
+    __shared__ __attribute__((aligned(16))) float s_r[NSLOT * CH * SP];   // slices R_2 .. R_5 in slots 0 .. 3
     const int tid = threadIdx.x, cx = tid & 63;
     const float *base = s_r + cx;
     const int rg = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -167,10 +167,10 @@ __global__ __launch_bounds__(NT) void max_filter_tile(const float *__restrict__ 
 #pragma unroll
             for (int j = 0; j < 4; j++) r5[j] = fmaxf(r4[j], nextlane(nextlane(nextlane(nextlane(r4[j])))));    // + 16
             float *w = s_r + qr * SP + 4 * qc;
-            *reinterpret_cast<mf_f4 *>(w + 1 * CH * SP) = mf_f4{r2[0], r2[1], r2[2], r2[3]};
-            *reinterpret_cast<mf_f4 *>(w + 2 * CH * SP) = mf_f4{r3[0], r3[1], r3[2], r3[3]};
-            *reinterpret_cast<mf_f4 *>(w + 3 * CH * SP) = mf_f4{r4[0], r4[1], r4[2], r4[3]};
-            *reinterpret_cast<mf_f4 *>(w + 4 * CH * SP) = mf_f4{r5[0], r5[1], r5[2], r5[3]};
+            *reinterpret_cast<mf_f4 *>(w + 0 * CH * SP) = mf_f4{r2[0], r2[1], r2[2], r2[3]};
+            *reinterpret_cast<mf_f4 *>(w + 1 * CH * SP) = mf_f4{r3[0], r3[1], r3[2], r3[3]};
+            *reinterpret_cast<mf_f4 *>(w + 2 * CH * SP) = mf_f4{r4[0], r4[1], r4[2], r4[3]};
+            *reinterpret_cast<mf_f4 *>(w + 3 * CH * SP) = mf_f4{r5[0], r5[1], r5[2], r5[3]};
         }
         __syncthreads();   // the slices of the chunk are complete
         switch (chunk - rg * (ORW / CH)) {   // wave-uniform

@@ -139,19 +139,19 @@ static inline float o_halide_log(float x_full) {
     return result;
 }
 
-/* pow(x, y) for non-constant y on LLVM CPU targets (src/CodeGen_LLVM.cpp:3925-3941):
- * exp(log(x) * y) with the select chain for x <= 0. */
+/* pow(x, y) for non-constant y on LLVM CPU targets (src/CodeGen_LLVM.cpp:3925-3941): exp(log(abs(x)) * y) under the select
+ * chain written there; abs clears the sign bit (of a NaN too); `iy % 2` on floats is a - b * floor(a / b) (src/CodeGen_LLVM.cpp
+ * visit(Mod)) with a / 2 folded to a * 0.5f. */
 static inline float o_halide_pow(float x, float y) {
-    float e = o_halide_exp(o_halide_log(x) * y);
+    const float ax = o_bits2f(o_f2bits(x) & 0x7fffffffu);
+    const float e = o_halide_exp(o_halide_log(ax) * y);
     if (x > 0.0f) return e;
     if (y == 0.0f) return 1.0f;
     if (x == 0.0f) return 0.0f;
-    /* negative base: integer y -> sign by parity, else NaN */
-    float yi = floorf(y);
-    if (yi != y) return NAN;
-    float mag = o_halide_exp(o_halide_log(-x) * y);
-    int odd = (((int64_t)yi) & 1) != 0;
-    return odd ? -mag : mag;
+    const float iy = floorf(y);
+    if (y != iy) return NAN;
+    const float r = iy - 2.0f * floorf(iy * 0.5f);
+    return (r == 0.0f) ? e : -e;
 }
 
 /* fast_exp (src/IROperator.cpp:1616-1643) */

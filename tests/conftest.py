@@ -12,6 +12,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """The absent Halide-produced goldens are expected failures (tests/test_reference_goldens.py), which a quiet run shows as a row of
+    `x`: say in words what they mean, every run."""
+    xf = [r for r in terminalreporter.stats.get("xfailed", []) if "test_reference_goldens" in r.nodeid]
+    if xf:
+        terminalreporter.write_line(
+            f"REFERENCE PINNING ABSENT for {len(xf)} pipeline cases: tests/golden/halide/ holds no output of a real Halide build (none can be "
+            "made in this environment: no LLVM). Every float pipeline is held to this repository's oracle only; "
+            "scripts/pin_against_halide.sh is the recipe that closes it.", yellow=True)
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _oracle_canon_follows_the_library():
     """The oracle has two canonical float forms (oracle/oracle_common.h); the parity tests compare a library with the form it

@@ -99,12 +99,12 @@ def test_oracle_preserves_constant_and_smooth_images(oracle):
     assert np.max(np.abs(oracle.bilateral_grid(s, 0.1) - s)) < 0.12
 
 
-@pytest.fixture(params=["one_launch", "two_launches"])
+@pytest.fixture(params=["two_launches", "one_launch"])
 def bg_path(request, monkeypatch):
-    """Grids of at most 16 planes run as one launch since round 6 (bg_blur_slice<.., HIST = true> builds the tile's blurz cells from the
-    input itself); HLMI_BG_TWO_LAUNCH=1 keeps the histogram + z blur as a launch of its own.  Both face the oracle."""
-    if request.param == "two_launches":
-        monkeypatch.setenv("HLMI_BG_TWO_LAUNCH", "1")
+    """Round 6 built a one-launch form for grids of at most 16 planes (bg_blur_slice<.., HIST = true> builds the tile's blurz cells from
+    the input itself; HLMI_BG_ONE_LAUNCH=1).  It is slower and therefore opt-in, but both paths face the oracle."""
+    if request.param == "one_launch":
+        monkeypatch.setenv("HLMI_BG_ONE_LAUNCH", "1")
     return request.param
 
 

@@ -23,6 +23,7 @@ def exact_upto(d, k, n):
     (35, 16, 11 * 35 + 1, "lens_blur.hip lb_divc<PM2W, PM2H * PM2W>"),
     (21, 16, 9 * 21 + 1, "lens_blur.hip lb_divc<PM3W, PM3H * PM3W>"),
     (3, 16, 128, "depthwise_separable_conv.hip: filter element -> (ry, rx), q < 128"),
+    (112, 21, 35 * 256, "bilateral_grid.hip bg_blur_slice<HIST>: staged pixel number -> row of the tile's 112 x 80 input region"),
 ])
 def test_division_by_a_constant_as_one_multiplication_is_exact_on_its_range(d, k, n, where):
     assert exact_upto(d, k, n), where
