@@ -928,7 +928,11 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         dst[2].x = rd(r1.l[0]), dst[3].x = rd(r1.l[1]), dst[2].y = rd(r1.l[2]), dst[3].y = rd(r1.l[3]);
     };
     auto plane_vals = [&](int kk, const Row &r0, const Row &r1, const f2 (&lv)[4], f2 (&v0)[2], f2 (&v1)[2]) {
-        if (kk < KCH) {
+        if (B1 && kk == 0) {
+            // level_0 = 0 * (1 / (levels - 1)) = +0 exactly and gray >= +0: (gray - 0) + 0 is gray bit for bit, two of the three
+            // passes of this plane are not issued (beta == 1 only: beta * gray would have to be)
+            v0[0] = r0.g[0] + lv[0], v0[1] = r0.g[1] + lv[1], v1[0] = r1.g[0] + lv[2], v1[1] = r1.g[1] + lv[3];
+        } else if (kk < KCH) {
             const f2 L = f2s(level[kk < KCH ? kk : 0]);
             f2 t[4] = {r0.g[0] - L, r0.g[1] - L, r1.g[0] - L, r1.g[1] - L};
             if (!B1 && !dev::CANON_FMA) {

@@ -12,6 +12,14 @@ find $OUT -name "*kernel_trace.csv" -delete
 PMC_CMD="python bench_apps.py --only nl_means,bilateral_grid,conv_layer_bf16,stencil_chain,camera_pipe --samples 1 --no-batched" bash scripts/gpu_pmc_cmd.sh $TAG/pmc_apps \
   "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
   "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES" "FETCH_SIZE" "WRITE_SIZE" 2>&1 | grep -E "^\(" | tee $OUT/apps_pmc.txt | cut -c1-200
+echo "== local_laplacian: instruction counters of the two big kernels (both canonical forms)"
+LLCMD="python scripts/ll_once.py"
+PMC_CMD="$LLCMD" bash scripts/gpu_pmc_cmd.sh $TAG/pmc_ll "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" 2>&1 | grep -E "^\(" | tee $OUT/ll_pmc_fma.txt | cut -c1-200
+if [ -f $R/halide_amd/lib/libhlmi_nofma.so ]; then
+  PMC_CMD="HLMI_LIB=$R/halide_amd/lib/libhlmi_nofma.so $LLCMD" bash scripts/gpu_pmc_cmd.sh $TAG/pmc_ll_nofma "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" 2>&1 | grep -E "^\(" | tee $OUT/ll_pmc_nofma.txt | cut -c1-200
+  echo "== full GPU suite against the canon-0 build"
+  HLMI_LIB=$R/halide_amd/lib/libhlmi_nofma.so timeout 1500 python -m pytest tests -m gpu -q --maxfail=10 --tb=short 2>&1 | tail -8 | tee $OUT/pytest_gpu_nofma.log
+fi
 echo "== HBM ceiling sweep + access-width calibration"
 timeout 600 python - <<PY 2>&1 | tee $OUT/membench.log
 import json, os, halide_amd as hl

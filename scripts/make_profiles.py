@@ -41,7 +41,8 @@ for name in ("bench.json", "bench_1stream.json", "bench_2streams.json", "bench_d
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f"{rnd}_{name}"))
 
-for name in ("apps_pmc.txt", "membench.log", "pmc_widths.txt", "pmc_ll_tcc.txt", "membench_sweep_1024MB.json"):   # scripts/gpu_r3_evidence.sh
+for name in ("apps_pmc.txt", "membench.log", "pmc_widths.txt", "pmc_ll_tcc.txt", "membench_sweep_1024MB.json", "ll_pmc_fma.txt", "ll_pmc_nofma.txt",
+             "pytest_gpu_nofma.log"):   # scripts/gpu_r3_evidence.sh
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f"{rnd}_{name}"))
