@@ -107,6 +107,6 @@ if rows:
     # bench.py prints `traffic` only while the kernel source is the one these counters were collected with
     json.dump({"source": f"profiles/{rnd}_pmc_traffic.csv", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per dispatch",
                "kernel_source": "halide_amd/csrc/local_laplacian.hip", "kernel_source_sha256": hashlib.sha256(open(ksrc, "rb").read()).hexdigest(),
-               "git_head_when_collected": head, "input": "smooth 3840x2160 frames of bench.py (the re-cut dataflow moves the same bytes for every input)",
+               "git_head_when_collected": head, "input": "3840x2160 frames of bench.py's headline input, uniform noise since round 6 (the re-cut dataflow moves the same bytes for every input)",
                "bytes_per_launch": per}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print("wrote", sorted(os.listdir(dst)))
