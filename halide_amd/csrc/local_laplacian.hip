@@ -69,6 +69,10 @@ struct Level {
 #ifndef HLMI_LL_PROBE
 #define HLMI_LL_PROBE 0
 #endif
+// A/B switch of round 6's 8-byte emission gathers (ll_down01e, em_gather): `make VARIANT=_emb64off EXTRA=-DHLMI_LL_EM_B64=0`
+#ifndef HLMI_LL_EM_B64
+#define HLMI_LL_EM_B64 1
+#endif
 #if HLMI_LL_PROBE
 __device__ unsigned long long g_probe[32];
 #define LL_PROBE_T(var) const unsigned long long var = wall_clock64()   // s_memrealtime: constant 100 MHz
@@ -989,8 +993,23 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         const int li = min(pos >> 10, KCH - 2);                    // (int)(gray * (K-1)), clamped (:66); gray >= 0
         const uint32_t po = (uint32_t)(li << 10) + (uint32_t)(COL[i] * 4);
         g.lut = rd2(alut + (uint32_t)n.l[i] - (uint32_t)(li << 10), desc);   // plane li + 1's entry is the lower address
-        g.qa = rd2(aq0 + po, asc), g.qb = rd2(aq0 + po + 4u, asc);
-        g.ta = rd2(at0 + po, asc), g.tb = rd2(at0 + po + 4u, asc);
+        if (HLMI_LL_EM_B64 && (COL[i] & 1) == 0) {
+            // round 6: the coarse column pair is one lane's float2 — ONE ds_read_b64 per plane fetches both columns, at the full LDS rate:
+            // lanes 8 bytes apart are conflict-free for 8-byte reads, while the dword gathers below walk the same rows at a stride of two
+            // words (2-way bank conflicts, 8 LDS cycles per instruction instead of 4; the LDS pipe is this kernel's co-limit).  The
+            // pairs arrive as (column c, column c + 1) per plane instead of (plane li, plane li + 1) per column: em_arith's `PAIR` form
+            auto rd64 = [](uint32_t addr, auto plane1) {
+                f2 v;
+                if (decltype(plane1)::value) asm volatile("ds_read_b64 %0, %1 offset:1024" : "=v"(v) : "v"(addr) : "memory");
+                else asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+                return v;
+            };
+            g.qa = rd64(aq0 + po, asc), g.qb = rd64(aq0 + po, desc);
+            g.ta = rd64(at0 + po, asc), g.tb = rd64(at0 + po, desc);
+        } else {
+            g.qa = rd2(aq0 + po, asc), g.qb = rd2(aq0 + po + 4u, asc);
+            g.ta = rd2(at0 + po, asc), g.tb = rd2(at0 + po + 4u, asc);
+        }
         g.lif = (float)li;
     };
     auto em_wait = [&](EmPix &g, auto after_tag) {   // `after` = gathers of how many pixels were requested after this one's
@@ -1019,7 +1038,22 @@ __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometr
         const float gr = n.g[i & 1][i >> 1];
         const float lf = gr * gm.Km1 - g.lif;   // `level` has two uses (:64-66): not contracted in either form
         const f2 lev = f2{g.lif, g.lif + 1.0f} * gm.inv_Km1;
-        const f2 u = vl(hl(g.qa, g.qb), hl(g.ta, g.tb));
+        constexpr int COLP[4] = {ODD0 ? -1 : -2, -1, ODD0 ? 0 : -1, 0};
+        f2 u;
+        if (HLMI_LL_EM_B64 && (COLP[i] & 1) == 0) {
+            // PAIR form (em_gather): qa / qb = (column c, column c + 1) of planes li / li + 1 in the row weighted 1/4, ta / tb in the other;
+            // the same lerps on scalars (a packed instruction costs two issue slots here: the same issue time)
+            auto hls = [&](float fa, float fb) {
+                if (xodd) return __builtin_fmaf(fb, 0.25f, fa * 0.75f);
+                return dev::CANON_FMA ? __builtin_fmaf(fb, 0.75f, fa * 0.25f) : __builtin_fmaf(fa, 0.25f, fb * 0.75f);
+            };
+            auto vls = [](float uq, float ut) {
+                return (dev::CANON_FMA && !YODD) ? __builtin_fmaf(ut, 0.75f, uq * 0.25f) : __builtin_fmaf(uq, 0.25f, ut * 0.75f);
+            };
+            u = f2{vls(hls(g.qa.x, g.qa.y), hls(g.ta.x, g.ta.y)), vls(hls(g.qb.x, g.qb.y), hls(g.tb.x, g.tb.y))};
+        } else {
+            u = vl(hl(g.qa, g.qb), hl(g.ta, g.tb));
+        }
         const f2 g2 = f2s(gr);
         const f2 l = (B1 ? ((g2 - lev) + lev) + g.lut : mad_2(f2s(p.beta), g2 - lev, lev) + g.lut) - u;   // g0_val of planes li, li + 1
         if (dev::CANON_FMA) return __builtin_fmaf(1.0f - lf, l.x, lf * l.y);
