@@ -15,6 +15,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import halide_amd as hl  # noqa: E402
 import oracle_lib as oracle  # noqa: E402
 
+oracle.set_canon(hl.canon_fma())   # the oracle evaluates the canonical form the loaded library was built for
+
 f32 = np.float32
 rng = np.random.default_rng(3)
 
