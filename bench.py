@@ -131,6 +131,8 @@ def cpu_baseline(frame):
     generator quotes 184 Mpx/s on 16 cores for it, local_laplacian_generator.cpp:139-140)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib  # cpu_baseline leg only
+    import halide_amd
+    oracle_lib.set_canon(halide_amd.canon_fma())   # the CPU evaluates the same canonical float form the library computes
     ncpu = os.cpu_count() or 1
     oracle_lib.local_laplacian(frame, LEVELS, ALPHA, BETA)       # the plain oracle, before the thread count is touched
     plain0 = time.perf_counter()

@@ -60,6 +60,7 @@ def run(only=(), samples=5, sink=None, cpu=False, batched=True):
             return {}
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib  # cpu_baseline leg only: the checker timed as the host-CPU reference point
+        oracle_lib.set_canon(hl.canon_fma())
         sec, n = cpu_time(lambda: fn(oracle_lib))
         return {"cpu_baseline": {"value": round(units / sec / 1e6, 3), "unit": unit, "cores": os.cpu_count() or 1, "kind": "port",
                                  "ms_per_call": round(sec * 1e3, 2), "sample": f"{n} calls of {what} (C oracle, OpenMP, all host threads)"}}
