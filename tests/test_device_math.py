@@ -66,7 +66,8 @@ def _same(got, want):
 def test_unary_primitives_over_the_whole_float_range(hl, oracle, fn, name):
     rng = np.random.default_rng(100 + fn)
     dense = {0: rng.uniform(-110.0, 95.0, N // 2), 1: np.exp(rng.uniform(-104.0, 89.0, N // 2)), 3: rng.uniform(-110.0, 95.0, N // 2)}[fn]
-    x = np.concatenate([_special(), _all_exponents(rng, N // 2), dense.astype(np.float32)])
+    with np.errstate(over="ignore"):   # the top of log's dense range rounds to +inf in float32: a wanted special value
+        x = np.concatenate([_special(), _all_exponents(rng, N // 2), dense.astype(np.float32)])
     if fn != 1:
         x = x[_int_cast_defined(x)]
     got, want = _device(hl, fn, x), _oracle_vec(oracle, name, x)
