@@ -72,8 +72,8 @@ def synth_frame(seed, w=W, h=H, kind="smooth"):
 
 
 class ClockSampler:
-    """Shader clock (MHz) and package power (W) of the device while a leg runs, read from the amdgpu driver's hwmon files every
-    20 ms on a thread: latency-shaped figures (one call + sync) move with the box's clock state, and a reader must be able to tell
+    """Shader clock (MHz) and socket power (W) of the device while a leg runs, read from the amdgpu driver's hwmon files every
+    20 ms on a thread (on a multi-GPU node: the k-th card that has the files, for local rank k): latency-shaped figures (one call + sync) move with the box's clock state, and a reader must be able to tell
     a regression from a box that was not clocked up.  Every field is None where the files are absent."""
 
     def __init__(self, device_index=0):
@@ -119,8 +119,13 @@ class ClockSampler:
         import statistics
         f = [a / 1e6 for a, _ in self.samples if a]
         p = [b / 1e6 for _, b in self.samples if b]
+        # freq1_input is the INSTANTANEOUS shader clock of the device (it reads ~100 MHz whenever a sample falls between two kernels of a
+        # call + sync pattern, scripts/clock_files_probe.sh): the maximum says what the clock reaches under the pattern, the median
+        # how much of the time the device was clocked up at all
         return {"sclk_mhz_median": round(statistics.median(f)) if f else None, "sclk_mhz_min": round(min(f)) if f else None,
-                "power_w_median": round(statistics.median(p)) if p else None, "samples": len(self.samples)}
+                "sclk_mhz_max": round(max(f)) if f else None,
+                "power_w_median": round(statistics.median(p)) if p else None, "power_w_max": round(max(p)) if p else None,
+                "samples": len(self.samples)}
 
 
 def cpu_baseline(frame):

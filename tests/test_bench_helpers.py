@@ -11,7 +11,7 @@ def test_clock_sampler_without_hwmon_files_reports_none():
     with bench.ClockSampler(0) as cs:
         time.sleep(0.05)
     s = cs.summary()
-    assert set(s) == {"sclk_mhz_median", "sclk_mhz_min", "power_w_median", "samples"}
+    assert set(s) == {"sclk_mhz_median", "sclk_mhz_min", "sclk_mhz_max", "power_w_median", "power_w_max", "samples"}
     assert s["samples"] >= 1
     if cs.freq is None:
         assert s["sclk_mhz_median"] is None and s["sclk_mhz_min"] is None
