@@ -418,7 +418,7 @@ def main():
             b.device_free()
         import bench_apps
         other_configs = []
-        bench_apps.run(("bilateral_grid", "nl_means", "conv_layer_bf16"), 3, other_configs.append, cpu=not args.no_cpu_baseline)
+        bench_apps.run(("bilateral_grid", "nl_means", "conv_layer_bf16"), 8, other_configs.append, cpu=not args.no_cpu_baseline)
         # configs[3] as BASELINE.json states it: the BATCH of 32 nl_means frames (bench_batch.py's workload at N = 1: resident on
         # this GPU, no exchange step), enqueued back to back, one sync at the end
         other_configs.append(bench_apps.nl_means_batch32())
