@@ -489,7 +489,7 @@ def test_hip_emit_launch_geometries_match_oracle(hl, oracle, monkeypatch, units,
         monkeypatch.setenv("HLMI_LL_UNITS0", str(units))
     if ru:
         monkeypatch.setenv("HLMI_LL_RU", str(ru))
-    for (w, h, origin) in [(2048, 700, (0, 0)), (520, 333, (-2, 7))]:
+    for (w, h, origin) in [(2048, 700, (0, 0)), (520, 333, (-2, 7)), (260, 4, (0, 0)), (132, 2, (2, 1))]:
         inp = _rand_image(w, h, seed=w + h + units, kind="uniform")
         a = hl.Buffer(inp).set_min(origin[0], origin[1], 0)
         o = hl.Buffer(np.zeros_like(inp)).set_min(origin[0], origin[1], 0)
