@@ -213,12 +213,13 @@ def main():
     ap.add_argument("--no-ceiling", action="store_true", help="skip the live HBM copy-ceiling sweep (profiler runs)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra input variants (uniform noise, 7680x4320)")
     ap.add_argument("--partitions", type=int, default=int(os.environ.get("HLMI_BENCH_PARTITIONS", "4")),
-                    help="frames of a step are spread over this many CU-partitioned streams (halide_hip_partition_stream: "
-                         "disjoint quarters of the chip by default), one frame per partition at a time: frames are "
-                         "independent units, so the latency-bound coarse pyramid levels of one frame run beside the large "
-                         "kernels of the others instead of competing with them; 0 = plain streams (--streams)")
+                    help="frames of a step are spread over this many frame-queue streams (halide_hip_partition_stream: library "
+                         "streams with a hardware queue each, launches sized for that many frames in flight; NOT CU "
+                         "partitions - profiles/NOTES.md round 6), one frame per queue at a time: frames are independent units, "
+                         "so the latency-bound coarse pyramid levels of one frame run beside the large kernels of the others; "
+                         "0 = plain streams (--streams)")
     ap.add_argument("--streams-per-partition", type=int, default=int(os.environ.get("HLMI_BENCH_SPP", "1")),
-                    help="streams on each CU partition: with 2, one frame's short launch chain runs under the other's large kernels")
+                    help="replicas of each frame queue (more queues of the same kind)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("HLMI_BENCH_STREAMS", "2")),
                     help="with --partitions 0: plain HIP streams the frames of a step are spread over")
     args = ap.parse_args()
@@ -304,7 +305,7 @@ def main():
     if args.partitions > 1:
         spp = max(1, args.streams_per_partition)
         streams = [hl.partition_stream(p, args.partitions, r) for r in range(spp) for p in range(args.partitions)]
-        mode = f"{args.partitions} CU-partitioned streams" + (f" x {spp}" if spp > 1 else "")
+        mode = f"{args.partitions} frame-queue streams" + (f" x {spp}" if spp > 1 else "")
         if not all(streams):
             streams = []            # the device refused a CU mask: plain streams instead
     if not streams and args.streams > 1:
@@ -526,11 +527,13 @@ def main():
                          # HIP-event brackets around each launch on ONE stream: they include the gap to the previous launch and read
                          # longer than the kernels run (rocprofv3's kernel trace, profiles/, has the durations) — relative weights
                          "kernel_ms_hip_events_one_stream": {k: round(v, 5) for k, v in per_frame.items()},
-                         # per-launch figures (HIP events, PMC) are taken on ONE device-wide stream; the headline loop runs on CU
-                         # partitions, where the kernels use non-temporal frame accesses and ll_up0h also collapses level 2 (same
-                         # bytes within 1 %), and where the package sits at its power limit from two busy partitions on
-                         "notes": "profiles/r04_power_and_partition_scaling.txt: 1040 W with one partition busy, ~1370 W (the limit) "
-                                  "with two or four; the frame rate on a whole device is energy per frame"},
+                         # per-launch figures (HIP events, PMC) are taken on ONE device-wide stream; the headline loop runs on four
+                         # frame queues, where the kernels use non-temporal frame accesses and a coarser launch geometry (same
+                         # bytes within 1 %)
+                         "notes": "the headline loop keeps four frames in flight on four hardware queues that all run on the whole "
+                                  "device (the CU masks of rounds 3-5 confined nothing: profiles/r06_cu_mask_probe.txt); the frame "
+                                  "time is the sum of the kernels' back-to-back floors (profiles/r06_partition_kernel_probe.txt); "
+                                  "profiles/r04_power_and_partition_scaling.txt read 1040 W with one queue busy, ~1370 W with two or four"},
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(frames[0])

@@ -91,7 +91,7 @@ def run(only=(), samples=5, sink=None, cpu=False, batched=True):
 
     def timed_batched(make_call, nframes=8, rounds=6):
         """Throughput mode: `nframes` independent frames (own inputs and outputs) enqueued back to back without host
-        synchronisation — on one stream, and spread over 2 / 4 CU-partitioned streams (halide_hip_partition_stream, as bench.py
+        synchronisation — on one stream, and spread over 2 / 4 frame-queue streams (halide_hip_partition_stream, as bench.py
         runs the headline pipeline); returns (seconds per frame, scheduling) of the fastest.  The single-call figure is a
         latency: two or three short dependent launches cannot fill 256 CUs, several frames side by side can."""
         if not batched:   # profiler runs (rocprofv3 over this script): one call at a time only
@@ -118,7 +118,7 @@ def run(only=(), samples=5, sink=None, cpu=False, batched=True):
                 hip.hipDeviceSynchronize()
                 dt = (time.perf_counter() - t0) / (rounds * nframes)
                 if dt < best:
-                    best, how = dt, ("1 stream, back to back" if nparts == 1 else f"{nparts} CU-partitioned streams")
+                    best, how = dt, ("1 stream, back to back" if nparts == 1 else f"{nparts} frame-queue streams")
         return best, how
 
     def batched_fields(tb, unit_work, peak, what):
@@ -440,7 +440,7 @@ def run(only=(), samples=5, sink=None, cpu=False, batched=True):
 def nl_means_batch32(samples=3):
     """BASELINE.json configs[3] at N = 1: the batch of 32 nl_means frames (7x7 search / 7x7 patch, f32 1920x1080x3, seeds 0..31 as
     SURVEY.md §8d names them) resident on one GPU — what every rank of bench_batch.py does with its share, without the exchange
-    step — enqueued back to back over four CU-partitioned streams, ONE sync at the end; min over `samples` batches."""
+    step — enqueued back to back over four frame-queue streams, ONE sync at the end; min over `samples` batches."""
     import numpy as np
     import halide_amd as hl
     W, H, B = 1920, 1080, 32
@@ -466,7 +466,7 @@ def nl_means_batch32(samples=3):
             t0 = time.perf_counter()
             batch()
             best = min(best, time.perf_counter() - t0)
-        results["1 stream" if nparts == 1 else f"{nparts} CU-partitioned streams"] = best
+        results["1 stream" if nparts == 1 else f"{nparts} frame-queue streams"] = best
     for b in ins + outs:
         b.device_free()
     how, t = min(results.items(), key=lambda kv: kv[1])

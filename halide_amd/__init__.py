@@ -241,8 +241,9 @@ def set_stream(stream_ptr: int | None) -> None:
 
 
 def partition_stream(part: int, nparts: int, replica: int = 0) -> int | None:
-    """hipStream_t of partition `part` of `nparts` disjoint CU partitions (include/hlmi_runtime.h), or None; `replica` > 0:
-    a further stream on the same compute units."""
+    """hipStream_t of frame queue `part` of `nparts` (a library-owned stream with a hardware queue of its own whose launches are
+    sized for `nparts` frames in flight; include/hlmi_runtime.h — the name dates from when its CU mask was believed to confine
+    it), or None; `replica` > 0: a further queue of the same kind."""
     lib.halide_hip_partition_stream_replica.restype = C.c_void_p
     lib.halide_hip_partition_stream_replica.argtypes = [C.c_int, C.c_int, C.c_int]
     return lib.halide_hip_partition_stream_replica(int(part), int(nparts), int(replica))

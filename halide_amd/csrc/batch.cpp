@@ -20,8 +20,8 @@ namespace {
 std::mutex g_batch_mu;
 std::map<std::pair<int, int>, hipStream_t> g_worker_streams;  // (device, worker slot on that device) -> stream
 
-// Library-owned stream of worker `slot` on `device`.  With `parts` > 1 the slot's stream is confined to CU partition
-// slot % parts (frames that share a GPU then run side by side instead of time-slicing it).
+// Library-owned stream of worker `slot` on `device`.  With `parts` > 1 the slot's stream is frame queue slot % parts
+// (a hardware queue of its own, launches sized for frames in flight: halide_hip_partition_stream).
 hipStream_t worker_stream(int device, int slot, int parts) {
     if (parts > 1) return (hipStream_t)halide_hip_partition_stream(slot % parts, parts);
     std::lock_guard<std::mutex> lock(g_batch_mu);

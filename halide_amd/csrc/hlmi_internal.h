@@ -118,7 +118,7 @@ void mark_output_written(halide_buffer_t *buf);  // device_dirty = 1, host_dirty
 // (device handle, version) identifies contents.  0 = memory this runtime does not own (wrapped native pointers: their
 // owner can rewrite them behind our back) — callers must not cache anything derived from such a buffer.
 uint64_t buffer_version(const halide_buffer_t *buf);
-// compute units a launch on `stream` can use (a CU-partitioned stream of halide_hip_partition_stream: its share)
+// compute units a launch on `stream` is sized for (a frame-queue stream of halide_hip_partition_stream: its 1 / nparts share)
 int stream_cu_count(int device, hipStream_t stream);
 
 // Bounds-query helpers.  A buffer takes part in deriving the other buffers' regions when it is real (host or device set) or,

@@ -205,7 +205,7 @@ __device__ __forceinline__ T pick4(T x, T y, T z, T w, int s) {
 // The u16 frames are touched exactly twice (input: the down and the up kernel; output: written once) and never again, while the
 // pyramid planes in between are re-read within tens of microseconds.  NT marks a frame access non-temporal so that it does
 // not displace the planes from L2 / Infinity Cache.  Round 3 measured nothing from it (the frame rate was set elsewhere);
-// with the re-cut dataflow the CU-partitioned frame rate is set by how the memory system digests the traffic (§4: the three
+// with the re-cut dataflow the frame rate with four frames in flight is set by how the memory system digests the traffic (§4: the three
 // parts of a frame add up, whatever runs beside them), and there the hints are worth 6-7 % (84.0 -> 77.9 us per frame,
 // five alternating runs each): non-temporal input loads in both kernels, outLPyramid[0] stores and loads, output stores; the
 // level-1 and level-2 planes stay cached (non-temporal: slower).  On a stream that owns the device they cost 2-3 %, so the
@@ -2108,7 +2108,7 @@ struct Up0HArgs {
     int l0_ws;                 // its row stride in floats (= input width)
     // FUSE2: outGPyramid[2] on the part of R_2 the workgroup's level-1 tile reads is produced here too (phase 0, an LDS tile of at
     // most 68 x (RU / 2 + 3) values, by the expression of ll_up) instead of by an ll_up:2 launch: one dependent launch less in the
-    // chain between the two big kernels, which costs a CU partition 8 us of every frame
+    // chain between the two big kernels, which costs a frame queue 8 us of every frame
     int fuse2;
     const float *g3, *out3;
     int lox3, loy3, ws3;
@@ -2409,7 +2409,7 @@ uint64_t g_lut_clock = 0;
 // private stream of the calling thread (capturing records, it does not execute — and a capture on the caller's own stream would
 // swallow or be invalidated by whatever another host thread enqueues there meanwhile, e.g. a halide_copy_to_host); the
 // instantiated graph is then launched on the caller's stream.
-// OPT-IN (HLMI_LL_GRAPH=1): measured on MI355X it buys nothing — 84.2 vs 83.4 Gpx/s on four CU-partitioned streams (inside the
+// OPT-IN (HLMI_LL_GRAPH=1): measured on MI355X it buys nothing — 84.2 vs 83.4 Gpx/s on four frame-queue streams (inside the
 // box-to-box noise) and 69.1 vs 72.7 Gpx/s on one stream (profiles/r03a_*): the GPU-side gap between dependent launches is the
 // same for a graph and for eager launches, and the host (44 us of enqueue per 99 us frame) is not the bottleneck.
 struct GraphKey {
@@ -2588,7 +2588,8 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         // opt-in up-chain, which starts at >= 1 and then owns level 1 itself)
         fuse1 = fast && SU >= 2;
         // rows per wave: taller tiles re-read less of level 1 (18 coarse rows per 16 output rows, 34 per 32) but keep a wave
-        // busy longer.  On a CU-partitioned stream, where several frames share the memory system and the frame rate is set by
+        // busy longer.  On a frame-queue stream (`partitioned`: one of several library queues with frames in flight, runtime.cpp),
+        // where several frames share the memory system and the frame rate is set by
         // bytes, 32 rows measure 2.7 % faster (84.8 vs 82.6 Gpx/s); on a stream that owns the device 16 rows do (72.7 vs 68.2).
         p.RU = dev_clamp_ru(env_int("HLMI_LL_RU", fuse1 ? (partitioned ? 32 : 16) : 8));
     }
@@ -2600,12 +2601,13 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     // (HLMI_LL_EMIT=0: the round-3 pair ll_down01f / ll_up0f with the materialised K + 1 level-1 planes)
     const bool emit = d01_possible && fast && fuse1 && lv[1].ws < (1 << 24) && env_int("HLMI_LL_EMIT", 1);   // ws: ll_up0h's 24-bit row products
     // ll_up0h has no data-dependent gathers to amortise over a tall tile: short tiles (more, smaller workgroups) are faster on a
-    // stream that owns the device (31.7 us at 8 rows per wave against 33.5 / 38.4 at 16 / 32); on CU partitions 8..32 measure the same
-    if (emit) p.RU = dev_clamp_ru(env_int("HLMI_LL_RU", partitioned ? 16 : 8));
-    // non-temporal frame / outLPyramid[0] accesses: +6-7 % frames per second on CU partitions, -2-3 % on a stream that owns the device
+    // stream that owns the device (31.7 us at 8 rows per wave against 33.5 / 38.4 at 16 / 32); with four frames in flight 8 / 12 / 16 /
+    // 24 / 32 rows measure 107.8 / 110.1 / 111.2 / 112.3 / 112.3 Gpx/s (profiles/r06_frame_queue_geometry.txt)
+    if (emit) p.RU = dev_clamp_ru(env_int("HLMI_LL_RU", partitioned ? 24 : 8));
+    // non-temporal frame / outLPyramid[0] accesses: +6-7 % frames per second with four frames in flight, -2-3 % on a stream that owns the device
     const bool nt = env_int("HLMI_LL_NT", partitioned ? 1 : 0) != 0;
     // ll_up0h also collapses level 2 (into an LDS tile) when level 3 is a stored level of its own: the ll_up:2 launch goes
-    // (on CU partitions, where every dependent launch of the chain idles the partition: 79.4 -> 76.4 us per frame; on a stream that
+    // (with four frames in flight: 79.4 -> 76.4 us per frame; on a stream that
     // owns the device the tile redundancy used to cost what the launch saved — 109 -> 111 us in round 4 — until round 5's batched
     // tile phases: 104.1 -> 98.7 us per frame, 115 -> 110.6 for one call + sync)
     const bool fuse2 = emit && SU >= 3 && SU < J && env_int("HLMI_LL_FUSE_UP2", 1);
@@ -2741,12 +2743,13 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             const int hi1 = d.lox + d.w - 1, hi2 = e.lox + e.w - 1;
             const int x2_first = odd1 ? (a.Pbase + 1) / 2 + 0 : a.Pbase / 2 + 1;   // Pbase + 1 (resp. Pbase) is even: exact
             a.nsx = max((hi2 - x2_first + a.S2) / a.S2, (hi1 - a.Pbase + 2 * a.S2) / (2 * a.S2));
-            // sized for the whole device even on a CU-partitioned stream: units sized for the partition's 64 CUs (one round
-            // of 18-row units) measured 2-3 % slower than 3.6 rounds of 5-row units (101.5 vs 98.9 us per frame)
-            // (ll_down01f).  ll_down01e on a partition: two rounds of taller units — a quarter fewer seam rows walked twice — measure
-            // 5-7 % more frames per second than 3.6 rounds of 5-row units (83.4 vs 88-89 us per frame on four partitions), while on
-            // a stream that owns the device one round of resident waves is what counts (52.7 us against 57.1)
-            const int target2 = env_int("HLMI_LL_UNITS0", emit && partitioned ? 16 * stream_cus : 8 * stream_cu_count(ctx.device, nullptr));
+            // ll_down01f: sized for the whole device on every stream (fewer, taller units measured 2-3 % slower: 101.5 vs 98.9 us per
+            // frame).  ll_down01e on a frame-queue stream (several frames in flight, the launches of different frames fill the device
+            // together): fewer and taller units — fewer seam rows walked twice, less per-workgroup set-up — measure 10 % more frames
+            // per second than the 2048 units of a launch that has the device to itself (round 6, four queues: 2048 / 1536 / 1024 /
+            // 896..384 / 256 units -> 109.4 / 110.2 / 111.3 / 112.1-112.5 / 103.3 Gpx/s, profiles/r06_frame_queue_geometry.txt),
+            // while on a stream that owns the device one round of resident waves is what counts (52.7 us against 57.1)
+            const int target2 = env_int("HLMI_LL_UNITS0", emit && partitioned ? 8 * stream_cus : 8 * stream_cu_count(ctx.device, nullptr));
             // EXCH: a workgroup = 4 vertically adjacent units exchanging their seam rows through LDS.  With n level-2 rows
             // per wave a workgroup owns R = 4 n - 1 rows (the bottom wave walks the two seam rows of the next workgroup
             // itself and owns one row less); n = the smallest that keeps the launch within `target2` resident waves.
@@ -2828,7 +2831,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     }
     fuse2_out = fuse2;
     // levels 3 and 4 from level 2 in one launch (ll_down_strip2) when the chain below would run ll_down_strip:2 and :3
-    // (one stream: 111.6 -> 105.1 us per frame back to back, 123 -> 116.6 for one call + sync; four partitions 75-77 -> 72-76)
+    // (one stream: 111.6 -> 105.1 us per frame back to back, 123 -> 116.6 for one call + sync; four frame queues 75-77 -> 72-76)
     const bool strip2 = fuse_d2 && S == 4;
     if (strip2) {
         const Level &sl = lv[2], &d = lv[3], &e = lv[4];

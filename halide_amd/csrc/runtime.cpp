@@ -441,22 +441,23 @@ static int note_use(void *uc, const DeviceCtx &ctx, uint64_t handle, const char 
 }
 
 static std::map<std::tuple<int, int, int, int>, hipStream_t> g_part_streams;   // (device, part, nparts, replica) -> stream (under g_mu)
-static std::unordered_map<hipStream_t, int> g_part_cus;                    // partition stream -> its number of CUs
+static std::unordered_map<hipStream_t, int> g_part_cus;                    // frame-queue stream -> the CU share its launches are sized for
 
-// compute units a launch on `stream` can use: the partition's share for a library-owned partition stream, else the device's
+// compute units a launch on `stream` is sized for: a 1 / nparts share for a library-owned frame-queue stream, else the device's
 int stream_cu_count(int device, hipStream_t stream) {
     {
         std::lock_guard<std::mutex> lock(g_mu);
         auto it = g_part_cus.find(stream);
         if (it != g_part_cus.end()) return it->second;
     }
+    static const int share = [] { const char *e = getenv("HLMI_STREAM_SHARE"); return e && atoi(e) > 1 ? atoi(e) : 1; }();   // experiment: caller-made streams take the throughput geometry too
     static std::atomic<int> cached[64];
     int c = cached[device & 63].load();
     if (c <= 0) {
         if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c <= 0) c = 256;
         cached[device & 63].store(c);
     }
-    return c;
+    return stream ? c / share : c;
 }
 
 uint64_t buffer_version(const halide_buffer_t *buf) {
@@ -1334,16 +1335,22 @@ int hlmi_device_count(void) {
 void halide_set_gpu_device(int n) { t_gpu_device = n; }
 int halide_get_gpu_device(void *) { return pick_device(); }
 void halide_hip_set_stream(void *stream) { t_stream_override = (hipStream_t)stream; }
-// A stream whose kernels may only use every `nparts`-th compute unit of the device's CU mask, starting at `part`:
-// the chip is split into `nparts` disjoint partitions.  Independent frames enqueued on different partitions progress
-// side by side without competing for the same CUs — the short, latency-bound launches of one frame run next to the
-// long kernels of the others instead of being starved by them (measured on MI355X, local_laplacian 4K: 4 partitions
-// 114-118 us per frame against 120-147 us on two unmasked streams; single-XCD partitions (8) are slower).
-// Streams are created once per (device, part, nparts) and owned by the library.  Returns NULL on failure.
+// One of `nparts` library-owned streams for frames in flight, each with a hardware queue of its own (a stream made by
+// hipExtStreamCreateWithCUMask never shares its HSA queue; plain hipStreamCreate streams are multiplexed onto a small pool,
+// which is what made four of them 20 % slower: 89 against 108-112 Gpx/s on local_laplacian 4K).  Launches on such a stream
+// size their grids for a 1 / nparts share of the device (stream_cu_count), i.e. for throughput with nparts frames in
+// flight rather than for the latency of one call.
+//
+// What the CU mask really does (round 6, scripts/ubench/cu_mask_probe.hip, profiles/r06_cu_mask_probe.txt): bit b names
+// compute unit b / 8 of XCD b % 8, and an XCD whose share of the mask is EMPTY runs the queue on ALL of its CUs.  Rounds
+// 3-5 set every nparts-th bit — for nparts = 4 all CUs of two XCDs and none of the other six — so what they called "four
+// 64-CU partitions" were four queues on the whole device.  Real partitions (HLMI_PART_MASK=1: the same CU slots on every
+// XCD, 2: contiguous slots) measure 3 % SLOWER than the unmasked queues (108.7 against 111.8 Gpx/s), so the default mask
+// is now explicitly the full one (layout 3); 0 is the old layout, kept for A/B.
+// Streams are created once per (device, part, nparts, replica) and owned by the library.  Returns NULL on failure.
 void *halide_hip_partition_stream(int part, int nparts) { return halide_hip_partition_stream_replica(part, nparts, 0); }
 
-// Several streams on the SAME compute units (replica 0, 1, ..): two frames in flight on a partition keep its CUs busy with
-// one frame's large kernels while the other's short launch chain (six latency-bound kernels of a few microseconds) runs.
+// Further queues with the same mask and geometry share (replica 0, 1, ..).
 void *halide_hip_partition_stream_replica(int part, int nparts, int replica) {
     DeviceCtx ctx;
     if (nparts < 1 || part < 0 || part >= nparts || replica < 0 || replica > 15 || acquire_device(nullptr, &ctx, false)) return nullptr;
@@ -1355,14 +1362,23 @@ void *halide_hip_partition_stream_replica(int part, int nparts, int replica) {
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx.device) != hipSuccess || ncu < nparts) return nullptr;
     std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-    for (int b = part; b < ncu; b += nparts) mask[(size_t)b / 32] |= 1u << (b % 32);
+    const char *ml = getenv("HLMI_PART_MASK");
+    const int layout = ml && *ml ? atoi(ml) : 3;
+    const int nxcc = ncu >= 64 ? ncu / 32 : 1, slots = ncu / nxcc;
+    int mine = 0;
+    for (int b = 0; b < ncu; b++) {
+        const int slot = b / nxcc;
+        const bool on = layout == 1 ? (slot % nparts == part) : layout == 2 ? (slot * nparts / slots == part) : layout == 3 ? true : (b % nparts == part);
+        if (on) mask[(size_t)b / 32] |= 1u << (b % 32), mine++;
+    }
     hipStream_t s = nullptr;
     if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }
     streams[key] = s;
-    g_part_cus[s] = (ncu - part + nparts - 1) / nparts;
+    const char *gc = getenv("HLMI_PART_GEOM_CUS");   // experiment: the CU count the launch geometry is sized for
+    g_part_cus[s] = gc && atoi(gc) > 0 ? atoi(gc) : layout == 3 ? ncu / nparts : mine;
     return (void *)s;
 }
 

@@ -108,11 +108,15 @@ int halide_get_gpu_device(void *user_context);
  * default stream of torch-ROCm) pass its explicit handle hipStreamLegacy, not 0. */
 void halide_hip_set_stream(void *stream);
 void *halide_hip_get_stream(void *user_context);
-/* A library-owned stream confined to partition `part` of `nparts` disjoint partitions of the device's compute units
- * (every nparts-th bit of the CU mask; hipExtStreamCreateWithCUMask).  For batches of independent frames: one frame per
- * partition at a time keeps the frames from slowing each other down.  NULL if the device refuses.  No reference counterpart. */
+/* One of `nparts` library-owned streams for independent frames in flight ("frame queues"): each has a hardware queue of its
+ * own (hipExtStreamCreateWithCUMask; caller-made hipStreamCreate streams share GPU_MAX_HW_QUEUES = 4 queues with every other
+ * stream of the process) and launches on it are sized for a 1 / nparts share of the device, i.e. for throughput with
+ * nparts frames in flight rather than for the latency of one call.  The queue's CU mask is the full device by default:
+ * real CU partitions (HLMI_PART_MASK=1 or 2) measured 3 % slower, and the every-nparts-th-bit mask of rounds 3-5
+ * (HLMI_PART_MASK=0) never confined anything on an 8-XCD device — halide_amd/csrc/runtime.cpp, profiles/NOTES.md round 6.
+ * The name is kept for callers.  NULL if the device refuses.  No reference counterpart. */
 void *halide_hip_partition_stream(int part, int nparts);
-/* another stream on the same compute units as partition `part` (replica 0 is halide_hip_partition_stream's) */
+/* another queue with the same mask and share as `part` (replica 0 is halide_hip_partition_stream's) */
 void *halide_hip_partition_stream_replica(int part, int nparts, int replica);
 
 /* ---- in-process frame sharder (no reference counterpart: the reference has no multi-device layer,
@@ -122,7 +126,7 @@ void *halide_hip_partition_stream_replica(int part, int nparts, int replica);
  * frame_args[i] its argument vector for frame i.  Frames are dealt round-robin to n_devices * streams_per_device
  * workers — one host thread and one HIP stream each, worker w on devices[w % n_devices]; a device listed twice gets
  * two workers (that is also how a one-GPU box exercises the path).  With streams_per_device > 1 the workers of a
- * device own disjoint CU partitions.  Buffers with host data are uploaded to the worker's device; outputs are left
+ * device each get a frame queue (halide_hip_partition_stream).  Buffers with host data are uploaded to the worker's device; outputs are left
  * device-dirty THERE (halide_copy_to_host / device_sync find the device and stream that produced them).  There is
  * no data-path collective: frames are independent.  Returns 0, or the first error code any frame returned; returns
  * only after every enqueued frame has completed. */

@@ -1,5 +1,5 @@
 """Torch-free timing of the headline workload (bench.py's step without the torch plumbing): us per 4K frame on one stream
-and on N CU-partitioned streams.  For quick A/B runs of kernel changes: python scripts/frame_bench.py [frames] [partitions]"""
+and on N frame-queue streams.  For quick A/B runs of kernel changes: python scripts/frame_bench.py [frames] [partitions]"""
 import ctypes as C
 import os
 import sys

@@ -75,13 +75,13 @@ def oracle():
 
 @pytest.fixture(params=["device", "partition"])
 def on_stream(request, hl):
-    """Runs the test twice: on the library's own device-wide stream and on a CU-partitioned stream
-    (halide_hip_partition_stream: partition 1 of 4, 64 CUs) — bench.py times the headline pipeline on partitions, where
+    """Runs the test twice: on the library's own device-wide stream and on a frame-queue stream
+    (halide_hip_partition_stream: queue 1 of 4) — bench.py times the headline pipeline on such queues, where
     local_laplacian switches its non-temporal frame accesses, the level-2 collapse inside ll_up0h and its launch geometry on by
     default, so those code paths must face the oracle too, not only the device-wide ones."""
     if request.param == "partition":
         s = hl.partition_stream(1, 4)
-        assert s, "the device refused a CU-masked stream"
+        assert s, "the device refused a frame-queue stream"
         hl.set_stream(s)
     yield request.param
     hl.set_stream(None)

@@ -42,7 +42,7 @@ def test_seeded_fuzz_slice(fuzz, name):
 
 @pytest.mark.gpu
 def test_seeded_fuzz_slice_local_laplacian_on_a_cu_partition(fuzz, on_stream):
-    """The headline pipeline's cases again with the calling thread on a CU-partitioned stream (and, for symmetry, on the device's
+    """The headline pipeline's cases again with the calling thread on a frame-queue stream (and, for symmetry, on the device's
     own): partitions switch other defaults on inside local_laplacian (non-temporal frame accesses, level 2 collapsed inside
     ll_up0h, taller units), and that is what bench.py times."""
     rng = np.random.default_rng(20260924)

@@ -462,7 +462,7 @@ def test_hip_emit_and_materialised_dataflows_match_oracle(hl, oracle, monkeypatc
     is preceded by a DIFFERENT frame through the same workspace: outLPyramid[0] rows or level-1 planes that a unit fails to
     emit would hold the other frame's values."""
     monkeypatch.setenv("HLMI_LL_EMIT", emit)
-    monkeypatch.setenv("HLMI_LL_FUSE_UP2", "1")   # outGPyramid[2] only in LDS tiles of ll_up0h (what CU-partitioned streams run)
+    monkeypatch.setenv("HLMI_LL_FUSE_UP2", "1")   # outGPyramid[2] only in LDS tiles of ll_up0h (what frame-queue streams run)
     other = _rand_image(w, h, seed=w + 3 * h + 2, kind="uniform" if kind == "smooth" else "smooth")
     inp = _rand_image(w, h, seed=w + h + 31, kind=kind)
     for img in (other, inp):
@@ -500,7 +500,7 @@ def test_hip_emit_launch_geometries_match_oracle(hl, oracle, monkeypatch, units,
 # ---- round 5
 @pytest.mark.gpu
 def test_hip_eight_4k_frames_in_flight_on_partitioned_and_plain_streams(hl, oracle):
-    """Eight 4K frames in flight on four CU-partitioned streams and four plain streams at once (every stream has its own
+    """Eight 4K frames in flight on four frame-queue streams and four plain streams at once (every stream has its own
     workspace; the launches' workgroups compete for the same compute units): every frame equals the oracle's, or — for the five
     frames the oracle is not run on — the same call alone on the device's own stream."""
     hip = hl.hip_runtime()

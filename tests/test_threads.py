@@ -61,8 +61,8 @@ def test_concurrent_calls_from_host_threads(hl, oracle, own_streams):
 
 @pytest.mark.gpu
 def test_partition_streams_are_distinct_and_compute_correctly(hl, oracle):
-    """halide_hip_partition_stream: library-owned streams confined to disjoint CU partitions (bench.py spreads the
-    frames of a step over four of them).  Results on a partition must be the oracle's; handles are cached."""
+    """halide_hip_partition_stream: library-owned frame-queue streams (bench.py spreads the
+    frames of a step over four of them).  Results on such a stream must be the oracle's; handles are cached."""
     streams = [hl.partition_stream(p, 4) for p in range(4)]
     assert all(streams) and len(set(streams)) == 4
     assert hl.partition_stream(2, 4) == streams[2]
@@ -79,6 +79,27 @@ def test_partition_streams_are_distinct_and_compute_correctly(hl, oracle):
     # read back with the thread's stream reset: copy_to_host orders itself behind the stream that PRODUCED each output
     for f, (a, o) in zip(frames, outs):
         assert np.array_equal(o.numpy(), oracle.local_laplacian(f, 8, 1.0 / 7.0, 1.0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout,nparts", [(0, 5), (1, 6), (2, 7), (3, 9)])
+def test_every_cu_mask_layout_computes_the_oracles_frame(hl, oracle, monkeypatch, layout, nparts):
+    """HLMI_PART_MASK: 3 = the full mask (default: a queue of its own on the whole device), 1 / 2 = real CU partitions (the same
+    CU slots on every XCD / contiguous slots), 0 = rounds 3-5's every-nparts-th bit.  The layout is read when a
+    (part, nparts) stream is first made, so each case takes an nparts nothing else in the suite uses.  A confined queue
+    must still produce the oracle's frame (launch geometry sized for its share, all workgroups on the CUs it has)."""
+    monkeypatch.setenv("HLMI_PART_MASK", str(layout))
+    streams = [hl.partition_stream(p, nparts) for p in (0, nparts - 1)]
+    assert all(streams) and streams[0] != streams[1]
+    rng = np.random.default_rng(20 + layout)
+    f = rng.integers(0, 65536, (3, 272, 512), dtype=np.uint16)
+    want = oracle.local_laplacian(f, 8, 1.0 / 7.0, 1.0)
+    for s in streams:
+        a, o = hl.Buffer(f), hl.Buffer(np.zeros_like(f))
+        hl.set_stream(s)
+        hl.local_laplacian(a, 8, 1.0 / 7.0, 1.0, o)
+        hl.set_stream(None)
+        assert np.array_equal(o.numpy(), want)
 
 
 @pytest.mark.gpu
@@ -101,7 +122,7 @@ def test_result_produced_on_another_stream_is_complete_when_read_back(hl, oracle
 @pytest.mark.timeout(300)
 def test_frames_in_flight_on_partition_streams_match_single_calls(hl, oracle):
     """bench_apps.py's throughput mode: distinct frames of bilateral_grid / nl_means / conv_layer_bf16 in flight on four
-    CU-partitioned streams (two frames per stream, back to back, no host synchronisation in between).  Every output must be
+    frame-queue streams (two frames per stream, back to back, no host synchronisation in between).  Every output must be
     what the same call produces alone on the default stream — and, for the bit-exact pipelines, the oracle's."""
     streams = [hl.partition_stream(p, 4) for p in range(4)]
     assert all(streams)
