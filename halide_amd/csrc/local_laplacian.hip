@@ -2602,8 +2602,9 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     const bool emit = d01_possible && fast && fuse1 && lv[1].ws < (1 << 24) && env_int("HLMI_LL_EMIT", 1);   // ws: ll_up0h's 24-bit row products
     // ll_up0h has no data-dependent gathers to amortise over a tall tile: short tiles (more, smaller workgroups) are faster on a
     // stream that owns the device (31.7 us at 8 rows per wave against 33.5 / 38.4 at 16 / 32); with four frames in flight 8 / 12 / 16 /
-    // 24 / 32 rows measure 107.8 / 110.1 / 111.2 / 112.3 / 112.3 Gpx/s (profiles/r06_frame_queue_geometry.txt)
-    if (emit) p.RU = dev_clamp_ru(env_int("HLMI_LL_RU", partitioned ? 24 : 8));
+    // 24 / 32 rows measure 107.8 / 110.1 / 111.2 / 112.3 / 112.3 Gpx/s (profiles/r06_frame_queue_geometry.txt), and next to ONE
+    // resident ll_down01e workgroup per CU 32 rows beat 24 / 40 / 48 / 64 (profiles/r06_coresidency_ab.txt)
+    if (emit) p.RU = dev_clamp_ru(env_int("HLMI_LL_RU", partitioned ? 32 : 8));
     // non-temporal frame / outLPyramid[0] accesses: +6-7 % frames per second with four frames in flight, -2-3 % on a stream that owns the device
     const bool nt = env_int("HLMI_LL_NT", partitioned ? 1 : 0) != 0;
     // ll_up0h also collapses level 2 (into an LDS tile) when level 3 is a stored level of its own: the ll_up:2 launch goes
@@ -2747,9 +2748,10 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             // frame).  ll_down01e on a frame-queue stream (several frames in flight, the launches of different frames fill the device
             // together): fewer and taller units — fewer seam rows walked twice, less per-workgroup set-up — measure 10 % more frames
             // per second than the 2048 units of a launch that has the device to itself (round 6, four queues: 2048 / 1536 / 1024 /
-            // 896..384 / 256 units -> 109.4 / 110.2 / 111.3 / 112.1-112.5 / 103.3 Gpx/s, profiles/r06_frame_queue_geometry.txt),
+            // 896..384 / 256 units -> 109.4 / 110.2 / 111.3 / 112.1-112.5 / 103.3 Gpx/s, profiles/r06_frame_queue_geometry.txt; with
+            // one workgroup per CU — below — 640 units = 160 workgroups of 55 level-2 rows measure best),
             // while on a stream that owns the device one round of resident waves is what counts (52.7 us against 57.1)
-            const int target2 = env_int("HLMI_LL_UNITS0", emit && partitioned ? 8 * stream_cus : 8 * stream_cu_count(ctx.device, nullptr));
+            const int target2 = env_int("HLMI_LL_UNITS0", emit && partitioned ? 10 * stream_cus : 8 * stream_cu_count(ctx.device, nullptr));
             // EXCH: a workgroup = 4 vertically adjacent units exchanging their seam rows through LDS.  With n level-2 rows
             // per wave a workgroup owns R = 4 n - 1 rows (the bottom wave walks the two seam rows of the next workgroup
             // itself and owns one row less); n = the smallest that keeps the launch within `target2` resident waves.
@@ -2772,7 +2774,20 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             a.nsy_magic = a.nsy == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)a.nsy + 1ull);   // 0: nsy == 1
             a.rows_base = e.h / a.nsy, a.rows_rem = e.h % a.nsy;
             dim3 grid2((a.nunits + WPB - 1) / WPB);
-            const size_t sh2 = sizeof(float) * ((nlut + 1) & ~1) + sizeof(float2) * D01_STATE * (WPB + (exch ? WPB - 1 : 0));
+            size_t sh2 = sizeof(float) * ((nlut + 1) & ~1) + sizeof(float2) * D01_STATE * (WPB + (exch ? WPB - 1 : 0));
+            // With frames in flight (a frame-queue stream) ll_down01e asks for so much LDS that only ONE of its workgroups fits a
+            // CU (2 x 77 KB would): the other half of the CU's registers and 77 KB of its LDS stay free for the workgroups of the
+            // OTHER frames' kernels — ll_up0h above all, which waits for memory while this one computes.  Four frames in flight,
+            // 40 steps, alternating A/B on three boxes: 110.3-114.5 -> 113.5-114.1 Gpx/s with the 512 units / 24 rows above,
+            // 115.8-121.8 with 640 units and 32 rows per ll_up0h wave (profiles/r06_coresidency_ab.txt).  On a stream that owns
+            // the device the second workgroup is what hides this kernel's own latencies (84.7 -> 74.7 Gpx/s without it).
+            // HLMI_LL_D01_PAD_LDS: bytes of unused LDS to add instead (experiments; 0 = two workgroups per CU).
+            {
+                const int pad = env_int("HLMI_LL_D01_PAD_LDS", emit && partitioned ? -1 : 0);
+                constexpr size_t kHalfCuLds = 160 * 1024 / 2;   // gfx950: 160 KB per CU
+                if (pad < 0) sh2 = max(sh2, kHalfCuLds + 2048);
+                else sh2 += (size_t)pad;
+            }
             if (emit) {
                 // input read once; outLPyramid[0] (4 B per output pixel), three level-1 planes and K + 1 level-2 planes written
                 timing_note_bytes(6.0 * iw * (gm.iy1 - gm.iy0 + 1) + 4.0 * iw * oh + 4.0 * 3.0 * d.w * d.h + 4.0 * (levels + 1) * e.w * e.h);
@@ -2929,7 +2944,8 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
             ph.u = p, ph.outl0 = outl0, ph.l0_ws = gm.ix1 - gm.ix0 + 1;
             ph.fuse2 = fuse2 ? 1 : 0;
             ph.g3 = lv[3].g, ph.out3 = lv[3].out, ph.lox3 = lv[3].lox, ph.loy3 = lv[3].loy, ph.ws3 = lv[3].ws, ph.ps3 = lv[3].ps;
-            const size_t sh_h = sizeof(float) * ((size_t)U0_TS * (p.RU + 2) + (size_t)U0H_T2 * (p.RU / 2 + 4));
+            const size_t sh_h = sizeof(float) * ((size_t)U0_TS * (p.RU + 2) + (size_t)U0H_T2 * (p.RU / 2 + 4)) +
+                                (size_t)env_int("HLMI_LL_UP0_PAD_LDS", 0);   // experiment: unused LDS (fewer workgroups per CU)
             if (nt) HLMI_LAUNCH(uc, "ll_up0", st, ll_up0h<true>, grid, block, sh_h, ph, gm);
             else HLMI_LAUNCH(uc, "ll_up0", st, ll_up0h<false>, grid, block, sh_h, ph, gm);
             return 0;
