@@ -82,6 +82,40 @@ __device__ unsigned long long g_probe[32];
 #define LL_PROBE_ADD(slot, val)
 #endif
 
+// HLMI_LL_RESIDENCY=1 (compile-time, `make VARIANT=_res EXTRA=-DHLMI_LL_RESIDENCY=1`): which kernels' workgroups share a compute unit?
+// Workgroups of ll_down01e (kind 0) and ll_up0h (kind 1) count themselves in and out per (XCD, SE, SH, CU) — HW_REG_XCC_ID / HW_REG_HW_ID —
+// and record, when they start, how many workgroups of the OTHER kind and of their OWN kind were resident on their CU
+// (g_res_hist[8 kind + min(other, 3)], [8 kind + 4 + min(own, 3)]); hlmi_debug_ll_residency reads and clears.  scripts/residency_probe.py.
+#ifndef HLMI_LL_RESIDENCY
+#define HLMI_LL_RESIDENCY 0
+#endif
+#if HLMI_LL_RESIDENCY
+__device__ int g_res[2][4096];
+__device__ unsigned long long g_res_hist[16];
+struct ResidencyProbe {
+    int kind, slot;
+    bool on;
+    __device__ explicit ResidencyProbe(int k) : kind(k), slot(0), on(threadIdx.x == 0) {
+        if (on) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            slot = (int)(((xcc & 0xfu) << 8) | ((hw >> 8) & 0xffu));   // CU_ID [11:8], SH_ID [12], SE_ID [15:13]
+            const int own = atomicAdd(&g_res[kind][slot], 1);
+            const int other = atomicAdd(&g_res[1 - kind][slot], 0);
+            atomicAdd(&g_res_hist[8 * kind + min(other, 3)], 1ull);
+            atomicAdd(&g_res_hist[8 * kind + 4 + min(own, 3)], 1ull);
+        }
+    }
+    __device__ ~ResidencyProbe() {
+        if (on) atomicSub(&g_res[kind][slot], 1);
+    }
+};
+#define LL_RESIDENCY(kind) ResidencyProbe residency_probe_(kind)
+#else
+#define LL_RESIDENCY(kind)
+#endif
+
 struct Geometry {
     int K, half;             // levels, (K-1)*256
     float Km1, inv_Km1;
@@ -823,6 +857,7 @@ __device__ __forceinline__ f2 mad2_2(f2 a, f2 b, f2 c, f2 d) { return dev::CANON
 template<bool ODD0, bool ODD1, bool B1, bool EXCH, bool NT>
 __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometry gm, Levels lev) {
     const D01Args &p = pe.d;
+    LL_RESIDENCY(0);
     extern __shared__ float slut[];
     for (int i = threadIdx.x; i <= 2 * gm.half; i += D0_THREADS) slut[i] = p.lut_g[i];
     __syncthreads();
@@ -2120,6 +2155,7 @@ template<bool NT, int CH = 2>  // CH: tile values a thread requests at a time in
                                // frame on one stream — 4 costs occupancy: 124 VGPRs against 66)
 __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
     const Up0Args &p = ph.u;
+    LL_RESIDENCY(1);
     extern __shared__ float s_out1[];
     // tiles in row-major order, a contiguous run of them per XCD (blocks are dealt round-robin over the 8 XCDs): a tile's
     // 130 x (RU + 2) coarse window overlaps its neighbours' by two columns / rows, and its 130-float rows start one float before a
@@ -3118,6 +3154,19 @@ extern "C" int hlmi_debug_ll_probe(unsigned long long *out32) {
     return 1;
 #else
     (void)out32;
+    return 0;
+#endif
+}
+
+extern "C" int hlmi_debug_ll_residency(unsigned long long *out16) {
+#if HLMI_LL_RESIDENCY
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_res_hist), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    unsigned long long zero[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_res_hist), zero, sizeof zero) != hipSuccess) return -1;
+    return 1;
+#else
+    (void)out16;
     return 0;
 #endif
 }

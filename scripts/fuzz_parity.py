@@ -311,10 +311,17 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--threads", type=int, default=1, help="> 1: concurrency stress — that many host threads draw random cases of ALL "
                     "pipelines for --seconds in total, every second thread on a stream of its own")
+    ap.add_argument("--frame-queue", action="store_true", help="run the cases with the calling thread on a frame-queue stream "
+                    "(halide_hip_partition_stream(1, 4)): local_laplacian takes its throughput geometry there — one ll_down01e "
+                    "workgroup per CU, fewer and taller units, taller ll_up0h tiles, non-temporal frame accesses")
     args = ap.parse_args()
     only = [s for s in args.only.split(",") if s]
     if args.threads > 1:
         return stress(args, only)
+    if args.frame_queue:
+        q = hl.partition_stream(1, 4)
+        assert q, "the device refused a frame-queue stream"
+        hl.set_stream(q)
     bad = 0
     for name, fn in CASES.items():
         if only and name not in only:

@@ -7,6 +7,8 @@ TAG=${1:-soak}; OUT=gpurun_out/$TAG; mkdir -p $OUT
   echo "Round 6 fuzz / stress runs on MI355X (scripts/fuzz_parity.py; library at $(cat $GRAFT_REPO_ROOT/.soak_head 2>/dev/null))."
   echo; echo "== python scripts/fuzz_parity.py --only local_laplacian --seconds 150 --seed 51"
   timeout 400 python scripts/fuzz_parity.py --only local_laplacian --seconds 150 --seed 51 2>&1 | tail -3
+  echo; echo "== python scripts/fuzz_parity.py --only local_laplacian --seconds 100 --seed 56 --frame-queue   (the throughput geometry: one ll_down01e workgroup per CU)"
+  timeout 400 python scripts/fuzz_parity.py --only local_laplacian --seconds 100 --seed 56 --frame-queue 2>&1 | tail -3
   echo; echo "== python scripts/fuzz_parity.py --only bilateral_grid,depthwise_separable_conv --seconds 25 --seed 52"
   timeout 300 python scripts/fuzz_parity.py --only bilateral_grid,depthwise_separable_conv --seconds 25 --seed 52 2>&1 | tail -4
   echo; echo "== python scripts/fuzz_parity.py --seconds 5 --seed 53   (all 17 pipelines)"
