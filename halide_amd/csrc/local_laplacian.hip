@@ -89,6 +89,13 @@ __device__ unsigned long long g_probe[32];
 #ifndef HLMI_LL_RESIDENCY
 #define HLMI_LL_RESIDENCY 0
 #endif
+// experiments: wave priority (s_setprio 0..3) of the two big kernels; `make VARIANT=_prio EXTRA=-DHLMI_LL_D01_PRIO=3`
+#ifndef HLMI_LL_D01_PRIO
+#define HLMI_LL_D01_PRIO 0
+#endif
+#ifndef HLMI_LL_UP0_PRIO
+#define HLMI_LL_UP0_PRIO 0
+#endif
 #if HLMI_LL_RESIDENCY
 __device__ int g_res[2][4096];
 __device__ unsigned long long g_res_hist[16];
@@ -858,6 +865,9 @@ template<bool ODD0, bool ODD1, bool B1, bool EXCH, bool NT>
 __global__ __launch_bounds__(D0_THREADS, 2) void ll_down01e(D01EArgs pe, Geometry gm, Levels lev) {
     const D01Args &p = pe.d;
     LL_RESIDENCY(0);
+#if HLMI_LL_D01_PRIO
+    __builtin_amdgcn_s_setprio(HLMI_LL_D01_PRIO);   // experiment: this kernel's waves before the co-resident kernels' in the SIMD's issue arbitration
+#endif
     extern __shared__ float slut[];
     for (int i = threadIdx.x; i <= 2 * gm.half; i += D0_THREADS) slut[i] = p.lut_g[i];
     __syncthreads();
@@ -2156,6 +2166,9 @@ template<bool NT, int CH = 2>  // CH: tile values a thread requests at a time in
 __global__ __launch_bounds__(256) void ll_up0h(Up0HArgs ph, Geometry gm) {
     const Up0Args &p = ph.u;
     LL_RESIDENCY(1);
+#if HLMI_LL_UP0_PRIO
+    __builtin_amdgcn_s_setprio(HLMI_LL_UP0_PRIO);
+#endif
     extern __shared__ float s_out1[];
     // tiles in row-major order, a contiguous run of them per XCD (blocks are dealt round-robin over the 8 XCDs): a tile's
     // 130 x (RU + 2) coarse window overlaps its neighbours' by two columns / rows, and its 130-float rows start one float before a
