@@ -456,11 +456,18 @@ def main():
             # NOT measured in this run: counters of a separate rocprofv3 PMC run (committed under profiles/).  Printed only while the
             # kernel source is byte for byte the one that run profiled — a later edit of the kernels makes them stale
             if tj.get("kernel_source_sha256") == sha_now:
-                traffic = per_launch.get(dom)
-                if all(k in per_launch for k in per_frame):
-                    frame_traffic = int(sum(per_launch[k] for k in per_frame))
+                traffic = per_launch.get(dom)      # the dominant kernel alone on a stream that owns the device: that geometry
+                # the whole frame: the counters of the geometry the headline loop ran — a frame queue's when it ran on frame queues
+                # (fewer seam rows and tile halos re-read than in the one-call geometry), else the device-wide ones
+                per_q = tj.get("bytes_per_launch_frame_queue") or {}
+                on_queues = args.partitions > 1 and bool(streams)
+                frame_set = per_q if (on_queues and all(k in per_q for k in per_frame)) else per_launch
+                if all(k in frame_set for k in per_frame):
+                    frame_traffic = int(sum(frame_set[k] for k in per_frame))
                 traffic_source = {"file": tj.get("source"), "git_head_when_collected": tj.get("git_head_when_collected"),
-                                  "measured_in_this_run": False}
+                                  "measured_in_this_run": False,
+                                  "pipeline_traffic_geometry": "frame queue (" + str(tj.get("frame_queue_source")) + ")" if frame_set is per_q
+                                  else "one stream that owns the device"}
             else:
                 traffic_source = {"file": tj.get("source"), "stale": "local_laplacian.hip changed since these counters were collected; traffic withheld"}
         result = {

@@ -18,5 +18,10 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o k
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- $CMD > $OUT/pmc_$c.log 2>&1
 done
+# the same counters with the launch geometry of a frame queue (HLMI_STREAM_SHARE=4: the caller's one stream is sized like one of four
+# queues — one ll_down01e workgroup per CU, 640 units, 32 rows per ll_up0h wave, non-temporal frame accesses): what the headline loop moves
+for c in FETCH_SIZE WRITE_SIZE; do
+  HLMI_STREAM_SHARE=4 timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmcq_$c -o pmc -- $CMD > $OUT/pmcq_$c.log 2>&1
+done
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.csv" -size +3M -delete
 ls -la $OUT $OUT/kt | head -30

@@ -55,48 +55,57 @@ if ka:
                 row[0] = short(row[0])
             w.writerow(row)
 
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-    for p in glob.glob(os.path.join(src, f"pmc_{ctr}", "*counter_collection.csv")):
-        for r in csv.DictReader(open(p)):
-            acc[(short(r["Kernel_Name"]), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
-rows = []
-for (k, grid), v in sorted(acc.items(), key=lambda kv: -sum(kv[1].get("FETCH_SIZE", [0]))):
-    if k.startswith("__amd"):
-        continue
-    f = sum(v.get("FETCH_SIZE", [0])) / max(1, len(v.get("FETCH_SIZE", [])))
-    w = sum(v.get("WRITE_SIZE", [0])) / max(1, len(v.get("WRITE_SIZE", [])))
-    rows.append((k, grid, len(v.get("FETCH_SIZE", [])), round(f, 1), round(w, 1), int((2 * f + w) * 1024)))
-if rows:
-    with open(os.path.join(dst, f"{rnd}_pmc_traffic.csv"), "w") as g:
-        w = csv.writer(g)
-        w.writerow(["kernel", "grid_size", "dispatches", "FETCH_SIZE_KB_mean", "WRITE_SIZE_KB_mean", "hbm_bytes_2xfetch_plus_write"])
-        w.writerows(rows)
-    # name the launches the way libhlmi's timing report does: strips and ups by descending grid size
-    per = {}
-    # level 1 -> 2 comes out of ll_down01f when that kernel ran (then the strips start at level 2); the level-1 collapse
-    # is part of ll_up0f when only two ll_up launches ran (levels 3 and 2)
-    for r in rows:   # round 5: levels 3 and 4 from level 2 in one launch, reported as ll_down_strip2:2
-        if r[0].startswith("ll_down_strip2"):
-            per["ll_down_strip2:2"] = r[5]
-    strips = sorted([r for r in rows if r[0].startswith("ll_down_strip") and not r[0].startswith("ll_down_strip2")], key=lambda r: -r[5])
-    first_strip = 2 if any(r[0].startswith("ll_down01") for r in rows) else 1
-    for i, r in enumerate(strips):
-        per[f"ll_down_strip:{i + first_strip}"] = r[5]
-    ups = sorted([r for r in rows if r[0] == "ll_up" or r[0].startswith("ll_up<")], key=lambda r: -r[5])
-    # the level-1 collapse is part of ll_up0f / ll_up0h (no ll_up:1 launch) whenever one of those ran
-    first_up = 2 if any(r[0].startswith("ll_up0f") or r[0].startswith("ll_up0h") for r in rows) else 1
-    for i, r in enumerate(ups):
-        per[f"ll_up:{i + first_up}"] = r[5]
-    for r in rows:
-        for base, name in (("ll_down01f", "ll_down01"), ("ll_down01e", "ll_down01"), ("ll_down0f", "ll_down0"), ("ll_down0<", "ll_down0"), ("ll_up0", "ll_up0"),
-                           ("ll_top", "ll_top"), ("ll_remap_lut", "ll_remap_lut")):
-            if r[0].startswith(base):
-                per[name] = r[5]
-        # the multi-level kernels are reported as ll_down_multi:<S> / ll_up_multi:<S>; one instantiation each per run
-        for base, depth_to_s in (("ll_down_multi", lambda d: 7 - d), ("ll_up_multi", lambda d: 7 - d)):
-            if r[0].startswith(base + "<"):
-                per[f"{base}:{depth_to_s(int(r[0].split('<')[1].split('>')[0]))}"] = r[5]
+def launch_bytes(prefix, csv_name):
+    """per-kernel counters of gpurun_out/<tag>/<prefix>FETCH_SIZE + <prefix>WRITE_SIZE -> profiles/<csv_name>, {launch name: HBM bytes}"""
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        for p in glob.glob(os.path.join(src, f"{prefix}{ctr}", "*counter_collection.csv")):
+            for r in csv.DictReader(open(p)):
+                acc[(short(r["Kernel_Name"]), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    rows = []
+    for (k, grid), v in sorted(acc.items(), key=lambda kv: -sum(kv[1].get("FETCH_SIZE", [0]))):
+        if k.startswith("__amd"):
+            continue
+        f = sum(v.get("FETCH_SIZE", [0])) / max(1, len(v.get("FETCH_SIZE", [])))
+        w = sum(v.get("WRITE_SIZE", [0])) / max(1, len(v.get("WRITE_SIZE", [])))
+        rows.append((k, grid, len(v.get("FETCH_SIZE", [])), round(f, 1), round(w, 1), int((2 * f + w) * 1024)))
+    if rows:
+        with open(os.path.join(dst, csv_name), "w") as g:
+            w = csv.writer(g)
+            w.writerow(["kernel", "grid_size", "dispatches", "FETCH_SIZE_KB_mean", "WRITE_SIZE_KB_mean", "hbm_bytes_2xfetch_plus_write"])
+            w.writerows(rows)
+        # name the launches the way libhlmi's timing report does: strips and ups by descending grid size
+        per = {}
+        # level 1 -> 2 comes out of ll_down01f when that kernel ran (then the strips start at level 2); the level-1 collapse
+        # is part of ll_up0f when only two ll_up launches ran (levels 3 and 2)
+        for r in rows:   # round 5: levels 3 and 4 from level 2 in one launch, reported as ll_down_strip2:2
+            if r[0].startswith("ll_down_strip2"):
+                per["ll_down_strip2:2"] = r[5]
+        strips = sorted([r for r in rows if r[0].startswith("ll_down_strip") and not r[0].startswith("ll_down_strip2")], key=lambda r: -r[5])
+        first_strip = 2 if any(r[0].startswith("ll_down01") for r in rows) else 1
+        for i, r in enumerate(strips):
+            per[f"ll_down_strip:{i + first_strip}"] = r[5]
+        ups = sorted([r for r in rows if r[0] == "ll_up" or r[0].startswith("ll_up<")], key=lambda r: -r[5])
+        # the level-1 collapse is part of ll_up0f / ll_up0h (no ll_up:1 launch) whenever one of those ran
+        first_up = 2 if any(r[0].startswith("ll_up0f") or r[0].startswith("ll_up0h") for r in rows) else 1
+        for i, r in enumerate(ups):
+            per[f"ll_up:{i + first_up}"] = r[5]
+        for r in rows:
+            for base, name in (("ll_down01f", "ll_down01"), ("ll_down01e", "ll_down01"), ("ll_down0f", "ll_down0"), ("ll_down0<", "ll_down0"), ("ll_up0", "ll_up0"),
+                               ("ll_top", "ll_top"), ("ll_remap_lut", "ll_remap_lut")):
+                if r[0].startswith(base):
+                    per[name] = r[5]
+            # the multi-level kernels are reported as ll_down_multi:<S> / ll_up_multi:<S>; one instantiation each per run
+            for base, depth_to_s in (("ll_down_multi", lambda d: 7 - d), ("ll_up_multi", lambda d: 7 - d)):
+                if r[0].startswith(base + "<"):
+                    per[f"{base}:{depth_to_s(int(r[0].split('<')[1].split('>')[0]))}"] = r[5]
+        return per
+    return None
+
+
+per = launch_bytes("pmc_", f"{rnd}_pmc_traffic.csv")
+perq = launch_bytes("pmcq_", f"{rnd}_pmc_traffic_frame_queue.csv")
+if per:
     import hashlib
     import subprocess
     ksrc = os.path.join(ROOT, "halide_amd", "csrc", "local_laplacian.hip")
@@ -108,5 +117,8 @@ if rows:
     json.dump({"source": f"profiles/{rnd}_pmc_traffic.csv", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per dispatch",
                "kernel_source": "halide_amd/csrc/local_laplacian.hip", "kernel_source_sha256": hashlib.sha256(open(ksrc, "rb").read()).hexdigest(),
                "git_head_when_collected": head, "input": "3840x2160 frames of bench.py's headline input, uniform noise since round 6 (the re-cut dataflow moves the same bytes for every input)",
-               "bytes_per_launch": per}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+               "bytes_per_launch": per,
+               "frame_queue_note": "bytes_per_launch_frame_queue: the same counters with HLMI_STREAM_SHARE=4, i.e. the launch geometry of one of four frame queues (what the headline loop runs)",
+               "frame_queue_source": f"profiles/{rnd}_pmc_traffic_frame_queue.csv" if perq else None,
+               "bytes_per_launch_frame_queue": perq}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print("wrote", sorted(os.listdir(dst)))
