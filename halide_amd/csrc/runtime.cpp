@@ -973,6 +973,16 @@ bool timing_enabled() { return g_timing.load(std::memory_order_relaxed) != 0; }
 static std::atomic<int> g_only_active{0};
 static std::string g_only_name;   // written under g_timing_mu, read only while g_only_active != 0
 bool launch_selected(const char *name) {
+    // timing experiments only (WRONG results): HLMI_SKIP_LAUNCH=name[,name..] leaves those launches out — what a launch costs the
+    // frame rate is the frame rate without it
+    static const std::string skip = [] { const char *e = getenv("HLMI_SKIP_LAUNCH"); return std::string(e ? e : ""); }();
+    if (!skip.empty()) {
+        const size_t n = strlen(name);
+        for (size_t pos = 0; (pos = skip.find(name, pos)) != std::string::npos; pos += n) {
+            const bool b0 = pos == 0 || skip[pos - 1] == ',', b1 = pos + n == skip.size() || skip[pos + n] == ',';
+            if (b0 && b1) return false;
+        }
+    }
     if (g_only_active.load(std::memory_order_acquire) == 0) return true;
     std::lock_guard<std::mutex> lock(g_timing_mu);
     return g_only_name == name;
