@@ -1418,6 +1418,10 @@ __global__ __launch_bounds__(256) void ll_down_strip(StripArgs a) {
 constexpr int S2_RPU = 2;                 // level-(j+2) rows per unit
 constexpr int S2_NT = 2 * S2_RPU + 2;     // level-(j+1) rows a unit walks
 constexpr int S2_NSRC = 2 * S2_NT + 2;    // level-j rows it reads
+// ll_mid's control words, one per 128-byte line: [0] planes finished, [1 .. MID_FLAGS] replicated "levels are there" flags,
+// [1 + MID_FLAGS + plane] producer blocks of that plane finished
+constexpr int MID_FLAGS = 64, MID_LINE = 32, MID_PLANES = MAX_K + 1;
+constexpr int MID_WORDS = MID_LINE * (1 + MID_FLAGS + MID_PLANES);
 struct Strip2Args {
     const float *src;        // level j, (K+1) planes
     int slox, sloy, sw, sh, sws;
@@ -1429,9 +1433,11 @@ struct Strip2Args {
     int so2, loy2, w2, h2, ws2;
     size_t ps2;
     int Pbase, S2, nsx, nsy, nunits;   // nunits = planes * nsx * nsy
+    unsigned *ctr;           // ll_mid's producer count of this call: zeroed here (nullptr: the chain runs ll_down_multi / ll_up_multi)
 };
 template<bool ODD0, bool ODD1>
 __global__ __launch_bounds__(256) void ll_down_strip2(Strip2Args p) {
+    if (p.ctr && blockIdx.x == 0 && threadIdx.x < MID_WORDS / MID_LINE) __hip_atomic_store(p.ctr + MID_LINE * (int)threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int unit = xcd_block() * 4 + wave;
     if (unit >= p.nunits) return;
@@ -1491,6 +1497,19 @@ __global__ __launch_bounds__(256) void ll_down_strip2(Strip2Args p) {
     }
 }
 
+// Agent-coherent accesses (global_load / global_store ... sc1, no cache maintenance): what one workgroup of a launch wrote is what
+// another workgroup of the SAME launch on another XCD reads (the XCDs' L2s are not coherent with each other for plain accesses
+// inside a launch).  Used by ll_mid for the three small levels its producer blocks hand to its consumer blocks.
+__device__ __forceinline__ float ld_f(const float *p, bool coh) {   // `coh` is a constant after unrolling wherever this is called
+    if (coh) return __hip_atomic_load(const_cast<float *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template<bool COH>
+__device__ __forceinline__ void st_f(float *p, float v) {
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // upsample(f)(X,Y) (:276-282) of a stored level plane `f` (origin lox/loy, row stride ws)
 // The four taps of the bilinear footprint and the lerps on them are separate steps so that a caller can REQUEST the taps of many
@@ -1504,6 +1523,15 @@ __device__ __forceinline__ UpTaps up_taps(const float *__restrict__ f, int lox, 
     UpTaps t;
     t.aa = f[(size_t)ya * ws + xa], t.ab = f[(size_t)ya * ws + xb];
     t.ba = f[(size_t)yb * ws + xa], t.bb = f[(size_t)yb * ws + xb];
+    return t;
+}
+__device__ __forceinline__ UpTaps up_taps_c(const float *__restrict__ f, int lox, int loy, int ws, int X, int Y, bool coh) {
+    if (!coh) return up_taps(f, lox, loy, ws, X, Y);
+    const int xa = dev::fdiv2(X + 1) - lox, xb = dev::fdiv2(X - 1) - lox;
+    const int ya = dev::fdiv2(Y + 1) - loy, yb = dev::fdiv2(Y - 1) - loy;
+    UpTaps t;
+    t.aa = ld_f(f + ((size_t)ya * ws + xa), true), t.ab = ld_f(f + ((size_t)ya * ws + xb), true);
+    t.ba = ld_f(f + ((size_t)yb * ws + xa), true), t.bb = ld_f(f + ((size_t)yb * ws + xb), true);
     return t;
 }
 __device__ __forceinline__ float up_from(const UpTaps &t, int X, int Y) {
@@ -1610,7 +1638,7 @@ __device__ __forceinline__ Range2 clamp_to_box(const DevLevel &L, int x0, int x1
     r.y0 = dev::clampi(y0, L.loy, L.loy + L.h - 1), r.y1 = dev::clampi(y1, L.loy, L.loy + L.h - 1);
     return r;
 }
-template<int DEPTH>
+template<int DEPTH, bool COH = false>   // COH: the levels it makes are stored agent-coherently (ll_mid)
 __device__ __forceinline__ void down_multi_tile(const CoarseArgs &a, int ntx, int nty, int b) {   // b = tile x + ntx (tile y + nty plane)
     constexpr int W1 = dm_win(DEPTH - 1), W2 = DEPTH >= 2 ? dm_win(DEPTH - 2) : 1, W3 = DEPTH >= 3 ? dm_win(DEPTH - 3) : 1,
                   W4 = DEPTH >= 4 ? dm_win(DEPTH - 4) : 1;
@@ -1672,7 +1700,7 @@ __device__ __forceinline__ void down_multi_tile(const CoarseArgs &a, int ntx, in
                 if (ok[u]) {
                     dst[yy[u] * ws_[d] + (X[u] - w.x0)] = val;
                     if (X[u] >= o.x0 && X[u] <= o.x1 && Y[u] >= o.y0 && Y[u] <= o.y1) {
-                        L.g[(size_t)plane * L.ps + (size_t)(Y[u] - L.loy) * L.ws + (X[u] - L.lox)] = val;
+                        st_f<COH>(L.g + ((size_t)plane * L.ps + (size_t)(Y[u] - L.loy) * L.ws + (X[u] - L.lox)), val);
                     }
                 }
             }
@@ -1703,7 +1731,7 @@ __host__ __device__ constexpr int um_off(int d) {  // offset of level S+d's regi
 }
 // up_multi_tile handles ONE element per thread and level (act[d] = tid < n): every region of a tile must fit 256 threads
 static_assert(UM_T * UM_T <= 256 && um_win(1) * um_win(1) <= 256, "ll_up_multi: a level's region of a tile exceeds the workgroup");
-template<int TOP>
+template<int TOP, int CF = TOP + 1>   // CF: levels S+CF .. were made by producer blocks of the SAME launch (ll_mid): agent-coherent loads
 __device__ __forceinline__ void up_multi_tile(const CoarseArgs &a, int ntx, int b) {
     __shared__ float tl[um_off(TOP + 1)];
     const int tx = b % ntx, ty = b / ntx;
@@ -1736,7 +1764,7 @@ __device__ __forceinline__ void up_multi_tile(const CoarseArgs &a, int ntx, int 
         const int e = act[d] ? (int)threadIdx.x : 0, yy = e / nx;   // idle threads re-read element 0 and store nothing
         eX[d] = r.x0 + (e - yy * nx), eY[d] = r.y0 + yy;
         eo[d] = (size_t)(eY[d] - L.loy) * L.ws + (eX[d] - L.lox);
-        lvl[d] = L.g[(size_t)a.K * L.ps + eo[d]];
+        lvl[d] = ld_f(L.g + ((size_t)a.K * L.ps + eo[d]), d >= CF);
     }
     __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler starts a level's gathers as soon as its first load is back)
     float lf[TOP + 1], g0[TOP + 1], g1[TOP + 1];
@@ -1747,11 +1775,11 @@ __device__ __forceinline__ void up_multi_tile(const CoarseArgs &a, int ntx, int 
         const float level = lvl[d] * a.Km1;
         const int li = dev::clampi((int)level, 0, a.K - 2);
         lf[d] = level - (float)li;
-        g0[d] = L.g[(size_t)li * L.ps + eo[d]], g1[d] = L.g[(size_t)(li + 1) * L.ps + eo[d]];
+        g0[d] = ld_f(L.g + ((size_t)li * L.ps + eo[d]), d >= CF), g1[d] = ld_f(L.g + ((size_t)(li + 1) * L.ps + eo[d]), d >= CF);
         if (d < TOP) {
             const DevLevel &C = a.lv[d + 1];
-            t0[d] = up_taps(C.g + (size_t)li * C.ps, C.lox, C.loy, C.ws, eX[d], eY[d]);
-            t1[d] = up_taps(C.g + (size_t)(li + 1) * C.ps, C.lox, C.loy, C.ws, eX[d], eY[d]);
+            t0[d] = up_taps_c(C.g + (size_t)li * C.ps, C.lox, C.loy, C.ws, eX[d], eY[d], d + 1 >= CF);
+            t1[d] = up_taps_c(C.g + (size_t)(li + 1) * C.ps, C.lox, C.loy, C.ws, eX[d], eY[d], d + 1 >= CF);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1797,6 +1825,43 @@ __device__ __forceinline__ void up_multi_tile(const CoarseArgs &a, int ntx, int 
 template<int TOP>
 __global__ __launch_bounds__(256) void ll_up_multi(CoarseArgs a, int ntx) {
     up_multi_tile<TOP>(a, ntx, (int)blockIdx.x);
+}
+
+// ---- ll_mid<DEPTH, TOP, CF>: ll_down_multi AND ll_up_multi as ONE launch (round 6).  With four frames in flight each of the three
+// short launches of the chain costs the frame ~3.2 us whatever it does (profiles/r06_launch_cost_skip_ab.txt: they do not overlap each
+// other across queues), so the last dependency that is small enough is carried inside a launch: blocks [0, nD) are ll_down_multi's
+// tiles — levels S+1 .. of every plane, stored agent-coherently (write-through) —, each bumps `ctr` once behind its stores; blocks
+// [nD, ..) are ll_up_multi's tiles, which wait until the count is full and read those levels agent-coherently.  Blocks are dispatched in
+// order, so a resident consumer implies every producer has been dispatched, and producers wait for nothing: no deadlock however few
+// workgroups are resident.  What round 5's ll_coarse (the WHOLE chain as tickets) paid — thousands of same-address atomics, megabytes
+// through 4-byte coherent accesses — is here nD (486) atomics on one word and the ~100 K values of levels 5-7.  `ctr` is zeroed by
+// ll_down_strip2 of the same call.  Same device functions as the two launches: same operations, same bits.
+template<int DEPTH, int TOP, int CF>
+__global__ __launch_bounds__(256) void ll_mid(CoarseArgs ad, int ntxd, int ntyd, int nD, CoarseArgs au, int ntxu, unsigned *ctr) {
+    const int b = (int)blockIdx.x;
+    __shared__ int s_last;
+    if (b < nD) {
+        down_multi_tile<DEPTH, true>(ad, ntxd, ntyd, b);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's write-through stores have been acknowledged
+        __syncthreads();
+        if (threadIdx.x == 0) {   // count per plane first (its own line), the last block of a plane counts the plane
+            const int per_plane = ntxd * ntyd, plane = b / per_plane;
+            bool last = __hip_atomic_fetch_add(ctr + MID_LINE * (1 + MID_FLAGS + plane), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)per_plane - 1u;
+            if (last) last = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nD / per_plane) - 1u;
+            s_last = last;
+        }
+        __syncthreads();
+        // the last producer raises the flags: consumers never touch the counter's line (same-address operations are served one
+        // per ~11 ns, profiles/r05_sync_cost.txt — 510 pollers on the counter itself delayed the producers' own increments by 16 us)
+        if (s_last && threadIdx.x < MID_FLAGS) __hip_atomic_store(ctr + MID_LINE * (1 + (int)threadIdx.x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        if (threadIdx.x == 0) {
+            const unsigned *flag = ctr + MID_LINE * (1 + (b & (MID_FLAGS - 1)));
+            while (__hip_atomic_load(const_cast<unsigned *>(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
+        }
+        __syncthreads();
+        up_multi_tile<TOP, CF>(au, ntxu, b - nD);
+    }
 }
 
 // Measured and not kept (round 5, git 5e5e508, profiles/r05_ll_coarse_*.txt, profiles/NOTES.md): the five launches between the two big
@@ -2662,9 +2727,16 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     // tile phases: 104.1 -> 98.7 us per frame, 115 -> 110.6 for one call + sync)
     const bool fuse2 = emit && SU >= 3 && SU < J && env_int("HLMI_LL_FUSE_UP2", 1);
 
+    // OPT-IN (HLMI_LL_FUSE_MID=1): ll_down_multi:4 and ll_up_multi:3 as ONE launch (ll_mid: levels 5-7 handed over inside the launch).
+    // Bit-exact; as fast as the two launches on one stream (97.9 us per frame back to back, 113-114 for one call + sync either way) and
+    // 1.5 us per frame SLOWER with four frames in flight (71.1 against 69.6: its 510 consumer workgroups sit on the CUs while the
+    // producers run) — profiles/r06_ll_mid_ab.txt
+    const bool mid = emit && S == 4 && SU == 3 && J == 8 && env_int("HLMI_LL_FUSE_MID", 0);
     // ---- workspace: the levels and outLPyramid[0] of the re-cut dataflow (input width x output rows)
     const size_t off_l0 = ws_floats;
     if (emit) ws_floats += ((size_t)(gm.ix1 - gm.ix0 + 1) * (size_t)oh + 63) & ~(size_t)63;
+    const size_t off_ctr = ws_floats;   // ll_mid's producer count (one word, a cache line of its own)
+    if (mid) ws_floats += (MID_WORDS + 63) & ~63;
     void *ws = nullptr;
     if ((r = get_workspace(uc, ctx, ws_floats * sizeof(float), &ws))) return r;
     float *wsf = (float *)ws;
@@ -2912,6 +2984,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         a.nsx = max((hi2 - x2_first + a.S2) / a.S2, (hi1 - a.Pbase + 2 * a.S2) / (2 * a.S2));
         a.nsy = (e.h + S2_RPU - 1) / S2_RPU;
         a.nunits = (levels + 1) * a.nsx * a.nsy;
+        a.ctr = mid ? reinterpret_cast<unsigned *>(wsf + off_ctr) : nullptr;
         timing_note_bytes(4.0 * (levels + 1) * ((double)sl.w * sl.h + (double)d.w * d.h + (double)e.w * e.h));
         dim3 grid((a.nunits + 3) / 4), block(256);
         switch ((odd0 ? 2 : 0) | (odd1 ? 1 : 0)) {
@@ -2923,6 +2996,7 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     }
     for (int j = 1; j + 1 < J; j++) {
         if (strip2 && (j == 2 || j == 3)) continue;
+        if (j == S && mid && strip2) break;   // ll_mid below makes levels S+1 .. J-1 itself
         if (j == S) {
             const CoarseArgs ca = coarse_args(S);
             long total = 0;
@@ -2948,7 +3022,17 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
         if (lv[j + 1].odd) HLMI_LAUNCH(uc, nm, st, (ll_down_strip<true>), grid, block, 0, sa);
         else HLMI_LAUNCH(uc, nm, st, (ll_down_strip<false>), grid, block, 0, sa);
     }
-    if (SU < J) {
+    if (mid && strip2) {
+        const CoarseArgs cd = coarse_args(S), cu = coarse_args(SU);
+        const int ntxd = (lv[J - 1].w + DM_T - 1) / DM_T, ntyd = (lv[J - 1].h + DM_T - 1) / DM_T, nD = ntxd * ntyd * (levels + 1);
+        const int ntxu = (cu.lv[0].rw + UM_T - 1) / UM_T, ntyu = (cu.lv[0].rh + UM_T - 1) / UM_T;
+        long total = 0;
+        for (int dl = 1; S + dl < J; dl++) total += (long)(levels + 1) * lv[S + dl].w * lv[S + dl].h;
+        // ll_down_multi:4's bytes (level 4 read, levels 5-7 written) + ll_up_multi:3's (as below)
+        timing_note_bytes(4.0 * ((double)(levels + 1) * lv[S].w * lv[S].h + (double)total) + 4.0 * 4.0 * (double)cu.lv[0].rw * cu.lv[0].rh * 4.0 / 3.0);
+        HLMI_LAUNCH(uc, "ll_mid:4", st, (ll_mid<3, 4, 2>), dim3((unsigned)(nD + ntxu * ntyu)), dim3(256), 0, cd, ntxd, ntyd, nD, cu, ntxu,
+                    reinterpret_cast<unsigned *>(wsf + off_ctr));
+    } else if (SU < J) {
         const CoarseArgs cu = coarse_args(SU);
         const int ntx = (cu.lv[0].rw + UM_T - 1) / UM_T, nty = (cu.lv[0].rh + UM_T - 1) / UM_T;
         dim3 grid((unsigned)(ntx * nty)), block(256);

@@ -92,7 +92,7 @@ def launch_bytes(prefix, csv_name):
             per[f"ll_up:{i + first_up}"] = r[5]
         for r in rows:
             for base, name in (("ll_down01f", "ll_down01"), ("ll_down01e", "ll_down01"), ("ll_down0f", "ll_down0"), ("ll_down0<", "ll_down0"), ("ll_up0", "ll_up0"),
-                               ("ll_top", "ll_top"), ("ll_remap_lut", "ll_remap_lut")):
+                               ("ll_top", "ll_top"), ("ll_remap_lut", "ll_remap_lut"), ("ll_mid", "ll_mid:4")):
                 if r[0].startswith(base):
                     per[name] = r[5]
             # the multi-level kernels are reported as ll_down_multi:<S> / ll_up_multi:<S>; one instantiation each per run

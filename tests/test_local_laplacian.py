@@ -497,6 +497,21 @@ def test_hip_emit_launch_geometries_match_oracle(hl, oracle, monkeypatch, units,
         assert np.array_equal(o.numpy(), oracle.local_laplacian(inp, 8, 1.0 / 7, 1.0, origin=origin))
 
 
+@pytest.mark.gpu
+def test_hip_ll_mid_one_launch_for_levels_5_to_7_and_the_collapse_matches_oracle(hl, oracle, monkeypatch, on_stream):
+    """HLMI_LL_FUSE_MID=1 (opt-in, round 6): ll_down_multi and ll_up_multi as ONE launch, levels 5-7 handed from its producer blocks to
+    its consumer blocks through agent-coherent stores / loads and a count.  DIFFERENT frames go through the same workspace back to
+    back (a consumer that read a stale copy of the previous frame's levels would show here), on the device's stream and on a frame
+    queue, at sizes where the default chain is the five-launch one (levels 5-7 exist) and at sizes where a level is a single row."""
+    monkeypatch.setenv("HLMI_LL_FUSE_MID", "1")
+    for (w, h) in [(1920, 1080), (520, 332), (2048, 64), (260, 40)]:
+        for seed in range(3):
+            inp = _rand_image(w, h, seed=100 * seed + w, kind="uniform" if seed != 1 else "smooth")
+            a, o = hl.Buffer(inp), hl.Buffer(np.zeros_like(inp))
+            hl.local_laplacian(a, 8, 1.0 / 7, 1.0, o)
+            assert np.array_equal(o.numpy(), oracle.local_laplacian(inp, 8, 1.0 / 7, 1.0)), (w, h, seed)
+
+
 # ---- round 5
 @pytest.mark.gpu
 def test_hip_eight_4k_frames_in_flight_on_partitioned_and_plain_streams(hl, oracle):
