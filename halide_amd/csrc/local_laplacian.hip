@@ -1625,7 +1625,10 @@ struct CoarseArgs {
 // exactly as a read of that level is): [clamp(2 lo_{d+1} - 1), clamp(2 hi_{d+1} + 2)].  Level S+1's window is
 // computed from global memory (16 clamped loads per value), the deeper ones from the previous window in LDS;
 // window values a workgroup does not own are recomputed by the neighbours (identical operations, identical bits).
-constexpr int DM_T = 4;                                      // tile edge at the deepest level
+#ifndef HLMI_LL_DM_T
+#define HLMI_LL_DM_T 4
+#endif
+constexpr int DM_T = HLMI_LL_DM_T;                           // tile edge at the deepest level (A/B: make VARIANT=_dm8 EXTRA=-DHLMI_LL_DM_T=8)
 __host__ __device__ constexpr int dm_win(int depth_below) {  // window edge `depth_below` levels above the deepest
     int w = DM_T;
     for (int i = 0; i < depth_below; i++) w = 2 * w + 2;
