@@ -1734,8 +1734,11 @@ __host__ __device__ constexpr int um_off(int d) {  // offset of level S+d's regi
 }
 // up_multi_tile handles ONE element per thread and level (act[d] = tid < n): every region of a tile must fit 256 threads
 static_assert(UM_T * UM_T <= 256 && um_win(1) * um_win(1) <= 256, "ll_up_multi: a level's region of a tile exceeds the workgroup");
-template<int TOP, int CF = TOP + 1>   // CF: levels S+CF .. were made by producer blocks of the SAME launch (ll_mid): agent-coherent loads
-__device__ __forceinline__ void up_multi_tile(const CoarseArgs &a, int ntx, int b) {
+struct NoWait { __device__ void operator()() const {} };
+// CF: levels S+CF .. were made by producer blocks of the SAME launch (ll_mid): agent-coherent loads, requested only after `wait()`
+// returns (everything that depends on the older levels alone is requested BEFORE it: those round trips run under the wait)
+template<int TOP, int CF = TOP + 1, class Wait = NoWait>
+__device__ __forceinline__ void up_multi_tile(const CoarseArgs &a, int ntx, int b, Wait wait = Wait()) {
     __shared__ float tl[um_off(TOP + 1)];
     const int tx = b % ntx, ty = b / ntx;
     Range2 reg[TOP + 1];
@@ -1767,22 +1770,51 @@ __device__ __forceinline__ void up_multi_tile(const CoarseArgs &a, int ntx, int 
         const int e = act[d] ? (int)threadIdx.x : 0, yy = e / nx;   // idle threads re-read element 0 and store nothing
         eX[d] = r.x0 + (e - yy * nx), eY[d] = r.y0 + yy;
         eo[d] = (size_t)(eY[d] - L.loy) * L.ws + (eX[d] - L.lox);
-        lvl[d] = ld_f(L.g + ((size_t)a.K * L.ps + eo[d]), d >= CF);
+        if (d < CF) lvl[d] = L.g[(size_t)a.K * L.ps + eo[d]];
     }
     __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler starts a level's gathers as soon as its first load is back)
     float lf[TOP + 1], g0[TOP + 1], g1[TOP + 1];
+    int lis[TOP + 1];
     UpTaps t0[TOP + 1], t1[TOP + 1];
-#pragma unroll
-    for (int d = 0; d <= TOP; d++) {
-        const DevLevel &L = a.lv[d];
+    auto planes_of = [&](int d) {
         const float level = lvl[d] * a.Km1;
-        const int li = dev::clampi((int)level, 0, a.K - 2);
-        lf[d] = level - (float)li;
-        g0[d] = ld_f(L.g + ((size_t)li * L.ps + eo[d]), d >= CF), g1[d] = ld_f(L.g + ((size_t)(li + 1) * L.ps + eo[d]), d >= CF);
-        if (d < TOP) {
-            const DevLevel &C = a.lv[d + 1];
-            t0[d] = up_taps_c(C.g + (size_t)li * C.ps, C.lox, C.loy, C.ws, eX[d], eY[d], d + 1 >= CF);
-            t1[d] = up_taps_c(C.g + (size_t)(li + 1) * C.ps, C.lox, C.loy, C.ws, eX[d], eY[d], d + 1 >= CF);
+        lis[d] = dev::clampi((int)level, 0, a.K - 2);
+        lf[d] = level - (float)lis[d];
+    };
+#pragma unroll
+    for (int d = 0; d <= TOP; d++) {   // gathers that touch the older levels only
+        if (d < CF) {
+            const DevLevel &L = a.lv[d];
+            planes_of(d);
+            const int li = lis[d];
+            g0[d] = L.g[(size_t)li * L.ps + eo[d]], g1[d] = L.g[(size_t)(li + 1) * L.ps + eo[d]];
+            if (d < TOP && d + 1 < CF) {
+                const DevLevel &C = a.lv[d + 1];
+                t0[d] = up_taps(C.g + (size_t)li * C.ps, C.lox, C.loy, C.ws, eX[d], eY[d]);
+                t1[d] = up_taps(C.g + (size_t)(li + 1) * C.ps, C.lox, C.loy, C.ws, eX[d], eY[d]);
+            }
+        }
+    }
+    if (CF <= TOP) {
+        __builtin_amdgcn_sched_barrier(0);
+        wait();
+#pragma unroll
+        for (int d = 0; d <= TOP; d++) {
+            if (d >= CF) lvl[d] = ld_f(a.lv[d].g + ((size_t)a.K * a.lv[d].ps + eo[d]), true);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int d = 0; d <= TOP; d++) {
+            const DevLevel &L = a.lv[d];
+            if (d >= CF) {
+                planes_of(d);
+                g0[d] = ld_f(L.g + ((size_t)lis[d] * L.ps + eo[d]), true), g1[d] = ld_f(L.g + ((size_t)(lis[d] + 1) * L.ps + eo[d]), true);
+            }
+            if (d < TOP && d + 1 >= CF) {
+                const DevLevel &C = a.lv[d + 1];
+                t0[d] = up_taps_c(C.g + (size_t)lis[d] * C.ps, C.lox, C.loy, C.ws, eX[d], eY[d], true);
+                t1[d] = up_taps_c(C.g + (size_t)(lis[d] + 1) * C.ps, C.lox, C.loy, C.ws, eX[d], eY[d], true);
+            }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1858,12 +1890,14 @@ __global__ __launch_bounds__(256) void ll_mid(CoarseArgs ad, int ntxd, int ntyd,
         // per ~11 ns, profiles/r05_sync_cost.txt — 510 pollers on the counter itself delayed the producers' own increments by 16 us)
         if (s_last && threadIdx.x < MID_FLAGS) __hip_atomic_store(ctr + MID_LINE * (1 + (int)threadIdx.x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-        if (threadIdx.x == 0) {
-            const unsigned *flag = ctr + MID_LINE * (1 + (b & (MID_FLAGS - 1)));
-            while (__hip_atomic_load(const_cast<unsigned *>(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
-        }
-        __syncthreads();
-        up_multi_tile<TOP, CF>(au, ntxu, b - nD);
+        const unsigned *flag = ctr + MID_LINE * (1 + (b & (MID_FLAGS - 1)));
+        auto wait = [flag]() {
+            if (threadIdx.x == 0) {
+                while (__hip_atomic_load(const_cast<unsigned *>(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
+            }
+            __syncthreads();
+        };
+        up_multi_tile<TOP, CF>(au, ntxu, b - nD, wait);
     }
 }
 
@@ -2731,9 +2765,11 @@ extern "C" int local_laplacian(halide_buffer_t *input, int32_t levels, float alp
     const bool fuse2 = emit && SU >= 3 && SU < J && env_int("HLMI_LL_FUSE_UP2", 1);
 
     // OPT-IN (HLMI_LL_FUSE_MID=1): ll_down_multi:4 and ll_up_multi:3 as ONE launch (ll_mid: levels 5-7 handed over inside the launch).
-    // Bit-exact; as fast as the two launches on one stream (97.9 us per frame back to back, 113-114 for one call + sync either way) and
-    // 1.5 us per frame SLOWER with four frames in flight (71.1 against 69.6: its 510 consumer workgroups sit on the CUs while the
-    // producers run) — profiles/r06_ll_mid_ab.txt
+    // Bit-exact; with the consumers' older-level loads requested before they wait it is 1.9 us per frame FASTER on one stream (96.0
+    // against 97.9 back to back, 111.5 against 113.0 for one call + sync) and 0.6 us per frame SLOWER with four frames in flight (71.4
+    // against 70.8: its consumer workgroups sit on the CUs while the producers run) — profiles/r06_ll_mid_ab.txt.  Not the default on
+    // any stream: ONE such launch cannot deadlock (ll_mid's comment), but the waiting consumers of SEVERAL of them in flight on
+    // different queues could in principle fill an XCD's workgroup slots while a producer of each still waits for one there.
     const bool mid = emit && S == 4 && SU == 3 && J == 8 && env_int("HLMI_LL_FUSE_MID", 0);
     // ---- workspace: the levels and outLPyramid[0] of the re-cut dataflow (input width x output rows)
     const size_t off_l0 = ws_floats;
