@@ -1381,6 +1381,7 @@ void *halide_hip_partition_stream_replica(int part, int nparts, int replica) {
         const bool on = layout == 1 ? (slot % nparts == part) : layout == 2 ? (slot * nparts / slots == part) : layout == 3 ? true : (b % nparts == part);
         if (on) mask[(size_t)b / 32] |= 1u << (b % 32), mine++;
     }
+    if (mine == 0) return nullptr;   // (a real partition of more parts than an XCD has CU slots: an empty mask would mean the whole device)
     hipStream_t s = nullptr;
     if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
         (void)hipGetLastError();
